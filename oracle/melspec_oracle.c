@@ -1,0 +1,520 @@
+/*
+ * melspec_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, f64 CPU restatement of the reference's log-mel hot path
+ * (wavey-ai/mel-spec v0.4.0).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library; the product
+ * (mel_spec_amd / libmelspec_hip.so) never links, imports or calls it.
+ *
+ * Parity pin: the reference is Rust and cannot be built in this image (no
+ * cargo/rustc), so this restatement is pinned against the reference's own
+ * fixtures (tests/test_oracle.py):
+ *   - mel()               vs testdata/mel_filters.npz      @1e-7  (src/mel.rs:838-850)
+ *   - mel(n_fft=512)      vs testdata/nemo_mel_filters.npz @1e-7  (src/mel.rs:853-871)
+ *   - streaming 512/160/80 on jfk_f32le.wav vs testdata/rust_jfk_golden.npy @1e-6
+ *                                                          (src/rb.rs:134-179)
+ *   - librosa scalar known-answers                         (src/mel.rs:787-835)
+ *   - fbank frame count 1098 on JFK; values informational  (src/fbank.rs:484-490)
+ * The FFT itself lives in a third-party crate (rustfft ^6.2.0, Cargo.toml:18, no
+ * Cargo.lock in tree); it computes the unnormalised forward DFT
+ * X[k] = sum_n x[n] exp(-2*pi*i*n*k/N), restated here as a mixed-radix
+ * Cooley-Tukey in f64.  Fbank VALUES are "parity unpinned" in the reference
+ * (shape-only test); they are pinned to this restatement only.
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+typedef struct { double re, im; } cplx;
+
+/* ------------------------------------------------------------------------- */
+/* Forward complex DFT of arbitrary length (restates what rustfft's            */
+/* plan_fft_forward(n).process_with_scratch computes; call sites               */
+/* src/stft.rs:99-110, src/fbank.rs:122-123,193-194).                          */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int n;
+    cplx *tw;      /* tw[j] = exp(-2*pi*i*j/n), j in [0,n) */
+    cplx *scratch; /* n entries */
+} fft_plan;
+
+static void fft_plan_init(fft_plan *p, int n) {
+    p->n = n;
+    p->tw = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    p->scratch = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    for (int j = 0; j < n; ++j) {
+        double a = -2.0 * M_PI * (double)j / (double)n;
+        p->tw[j].re = cos(a);
+        p->tw[j].im = sin(a);
+    }
+}
+static void fft_plan_free(fft_plan *p) { free(p->tw); free(p->scratch); p->tw = p->scratch = NULL; }
+
+static inline cplx cmul(cplx a, cplx b) { cplx r = { a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re }; return r; }
+static inline cplx cadd(cplx a, cplx b) { cplx r = { a.re + b.re, a.im + b.im }; return r; }
+static inline cplx csub(cplx a, cplx b) { cplx r = { a.re - b.re, a.im - b.im }; return r; }
+
+static int pick_radix(int n) {
+    if (n % 4 == 0) return 4;
+    if (n % 2 == 0) return 2;
+    if (n % 5 == 0) return 5;
+    if (n % 3 == 0) return 3;
+    for (int p = 7; p * p <= n; p += 2) if (n % p == 0) return p;
+    return n;
+}
+
+/* Decimation-in-time recursion: out[0..n) = DFT_n(in[0], in[stride], ...). */
+static void fft_rec(const fft_plan *pl, int n, int stride, const cplx *in, cplx *out) {
+    if (n == 1) { out[0] = in[0]; return; }
+    const int N = pl->n;
+    const int p = pick_radix(n);
+    const int m = n / p;
+    for (int q = 0; q < p; ++q) fft_rec(pl, m, stride * p, in + (size_t)q * stride, out + (size_t)q * m);
+    const int tstep = N / n;      /* W_n^j = tw[j * tstep] */
+    const int pstep = N / p;      /* W_p^j = tw[(j % p) * pstep] */
+    if (p == 2) {
+        for (int k = 0; k < m; ++k) {
+            cplx a = out[k], b = cmul(out[m + k], pl->tw[k * tstep]);
+            out[k] = cadd(a, b); out[m + k] = csub(a, b);
+        }
+    } else if (p == 4) {
+        for (int k = 0; k < m; ++k) {
+            cplx a = out[k];
+            cplx b = cmul(out[m + k],     pl->tw[k * tstep]);
+            cplx c = cmul(out[2 * m + k], pl->tw[2 * k * tstep]);
+            cplx d = cmul(out[3 * m + k], pl->tw[3 * k * tstep]);
+            cplx s0 = cadd(a, c), s1 = csub(a, c), s2 = cadd(b, d), s3 = csub(b, d);
+            cplx js3 = { s3.im, -s3.re };            /* -i * s3 */
+            out[k]         = cadd(s0, s2);
+            out[m + k]     = cadd(s1, js3);
+            out[2 * m + k] = csub(s0, s2);
+            out[3 * m + k] = csub(s1, js3);
+        }
+    } else {
+        cplx tmp[64];
+        cplx *t = (p <= 64) ? tmp : (cplx *)malloc(sizeof(cplx) * (size_t)p);
+        for (int k = 0; k < m; ++k) {
+            for (int q = 0; q < p; ++q) t[q] = cmul(out[q * m + k], pl->tw[(q * k) * tstep]);
+            for (int r = 0; r < p; ++r) {
+                cplx acc = t[0];
+                for (int q = 1; q < p; ++q) acc = cadd(acc, cmul(t[q], pl->tw[((q * r) % p) * pstep]));
+                out[r * m + k] = acc;
+            }
+        }
+        if (t != tmp) free(t);
+    }
+}
+
+static void fft_forward_inplace(const fft_plan *pl, cplx *buf) {
+    memcpy(pl->scratch, buf, sizeof(cplx) * (size_t)pl->n);
+    fft_rec(pl, pl->n, 1, pl->scratch, buf);
+}
+
+/* Exposed for tests: forward DFT of n complex points (interleaved re,im). */
+void oracle_fft_forward(int n, double *interleaved) {
+    fft_plan pl; fft_plan_init(&pl, n);
+    fft_forward_inplace(&pl, (cplx *)interleaved);
+    fft_plan_free(&pl);
+}
+
+/* ------------------------------------------------------------------------- */
+/* src/stft.rs:141-145 hann_window (periodic, f64)                             */
+/* ------------------------------------------------------------------------- */
+void oracle_hann_window(int n, double *w) {
+    for (int i = 0; i < n; ++i) w[i] = 0.5 * (1.0 - cos((2.0 * M_PI * (double)i) / (double)n));
+}
+
+/* src/stft.rs:153-157 frame count of frame_windows (no padding, no centring) */
+int64_t oracle_num_frames(int64_t len, int n_fft, int hop) {
+    if (len < n_fft) return 0;
+    return (len - n_fft) / hop + 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* src/mel.rs:591-643 hz_to_mel / mel_to_hz / mel_frequencies / fft_frequencies */
+/* ------------------------------------------------------------------------- */
+double oracle_hz_to_mel(double f, int htk) {
+    if (htk) return 2595.0 * log10(1.0 + f / 700.0);
+    const double f_min = 0.0, f_sp = 200.0 / 3.0, min_log_hz = 1000.0;
+    const double min_log_mel = (min_log_hz - f_min) / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    if (f >= min_log_hz) return min_log_mel + (log(f / min_log_hz) / logstep);
+    return (f - f_min) / f_sp;
+}
+double oracle_mel_to_hz(double mel, int htk) {
+    if (htk) return 700.0 * (pow(10.0, mel / 2595.0) - 1.0);
+    const double f_min = 0.0, f_sp = 200.0 / 3.0, min_log_hz = 1000.0;
+    const double min_log_mel = (min_log_hz - f_min) / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    if (mel >= min_log_mel) return min_log_hz * exp(logstep * (mel - min_log_mel));
+    return f_min + f_sp * mel;
+}
+/* src/mel.rs:631-637; Array1::linspace(a,b,n)[i] = a + i*(b-a)/(n-1) */
+void oracle_mel_frequencies(int n, double fmin, double fmax, int htk, double *out) {
+    const double lo = oracle_hz_to_mel(fmin, htk), hi = oracle_hz_to_mel(fmax, htk);
+    const double step = (n > 1) ? (hi - lo) / (double)(n - 1) : 0.0;
+    for (int i = 0; i < n; ++i) out[i] = oracle_mel_to_hz(lo + step * (double)i, htk);
+}
+void oracle_fft_frequencies(double sr, int n_fft, double *out) {
+    const double step = sr / (double)n_fft;
+    for (int i = 0; i <= n_fft / 2; ++i) out[i] = step * (double)i;
+}
+
+/* ------------------------------------------------------------------------- */
+/* src/mel.rs:547-589 mel(): dense Slaney/HTK filterbank [n_mels, n_fft/2+1]   */
+/* f_min < 0 means None (0.0); f_max <= 0 means None (sr/2).                    */
+/* ------------------------------------------------------------------------- */
+void oracle_mel_filterbank(double sr, int n_fft, int n_mels, double f_min, double f_max,
+                           int htk, int norm, double *weights /* n_mels*(n_fft/2+1) */) {
+    const int bins = n_fft / 2 + 1;
+    if (f_min < 0.0) f_min = 0.0;
+    if (f_max <= 0.0) f_max = sr / 2.0;
+    double *fftfreqs = (double *)malloc(sizeof(double) * (size_t)bins);
+    double *mel_f = (double *)malloc(sizeof(double) * (size_t)(n_mels + 2));
+    oracle_fft_frequencies(sr, n_fft, fftfreqs);
+    oracle_mel_frequencies(n_mels + 2, f_min, f_max, htk, mel_f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = mel_f[i + 1] - mel_f[i];
+        const double fd1 = mel_f[i + 2] - mel_f[i + 1];
+        for (int b = 0; b < bins; ++b) {
+            /* ramps[i][b] = mel_f[i] - fftfreqs[b] */
+            double lower = -(mel_f[i] - fftfreqs[b]) / fd0;
+            double upper = (mel_f[i + 2] - fftfreqs[b]) / fd1;
+            lower = fmin(fmax(lower, 0.0), 1.0);
+            upper = fmin(fmax(upper, 0.0), 1.0);
+            weights[(size_t)i * bins + b] = fmin(lower, upper);
+        }
+        if (norm) {
+            const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+            for (int b = 0; b < bins; ++b) weights[(size_t)i * bins + b] *= enorm;
+        }
+    }
+    free(fftfreqs); free(mel_f);
+}
+
+/* ------------------------------------------------------------------------- */
+/* src/mel.rs:34-71 SparseMelFilterbank::from_dense (rows of (bin, weight))     */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int n_mels, bins, nnz;
+    int *row_ptr;   /* n_mels+1 */
+    int *bin;       /* nnz */
+    double *w;      /* nnz */
+} sparse_fb;
+
+static void sparse_from_dense(sparse_fb *s, const double *dense, int n_mels, int bins) {
+    s->n_mels = n_mels; s->bins = bins;
+    int nnz = 0;
+    for (int i = 0; i < n_mels * bins; ++i) nnz += (dense[i] != 0.0);
+    s->nnz = nnz;
+    s->row_ptr = (int *)malloc(sizeof(int) * (size_t)(n_mels + 1));
+    s->bin = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    s->w = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
+    int k = 0;
+    for (int m = 0; m < n_mels; ++m) {
+        s->row_ptr[m] = k;
+        for (int b = 0; b < bins; ++b) {
+            double v = dense[(size_t)m * bins + b];
+            if (v != 0.0) { s->bin[k] = b; s->w[k] = v; ++k; }
+        }
+    }
+    s->row_ptr[n_mels] = k;
+}
+static void sparse_free(sparse_fb *s) { free(s->row_ptr); free(s->bin); free(s->w); }
+
+/* Returns nnz and (optionally) per-row start/len for the layout tests. */
+int oracle_sparse_stats(const double *dense, int n_mels, int bins, int *row_start, int *row_len) {
+    sparse_fb s; sparse_from_dense(&s, dense, n_mels, bins);
+    for (int m = 0; m < n_mels; ++m) {
+        int a = s.row_ptr[m], b = s.row_ptr[m + 1];
+        if (row_start) row_start[m] = (b > a) ? s.bin[a] : 0;
+        if (row_len) row_len[m] = b - a;
+    }
+    int nnz = s.nnz; sparse_free(&s); return nnz;
+}
+
+/* src/mel.rs:148-168 project_stft_log10 + src/mel.rs:645-654 norm_mel_slice_f64 */
+static void mel_add_frame(const sparse_fb *fb, const cplx *stft, int n_fft, double *mel_buf, float *out_row) {
+    const int half = n_fft / 2;
+    for (int m = 0; m < fb->n_mels; ++m) {
+        double energy = 0.0;
+        for (int j = fb->row_ptr[m]; j < fb->row_ptr[m + 1]; ++j) {
+            const int b = fb->bin[j];
+            const double power = (b < half) ? (stft[b].re * stft[b].re + stft[b].im * stft[b].im) : 0.0;
+            energy += fb->w[j] * power;
+        }
+        mel_buf[m] = log10(fmax(energy, 1e-10));
+    }
+    double mmax = -INFINITY;
+    for (int m = 0; m < fb->n_mels; ++m) mmax = fmax(mmax, mel_buf[m]);
+    mmax -= 8.0;
+    for (int m = 0; m < fb->n_mels; ++m) out_row[m] = (float)((fmax(mel_buf[m], mmax) + 4.0) / 4.0);
+}
+
+/* ------------------------------------------------------------------------- */
+/* src/stft.rs:119-138 Spectrogram::compute_mel_spectrogram_cpu                 */
+/*   -> compute_all_cpu (89-115) -> frame_windows (147-169) -> MelSpectrogram   */
+/* out: [frames][n_mels] f32 row-major.  Returns the number of frames.          */
+/* ------------------------------------------------------------------------- */
+int64_t oracle_compute_mel_spectrogram_cpu(const float *samples, int64_t len, int fft_size, int hop_size,
+                                           int n_mels, double sampling_rate, float *out) {
+    const int64_t frames = oracle_num_frames(len, fft_size, hop_size);
+    if (frames == 0) return 0;
+    const int bins = fft_size / 2 + 1;
+    double *window = (double *)malloc(sizeof(double) * (size_t)fft_size);
+    double *dense = (double *)malloc(sizeof(double) * (size_t)n_mels * bins);
+    double *mel_buf = (double *)malloc(sizeof(double) * (size_t)n_mels);
+    cplx *buf = (cplx *)malloc(sizeof(cplx) * (size_t)fft_size);
+    oracle_hann_window(fft_size, window);
+    /* MelSpectrogram::new: mel(sr, fft, n_mels, None, None, false, true)  (src/mel.rs:19-24) */
+    oracle_mel_filterbank(sampling_rate, fft_size, n_mels, -1.0, -1.0, 0, 1, dense);
+    sparse_fb fb; sparse_from_dense(&fb, dense, n_mels, bins);
+    fft_plan pl; fft_plan_init(&pl, fft_size);
+    for (int64_t f = 0; f < frames; ++f) {
+        const float *x = samples + f * hop_size;
+        for (int i = 0; i < fft_size; ++i) { buf[i].re = (double)x[i] * window[i]; buf[i].im = 0.0; }
+        fft_forward_inplace(&pl, buf);
+        mel_add_frame(&fb, buf, fft_size, mel_buf, out + f * n_mels);
+    }
+    fft_plan_free(&pl); sparse_free(&fb);
+    free(window); free(dense); free(mel_buf); free(buf);
+    return frames;
+}
+
+/* Many clips, clips split across OpenMP threads (the all-cores CPU baseline of
+ * bench.py).  Clip c is samples[c*clip_stride .. +clip_len); out is
+ * [clip][frame][mel].  Same arithmetic as the function above. */
+int64_t oracle_compute_mel_batch(const float *samples, int64_t clip_stride, int64_t clip_len, int n_clips,
+                                 int fft_size, int hop_size, int n_mels, double sampling_rate,
+                                 float *out, int n_threads) {
+    const int64_t fpc = oracle_num_frames(clip_len, fft_size, hop_size);
+    if (fpc == 0) return 0;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int c = 0; c < n_clips; ++c) {
+        oracle_compute_mel_spectrogram_cpu(samples + (int64_t)c * clip_stride, clip_len, fft_size, hop_size,
+                                           n_mels, sampling_rate, out + (int64_t)c * fpc * n_mels);
+    }
+    (void)n_threads;
+    return fpc * n_clips;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* Streaming path: src/stft.rs:25-86 Spectrogram::{new,add} driven hop-by-hop   */
+/* as src/rb.rs:86-121 RingBuffer::maybe_mel does, then MelSpectrogram::add.    */
+/* out: [emitted][n_mels]; returns frames emitted.  This is what                */
+/* testdata/rust_jfk_golden.npy pins (src/rb.rs:134-179, 512/160/80).           */
+/* ------------------------------------------------------------------------- */
+int64_t oracle_stream_mel(const float *samples, int64_t len, int fft_size, int hop_size, int n_mels,
+                          double sampling_rate, float *out, int64_t out_cap_frames) {
+    const int bins = fft_size / 2 + 1;
+    double *window = (double *)malloc(sizeof(double) * (size_t)fft_size);
+    double *hop_buf = (double *)calloc((size_t)fft_size, sizeof(double));
+    double *dense = (double *)malloc(sizeof(double) * (size_t)n_mels * bins);
+    double *mel_buf = (double *)malloc(sizeof(double) * (size_t)n_mels);
+    cplx *buf = (cplx *)malloc(sizeof(cplx) * (size_t)fft_size);
+    oracle_hann_window(fft_size, window);
+    oracle_mel_filterbank(sampling_rate, fft_size, n_mels, -1.0, -1.0, 0, 1, dense);
+    sparse_fb fb; sparse_from_dense(&fb, dense, n_mels, bins);
+    fft_plan pl; fft_plan_init(&pl, fft_size);
+    uint64_t idx = 0;
+    int64_t emitted = 0;
+    /* RingBuffer::maybe_mel only calls Spectrogram::add with exactly hop_size samples. */
+    for (int64_t pos = 0; pos + hop_size <= len; pos += hop_size) {
+        memmove(hop_buf, hop_buf + hop_size, sizeof(double) * (size_t)(fft_size - hop_size));
+        for (int i = 0; i < hop_size; ++i) hop_buf[fft_size - hop_size + i] = (double)samples[pos + i];
+        idx += (uint64_t)hop_size;
+        if (idx >= (uint64_t)fft_size) {
+            if (emitted >= out_cap_frames) break;
+            for (int j = 0; j < fft_size; ++j) { buf[j].re = hop_buf[j] * window[j]; buf[j].im = 0.0; }
+            fft_forward_inplace(&pl, buf);
+            mel_add_frame(&fb, buf, fft_size, mel_buf, out + emitted * n_mels);
+            ++emitted;
+        }
+    }
+    fft_plan_free(&pl); sparse_free(&fb);
+    free(window); free(hop_buf); free(dense); free(mel_buf); free(buf);
+    return emitted;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Kaldi fbank: src/fbank.rs                                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    double sample_rate;      /* FbankConfig (src/fbank.rs:25-64) */
+    int num_mel_bins;
+    double frame_length_ms;
+    double frame_shift_ms;
+    double energy_floor;
+    int use_log_fbank;
+    int use_power;
+    double preemphasis;
+    int apply_cmn;
+    double low_freq;
+    double high_freq;
+} oracle_fbank_config;
+
+void oracle_fbank_default_config(oracle_fbank_config *c) { /* src/fbank.rs:46-64 */
+    c->sample_rate = 16000.0; c->num_mel_bins = 80; c->frame_length_ms = 25.0; c->frame_shift_ms = 10.0;
+    c->energy_floor = 0.0; c->use_log_fbank = 1; c->use_power = 1; c->preemphasis = 0.97;
+    c->apply_cmn = 1; c->low_freq = 20.0; c->high_freq = 0.0;
+}
+/* src/fbank.rs:66-82 */
+int oracle_fbank_frame_length(const oracle_fbank_config *c) { return (int)round((c->frame_length_ms / 1000.0) * c->sample_rate); }
+int oracle_fbank_frame_shift(const oracle_fbank_config *c) { return (int)round((c->frame_shift_ms / 1000.0) * c->sample_rate); }
+int oracle_fbank_fft_size(const oracle_fbank_config *c) {
+    int n = oracle_fbank_frame_length(c), p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+/* src/fbank.rs:303-313 */
+static double kaldi_hz_to_mel(double hz) { return 1127.0 * log(1.0 + hz / 700.0); }
+static double kaldi_mel_to_hz(double mel) { return 700.0 * (exp(mel / 1127.0) - 1.0); }
+
+/* src/fbank.rs:253-301 kaldi_mel_filterbank -> dense [num_mel_bins, fft_size/2+1] */
+void oracle_kaldi_mel_filterbank(double sample_rate, int fft_size, int num_mel_bins, double low_freq,
+                                 double high_freq, double *filters) {
+    const int nb = fft_size / 2 + 1;
+    const double mel_low = kaldi_hz_to_mel(low_freq), mel_high = kaldi_hz_to_mel(high_freq);
+    double *hz = (double *)malloc(sizeof(double) * (size_t)(num_mel_bins + 2));
+    for (int i = 0; i <= num_mel_bins + 1; ++i) {
+        double mp = mel_low + (mel_high - mel_low) * (double)i / (double)(num_mel_bins + 1);
+        hz[i] = kaldi_mel_to_hz(mp);
+    }
+    memset(filters, 0, sizeof(double) * (size_t)num_mel_bins * nb);
+    for (int m = 0; m < num_mel_bins; ++m) {
+        const double left = hz[m], center = hz[m + 1], right = hz[m + 2];
+        if (center <= left || right <= center) continue;
+        for (int b = 0; b < nb; ++b) {
+            const double f = (double)b * sample_rate / (double)fft_size;
+            if (f > left && f <= center) filters[(size_t)m * nb + b] = (f - left) / (center - left);
+            else if (f > center && f < right) filters[(size_t)m * nb + b] = (right - f) / (right - center);
+        }
+    }
+    free(hz);
+}
+
+/* src/fbank.rs:141-236 Fbank::compute -> out [frames][num_mel_bins] f32. Returns frames. */
+int64_t oracle_fbank_compute(const oracle_fbank_config *cfg, const float *samples, int64_t len, float *out) {
+    const int frame_len = oracle_fbank_frame_length(cfg);
+    const int frame_shift = oracle_fbank_frame_shift(cfg);
+    const int fft_size = oracle_fbank_fft_size(cfg);
+    const int nb = fft_size / 2 + 1;
+    const int nm = cfg->num_mel_bins;
+    const double preemph = cfg->preemphasis;
+    if (len < frame_len) return 0;
+    const int64_t num_frames = 1 + (len - frame_len) / frame_shift;
+
+    /* Fbank::new (src/fbank.rs:94-132): povey window, filterbank, plan */
+    double *window = (double *)malloc(sizeof(double) * (size_t)frame_len);
+    for (int i = 0; i < frame_len; ++i) {
+        double a = 2.0 * M_PI * (double)i / (double)(frame_len - 1);
+        window[i] = pow(0.5 - 0.5 * cos(a), 0.85);
+    }
+    const double high = (cfg->high_freq == 0.0) ? cfg->sample_rate / 2.0 : cfg->high_freq;
+    double *dense = (double *)malloc(sizeof(double) * (size_t)nm * nb);
+    oracle_kaldi_mel_filterbank(cfg->sample_rate, fft_size, nm, cfg->low_freq, high, dense);
+    sparse_fb fb; sparse_from_dense(&fb, dense, nm, nb);
+    fft_plan pl; fft_plan_init(&pl, fft_size);
+
+    cplx *cbuf = (cplx *)malloc(sizeof(cplx) * (size_t)fft_size);
+    double *frame_buf = (double *)malloc(sizeof(double) * (size_t)frame_len);
+    double *power = (double *)malloc(sizeof(double) * (size_t)nb);
+
+    for (int64_t f = 0; f < num_frames; ++f) {
+        const int64_t start = f * frame_shift;
+        const float *x = samples + start;
+        double mean = 0.0;
+        for (int i = 0; i < frame_len; ++i) mean += (double)x[i];
+        mean /= (double)frame_len;
+        for (int i = 0; i < frame_len; ++i) frame_buf[i] = (double)x[i] - mean;
+        if (preemph > 0.0) {
+            for (int i = frame_len - 1; i >= 1; --i) frame_buf[i] -= preemph * frame_buf[i - 1];
+            if (start > 0) frame_buf[0] -= preemph * ((double)samples[start - 1] - mean);
+        }
+        for (int i = 0; i < frame_len; ++i) { cbuf[i].re = frame_buf[i] * window[i]; cbuf[i].im = 0.0; }
+        for (int i = frame_len; i < fft_size; ++i) { cbuf[i].re = 0.0; cbuf[i].im = 0.0; }
+        fft_forward_inplace(&pl, cbuf);
+        for (int b = 0; b < nb; ++b) {
+            double ns = cbuf[b].re * cbuf[b].re + cbuf[b].im * cbuf[b].im;
+            power[b] = cfg->use_power ? ns : sqrt(ns);
+        }
+        /* project_power_f64 (src/mel.rs:106-125) */
+        for (int m = 0; m < nm; ++m) {
+            double e = 0.0;
+            for (int j = fb.row_ptr[m]; j < fb.row_ptr[m + 1]; ++j) e += fb.w[j] * power[fb.bin[j]];
+            const double floor_v = (cfg->energy_floor > 0.0) ? cfg->energy_floor : (double)FLT_EPSILON;
+            e = fmax(e, floor_v);
+            if (cfg->use_log_fbank) e = log(e);
+            out[f * nm + m] = (float)e;
+        }
+    }
+    /* CMN (src/fbank.rs:224-233): per mel column, f32 mean = sequential f32 sum / n
+     * (ndarray's mean() on a strided column view folds left-to-right in f32). */
+    if (cfg->apply_cmn && num_frames > 0) {
+        for (int m = 0; m < nm; ++m) {
+            float sum = 0.0f;
+            for (int64_t f = 0; f < num_frames; ++f) sum = sum + out[f * nm + m];
+            const float mean = sum / (float)num_frames;
+            for (int64_t f = 0; f < num_frames; ++f) out[f * nm + m] -= mean;
+        }
+    }
+    fft_plan_free(&pl); sparse_free(&fb);
+    free(window); free(dense); free(cbuf); free(frame_buf); free(power);
+    return num_frames;
+}
+
+/* Many clips through fbank, clips across OpenMP threads. out [clip][frame][mel]. */
+int64_t oracle_fbank_batch(const oracle_fbank_config *cfg, const float *samples, int64_t clip_stride,
+                           int64_t clip_len, int n_clips, float *out, int n_threads) {
+    const int frame_len = oracle_fbank_frame_length(cfg);
+    const int frame_shift = oracle_fbank_frame_shift(cfg);
+    if (clip_len < frame_len) return 0;
+    const int64_t fpc = 1 + (clip_len - frame_len) / frame_shift;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(static)
+#endif
+    for (int c = 0; c < n_clips; ++c)
+        oracle_fbank_compute(cfg, samples + (int64_t)c * clip_stride, clip_len, out + (int64_t)c * fpc * cfg->num_mel_bins);
+    (void)n_threads;
+    return fpc * n_clips;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic PCM generator of SURVEY.md §8(d): bit-identical on CPU and GPU,    */
+/* no libm.  x[clip][i] = u * 2^-(clip & 7), u in [-1,1).                       */
+/* ------------------------------------------------------------------------- */
+static inline uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h;
+}
+void oracle_synth_pcm(uint32_t seed, uint64_t clip, uint64_t n, float *out) {
+    const float scale = 1.0f / (float)(1u << (clip & 7u));
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t h = fmix32(seed ^ ((uint32_t)clip * 0x9E3779B1u) ^ ((uint32_t)i * 0x85EBCA6Bu));
+        float u = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        out[i] = u * scale;
+    }
+}

@@ -1,0 +1,231 @@
+"""ctypes binding of the CPU oracle (oracle/melspec_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.  The product package (mel_spec_amd) must never
+import this module -- tests/test_boundary.py greps for that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmelspec_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "melspec_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _SO
+
+
+class FbankConfig(C.Structure):
+    """Mirror of oracle_fbank_config (FbankConfig, src/fbank.rs:25-64)."""
+    _fields_ = [
+        ("sample_rate", C.c_double), ("num_mel_bins", C.c_int),
+        ("frame_length_ms", C.c_double), ("frame_shift_ms", C.c_double),
+        ("energy_floor", C.c_double), ("use_log_fbank", C.c_int), ("use_power", C.c_int),
+        ("preemphasis", C.c_double), ("apply_cmn", C.c_int),
+        ("low_freq", C.c_double), ("high_freq", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        f32p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)
+        L.oracle_num_frames.restype = C.c_int64
+        L.oracle_num_frames.argtypes = [C.c_int64, C.c_int, C.c_int]
+        L.oracle_hz_to_mel.restype = C.c_double
+        L.oracle_hz_to_mel.argtypes = [C.c_double, C.c_int]
+        L.oracle_mel_to_hz.restype = C.c_double
+        L.oracle_mel_to_hz.argtypes = [C.c_double, C.c_int]
+        L.oracle_mel_frequencies.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, f64p]
+        L.oracle_fft_frequencies.argtypes = [C.c_double, C.c_int, f64p]
+        L.oracle_hann_window.argtypes = [C.c_int, f64p]
+        L.oracle_fft_forward.argtypes = [C.c_int, f64p]
+        L.oracle_mel_filterbank.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, f64p]
+        L.oracle_sparse_stats.restype = C.c_int
+        L.oracle_sparse_stats.argtypes = [f64p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_compute_mel_spectrogram_cpu.restype = C.c_int64
+        L.oracle_compute_mel_spectrogram_cpu.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p]
+        L.oracle_compute_mel_batch.restype = C.c_int64
+        L.oracle_compute_mel_batch.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
+        L.oracle_max_threads.restype = C.c_int
+        L.oracle_stream_mel.restype = C.c_int64
+        L.oracle_stream_mel.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int64]
+        L.oracle_fbank_default_config.argtypes = [C.POINTER(FbankConfig)]
+        L.oracle_fbank_frame_length.argtypes = [C.POINTER(FbankConfig)]
+        L.oracle_fbank_frame_shift.argtypes = [C.POINTER(FbankConfig)]
+        L.oracle_fbank_fft_size.argtypes = [C.POINTER(FbankConfig)]
+        L.oracle_kaldi_mel_filterbank.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, f64p]
+        L.oracle_fbank_compute.restype = C.c_int64
+        L.oracle_fbank_compute.argtypes = [C.POINTER(FbankConfig), f32p, C.c_int64, f32p]
+        L.oracle_fbank_batch.restype = C.c_int64
+        L.oracle_fbank_batch.argtypes = [C.POINTER(FbankConfig), f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int]
+        L.oracle_synth_pcm.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, f32p]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def num_frames(n: int, n_fft: int, hop: int) -> int:
+    return int(lib().oracle_num_frames(n, n_fft, hop))
+
+
+def hann_window(n: int) -> np.ndarray:
+    w = np.empty(n, np.float64)
+    lib().oracle_hann_window(n, _p(w, C.c_double))
+    return w
+
+
+def fft_forward(z: np.ndarray) -> np.ndarray:
+    z = np.ascontiguousarray(z, dtype=np.complex128).copy()
+    lib().oracle_fft_forward(z.shape[0], _p(z.view(np.float64), C.c_double))
+    return z
+
+
+def mel_filterbank(sr: float, n_fft: int, n_mels: int, f_min=None, f_max=None, htk=False, norm=True) -> np.ndarray:
+    """mel() of src/mel.rs:547-589 -> dense f64 [n_mels, n_fft//2+1]."""
+    out = np.empty((n_mels, n_fft // 2 + 1), np.float64)
+    lib().oracle_mel_filterbank(sr, n_fft, n_mels, -1.0 if f_min is None else f_min,
+                                -1.0 if f_max is None else f_max, int(htk), int(norm), _p(out, C.c_double))
+    return out
+
+
+def mel_frequencies(n: int, fmin: float, fmax: float, htk=False) -> np.ndarray:
+    out = np.empty(n, np.float64)
+    lib().oracle_mel_frequencies(n, fmin, fmax, int(htk), _p(out, C.c_double))
+    return out
+
+
+def fft_frequencies(sr: float, n_fft: int) -> np.ndarray:
+    out = np.empty(n_fft // 2 + 1, np.float64)
+    lib().oracle_fft_frequencies(sr, n_fft, _p(out, C.c_double))
+    return out
+
+
+def hz_to_mel(f, htk=False):
+    return float(lib().oracle_hz_to_mel(f, int(htk)))
+
+
+def mel_to_hz(m, htk=False):
+    return float(lib().oracle_mel_to_hz(m, int(htk)))
+
+
+def compute_mel_spectrogram_cpu(samples, fft_size=400, hop_size=160, n_mels=80, sampling_rate=16000.0) -> np.ndarray:
+    """Spectrogram::compute_mel_spectrogram_cpu (src/stft.rs:119-138) -> f32 [frames, n_mels]."""
+    x = _f32(samples)
+    nf = num_frames(x.shape[0], fft_size, hop_size)
+    out = np.empty((nf, n_mels), np.float32)
+    if nf:
+        got = lib().oracle_compute_mel_spectrogram_cpu(_p(x, C.c_float), x.shape[0], fft_size, hop_size, n_mels,
+                                                       sampling_rate, _p(out, C.c_float))
+        assert got == nf
+    return out
+
+
+def compute_mel_batch(clips, fft_size=400, hop_size=160, n_mels=80, sampling_rate=16000.0, n_threads=0) -> np.ndarray:
+    """[n_clips, clip_len] f32 -> [n_clips, frames, n_mels] f32, clips across OpenMP threads."""
+    x = _f32(clips)
+    assert x.ndim == 2
+    nf = num_frames(x.shape[1], fft_size, hop_size)
+    out = np.empty((x.shape[0], nf, n_mels), np.float32)
+    if nf and x.shape[0]:
+        lib().oracle_compute_mel_batch(_p(x, C.c_float), x.shape[1], x.shape[1], x.shape[0], fft_size, hop_size,
+                                       n_mels, sampling_rate, _p(out, C.c_float), n_threads)
+    return out
+
+
+def max_threads() -> int:
+    return int(lib().oracle_max_threads())
+
+
+def stream_mel(samples, fft_size=512, hop_size=160, n_mels=80, sampling_rate=16000.0) -> np.ndarray:
+    """Streaming Spectrogram::add + MelSpectrogram::add (src/stft.rs:48-86, src/rb.rs:86-121)."""
+    x = _f32(samples)
+    cap = x.shape[0] // hop_size + 1
+    out = np.empty((cap, n_mels), np.float32)
+    n = lib().oracle_stream_mel(_p(x, C.c_float), x.shape[0], fft_size, hop_size, n_mels, sampling_rate,
+                                _p(out, C.c_float), cap)
+    return out[:n].copy()
+
+
+def fbank_default_config() -> FbankConfig:
+    c = FbankConfig()
+    lib().oracle_fbank_default_config(C.byref(c))
+    return c
+
+
+def kaldi_mel_filterbank(sample_rate=16000.0, fft_size=512, num_mel_bins=80, low_freq=20.0, high_freq=8000.0):
+    out = np.empty((num_mel_bins, fft_size // 2 + 1), np.float64)
+    lib().oracle_kaldi_mel_filterbank(sample_rate, fft_size, num_mel_bins, low_freq, high_freq, _p(out, C.c_double))
+    return out
+
+
+def fbank_compute(samples, cfg: FbankConfig | None = None) -> np.ndarray:
+    """Fbank::compute (src/fbank.rs:141-236) -> f32 [frames, num_mel_bins]."""
+    cfg = cfg or fbank_default_config()
+    x = _f32(samples)
+    fl = lib().oracle_fbank_frame_length(C.byref(cfg))
+    fs = lib().oracle_fbank_frame_shift(C.byref(cfg))
+    nf = 0 if x.shape[0] < fl else 1 + (x.shape[0] - fl) // fs
+    out = np.zeros((nf, cfg.num_mel_bins), np.float32)
+    if nf:
+        got = lib().oracle_fbank_compute(C.byref(cfg), _p(x, C.c_float), x.shape[0], _p(out, C.c_float))
+        assert got == nf
+    return out
+
+
+def fbank_batch(clips, cfg: FbankConfig | None = None, n_threads=0) -> np.ndarray:
+    cfg = cfg or fbank_default_config()
+    x = _f32(clips)
+    fl = lib().oracle_fbank_frame_length(C.byref(cfg))
+    fs = lib().oracle_fbank_frame_shift(C.byref(cfg))
+    nf = 0 if x.shape[1] < fl else 1 + (x.shape[1] - fl) // fs
+    out = np.zeros((x.shape[0], nf, cfg.num_mel_bins), np.float32)
+    if nf and x.shape[0]:
+        lib().oracle_fbank_batch(C.byref(cfg), _p(x, C.c_float), x.shape[1], x.shape[1], x.shape[0],
+                                 _p(out, C.c_float), n_threads)
+    return out
+
+
+SYNTH_SEED = 0x4D454C53
+
+
+def synth_pcm(clip: int, n: int, seed: int = SYNTH_SEED) -> np.ndarray:
+    """Hash-noise PCM of SURVEY.md §8(d) (bit-identical twin of the device generator)."""
+    out = np.empty(n, np.float32)
+    lib().oracle_synth_pcm(seed, clip, n, _p(out, C.c_float))
+    return out
+
+
+def load_wav_f32(path: str) -> np.ndarray:
+    """Find the 'data' chunk like src/fbank.rs:324-352 and return the f32le payload."""
+    b = open(path, "rb").read()
+    pos = 12
+    while pos + 8 <= len(b):
+        cid = b[pos:pos + 4]
+        size = int.from_bytes(b[pos + 4:pos + 8], "little")
+        if cid == b"data":
+            start = pos + 8
+            n = (len(b) - start) // 4
+            return np.frombuffer(b, dtype="<f4", count=n, offset=start).astype(np.float32)
+        pos += 8 + size + (size & 1)
+    raise ValueError("no data chunk")
