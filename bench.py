@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- mel frames/s of the fused MI355X log-mel kernel (Whisper 400/160/80 @16 kHz).
+
+A "step" is one pass of the hot path over one batch of synthetic PCM that is already
+resident in HBM: BASELINE.json configs[1], 1024 x 10 s f32 clips per GPU -> 1 021 952 frames
+of 80 mels per step.  N>1: one process per GPU (torch.distributed / RCCL), every rank owns its
+own 1024 clips (weak scaling, per-clip split, no data-path collective); the timed region is
+bracketed by barrier + synchronize and the MAX over ranks is reported.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     algorithmic bytes (640 B PCM in + 4*n_mels B out per frame) / kernel time vs 8 TB/s
+  cpu_baseline the C oracle (a port of Spectrogram::compute_mel_spectrogram_cpu) on the host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SR = 16000.0
+N_FFT, HOP, N_MELS = 400, 160, 80
+CLIP_SECONDS = 10
+CLIPS_PER_GPU = 1024
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
+    ap.add_argument("--clip-seconds", type=int, default=CLIP_SECONDS)
+    ap.add_argument("--n-mels", type=int, default=N_MELS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--host-io", action="store_true", help="also time the PCIe-inclusive host API (not `value`)")
+    return ap.parse_args()
+
+
+def cpu_baseline(clip_len: int, n_mels: int, target_s: float) -> dict:
+    """Time the oracle (port of compute_mel_spectrogram_cpu) on a bounded sample of the same
+    synthetic workload, all host cores (clips split across OpenMP threads)."""
+    import numpy as np
+    from oracle import oracle as O
+    cores = O.max_threads()
+    probe = np.stack([O.synth_pcm(c, clip_len) for c in range(cores)])
+    t0 = time.perf_counter()
+    O.compute_mel_batch(probe, N_FFT, HOP, n_mels, SR, n_threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(CLIPS_PER_GPU, max(cores, round(cores * target_s / dt))))
+    n -= n % cores or 0
+    n = max(n, cores)
+    clips = np.stack([O.synth_pcm(c, clip_len) for c in range(n)])
+    t0 = time.perf_counter()
+    out = O.compute_mel_batch(clips, N_FFT, HOP, n_mels, SR, n_threads=cores)
+    dt = time.perf_counter() - t0
+    frames = out.shape[0] * out.shape[1]
+    # single-thread figure on a smaller slice, for the DESIGN.md table
+    k = max(1, n // (2 * cores))
+    t1 = time.perf_counter()
+    o1 = O.compute_mel_batch(clips[:k], N_FFT, HOP, n_mels, SR, n_threads=1)
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": frames / dt, "unit": "mel frames/s", "cores": cores, "kind": "port",
+        "sample": f"{n} of the {CLIPS_PER_GPU} synthetic {clip_len / SR:.0f} s clips ({frames} frames) in {dt:.2f} s, "
+                  f"oracle/melspec_oracle.c (f64 restatement of Spectrogram::compute_mel_spectrogram_cpu), OpenMP over clips",
+        "single_thread_frames_per_s": o1.shape[0] * o1.shape[1] / dt1,
+    }
+
+
+def main() -> None:
+    args = parse_args()
+    import numpy as np
+    import torch
+    import mel_spec_amd as M
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_mels = args.n_mels
+    clip_len = int(args.clip_seconds * SR)
+    n_clips = args.clips
+    first_clip = rank * n_clips            # weak scaling: rank r owns clips [r*n, (r+1)*n)
+    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, n_mels, device=local_rank)
+    fpc = mel.num_frames(clip_len)
+    frames_per_step = fpc * n_clips
+
+    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
+    out = torch.empty(frames_per_step * n_mels, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, first_clip, n_clips, stream=stream)
+    torch.cuda.synchronize()
+
+    def step():
+        mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    # quick parity spot check outside the timed region (3 clips vs the oracle)
+    parity = None
+    if rank == 0:
+        from oracle import oracle as O
+        worst = 0.0
+        o3 = out.view(n_clips, fpc, n_mels)
+        for c in sorted({0, n_clips // 2, n_clips - 1}):
+            want = O.compute_mel_spectrogram_cpu(O.synth_pcm(first_clip + c, clip_len), N_FFT, HOP, n_mels, SR)
+            worst = max(worst, float((o3[c].cpu().numpy() - want).__abs__().max()))
+        parity = worst
+        if worst > 1e-4:
+            raise SystemExit(f"parity check failed before timing: max|diff| = {worst}")
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kernel_ms = float(k.item())
+
+    host_io = None
+    if args.host_io and rank == 0:
+        from oracle import oracle as O
+        x = np.concatenate([O.synth_pcm(c, clip_len) for c in range(8)])
+        mel.compute_mel_spectrogram(x)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            y = mel.compute_mel_spectrogram(x)
+        host_io = 5 * y.shape[0] / (time.perf_counter() - t1)
+
+    if rank == 0:
+        total_frames = frames_per_step * world * args.steps
+        value = total_frames / elapsed
+        bytes_per_frame = HOP * 4 + n_mels * 4
+        algo_bytes_per_launch = frames_per_step * bytes_per_frame
+        achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("clips") == n_clips and tj.get("clip_seconds") == args.clip_seconds and tj.get("n_mels") == n_mels:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "mel frames/sec/GPU (Whisper 400/160/80 @16 kHz); realtime x vs CPU ref",
+            "value": value, "unit": "mel frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: batched {n_clips} synthetic {args.clip_seconds} s f32 clips @16 kHz per GPU, "
+                                   f"Whisper n_fft={N_FFT} hop={HOP} n_mels={n_mels}, PCM and mel resident in HBM",
+                       "clips_per_gpu": n_clips, "frames_per_step_per_gpu": frames_per_step,
+                       "parallelism": f"per-clip split x{world}, no data-path collective"},
+            "per_gpu_frames_per_s": value / world,
+            "realtime_x": value * (HOP / SR),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "whisper400_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes_per_launch},
+            "parity_max_abs_diff": parity,
+        }
+        if host_io is not None:
+            res["host_api_frames_per_s_pcie_inclusive"] = host_io
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(clip_len, n_mels, args.cpu_seconds)
+            res["cpu_baseline"] = cb
+            res["realtime_x_vs_cpu"] = value / cb["value"]
+        print(json.dumps(res), flush=True)
+
+    mel.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+/*
+ * melspec_hip.h -- C ABI of libmelspec_hip.so, the MI355X (gfx950) log-mel frontend.
+ *
+ * This is the drop-in boundary for the reference's GPU plugin slot.  Each entry point
+ * names the reference interface it replaces (paths relative to wavey-ai/mel-spec v0.4.0).
+ * The reference binds its CUDA plugin per *stage* (cufftExecZ2Z + launch_mel_kernel,
+ * src/cuda.rs:185-219, src/cuda_kernels.cu:49-66); this library is bound per *batch*:
+ * one call = framing + Hann + FFT + power + mel + log10 + per-frame normalisation.
+ *
+ * Conventions (mirroring src/cuda.rs:10-25,164 and src/cuda_kernels.cu:56-58):
+ *   - every function returns int; 0 == success (CUDA_SUCCESS analogue);
+ *     > 0  == a hipError_t raised by the runtime (maps to CudaError::Runtime);
+ *     < 0  == a library code below (INVALID_ARG / UNAVAILABLE map to
+ *             CudaError::Unavailable when raised by *_create, Runtime otherwise);
+ *   - nothing throws or aborts across the ABI;
+ *   - plain pointers and sizes only; the caller owns every buffer it passes in;
+ *     the context owns its device tables, scratch, pinned staging and stream;
+ *   - a context is single-threaded (one per host thread per device), like
+ *     `&mut self` + raw device pointers in CudaMelSpectrogram (src/cuda.rs:27-36);
+ *   - *_host calls are synchronous; *_device calls are stream-ordered and asynchronous.
+ */
+#ifndef MELSPEC_HIP_H
+#define MELSPEC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MELSPEC_OK                 0
+#define MELSPEC_ERR_INVALID_ARG   (-1)  /* zero/oversized sizes, NULL pointers (src/cuda.rs:45-49) */
+#define MELSPEC_ERR_UNAVAILABLE   (-2)  /* no HIP device / not gfx950 / runtime missing (tests self-skip, src/cuda.rs:512-518) */
+#define MELSPEC_ERR_CAPACITY      (-3)  /* caller's output buffer is too small */
+#define MELSPEC_ERR_UNSUPPORTED   (-4)  /* geometry outside what the kernels cover */
+#define MELSPEC_ERR_INTERNAL      (-5)
+
+typedef struct melspec_ctx melspec_ctx;      /* Whisper-style log-mel (HipMelSpectrogram) */
+typedef struct melspec_fbank melspec_fbank;  /* Kaldi-style fbank (Fbank)                  */
+
+/* ---- library / device ------------------------------------------------------------- */
+
+/* ABI version of this header (bumped on incompatible change). */
+int melspec_abi_version(void);
+/* Number of usable gfx950 devices, or MELSPEC_ERR_UNAVAILABLE. */
+int melspec_device_count(void);
+/* Message for the last failure on this thread (valid until the next failing call).
+ * Counterpart of the String inside CudaError::Runtime (src/cuda.rs:10-25). */
+const char *melspec_last_error(void);
+
+/* ---- Whisper log-mel: replaces CudaMelSpectrogram (src/cuda.rs:27-140) ------------- */
+
+/* CudaMelSpectrogram::new(fft_size, hop_size, sampling_rate, n_mels) (src/cuda.rs:39-82).
+ * Builds the periodic Hann window (src/stft.rs:141-145), the Slaney filterbank
+ * mel(sr, fft, n_mels, None, None, false, true) (src/mel.rs:19-24,547-589) and FFT
+ * twiddles in f64 on the host, uploads them as f32 tables.  device < 0 -> current device. */
+int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size,
+                   double sampling_rate, int n_mels);
+void melspec_destroy(melspec_ctx *ctx);   /* Drop (src/cuda.rs:142-148,366-375) */
+
+/* frame_windows' count: len < fft ? 0 : (len - fft)/hop + 1 (src/stft.rs:153-157). */
+size_t melspec_num_frames(const melspec_ctx *ctx, size_t n_samples);
+int melspec_fft_size(const melspec_ctx *ctx);
+int melspec_hop_size(const melspec_ctx *ctx);
+int melspec_n_mels(const melspec_ctx *ctx);
+/* 1 if this geometry runs on the fused FFT kernel, 0 if on the generic DFT kernel. */
+int melspec_uses_fast_path(const melspec_ctx *ctx);
+
+/* compute_mel_spectrogram(&mut self, samples: &[f32]) -> Vec<Vec<f32>> (src/cuda.rs:88-101)
+ * == Spectrogram::compute_mel_spectrogram_cpu (src/stft.rs:119-138) on the GPU.
+ * Host PCM in, host [frames][n_mels] f32 out (row-major, src/stft.rs:133-134).
+ * Empty/short input -> *n_frames = 0, MELSPEC_OK (src/cuda.rs:91-93). Synchronous. */
+int melspec_compute_host(melspec_ctx *ctx, const float *samples, size_t n_samples,
+                         float *out, size_t out_capacity_floats, size_t *n_frames);
+
+/* Additive surface (the reference has no multi-clip call): many equal-length clips in
+ * one launch, PCM and output resident in HBM.  Clip c = d_pcm[c*clip_stride .. +clip_len).
+ * d_out = [clip][frame][mel] f32, frames = melspec_num_frames(clip_len).
+ * stream: hipStream_t (NULL = the context's own stream).  Asynchronous. */
+int melspec_compute_uniform_device(melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride,
+                                   uint64_t clip_len, uint32_t n_clips, float *d_out, void *stream);
+
+/* Ragged batch: clip c = d_pcm[h_offsets[c] .. + h_lengths[c]) (sample units, host arrays).
+ * Output of clip c starts at d_out + h_out_offsets[c] (float units); pass NULL to pack the
+ * clips back to back in order.  Clips shorter than fft_size produce zero frames. */
+int melspec_compute_ragged_device(melspec_ctx *ctx, const float *d_pcm, const uint64_t *h_offsets,
+                                  const uint64_t *h_lengths, uint32_t n_clips, float *d_out,
+                                  const uint64_t *h_out_offsets, void *stream);
+
+/* Wait for everything this context has queued on `stream` (cudaStreamSynchronize, src/cuda.rs:129). */
+int melspec_synchronize(melspec_ctx *ctx, void *stream);
+
+/* ---- host-side table builders (pure CPU, usable without a GPU) --------------------- */
+
+/* mel(sr, n_fft, n_mels, f_min, f_max, htk, norm) (src/mel.rs:547-589): dense row-major
+ * [n_mels][n_fft/2+1] f64.  f_min < 0 == None (0 Hz); f_max <= 0 == None (sr/2).
+ * Pinned by testdata/mel_filters.npz @1e-7 (src/mel.rs:838-850). */
+int melspec_mel_filterbank(double sr, int n_fft, int n_mels, double f_min, double f_max,
+                           int htk, int norm, double *out);
+/* hann_window (src/stft.rs:141-145), periodic, f64. */
+int melspec_hann_window(int n, double *out);
+/* kaldi_mel_filterbank (src/fbank.rs:253-301): dense [num_mel_bins][fft_size/2+1] f64. */
+int melspec_kaldi_mel_filterbank(double sample_rate, int fft_size, int num_mel_bins,
+                                 double low_freq, double high_freq, double *out);
+
+/* ---- Kaldi fbank: replaces Fbank (src/fbank.rs:85-247) ------------------------------ */
+
+/* FbankConfig (src/fbank.rs:25-64); `dither` and `use_energy` exist in the reference
+ * struct but are never read by Fbank::compute, so they are not carried. */
+typedef struct melspec_fbank_config {
+    double sample_rate;       /* 16000.0 */
+    int32_t num_mel_bins;     /* 80 */
+    double frame_length_ms;   /* 25.0 */
+    double frame_shift_ms;    /* 10.0 */
+    double energy_floor;      /* 0.0 -> FLT_EPSILON (src/fbank.rs:210-214) */
+    int32_t use_log_fbank;    /* 1 */
+    int32_t use_power;        /* 1 */
+    double preemphasis;       /* 0.97 */
+    int32_t apply_cmn;        /* 1 */
+    double low_freq;          /* 20.0 */
+    double high_freq;         /* 0.0 == Nyquist */
+} melspec_fbank_config;
+
+void melspec_fbank_default_config(melspec_fbank_config *cfg);          /* FbankConfig::default (src/fbank.rs:46-64) */
+int melspec_fbank_create(melspec_fbank **out, int device, const melspec_fbank_config *cfg); /* Fbank::new (src/fbank.rs:94-132) */
+void melspec_fbank_destroy(melspec_fbank *fb);
+size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples); /* src/fbank.rs:147-151 */
+int melspec_fbank_num_mel_bins(const melspec_fbank *fb);
+/* Fbank::compute(&self, samples) -> Array2<f32> (frames, num_mel_bins) (src/fbank.rs:141-236). */
+int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n_samples,
+                               float *out, size_t out_capacity_floats, size_t *n_frames);
+/* Many equal-length clips, device resident; CMN (src/fbank.rs:224-233) is per clip. */
+int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride,
+                                         uint64_t clip_len, uint32_t n_clips, float *d_out, void *stream);
+int melspec_fbank_synchronize(melspec_fbank *fb, void *stream);
+
+/* ---- device memory helpers for hosts with no HIP binding of their own --------------- */
+/* (what the cudaMalloc/cudaMemcpyAsync externs of src/cuda.rs:185-199 give the Rust side) */
+int melspec_malloc(void **dptr, size_t bytes);
+int melspec_free(void *dptr);
+int melspec_memcpy_h2d(void *dst_device, const void *src_host, size_t bytes);
+int melspec_memcpy_d2h(void *dst_host, const void *src_device, size_t bytes);
+int melspec_device_synchronize(void);
+
+/* Synthetic PCM of SURVEY.md §8(d), generated on the device for benches/tests:
+ * d_out[c*clip_stride + i] = hashnoise(seed, first_clip + c, i), c < n_clips, i < clip_len. */
+int melspec_synth_pcm_device(float *d_out, uint64_t clip_stride, uint64_t clip_len,
+                             uint64_t first_clip, uint32_t n_clips, uint32_t seed, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MELSPEC_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes loader of libmelspec_hip.so.  There is no CPU fallback: if the HIP library is
+missing or fails to load, importing the product API raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_UNAVAILABLE = -2
+ERR_CAPACITY = -3
+ERR_UNSUPPORTED = -4
+ERR_INTERNAL = -5
+
+
+class FbankConfigC(C.Structure):
+    """melspec_fbank_config (include/melspec_hip.h) == FbankConfig (src/fbank.rs:25-64)."""
+    _fields_ = [
+        ("sample_rate", C.c_double), ("num_mel_bins", C.c_int32),
+        ("frame_length_ms", C.c_double), ("frame_shift_ms", C.c_double),
+        ("energy_floor", C.c_double), ("use_log_fbank", C.c_int32), ("use_power", C.c_int32),
+        ("preemphasis", C.c_double), ("apply_cmn", C.c_int32),
+        ("low_freq", C.c_double), ("high_freq", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/melspec_hip.h declares
+_vp, _f32p, _f64p, _u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+SIGNATURES = {
+    "melspec_abi_version": (C.c_int, []),
+    "melspec_device_count": (C.c_int, []),
+    "melspec_last_error": (C.c_char_p, []),
+    "melspec_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "melspec_destroy": (None, [_vp]),
+    "melspec_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
+    "melspec_fft_size": (C.c_int, [_vp]),
+    "melspec_hop_size": (C.c_int, [_vp]),
+    "melspec_n_mels": (C.c_int, [_vp]),
+    "melspec_uses_fast_path": (C.c_int, [_vp]),
+    "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "melspec_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
+    "melspec_synchronize": (C.c_int, [_vp, _vp]),
+    "melspec_mel_filterbank": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _f64p]),
+    "melspec_hann_window": (C.c_int, [C.c_int, _f64p]),
+    "melspec_kaldi_mel_filterbank": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, _f64p]),
+    "melspec_fbank_default_config": (None, [C.POINTER(FbankConfigC)]),
+    "melspec_fbank_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(FbankConfigC)]),
+    "melspec_fbank_destroy": (None, [_vp]),
+    "melspec_fbank_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
+    "melspec_fbank_num_mel_bins": (C.c_int, [_vp]),
+    "melspec_fbank_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "melspec_fbank_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_fbank_synchronize": (C.c_int, [_vp, _vp]),
+    "melspec_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "melspec_free": (C.c_int, [_vp]),
+    "melspec_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "melspec_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "melspec_device_synchronize": (C.c_int, []),
+    "melspec_synth_pcm_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmelspec_hip.so (built in-tree by mel_spec_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -m mel_spec_amd.build`). mel_spec_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    msg = lib().melspec_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""

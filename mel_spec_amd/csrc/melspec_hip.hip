@@ -1,0 +1,619 @@
+// melspec_hip.hip -- C ABI of libmelspec_hip.so (see include/melspec_hip.h) and the host
+// objects behind it.  Host logic is C++ because the reference's host side is compiled code
+// (Rust, src/cuda.rs); this image has no Rust toolchain, so the Rust shim that binds this
+// ABI is shipped as source in INTEGRATION.md / mel_spec_amd/rust/.
+//
+// HipMelCtx mirrors CudaMelSpectrogram (src/cuda.rs:27-148): it owns the device tables, a
+// stream, and grow-only device scratch; `compute_host` is compute_mel_spectrogram.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/melspec_hip.h"
+#include "fast_tables.hpp"
+#include "melspec_kernels.hpp"
+#include "tables.hpp"
+
+using namespace melspec;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *what) {
+    g_last_error = what;
+    return code;
+}
+int fail_hip(hipError_t e, const char *where) {
+    g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    const int c = static_cast<int>(e);
+    return c > 0 ? c : MELSPEC_ERR_INTERNAL;
+}
+#define HIP_TRY(expr)                                         \
+    do {                                                      \
+        const hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return fail_hip(e_, #expr);     \
+    } while (0)
+
+constexpr int kFPB = 23;       // frames per workgroup tile (23*11 = 253 <= 256 threads)
+constexpr int kNT = 256;
+constexpr int kGenericNT = 256;
+constexpr int kMaxGenericFft = 4096;
+constexpr int kMaxGenericMels = 1024;
+constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
+
+template <typename K>
+int allow_big_lds(K kernel, const char *name) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(kLdsLimit));
+    if (e != hipSuccess) return fail_hip(e, name);
+    return MELSPEC_OK;
+}
+
+struct DeviceInfo {
+    int device = -1;
+    int cus = 0;
+    size_t lds_per_block = 0;
+};
+
+int pick_device(int device, DeviceInfo &info) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(MELSPEC_ERR_UNAVAILABLE, "no HIP device visible");
+    }
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= count) return fail(MELSPEC_ERR_INVALID_ARG, "device index out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(MELSPEC_ERR_UNAVAILABLE, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MELSPEC_ERR_UNAVAILABLE, "device is not gfx950 (MI355X); this library ships gfx950 code only");
+    info.device = device;
+    info.cus = prop.multiProcessorCount;
+    info.lds_per_block = prop.sharedMemPerBlock;
+    return MELSPEC_OK;
+}
+
+// Grow-only device buffer.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MELSPEC_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+        return MELSPEC_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+template <typename T>
+int upload(DevBuf &buf, const std::vector<T> &v) {
+    const size_t bytes = v.size() * sizeof(T);
+    int rc = buf.ensure(bytes ? bytes : 16);
+    if (rc) return rc;
+    if (bytes) HIP_TRY(hipMemcpy(buf.p, v.data(), bytes, hipMemcpyHostToDevice));
+    return MELSPEC_OK;
+}
+
+// Tables of the generic (f64 DFT) kernel.
+struct GenericTables {
+    DevBuf win, tw, mstart, mlen, moff, mw;
+    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0;
+    size_t lds_bytes = 0;
+    int build(int n_fft_, int frame_len_, int n_bins_, const std::vector<double> &window,
+              const std::vector<double> &dense, int n_mels_, int dense_bins) {
+        n_fft = n_fft_; frame_len = frame_len_; n_bins = n_bins_; n_mels = n_mels_;
+        std::vector<double> twv(2 * static_cast<size_t>(n_fft));
+        for (int j = 0; j < n_fft; ++j) {
+            const double a = 2.0 * kPi * j / n_fft;
+            twv[2 * j] = std::cos(a);
+            twv[2 * j + 1] = -std::sin(a);
+        }
+        const BandedFilterbank fb = band_filterbank(dense, n_mels, dense_bins, n_bins);
+        int rc;
+        if ((rc = upload(win, window))) return rc;
+        if ((rc = upload(tw, twv))) return rc;
+        if ((rc = upload(mstart, fb.start))) return rc;
+        if ((rc = upload(mlen, fb.len))) return rc;
+        if ((rc = upload(moff, fb.offset))) return rc;
+        if ((rc = upload(mw, fb.w))) return rc;
+        lds_bytes = sizeof(double) * (2 * static_cast<size_t>(n_fft) + frame_len + n_bins + n_mels + kGenericNT);
+        return MELSPEC_OK;
+    }
+    void release() { win.release(); tw.release(); mstart.release(); mlen.release(); moff.release(); mw.release(); }
+};
+
+// Device-side copies of a ragged batch description.
+struct RaggedScratch {
+    DevBuf buf;
+    const uint64_t *d_off = nullptr, *d_frames = nullptr, *d_out_off = nullptr, *d_prefix = nullptr;
+};
+
+struct BatchPlan {
+    BatchDesc desc{};
+    uint64_t total_frames = 0;
+};
+
+// Fill a BatchDesc for n_clips equal-length clips.
+BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, uint64_t frames_per_clip,
+                       uint32_t n_clips, int n_mels, int frames_per_unit) {
+    BatchPlan pl;
+    BatchDesc &b = pl.desc;
+    b.pcm = d_pcm; b.out = d_out;
+    b.clip_stride = clip_stride;
+    b.out_stride = frames_per_clip * static_cast<uint64_t>(n_mels);
+    b.frames_per_clip = frames_per_clip;
+    b.units_per_clip = static_cast<uint32_t>((frames_per_clip + frames_per_unit - 1) / frames_per_unit);
+    b.n_clips = n_clips;
+    b.n_units = static_cast<uint64_t>(b.units_per_clip) * n_clips;
+    pl.total_frames = frames_per_clip * n_clips;
+    return pl;
+}
+
+int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float *d_out, const uint64_t *h_off,
+                const std::vector<uint64_t> &frames, const uint64_t *h_out_off, uint32_t n_clips, int n_mels,
+                int frames_per_unit, BatchPlan &pl) {
+    std::vector<uint64_t> host(static_cast<size_t>(n_clips) * 4 + 1);
+    uint64_t *off = host.data(), *fr = off + n_clips, *oo = fr + n_clips, *pre = oo + n_clips;
+    uint64_t units = 0, out_cursor = 0, total = 0;
+    for (uint32_t c = 0; c < n_clips; ++c) {
+        off[c] = h_off[c];
+        fr[c] = frames[c];
+        oo[c] = h_out_off ? h_out_off[c] : out_cursor;
+        out_cursor += frames[c] * static_cast<uint64_t>(n_mels);
+        pre[c] = units;
+        units += (frames[c] + frames_per_unit - 1) / frames_per_unit;
+        total += frames[c];
+    }
+    pre[n_clips] = units;
+    int rc = rs.buf.ensure(host.size() * sizeof(uint64_t));
+    if (rc) return rc;
+    // pageable source: the runtime stages it before returning, so `host` may die here
+    HIP_TRY(hipMemcpyAsync(rs.buf.p, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t *d = static_cast<const uint64_t *>(rs.buf.p);
+    BatchDesc &b = pl.desc;
+    b = BatchDesc{};
+    b.pcm = d_pcm; b.out = d_out; b.n_clips = n_clips; b.n_units = units;
+    b.d_off = d; b.d_frames = d + n_clips; b.d_out_off = d + 2 * n_clips; b.d_unit_prefix = d + 3 * n_clips;
+    pl.total_frames = total;
+    return MELSPEC_OK;
+}
+
+unsigned grid_for(uint64_t units, int cus, int per_cu) {
+    const uint64_t cap = static_cast<uint64_t>(cus > 0 ? cus : 256) * per_cu;
+    const uint64_t g = units < cap ? units : cap;
+    return static_cast<unsigned>(g ? g : 1);
+}
+
+int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, bool fbank, int use_log, int use_power,
+                   double preemph, double floor_v, int cus, hipStream_t stream) {
+    if (desc.n_units == 0) return MELSPEC_OK;
+    GenericParams gp{};
+    gp.b = desc;
+    gp.n_fft = gt.n_fft; gp.frame_len = gt.frame_len; gp.hop = hop; gp.n_bins = gt.n_bins; gp.n_mels = gt.n_mels;
+    gp.fbank = fbank ? 1 : 0; gp.use_log = use_log; gp.use_power = use_power; gp.preemph = preemph; gp.floor_v = floor_v;
+    gp.d_win = static_cast<const double *>(gt.win.p);
+    gp.d_tw = static_cast<const double *>(gt.tw.p);
+    gp.d_mstart = static_cast<const int *>(gt.mstart.p);
+    gp.d_mlen = static_cast<const int *>(gt.mlen.p);
+    gp.d_moff = static_cast<const int *>(gt.moff.p);
+    gp.d_mw = static_cast<const double *>(gt.mw.p);
+    const unsigned grid = grid_for(desc.n_units, cus, 8);
+    hipLaunchKernelGGL(generic_frame_kernel<kGenericNT>, dim3(grid), dim3(kGenericNT), gt.lds_bytes, stream, gp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// Whisper log-mel context
+// ------------------------------------------------------------------------------------
+struct melspec_ctx {
+    DeviceInfo dev;
+    int fft_size = 0, hop_size = 0, n_mels = 0;
+    double sr = 0.0;
+    bool fast = false;
+    hipStream_t stream = nullptr;
+    // fast path
+    FastTables ft;
+    DevBuf d_blob;
+    size_t fast_lds = 0;
+    int region_a = 0;
+    // generic path
+    GenericTables gt;
+    // scratch
+    RaggedScratch ragged;
+    DevBuf h2d, d2h;
+};
+
+namespace {
+
+int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
+    frames = n < static_cast<uint64_t>(c->fft_size) ? 0 : (n - c->fft_size) / c->hop_size + 1;
+    return MELSPEC_OK;
+}
+
+template <int NSLOTS>
+int launch_fast_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    FastParams fp{};
+    fp.b = desc;
+    fp.d_blob = static_cast<const float *>(c->d_blob.p);
+    fp.blob_len = static_cast<int>(c->ft.blob.size());
+    fp.hop = c->hop_size;
+    fp.n_mels = c->n_mels;
+    fp.region_a = c->region_a;
+    fp.slots = c->ft.slots;
+    const unsigned grid = grid_for(desc.n_units, c->dev.cus, 8);
+    hipLaunchKernelGGL((whisper400_kernel<kFPB, kNT, NSLOTS>), dim3(grid), dim3(kNT), c->fast_lds, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    if (desc.n_units == 0) return MELSPEC_OK;
+    if (c->fast) {
+        if (c->ft.slots.n_slots <= 8) return launch_fast_t<8>(c, desc, stream);
+        return launch_fast_t<12>(c, desc, stream);
+    }
+    return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int melspec_abi_version(void) { return 1; }
+
+int melspec_device_count(void) {
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MELSPEC_ERR_UNAVAILABLE, "no HIP device visible");
+    }
+    int usable = 0;
+    for (int d = 0; d < count; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable;
+    }
+    if (usable == 0) return fail(MELSPEC_ERR_UNAVAILABLE, "no gfx950 device visible");
+    return usable;
+}
+
+const char *melspec_last_error(void) { return g_last_error.c_str(); }
+
+int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    // src/cuda.rs:45-49
+    if (fft_size <= 0 || hop_size <= 0 || n_mels <= 0)
+        return fail(MELSPEC_ERR_INVALID_ARG, "fft_size, hop_size, and n_mels must be non-zero");
+    if (!(sampling_rate > 0.0)) return fail(MELSPEC_ERR_INVALID_ARG, "sampling_rate must be > 0");
+    if (fft_size < 2 || fft_size > kMaxGenericFft || n_mels > kMaxGenericMels)
+        return fail(MELSPEC_ERR_UNSUPPORTED, "fft_size must be in [2,4096] and n_mels <= 1024");
+    DeviceInfo info;
+    int rc = pick_device(device, info);
+    if (rc) return rc;
+    melspec_ctx *c = new (std::nothrow) melspec_ctx();
+    if (!c) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    c->dev = info; c->fft_size = fft_size; c->hop_size = hop_size; c->n_mels = n_mels; c->sr = sampling_rate;
+    auto bail = [&](int code) { melspec_destroy(c); return code; };
+    if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
+    if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
+
+    // fused kernel: n_fft == 400, even hop (8-byte aligned LDS reads), n_mels <= 132
+    c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft);
+    if (c->fast) {
+        using L = FastLayout<kFPB>;
+        c->region_a = L::region_a(hop_size);
+        c->fast_lds = sizeof(float) * (c->ft.blob.size() + c->region_a + L::region_b() + L::region_max());
+        if (c->fast_lds > kLdsLimit) c->fast = false;
+    }
+    if (c->fast) {
+        if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
+        if ((rc = allow_big_lds(&whisper400_kernel<kFPB, kNT, 8>, "hipFuncSetAttribute(whisper400_kernel<8>)"))) return bail(rc);
+        if ((rc = allow_big_lds(&whisper400_kernel<kFPB, kNT, 12>, "hipFuncSetAttribute(whisper400_kernel<12>)"))) return bail(rc);
+    } else {
+        const int bins = fft_size / 2 + 1;
+        const std::vector<double> dense = mel_filterbank(sampling_rate, fft_size, n_mels, -1.0, -1.0, false, true);
+        // bins >= n_fft/2 contribute nothing (src/mel.rs:155-163)
+        if ((rc = c->gt.build(fft_size, fft_size, fft_size / 2, hann_window(fft_size), dense, n_mels, bins))) return bail(rc);
+        if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
+        if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
+    }
+    *out = c;
+    return MELSPEC_OK;
+}
+
+void melspec_destroy(melspec_ctx *c) {
+    if (!c) return;
+    if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    c->d_blob.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
+    delete c;
+}
+
+size_t melspec_num_frames(const melspec_ctx *c, size_t n_samples) {
+    if (!c) return 0;
+    uint64_t f; ctx_num_frames(c, n_samples, f);
+    return static_cast<size_t>(f);
+}
+int melspec_fft_size(const melspec_ctx *c) { return c ? c->fft_size : 0; }
+int melspec_hop_size(const melspec_ctx *c) { return c ? c->hop_size : 0; }
+int melspec_n_mels(const melspec_ctx *c) { return c ? c->n_mels : 0; }
+int melspec_uses_fast_path(const melspec_ctx *c) { return c && c->fast ? 1 : 0; }
+
+int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                   uint32_t n_clips, float *d_out, void *stream) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (n_clips == 0) return MELSPEC_OK;
+    uint64_t fpc; ctx_num_frames(c, clip_len, fpc);
+    if (fpc == 0) return MELSPEC_OK;   // empty output, like src/cuda.rs:91-93
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    if (n_clips > 1 && clip_stride < clip_len && clip_stride != 0)
+        return fail(MELSPEC_ERR_INVALID_ARG, "clip_stride smaller than clip_len");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? kFPB : 1);
+    return launch_ctx(c, pl.desc, s);
+}
+
+int melspec_compute_ragged_device(melspec_ctx *c, const float *d_pcm, const uint64_t *h_offsets,
+                                  const uint64_t *h_lengths, uint32_t n_clips, float *d_out,
+                                  const uint64_t *h_out_offsets, void *stream) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!h_offsets || !h_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    std::vector<uint64_t> frames(n_clips);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) { ctx_num_frames(c, h_lengths[i], frames[i]); total += frames[i]; }
+    if (total == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    BatchPlan pl;
+    int rc = plan_ragged(c->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, c->n_mels,
+                         c->fast ? kFPB : 1, pl);
+    if (rc) return rc;
+    return launch_ctx(c, pl.desc, s);
+}
+
+int melspec_synchronize(melspec_ctx *c, void *stream) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    HIP_TRY(hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : c->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_compute_host(melspec_ctx *c, const float *samples, size_t n_samples, float *out,
+                         size_t out_capacity_floats, size_t *n_frames) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (n_frames) *n_frames = 0;
+    uint64_t frames; ctx_num_frames(c, n_samples, frames);
+    if (frames == 0) return MELSPEC_OK;            // Ok(Vec::new()), src/cuda.rs:91-93
+    if (!samples || !out) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+    const uint64_t need = frames * static_cast<uint64_t>(c->n_mels);
+    if (out_capacity_floats < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    int rc;
+    if ((rc = c->h2d.ensure(n_samples * sizeof(float)))) return rc;
+    if ((rc = c->d2h.ensure(need * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h2d.p, samples, n_samples * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    rc = melspec_compute_uniform_device(c, static_cast<const float *>(c->h2d.p), n_samples, n_samples, 1,
+                                        static_cast<float *>(c->d2h.p), c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d2h.p, need * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (n_frames) *n_frames = static_cast<size_t>(frames);
+    return MELSPEC_OK;
+}
+
+// ---- host-side table builders ------------------------------------------------------------
+
+int melspec_mel_filterbank(double sr, int n_fft, int n_mels, double f_min, double f_max, int htk, int norm, double *out) {
+    if (!out || n_fft < 2 || n_mels < 1 || !(sr > 0.0)) return fail(MELSPEC_ERR_INVALID_ARG, "bad mel_filterbank argument");
+    const std::vector<double> w = mel_filterbank(sr, n_fft, n_mels, f_min, f_max, htk != 0, norm != 0);
+    std::memcpy(out, w.data(), w.size() * sizeof(double));
+    return MELSPEC_OK;
+}
+
+int melspec_hann_window(int n, double *out) {
+    if (!out || n < 1) return fail(MELSPEC_ERR_INVALID_ARG, "bad hann_window argument");
+    const std::vector<double> w = hann_window(n);
+    std::memcpy(out, w.data(), w.size() * sizeof(double));
+    return MELSPEC_OK;
+}
+
+int melspec_kaldi_mel_filterbank(double sample_rate, int fft_size, int num_mel_bins, double low_freq,
+                                 double high_freq, double *out) {
+    if (!out || fft_size < 2 || num_mel_bins < 1 || !(sample_rate > 0.0))
+        return fail(MELSPEC_ERR_INVALID_ARG, "bad kaldi_mel_filterbank argument");
+    const std::vector<double> w = kaldi_mel_filterbank(sample_rate, fft_size, num_mel_bins, low_freq, high_freq);
+    std::memcpy(out, w.data(), w.size() * sizeof(double));
+    return MELSPEC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// Kaldi fbank context
+// ------------------------------------------------------------------------------------
+struct melspec_fbank {
+    DeviceInfo dev;
+    melspec_fbank_config cfg{};
+    int frame_len = 0, frame_shift = 0, fft_size = 0;
+    hipStream_t stream = nullptr;
+    GenericTables gt;
+    DevBuf h2d, d2h;
+};
+
+namespace {
+uint64_t fbank_frames(const melspec_fbank *fb, uint64_t n) {
+    return n < static_cast<uint64_t>(fb->frame_len) ? 0 : 1 + (n - fb->frame_len) / fb->frame_shift;   // src/fbank.rs:147-151
+}
+}  // namespace
+
+extern "C" {
+
+void melspec_fbank_default_config(melspec_fbank_config *c) {
+    if (!c) return;
+    c->sample_rate = 16000.0; c->num_mel_bins = 80; c->frame_length_ms = 25.0; c->frame_shift_ms = 10.0;
+    c->energy_floor = 0.0; c->use_log_fbank = 1; c->use_power = 1; c->preemphasis = 0.97; c->apply_cmn = 1;
+    c->low_freq = 20.0; c->high_freq = 0.0;
+}
+
+int melspec_fbank_create(melspec_fbank **out, int device, const melspec_fbank_config *cfg) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!cfg) return fail(MELSPEC_ERR_INVALID_ARG, "cfg is NULL");
+    if (!(cfg->sample_rate > 0.0) || cfg->num_mel_bins <= 0 || !(cfg->frame_length_ms > 0.0) || !(cfg->frame_shift_ms > 0.0))
+        return fail(MELSPEC_ERR_INVALID_ARG, "sample_rate, num_mel_bins, frame length and shift must be positive");
+    // FbankConfig::{frame_length_samples, frame_shift_samples, fft_size}  (src/fbank.rs:66-82)
+    const int frame_len = static_cast<int>(std::llround((cfg->frame_length_ms / 1000.0) * cfg->sample_rate));
+    const int frame_shift = static_cast<int>(std::llround((cfg->frame_shift_ms / 1000.0) * cfg->sample_rate));
+    if (frame_len < 2 || frame_shift < 1) return fail(MELSPEC_ERR_INVALID_ARG, "frame length/shift round to zero samples");
+    int fft_size = 1;
+    while (fft_size < frame_len) fft_size <<= 1;
+    if (fft_size > kMaxGenericFft || cfg->num_mel_bins > kMaxGenericMels)
+        return fail(MELSPEC_ERR_UNSUPPORTED, "fft_size must be <= 4096 and num_mel_bins <= 1024");
+    DeviceInfo info;
+    int rc = pick_device(device, info);
+    if (rc) return rc;
+    melspec_fbank *fb = new (std::nothrow) melspec_fbank();
+    if (!fb) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    fb->dev = info; fb->cfg = *cfg; fb->frame_len = frame_len; fb->frame_shift = frame_shift; fb->fft_size = fft_size;
+    auto bail = [&](int code) { melspec_fbank_destroy(fb); return code; };
+    if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
+    if (hipStreamCreate(&fb->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
+    const double high = cfg->high_freq == 0.0 ? cfg->sample_rate / 2.0 : cfg->high_freq;
+    const int bins = fft_size / 2 + 1;
+    const std::vector<double> dense = kaldi_mel_filterbank(cfg->sample_rate, fft_size, cfg->num_mel_bins, cfg->low_freq, high);
+    if ((rc = fb->gt.build(fft_size, frame_len, bins, povey_window(frame_len), dense, cfg->num_mel_bins, bins))) return bail(rc);
+    if (fb->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
+    if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
+    *out = fb;
+    return MELSPEC_OK;
+}
+
+void melspec_fbank_destroy(melspec_fbank *fb) {
+    if (!fb) return;
+    if (fb->dev.device >= 0) (void)hipSetDevice(fb->dev.device);
+    if (fb->stream) { (void)hipStreamSynchronize(fb->stream); (void)hipStreamDestroy(fb->stream); }
+    fb->gt.release(); fb->h2d.release(); fb->d2h.release();
+    delete fb;
+}
+
+size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples) {
+    return fb ? static_cast<size_t>(fbank_frames(fb, n_samples)) : 0;
+}
+int melspec_fbank_num_mel_bins(const melspec_fbank *fb) { return fb ? fb->cfg.num_mel_bins : 0; }
+
+int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                         uint32_t n_clips, float *d_out, void *stream) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    if (n_clips == 0) return MELSPEC_OK;
+    const uint64_t fpc = fbank_frames(fb, clip_len);
+    if (fpc == 0) return MELSPEC_OK;   // zeros((0, num_mel_bins)), src/fbank.rs:147-149
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fb->stream;
+    const int nm = fb->cfg.num_mel_bins;
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, nm, 1);
+    const double floor_v = fb->cfg.energy_floor > 0.0 ? fb->cfg.energy_floor : static_cast<double>(FLT_EPSILON);
+    int rc = launch_generic(fb->gt, pl.desc, fb->frame_shift, true, fb->cfg.use_log_fbank, fb->cfg.use_power,
+                            fb->cfg.preemphasis, floor_v, fb->dev.cus, s);
+    if (rc) return rc;
+    if (fb->cfg.apply_cmn) {
+        CmnParams cp{};
+        cp.b = pl.desc;
+        cp.n_mels = nm;
+        const unsigned grid = grid_for(n_clips, fb->dev.cus, 8);
+        hipLaunchKernelGGL(cmn_kernel<128>, dim3(grid), dim3(128), 0, s, cp);
+        HIP_TRY(hipGetLastError());
+    }
+    return MELSPEC_OK;
+}
+
+int melspec_fbank_synchronize(melspec_fbank *fb, void *stream) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    HIP_TRY(hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : fb->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n_samples, float *out,
+                               size_t out_capacity_floats, size_t *n_frames) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    if (n_frames) *n_frames = 0;
+    const uint64_t frames = fbank_frames(fb, n_samples);
+    if (frames == 0) return MELSPEC_OK;
+    if (!samples || !out) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+    const uint64_t need = frames * static_cast<uint64_t>(fb->cfg.num_mel_bins);
+    if (out_capacity_floats < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    int rc;
+    if ((rc = fb->h2d.ensure(n_samples * sizeof(float)))) return rc;
+    if ((rc = fb->d2h.ensure(need * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpyAsync(fb->h2d.p, samples, n_samples * sizeof(float), hipMemcpyHostToDevice, fb->stream));
+    rc = melspec_fbank_compute_uniform_device(fb, static_cast<const float *>(fb->h2d.p), n_samples, n_samples, 1,
+                                              static_cast<float *>(fb->d2h.p), fb->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, fb->d2h.p, need * sizeof(float), hipMemcpyDeviceToHost, fb->stream));
+    HIP_TRY(hipStreamSynchronize(fb->stream));
+    if (n_frames) *n_frames = static_cast<size_t>(frames);
+    return MELSPEC_OK;
+}
+
+// ---- device memory helpers --------------------------------------------------------------
+
+int melspec_malloc(void **dptr, size_t bytes) {
+    if (!dptr) return fail(MELSPEC_ERR_INVALID_ARG, "dptr is NULL");
+    *dptr = nullptr;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return MELSPEC_OK;
+}
+int melspec_free(void *dptr) {
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return MELSPEC_OK;
+}
+int melspec_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MELSPEC_OK;
+}
+int melspec_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    if (bytes) HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MELSPEC_OK;
+}
+int melspec_device_synchronize(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    return MELSPEC_OK;
+}
+
+int melspec_synth_pcm_device(float *d_out, uint64_t clip_stride, uint64_t clip_len, uint64_t first_clip,
+                             uint32_t n_clips, uint32_t seed, void *stream) {
+    if (n_clips == 0 || clip_len == 0) return MELSPEC_OK;
+    if (!d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");
+    const uint64_t total = static_cast<uint64_t>(n_clips) * clip_len;
+    uint64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(synth_pcm_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_out, clip_stride, clip_len, first_clip, n_clips, seed);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+}  // extern "C"

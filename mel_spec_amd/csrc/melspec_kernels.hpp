@@ -1,0 +1,275 @@
+// melspec_kernels.hpp -- gfx950 kernels of libmelspec_hip.so (included once, by melspec_hip.hip).
+//
+//   whisper400_kernel   fused n_fft=400 log-mel (phases in whisper_fast.hpp), f32
+//   generic_frame_kernel  any-geometry log-mel / Kaldi fbank, one frame per workgroup, f64 DFT
+//   cmn_kernel          per-clip cepstral mean normalisation (src/fbank.rs:224-233)
+//   synth_pcm_kernel    hash-noise PCM generator for benches/tests
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "whisper_fast.hpp"
+
+namespace melspec {
+
+// How work units (tiles of frames) map onto clips.  Uniform batches are pure arithmetic;
+// ragged batches binary-search a prefix table of units per clip.
+struct BatchDesc {
+    const float *pcm;
+    float *out;
+    uint64_t clip_stride;      // uniform: samples between clip starts
+    uint64_t out_stride;       // uniform: floats between clip outputs
+    uint64_t frames_per_clip;  // uniform
+    uint32_t units_per_clip;   // uniform
+    uint32_t n_clips;
+    uint64_t n_units;
+    const uint64_t *d_off;       // ragged (device): first sample of clip c
+    const uint64_t *d_frames;    // ragged: frames in clip c
+    const uint64_t *d_out_off;   // ragged: first output float of clip c
+    const uint64_t *d_unit_prefix;  // ragged: first unit of clip c, [n_clips+1]
+};
+
+struct UnitLoc {
+    const float *pcm;   // first sample of the clip
+    float *out;         // first output float of the clip
+    uint64_t frames;    // frames in the clip
+    uint64_t unit;      // unit index inside the clip
+};
+
+__device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit) {
+    UnitLoc r;
+    if (b.d_unit_prefix == nullptr) {
+        const uint64_t clip = unit / b.units_per_clip;
+        r.unit = unit - clip * b.units_per_clip;
+        r.pcm = b.pcm + clip * b.clip_stride;
+        r.out = b.out + clip * b.out_stride;
+        r.frames = b.frames_per_clip;
+    } else {
+        uint32_t lo = 0, hi = b.n_clips;   // prefix[lo] <= unit < prefix[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (b.d_unit_prefix[mid] <= unit) lo = mid; else hi = mid;
+        }
+        r.unit = unit - b.d_unit_prefix[lo];
+        r.pcm = b.pcm + b.d_off[lo];
+        r.out = b.out + b.d_out_off[lo];
+        r.frames = b.d_frames[lo];
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------
+// Fused Whisper kernel, n_fft = 400.  One workgroup walks tiles of FPB consecutive frames.
+// LDS: [table blob][region A: PCM tile / power rows][region B: FFT exchange][frame maxima]
+// ------------------------------------------------------------------------------------
+struct FastParams {
+    BatchDesc b;
+    const float *d_blob;
+    int blob_len;      // floats, multiple of 4
+    int hop;
+    int n_mels;
+    int region_a;      // floats
+    MelSlots slots;
+};
+
+template <int FPB, int NT, int NSLOTS>
+__global__ __launch_bounds__(NT) void whisper400_kernel(const FastParams p) {
+    using L = FastLayout<FPB>;
+    static_assert(L::kP2Threads <= NT, "workgroup too small for FPB frames");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *blob = lds;
+    float *reg_a = blob + p.blob_len;
+    float *reg_b = reg_a + p.region_a;
+    float *pmax = reg_b + L::region_b();
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < p.blob_len; i += NT) blob[i] = p.d_blob[i];
+
+    for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * FPB;
+        const uint64_t left = loc.frames - f0;
+        const int nv = left < (uint64_t)FPB ? (int)left : FPB;
+        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
+        const int need = (nv - 1) * p.hop + 400;
+        for (int i = tid; i < need; i += NT) reg_a[i] = src[i];
+        __syncthreads();
+        fast_phase1<FPB>(tid, nv, p.hop, blob, reg_a, reg_b);
+        __syncthreads();
+        fast_phase2<FPB>(tid, nv, blob, reg_b, reg_a);
+        __syncthreads();
+        float vals[NSLOTS];
+        fast_phase3<FPB, NSLOTS>(tid, nv, p.n_mels, p.slots, blob, reg_a, pmax, vals);
+        __syncthreads();
+        fast_phase4<FPB, NSLOTS>(tid, nv, p.n_mels, pmax, vals, loc.out + f0 * (uint64_t)p.n_mels);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Generic kernel: any n_fft / hop / n_mels, Whisper or Kaldi-fbank flavour, one frame per
+// workgroup iteration, direct DFT in f64 from an LDS twiddle table.  It follows the
+// reference's f64 arithmetic step by step (src/stft.rs:119-138, src/fbank.rs:160-222) and
+// exists for coverage and as the on-device cross-check of the fused f32 kernels; it is not
+// a throughput path.
+// ------------------------------------------------------------------------------------
+struct GenericParams {
+    BatchDesc b;           // units == frames
+    int n_fft;             // DFT length
+    int frame_len;         // non-zero samples per frame (== n_fft for Whisper)
+    int hop;
+    int n_bins;            // bins whose power is needed: n_fft/2 (Whisper) or n_fft/2+1 (fbank)
+    int n_mels;
+    int fbank;             // 0: Whisper log10 + per-frame norm; 1: Kaldi fbank
+    int use_log, use_power;
+    double preemph, floor_v;
+    const double *d_win;   // [frame_len]
+    const double *d_tw;    // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
+    const int *d_mstart;   // [n_mels]
+    const int *d_mlen;     // [n_mels]
+    const int *d_moff;     // [n_mels] offset into d_mw
+    const double *d_mw;    // concatenated spans
+};
+
+template <int NT>
+__device__ __forceinline__ double block_reduce(double v, double *red, bool is_max) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double o = red[tid + s];
+            red[tid] = is_max ? (red[tid] > o ? red[tid] : o) : (red[tid] + o);
+        }
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    double *tw = ldsd;                       // 2*n_fft
+    double *xw = tw + 2 * p.n_fft;           // frame_len
+    double *pw = xw + p.frame_len;           // n_bins
+    double *mv = pw + p.n_bins;              // n_mels
+    double *red = mv + p.n_mels;             // NT
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * p.n_fft; i += NT) tw[i] = p.d_tw[i];
+
+    for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t start = loc.unit * (uint64_t)p.hop;
+        const float *x = loc.pcm + start;
+        __syncthreads();
+        if (!p.fbank) {
+            // frame_windows: x[start+i] as f64 * window[i]   (src/stft.rs:160-165)
+            for (int i = tid; i < p.frame_len; i += NT) xw[i] = (double)x[i] * p.d_win[i];
+        } else {
+            // DC removal, pre-emphasis, Povey window   (src/fbank.rs:164-190)
+            double part = 0.0;
+            for (int i = tid; i < p.frame_len; i += NT) part += (double)x[i];
+            const double mean = block_reduce<NT>(part, red, false) / (double)p.frame_len;
+            for (int i = tid; i < p.frame_len; i += NT) {
+                double v = (double)x[i] - mean;
+                if (p.preemph > 0.0) {
+                    if (i > 0) v -= p.preemph * ((double)x[i - 1] - mean);
+                    else if (start > 0) v -= p.preemph * ((double)*(x - 1) - mean);
+                }
+                xw[i] = v * p.d_win[i];
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < p.n_bins; k += NT) {
+            double re = 0.0, im = 0.0;
+            int idx = 0;
+            for (int n = 0; n < p.frame_len; ++n) {
+                const double c = tw[2 * idx], s = tw[2 * idx + 1];
+                re += xw[n] * c;
+                im += xw[n] * s;
+                idx += k;
+                if (idx >= p.n_fft) idx -= p.n_fft;
+            }
+            const double ns = re * re + im * im;
+            pw[k] = (p.fbank && !p.use_power) ? sqrt(ns) : ns;
+        }
+        __syncthreads();
+        double mx = -1.0e300;
+        for (int m = tid; m < p.n_mels; m += NT) {
+            const int st = p.d_mstart[m], len = p.d_mlen[m];
+            const double *w = p.d_mw + p.d_moff[m];
+            double e = 0.0;
+            for (int r = 0; r < len; ++r) e += w[r] * pw[st + r];
+            double v;
+            if (!p.fbank) {
+                v = log10(e > 1e-10 ? e : 1e-10);          // src/mel.rs:166
+            } else {
+                v = e > p.floor_v ? e : p.floor_v;           // src/fbank.rs:210-218
+                if (p.use_log) v = log(v);
+            }
+            mv[m] = v;
+            mx = mx > v ? mx : v;
+        }
+        float *o = loc.out + loc.unit * (uint64_t)p.n_mels;
+        if (!p.fbank) {
+            const double lo = block_reduce<NT>(mx, red, true) - 8.0;   // src/mel.rs:645-654
+            for (int m = tid; m < p.n_mels; m += NT) {
+                const double v = mv[m] > lo ? mv[m] : lo;
+                o[m] = (float)((v + 4.0) / 4.0);
+            }
+        } else {
+            for (int m = tid; m < p.n_mels; m += NT) o[m] = (float)mv[m];
+        }
+    }
+}
+
+// CMN: per clip and mel column, mean = (sequential f32 sum over frames) / frames, then
+// subtract -- the same order as ndarray's mean() on a strided column (src/fbank.rs:226-233).
+struct CmnParams {
+    BatchDesc b;   // only the clip geometry is used
+    int n_mels;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
+    for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x) {
+        float *o;
+        uint64_t frames;
+        if (p.b.d_unit_prefix == nullptr) {
+            o = p.b.out + (uint64_t)clip * p.b.out_stride;
+            frames = p.b.frames_per_clip;
+        } else {
+            o = p.b.out + p.b.d_out_off[clip];
+            frames = p.b.d_frames[clip];
+        }
+        if (frames == 0) continue;
+        for (int m = threadIdx.x; m < p.n_mels; m += NT) {
+            float sum = 0.0f;
+            for (uint64_t f = 0; f < frames; ++f) sum = sum + o[f * p.n_mels + m];
+            const float mean = sum / (float)frames;
+            for (uint64_t f = 0; f < frames; ++f) o[f * p.n_mels + m] -= mean;
+        }
+    }
+}
+
+// Hash-noise PCM (murmur3 finaliser) of SURVEY.md §8(d); the CPU tests regenerate the same bits.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+__global__ __launch_bounds__(256) void synth_pcm_kernel(float *out, uint64_t clip_stride, uint64_t clip_len,
+                                                        uint64_t first_clip, uint32_t n_clips, uint32_t seed) {
+    const uint64_t total = (uint64_t)n_clips * clip_len;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (uint64_t)gridDim.x * 256) {
+        const uint64_t c = g / clip_len, i = g - c * clip_len;
+        const uint64_t clip = first_clip + c;
+        const uint32_t h = fmix32(seed ^ ((uint32_t)clip * 0x9E3779B1u) ^ ((uint32_t)i * 0x85EBCA6Bu));
+        const float u = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+        out[c * clip_stride + i] = u * (1.0f / (float)(1u << (clip & 7u)));
+    }
+}
+
+}  // namespace melspec

@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's GPU plugin interface, over the C ABI.
+
+Names, argument order and error behaviour follow the reference (wavey-ai/mel-spec v0.4.0):
+
+  HipMelSpectrogram(fft_size, hop_size, sampling_rate, n_mels)   CudaMelSpectrogram::new       src/cuda.rs:39-82
+  .compute_mel_spectrogram(samples) -> [frames, n_mels] f32      ::compute_mel_spectrogram     src/cuda.rs:88-101
+  Fbank(FbankConfig()).compute(samples) -> [frames, n_mels] f32  Fbank::{new,compute}          src/fbank.rs:94,141
+  mel(sr, n_fft, n_mels, f_min, f_max, htk, norm)                mel()                         src/mel.rs:547-589
+
+Errors: HipUnavailable == CudaError::Unavailable (construction problems; tests skip on it,
+src/cuda.rs:512-518), HipRuntimeError == CudaError::Runtime (per-call problems).
+All compute goes through libmelspec_hip.so; there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import FbankConfigC, lib
+
+
+class HipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+class HipUnavailable(HipError):
+    """CudaError::Unavailable (src/cuda.rs:10-25)."""
+
+
+class HipRuntimeError(HipError):
+    """CudaError::Runtime (src/cuda.rs:10-25)."""
+
+
+def _check(rc: int, construct: bool = False) -> None:
+    if rc == 0:
+        return
+    msg = _lib.last_error()
+    if construct or rc == _lib.ERR_UNAVAILABLE:
+        raise HipUnavailable(rc, msg)
+    raise HipRuntimeError(rc, msg)
+
+
+def device_count() -> int:
+    """Usable gfx950 devices (0 if none / runtime unavailable)."""
+    n = lib().melspec_device_count()
+    return n if n > 0 else 0
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class DeviceBuffer:
+    """A raw HBM allocation made through the C ABI (melspec_malloc)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        _check(lib().melspec_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, a: np.ndarray, offset_bytes: int = 0) -> None:
+        a = np.ascontiguousarray(a)
+        assert offset_bytes + a.nbytes <= self.nbytes
+        _check(lib().melspec_memcpy_h2d(C.c_void_p(self.ptr + offset_bytes), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def download(self, shape, dtype=np.float32, offset_bytes: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert offset_bytes + out.nbytes <= self.nbytes
+        _check(lib().melspec_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr + offset_bytes), out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().melspec_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synth_pcm_device(buf_ptr: int, clip_stride: int, clip_len: int, first_clip: int, n_clips: int,
+                     seed: int = 0x4D454C53, stream: int = 0) -> None:
+    _check(lib().melspec_synth_pcm_device(C.c_void_p(buf_ptr), clip_stride, clip_len, first_clip, n_clips, seed,
+                                          C.c_void_p(stream)))
+
+
+def device_synchronize() -> None:
+    _check(lib().melspec_device_synchronize())
+
+
+class HipMelSpectrogram:
+    """MI355X twin of CudaMelSpectrogram (src/cuda.rs:27-140)."""
+
+    def __init__(self, fft_size: int, hop_size: int, sampling_rate: float, n_mels: int, device: int = -1):
+        self._h = None
+        h = C.c_void_p()
+        rc = lib().melspec_create(C.byref(h), device, int(fft_size), int(hop_size), float(sampling_rate), int(n_mels))
+        _check(rc, construct=True)
+        self._h = h
+        self.fft_size, self.hop_size, self.n_mels = int(fft_size), int(hop_size), int(n_mels)
+        self.sampling_rate = float(sampling_rate)
+
+    # -- reference surface --------------------------------------------------------------
+    def compute_mel_spectrogram(self, samples) -> np.ndarray:
+        """&[f32] -> [frames][n_mels] f32 (Vec<Vec<f32>> in the reference)."""
+        x = _f32(samples).reshape(-1)
+        nf = self.num_frames(x.shape[0])
+        out = np.empty((nf, self.n_mels), np.float32)
+        got = C.c_size_t(0)
+        _check(lib().melspec_compute_host(self._h, _fp(x), x.shape[0], _fp(out), out.size, C.byref(got)))
+        assert got.value == nf
+        return out
+
+    # -- additive surface ---------------------------------------------------------------
+    def num_frames(self, n_samples: int) -> int:
+        return int(lib().melspec_num_frames(self._h, n_samples))
+
+    @property
+    def uses_fast_path(self) -> bool:
+        return bool(lib().melspec_uses_fast_path(self._h))
+
+    def compute_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
+                               stream: int = 0) -> None:
+        """Device pointers in, device pointers out, asynchronous on `stream`."""
+        _check(lib().melspec_compute_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
+                                                    C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def compute_ragged_device(self, d_pcm: int, offsets, lengths, d_out: int, out_offsets=None, stream: int = 0) -> None:
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        _check(lib().melspec_compute_ragged_device(
+            self._h, C.c_void_p(d_pcm), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
+            C.c_void_p(d_out), None if oo is None else oo.ctypes.data_as(u64p), C.c_void_p(stream)))
+
+    def synchronize(self, stream: int = 0) -> None:
+        _check(lib().melspec_synchronize(self._h, C.c_void_p(stream)))
+
+    def compute_batch(self, clips) -> np.ndarray:
+        """[n_clips, clip_len] host f32 -> [n_clips, frames, n_mels] host f32 in one launch."""
+        x = _f32(clips)
+        assert x.ndim == 2
+        n_clips, clip_len = x.shape
+        nf = self.num_frames(clip_len)
+        out = np.empty((n_clips, nf, self.n_mels), np.float32)
+        if out.size == 0:
+            return out
+        din, dout = DeviceBuffer(x.nbytes), DeviceBuffer(out.nbytes)
+        try:
+            din.upload(x)
+            self.compute_uniform_device(din.ptr, clip_len, clip_len, n_clips, dout.ptr)
+            self.synchronize()
+            out = dout.download(out.shape)
+        finally:
+            din.free(); dout.free()
+        return out
+
+    def compute_ragged(self, clips) -> list:
+        """List of 1-D host arrays of any lengths -> list of [frames_i, n_mels] arrays, one launch."""
+        arrs = [_f32(c).reshape(-1) for c in clips]
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
+        frames = [self.num_frames(int(n)) for n in lens]
+        total_out = sum(frames) * self.n_mels
+        flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
+        din, dout = DeviceBuffer(max(flat.nbytes, 16)), DeviceBuffer(max(total_out * 4, 16))
+        try:
+            din.upload(flat)
+            self.compute_ragged_device(din.ptr, offs, lens, dout.ptr)
+            self.synchronize()
+            host = dout.download((total_out,)) if total_out else np.zeros(0, np.float32)
+        finally:
+            din.free(); dout.free()
+        res, cur = [], 0
+        for f in frames:
+            res.append(host[cur:cur + f * self.n_mels].reshape(f, self.n_mels).copy())
+            cur += f * self.n_mels
+        return res
+
+    def close(self) -> None:
+        if self._h is not None:
+            lib().melspec_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class FbankConfig:
+    """FbankConfig::default (src/fbank.rs:46-64)."""
+    sample_rate: float = 16000.0
+    num_mel_bins: int = 80
+    frame_length_ms: float = 25.0
+    frame_shift_ms: float = 10.0
+    energy_floor: float = 0.0
+    use_log_fbank: bool = True
+    use_power: bool = True
+    preemphasis: float = 0.97
+    apply_cmn: bool = True
+    low_freq: float = 20.0
+    high_freq: float = 0.0
+
+    def to_c(self) -> FbankConfigC:
+        return FbankConfigC(self.sample_rate, self.num_mel_bins, self.frame_length_ms, self.frame_shift_ms,
+                            self.energy_floor, int(self.use_log_fbank), int(self.use_power), self.preemphasis,
+                            int(self.apply_cmn), self.low_freq, self.high_freq)
+
+    def frame_length_samples(self) -> int:   # src/fbank.rs:68-70 (f64::round: half away from zero)
+        return int(np.floor((self.frame_length_ms / 1000.0) * self.sample_rate + 0.5))
+
+    def frame_shift_samples(self) -> int:    # src/fbank.rs:73-75
+        return int(np.floor((self.frame_shift_ms / 1000.0) * self.sample_rate + 0.5))
+
+    def fft_size(self) -> int:               # src/fbank.rs:78-81
+        n, p = self.frame_length_samples(), 1
+        while p < n:
+            p <<= 1
+        return p
+
+
+class Fbank:
+    """MI355X twin of Fbank (src/fbank.rs:85-247)."""
+
+    def __init__(self, config: FbankConfig | None = None, device: int = -1):
+        self._h = None
+        self.config = config or FbankConfig()
+        h = C.c_void_p()
+        cc = self.config.to_c()
+        _check(lib().melspec_fbank_create(C.byref(h), device, C.byref(cc)), construct=True)
+        self._h = h
+        self.num_mel_bins = self.config.num_mel_bins
+
+    def num_frames(self, n_samples: int) -> int:
+        return int(lib().melspec_fbank_num_frames(self._h, n_samples))
+
+    def compute(self, samples) -> np.ndarray:
+        """&[f32] -> Array2<f32> (num_frames, num_mel_bins)."""
+        x = _f32(samples).reshape(-1)
+        nf = self.num_frames(x.shape[0])
+        out = np.zeros((nf, self.num_mel_bins), np.float32)
+        got = C.c_size_t(0)
+        _check(lib().melspec_fbank_compute_host(self._h, _fp(x), x.shape[0], _fp(out), out.size, C.byref(got)))
+        assert got.value == nf
+        return out
+
+    def compute_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
+                               stream: int = 0) -> None:
+        _check(lib().melspec_fbank_compute_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
+                                                          C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def synchronize(self, stream: int = 0) -> None:
+        _check(lib().melspec_fbank_synchronize(self._h, C.c_void_p(stream)))
+
+    def compute_batch(self, clips) -> np.ndarray:
+        x = _f32(clips)
+        n_clips, clip_len = x.shape
+        nf = self.num_frames(clip_len)
+        out = np.zeros((n_clips, nf, self.num_mel_bins), np.float32)
+        if out.size == 0:
+            return out
+        din, dout = DeviceBuffer(x.nbytes), DeviceBuffer(out.nbytes)
+        try:
+            din.upload(x)
+            self.compute_uniform_device(din.ptr, clip_len, clip_len, n_clips, dout.ptr)
+            self.synchronize()
+            out = dout.download(out.shape)
+        finally:
+            din.free(); dout.free()
+        return out
+
+    def close(self) -> None:
+        if self._h is not None:
+            lib().melspec_fbank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# -- host-side table builders (CPU only; no GPU needed) ------------------------------------
+
+def mel(sr: float, n_fft: int, n_mels: int, f_min=None, f_max=None, htk: bool = False, norm: bool = True) -> np.ndarray:
+    """mel() of src/mel.rs:547-589 -> dense f64 [n_mels, n_fft//2+1]."""
+    out = np.empty((n_mels, n_fft // 2 + 1), np.float64)
+    _check(lib().melspec_mel_filterbank(sr, n_fft, n_mels, -1.0 if f_min is None else f_min,
+                                        -1.0 if f_max is None else f_max, int(htk), int(norm),
+                                        out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def hann_window(n: int) -> np.ndarray:
+    out = np.empty(n, np.float64)
+    _check(lib().melspec_hann_window(n, out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def kaldi_mel_filterbank(sample_rate=16000.0, fft_size=512, num_mel_bins=80, low_freq=20.0, high_freq=8000.0) -> np.ndarray:
+    out = np.empty((num_mel_bins, fft_size // 2 + 1), np.float64)
+    _check(lib().melspec_kaldi_mel_filterbank(sample_rate, fft_size, num_mel_bins, low_freq, high_freq,
+                                              out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def jfk(oracle):
+    return oracle.load_wav_f32(os.path.join(GOLDEN, "jfk_f32le.wav"))
+
+
+@pytest.fixture(scope="session")
+def four_tone():
+    """The reference's GPU-vs-CPU test signal (src/cuda.rs:494-502), 1 s, f32 arithmetic."""
+    sr = np.float32(16000.0)
+    t = np.arange(16000, dtype=np.float32) / sr
+    two_pi = np.float32(2.0) * np.float32(np.pi)
+    return (np.float32(0.6) * np.sin(two_pi * np.float32(220.0) * t)
+            + np.float32(0.25) * np.sin(two_pi * np.float32(440.0) * t)
+            + np.float32(0.10) * np.sin(two_pi * np.float32(880.0) * t)
+            + np.float32(0.05) * np.sin(two_pi * np.float32(1760.0) * t)).astype(np.float32)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(GOLDEN, "oracle_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The product package on a real device.  No skip: on a GPU box a missing device or a
+    missing HIP library is a failure (the HIP path must be the one that runs)."""
+    import mel_spec_amd as M
+    assert M.device_count() >= 1, "no gfx950 device visible to libmelspec_hip.so"
+    return M

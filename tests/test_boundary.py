@@ -1,0 +1,79 @@
+"""The drop-in boundary: the C-ABI library loads, exports every symbol the header declares,
+validates arguments like the reference, and the product never touches the oracle."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import mel_spec_amd as M
+from mel_spec_amd import _lib
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "melspec_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(melspec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/melspec_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES out of sync with the header"
+    assert L.melspec_abi_version() == 1
+
+
+def test_argument_validation_matches_reference():
+    # src/cuda.rs:45-49: zero sizes are rejected at construction -> Unavailable
+    for args in ((0, 160, 16000.0, 80), (400, 0, 16000.0, 80), (400, 160, 16000.0, 0), (400, 160, 0.0, 80)):
+        with pytest.raises(M.HipUnavailable):
+            M.HipMelSpectrogram(*args)
+    h = C.c_void_p()
+    assert _lib.lib().melspec_create(C.byref(h), -1, 0, 160, 16000.0, 80) == _lib.ERR_INVALID_ARG
+    assert "non-zero" in _lib.last_error()
+    assert _lib.lib().melspec_create(None, -1, 400, 160, 16000.0, 80) == _lib.ERR_INVALID_ARG
+    with pytest.raises(M.HipUnavailable):
+        M.Fbank(M.FbankConfig(num_mel_bins=0))
+
+
+def test_no_device_is_reported_as_unavailable():
+    if M.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(M.HipUnavailable) as e:
+        M.HipMelSpectrogram(400, 160, 16000.0, 80)
+    assert e.value.code == _lib.ERR_UNAVAILABLE       # lets callers self-skip like src/cuda.rs:512-518
+    with pytest.raises(M.HipUnavailable):
+        M.Fbank()
+
+
+def test_fbank_config_defaults_match_reference():
+    c = M.FbankConfig()   # src/fbank.rs:354-362
+    assert (c.sample_rate, c.num_mel_bins, c.frame_length_samples(), c.frame_shift_samples(), c.fft_size()) == \
+        (16000.0, 80, 400, 160, 512)
+    cc = _lib.FbankConfigC()
+    _lib.lib().melspec_fbank_default_config(C.byref(cc))
+    d = c.to_c()
+    for name, _ in _lib.FbankConfigC._fields_:
+        assert getattr(cc, name) == getattr(d, name), name
+
+
+def test_product_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "mel_spec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".rs")):
+                src = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"oracle[/\\.]", r"melspec_oracle", r"oracle_[a-z]"):
+                    assert not re.search(pat, src), f"{f} references the oracle ({pat})"
+    assert "oracle" not in open(os.path.join(ROOT, "include", "melspec_hip.h")).read()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmelspec_hip.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()

@@ -1,0 +1,262 @@
+"""Parity tests proper: the HIP path (through the C ABI) vs the CPU oracle and the committed
+golden vectors, on a real MI355X.  Tolerance for the f32 fused kernels is the north-star's
+1e-4; integer-valued facts (frame counts, shapes, determinism) are exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+SR = 16000.0
+
+
+@pytest.fixture(scope="module")
+def w80(gpu):
+    m = gpu.HipMelSpectrogram(400, 160, SR, 80)
+    assert m.uses_fast_path
+    yield m
+    m.close()
+
+
+def test_library_is_the_hip_one(gpu):
+    from mel_spec_amd import _lib
+    assert os.path.basename(_lib.LIB_PATH) == "libmelspec_hip.so" and gpu.device_count() >= 1
+
+
+def test_jfk_whisper_80(w80, oracle, jfk, golden):
+    got = w80.compute_mel_spectrogram(jfk)
+    want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, 80, SR)
+    assert got.shape == want.shape == (1098, 80)
+    assert np.abs(got - want).max() <= TOL
+    assert np.abs(got - golden["jfk_w80"]).max() <= TOL
+
+
+def test_jfk_whisper_128(gpu, oracle, jfk, golden):
+    m = gpu.HipMelSpectrogram(400, 160, SR, 128)
+    assert m.uses_fast_path
+    got = m.compute_mel_spectrogram(jfk)
+    assert got.shape == (1098, 128)
+    assert np.abs(got - oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, 128, SR)).max() <= TOL
+    assert np.abs(got - golden["jfk_w128"]).max() <= TOL
+
+
+def test_reference_golden_512_160_80(gpu, jfk):
+    """rust_jfk_golden.npy (src/rb.rs:134-179) is the reference's only value-level pin; the
+    streaming alignment is samples[128:] in batch terms.  n_fft=512 runs on the generic f64 kernel."""
+    want = np.load(os.path.join(GOLDEN, "rust_jfk_golden.npy"))
+    m = gpu.HipMelSpectrogram(512, 160, SR, 80)
+    got = m.compute_mel_spectrogram(jfk[128:])
+    assert got[:1097].T.shape == want.shape
+    assert np.abs(got[:1097].T - want).max() <= 2e-6
+
+
+def test_reference_gpu_parity_signal(w80, oracle, four_tone, golden):
+    # the reference's own GPU-vs-CPU test (src/cuda.rs:489-545) accepts max 0.08 / mean 0.01
+    got = w80.compute_mel_spectrogram(four_tone)
+    want = oracle.compute_mel_spectrogram_cpu(four_tone, 400, 160, 80, SR)
+    d = np.abs(got - want)
+    assert got.shape == (98, 80) and d.max() <= TOL and d.mean() < 1e-5
+    assert np.abs(got - golden["tone_w80"]).max() <= TOL
+
+
+def test_generic_kernel_agrees_with_fused_kernel(gpu, w80, oracle, jfk):
+    """hop=161 is odd, so that geometry takes the f64 generic kernel; on the same frames the two
+    device paths and the oracle must agree."""
+    g = gpu.HipMelSpectrogram(400, 161, SR, 80)
+    assert not g.uses_fast_path
+    x = jfk[30000:60000]
+    got = g.compute_mel_spectrogram(x)
+    assert np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, 161, 80, SR)).max() <= 2e-6
+
+
+@pytest.mark.parametrize("n", [0, 1, 399, 400, 559, 560, 400 + 22 * 160, 400 + 23 * 160, 400 + 45 * 160 + 7])
+def test_edge_lengths(w80, oracle, n):
+    x = oracle.synth_pcm(2, n) if n else np.zeros(0, np.float32)
+    got = w80.compute_mel_spectrogram(x)
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, 80, SR)
+    assert got.shape == want.shape
+    if want.size:
+        assert np.abs(got - want).max() <= TOL
+
+
+def test_silence_and_click(w80, oracle):
+    assert np.all(w80.compute_mel_spectrogram(np.zeros(16000, np.float32)) == np.float32(-1.5))
+    x = np.zeros(8000, np.float32); x[4321] = 1.0
+    assert np.abs(w80.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_cpu(x)).max() <= TOL
+
+
+@pytest.mark.parametrize("hop,n_mels", [(160, 64), (128, 80), (200, 40), (320, 100), (160, 1), (160, 132)])
+def test_other_geometries_fast_path(gpu, oracle, jfk, hop, n_mels):
+    m = gpu.HipMelSpectrogram(400, hop, SR, n_mels)
+    assert m.uses_fast_path
+    x = jfk[20000:52000]
+    got = m.compute_mel_spectrogram(x)
+    assert np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, SR)).max() <= TOL
+
+
+@pytest.mark.parametrize("fft,hop,n_mels", [(256, 64, 40), (1024, 256, 80), (400, 160, 200), (100, 50, 20)])
+def test_other_geometries_generic_path(gpu, oracle, jfk, fft, hop, n_mels):
+    m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
+    assert not m.uses_fast_path
+    x = jfk[20000:36000]
+    got = m.compute_mel_spectrogram(x)
+    assert np.abs(got - oracle.compute_mel_spectrogram_cpu(x, fft, hop, n_mels, SR)).max() <= 2e-6
+
+
+def test_uniform_batch_matches_oracle_and_golden(w80, oracle, golden):
+    clips = np.stack([oracle.synth_pcm(c, 16000) for c in range(8)])
+    got = w80.compute_batch(clips)
+    assert got.shape == (8, 98, 80)
+    for c in range(8):
+        assert np.abs(got[c] - golden[f"noise{c}_w80"]).max() <= TOL
+    want = oracle.compute_mel_batch(clips, 400, 160, 80, SR)
+    assert np.abs(got - want).max() <= TOL
+
+
+def test_ragged_batch_with_empty_and_short_clips(w80, oracle, jfk):
+    lens = [0, 399, 400, 16000, 5, 48000, 560, 12345, 0]
+    clips = [oracle.synth_pcm(i, n) if i % 2 else jfk[1000 * i:1000 * i + n].copy() for i, n in enumerate(lens)]
+    got = w80.compute_ragged(clips)
+    assert len(got) == len(clips)
+    for g, c in zip(got, clips):
+        want = oracle.compute_mel_spectrogram_cpu(c, 400, 160, 80, SR)
+        assert g.shape == want.shape
+        if want.size:
+            assert np.abs(g - want).max() <= TOL
+
+
+def test_device_synth_is_bit_identical_to_cpu_twin(gpu, oracle):
+    n_clips, n = 11, 5000
+    buf = gpu.DeviceBuffer(n_clips * n * 4)
+    gpu.synth_pcm_device(buf.ptr, n, n, 5, n_clips)
+    gpu.device_synchronize()
+    got = buf.download((n_clips, n))
+    for c in range(n_clips):
+        assert np.array_equal(got[c], oracle.synth_pcm(5 + c, n))
+    buf.free()
+
+
+def _sampled_parity(oracle, out3, first_clip, clip_len, n_mels, picks, tol=TOL):
+    worst = 0.0
+    for c in picks:
+        want = oracle.compute_mel_spectrogram_cpu(oracle.synth_pcm(first_clip + c, clip_len), 400, 160, n_mels, SR)
+        worst = max(worst, float(np.abs(out3[c] - want).max()))
+    assert worst <= tol, worst
+    return worst
+
+
+def test_config2_full_size_1024x10s(gpu, w80, oracle):
+    """BASELINE configs[1] at full size: 1024 x 10 s clips -> 1 021 952 frames, resident in HBM.
+    Sampled clips vs the oracle + size-independent properties over the whole output."""
+    n_clips, clip_len, fpc = 1024, 160000, 998
+    pcm = gpu.DeviceBuffer(n_clips * clip_len * 4)
+    out = gpu.DeviceBuffer(n_clips * fpc * 80 * 4)
+    gpu.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
+    w80.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+    w80.synchronize()
+    a = out.download((n_clips, fpc, 80))
+    _sampled_parity(oracle, a, 0, clip_len, 80, [0, 1, 7, 255, 256, 511, 777, 1023])
+    # properties: finite; per-frame normalisation puts every frame's max-min within 2.0 exactly
+    assert np.all(np.isfinite(a))
+    fmax, fmin = a.max(axis=2), a.min(axis=2)
+    assert np.all(fmax - fmin <= 2.0 + 1e-6)
+    # determinism: a second launch is bit-identical
+    w80.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+    w80.synchronize()
+    assert np.array_equal(a, out.download((n_clips, fpc, 80)))
+    # batching invariance: clip 300 alone == clip 300 inside the batch (frames are independent)
+    solo = gpu.DeviceBuffer(fpc * 80 * 4)
+    w80.compute_uniform_device(pcm.ptr + 300 * clip_len * 4, clip_len, clip_len, 1, solo.ptr)
+    w80.synchronize()
+    assert np.array_equal(solo.download((fpc, 80)), a[300])
+    # clips differ only by a power-of-two gain (clip & 7): log-mel is shift-equivariant per frame, so
+    # the normalised output of clip c and the unit-gain hash of the same clip index agree where unclamped
+    for b in (pcm, out, solo):
+        b.free()
+
+
+def test_config4_large_v3_128_mels_30s(gpu, oracle):
+    """BASELINE configs[3] geometry (n_mels=128, 30 s clips) at 512 clips (1.5 M frames); the
+    8192-clip size is the same launch with a longer grid-stride loop."""
+    n_clips, clip_len, fpc, nm = 512, 480000, 2998, 128
+    m = gpu.HipMelSpectrogram(400, 160, SR, nm)
+    pcm = gpu.DeviceBuffer(n_clips * clip_len * 4)
+    out = gpu.DeviceBuffer(n_clips * fpc * nm * 4)
+    gpu.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
+    m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+    m.synchronize()
+    for c in (0, 255, 511):
+        got = out.download((fpc, nm), offset_bytes=c * fpc * nm * 4)
+        want = oracle.compute_mel_spectrogram_cpu(oracle.synth_pcm(c, clip_len), 400, 160, nm, SR)
+        assert np.abs(got - want).max() <= TOL
+    pcm.free(); out.free(); m.close()
+
+
+def test_sample_offsets_beyond_32_bits(gpu, w80, oracle):
+    """configs[4] has > 2^31 samples per GPU: clip starts must be 64-bit.  9000 x 30 s = 4.32e9 samples."""
+    n_clips, clip_len, fpc = 9000, 480000, 2998
+    pcm = gpu.DeviceBuffer(n_clips * clip_len * 4)
+    out = gpu.DeviceBuffer(n_clips * fpc * 80 * 4)
+    gpu.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
+    w80.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+    w80.synchronize()
+    for c in (0, 4473, 4474, 8999):      # 4474 * 480000 > 2^31
+        got = out.download((fpc, 80), offset_bytes=c * fpc * 80 * 4)
+        want = oracle.compute_mel_spectrogram_cpu(oracle.synth_pcm(c, clip_len), 400, 160, 80, SR)
+        assert np.abs(got - want).max() <= TOL
+    pcm.free(); out.free()
+
+
+# ---- Kaldi fbank -----------------------------------------------------------------------------
+
+def test_fbank_jfk(gpu, oracle, jfk, golden):
+    fb = gpu.Fbank(gpu.FbankConfig())
+    got = fb.compute(jfk)
+    want = oracle.fbank_compute(jfk)
+    assert got.shape == want.shape == (1098, 80)
+    assert np.abs(got - want).max() <= TOL
+    assert np.abs(got - golden["jfk_fbank_cmn"]).max() <= TOL
+    # informational in the reference (src/fbank.rs:522-526): distance to kaldi_native_fbank
+    k = np.load(os.path.join(GOLDEN, "kaldi_native_fbank_jfk.npz"))["features"]
+    assert np.abs(got.T - k).max() < 0.02
+    raw = gpu.Fbank(gpu.FbankConfig(apply_cmn=False)).compute(jfk)
+    assert np.abs(raw - golden["jfk_fbank_nocmn"]).max() <= TOL
+    assert abs(float(raw[0, 0]) - float(np.log(np.float64(np.finfo(np.float32).eps)))) < 1e-4
+
+
+def test_fbank_variants_and_edges(gpu, oracle, jfk):
+    x = jfk[40000:56000]
+    for kw in (dict(num_mel_bins=40), dict(preemphasis=0.0), dict(use_log_fbank=False, apply_cmn=False),
+               dict(use_power=False), dict(energy_floor=1e-3), dict(low_freq=100.0, high_freq=7000.0),
+               dict(frame_length_ms=20.0, frame_shift_ms=8.0), dict(sample_rate=8000.0)):
+        cfg = gpu.FbankConfig(**kw)
+        oc = oracle.fbank_default_config()
+        for k_, v in kw.items():
+            setattr(oc, k_, type(getattr(oc, k_))(v))
+        got = gpu.Fbank(cfg).compute(x)
+        want = oracle.fbank_compute(x, oc)
+        assert got.shape == want.shape and want.shape[0] > 0
+        tol = TOL if kw.get("use_log_fbank", True) else 1e-4 * max(1.0, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= tol, kw
+    fb = gpu.Fbank()
+    assert fb.compute(np.zeros(399, np.float32)).shape == (0, 80)
+    assert fb.compute(np.zeros(16000, np.float32)).shape == (98, 80)
+
+
+def test_fbank_batch_config3_sampled(gpu, oracle):
+    """BASELINE configs[2]: 80-bin fbank over a batch of 10 s clips (per-clip CMN), sampled vs the oracle."""
+    n_clips, clip_len, fpc = 64, 160000, 998
+    fb = gpu.Fbank()
+    pcm = gpu.DeviceBuffer(n_clips * clip_len * 4)
+    out = gpu.DeviceBuffer(n_clips * fpc * 80 * 4)
+    gpu.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
+    fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+    fb.synchronize()
+    for c in (0, 31, 63):
+        got = out.download((fpc, 80), offset_bytes=c * fpc * 80 * 4)
+        assert np.abs(got - oracle.fbank_compute(oracle.synth_pcm(c, clip_len))).max() <= TOL
+        assert np.abs(got.mean(axis=0)).max() < 1e-4          # CMN leaves zero column means
+    pcm.free(); out.free()

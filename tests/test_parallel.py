@@ -1,0 +1,73 @@
+"""Multi-GPU path: per-clip sharding with no data-path collective.  The N>1 logic is exercised
+with world_size-2 gloo processes on CPU (the oracle stands in for the kernel as the per-rank
+work; what is under test is the partition and the barrier/max-over-ranks timing protocol)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mel_spec_amd.parallel import shard_by_samples, shard_range
+from conftest import ROOT
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 1024, 65536, 65537):
+        for w in (1, 2, 3, 4, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_shard_by_samples_balances_ragged():
+    lengths = [480000] * 10 + [16000] * 300 + [160000] * 50
+    for w in (2, 4, 8):
+        b = shard_by_samples(lengths, w)
+        assert len(b) == w and b[0][0] == 0 and b[-1][1] == len(lengths)
+        assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        loads = [sum(lengths[lo:hi]) for lo, hi in b]
+        assert max(loads) <= sum(lengths) / w + max(lengths)
+
+
+WORKER = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from mel_spec_amd.parallel import shard_range
+from oracle import oracle as O
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n_clips, clip_len = 6, 4000
+lo, hi = shard_range(n_clips, rank, world)
+dist.barrier(); t0 = time.perf_counter()
+outs = [O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len)) for c in range(lo, hi)]
+dist.barrier(); dt = time.perf_counter() - t0
+t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+frames = torch.tensor([sum(o.shape[0] for o in outs)], dtype=torch.int64); dist.all_reduce(frames)
+chk = torch.tensor([float(sum(np.float64(o).sum() for o in outs))], dtype=torch.float64); dist.all_reduce(chk)
+if rank == 0:
+    print("RESULT", int(frames.item()), repr(float(chk.item())), float(t.item()) >= dt - 1e-9)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_run_covers_every_clip_once(tmp_path, oracle):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    want = [oracle.compute_mel_spectrogram_cpu(oracle.synth_pcm(c, 4000)) for c in range(6)]
+    assert int(line[1]) == sum(o.shape[0] for o in want)
+    assert abs(float(line[2]) - float(sum(np.float64(o).sum() for o in want))) < 1e-6
+    assert line[3] == "True"
