@@ -168,7 +168,8 @@ MS_DEV void fast_phase3(int tid, int n_valid, int n_mels, const MelSlots &ms, co
             const int len = ms.len[i];
             for (int r = 0; r < len; ++r) acc += wrow[r * kMelJobs] * p[st + r];
         }
-        const float v = fast_log2(acc > 1e-10f ? acc : 1e-10f) * 0.30102999566398120f;
+        // log10(max(E, 1e-10)); the floored case is exactly -10 like the reference's f64 log10(1e-10)
+        const float v = acc > 1e-10f ? fast_log2(acc) * 0.30102999566398120f : -10.0f;
         vals[i] = v;
         if (j + kMelJobs * i < n_mels) mx = mx > v ? mx : v;
     }
