@@ -88,6 +88,13 @@ int melspec_compute_ragged_device(melspec_ctx *ctx, const float *d_pcm, const ui
                                   const uint64_t *h_lengths, uint32_t n_clips, float *d_out,
                                   const uint64_t *h_out_offsets, void *stream);
 
+/* Benchmark helper (the reference's #[ignore] Instant-timed benches, src/cuda.rs:547-613): runs
+ * `warmup` untimed and `iters` timed melspec_compute_uniform_device calls on the context's own
+ * stream between two HIP events and returns the average milliseconds per call. */
+int melspec_time_uniform_device(melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride,
+                                uint64_t clip_len, uint32_t n_clips, float *d_out,
+                                int warmup, int iters, float *avg_ms);
+
 /* Wait for everything this context has queued on `stream` (cudaStreamSynchronize, src/cuda.rs:129). */
 int melspec_synchronize(melspec_ctx *ctx, void *stream);
 

@@ -14,8 +14,10 @@
 
 #if defined(__HIPCC__)
 #define MS_DEV __device__ __forceinline__
+#define MS_HD __host__ __device__ __forceinline__
 #else
 #define MS_DEV inline
+#define MS_HD inline
 #endif
 
 namespace melspec {

@@ -9,6 +9,7 @@
 
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -44,6 +45,7 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kFPB = 23;       // frames per workgroup tile (23*11 = 253 <= 256 threads)
 constexpr int kNT = 256;
 constexpr int kGenericNT = 256;
+constexpr int kDefaultVariant = 5;   // wave kernel, 8 waves/workgroup, direct global reads, <=128 VGPRs
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
@@ -233,6 +235,10 @@ struct melspec_ctx {
     DevBuf d_blob;
     size_t fast_lds = 0;
     int region_a = 0;
+    int variant = 0;        // 0: block kernel (23 frames / 256 threads); 1..4: wave kernels (see launch_ctx)
+    int lens_kind = 0;      // 0 runtime slot lengths, 1 static Whisper-80, 2 static Whisper-128
+    int slice_floats = 0;
+    int frames_per_unit = 1;
     // generic path
     GenericTables gt;
     // scratch
@@ -247,8 +253,7 @@ int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
     return MELSPEC_OK;
 }
 
-template <int NSLOTS>
-int launch_fast_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+FastParams fast_params(melspec_ctx *c, const BatchDesc &desc) {
     FastParams fp{};
     fp.b = desc;
     fp.d_blob = static_cast<const float *>(c->d_blob.p);
@@ -256,20 +261,77 @@ int launch_fast_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     fp.hop = c->hop_size;
     fp.n_mels = c->n_mels;
     fp.region_a = c->region_a;
+    fp.slice_floats = c->slice_floats;
     fp.slots = c->ft.slots;
+    return fp;
+}
+
+template <int NSLOTS>
+int launch_block_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    const FastParams fp = fast_params(c, desc);
     const unsigned grid = grid_for(desc.n_units, c->dev.cus, 8);
     hipLaunchKernelGGL((whisper400_kernel<kFPB, kNT, NSLOTS>), dim3(grid), dim3(kNT), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
 
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1>
+int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW>, "hipFuncSetAttribute(whisper400_wave_kernel)");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const FastParams fp = fast_params(c, desc);
+    const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
+    const unsigned grid = grid_for(blocks, c->dev.cus, 16);
+    hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW>), dim3(grid), dim3(WAVES * 64),
+                       c->fast_lds, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+template <int NSLOTS, class StaticLens>
+int launch_wave_v(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool static_ok) {
+    // 1: 4 waves direct, 2: 4 waves staged, 3: 8 waves direct, 4: 8 waves staged,
+    // 5/6: as 3/4 with the register budget capped for 4 waves per SIMD (<=128 VGPRs)
+    const int v = c->variant;
+    if (static_ok) {
+        switch (v) {
+            case 1: return launch_wave_t<NSLOTS, true, 4, StaticLens>(c, desc, stream);
+            case 2: return launch_wave_t<NSLOTS, false, 4, StaticLens>(c, desc, stream);
+            case 3: return launch_wave_t<NSLOTS, true, 8, StaticLens>(c, desc, stream);
+            case 4: return launch_wave_t<NSLOTS, false, 8, StaticLens>(c, desc, stream);
+            case 5: return launch_wave_t<NSLOTS, true, 8, StaticLens, 4>(c, desc, stream);
+            default: return launch_wave_t<NSLOTS, false, 8, StaticLens, 4>(c, desc, stream);
+        }
+    }
+    switch (v) {
+        case 1: return launch_wave_t<NSLOTS, true, 4, LensRuntime>(c, desc, stream);
+        case 2: return launch_wave_t<NSLOTS, false, 4, LensRuntime>(c, desc, stream);
+        case 3: return launch_wave_t<NSLOTS, true, 8, LensRuntime>(c, desc, stream);
+        case 4: return launch_wave_t<NSLOTS, false, 8, LensRuntime>(c, desc, stream);
+        case 5: return launch_wave_t<NSLOTS, true, 8, LensRuntime, 4>(c, desc, stream);
+        default: return launch_wave_t<NSLOTS, false, 8, LensRuntime, 4>(c, desc, stream);
+    }
+}
+
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     if (desc.n_units == 0) return MELSPEC_OK;
-    if (c->fast) {
-        if (c->ft.slots.n_slots <= 8) return launch_fast_t<8>(c, desc, stream);
-        return launch_fast_t<12>(c, desc, stream);
-    }
-    return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
+    if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
+    const bool small = c->ft.slots.n_slots <= 8;
+    if (c->variant == 0) return small ? launch_block_t<8>(c, desc, stream) : launch_block_t<12>(c, desc, stream);
+    if (small) return launch_wave_v<8, LensW80>(c, desc, stream, c->lens_kind == 1);
+    return launch_wave_v<12, LensW128>(c, desc, stream, c->lens_kind == 2);
+}
+
+template <class Lens>
+bool lens_match(const MelSlots &ms) {
+    if (ms.n_slots != Lens::kSlots) return false;
+    for (int i = 0; i < Lens::kSlots; ++i)
+        if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
+    return true;
 }
 
 }  // namespace
@@ -318,9 +380,24 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     // fused kernel: n_fft == 400, even hop (8-byte aligned LDS reads), n_mels <= 132
     c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft);
     if (c->fast) {
-        using L = FastLayout<kFPB>;
-        c->region_a = L::region_a(hop_size);
-        c->fast_lds = sizeof(float) * (c->ft.blob.size() + c->region_a + L::region_b() + L::region_max());
+        const char *ev = std::getenv("MELSPEC_VARIANT");
+        const char *el = std::getenv("MELSPEC_RUNTIME_LENS");
+        c->variant = ev ? std::atoi(ev) : kDefaultVariant;
+        if (c->variant < 0 || c->variant > 6) c->variant = kDefaultVariant;
+        c->lens_kind = lens_match<LensW80>(c->ft.slots) ? 1 : (lens_match<LensW128>(c->ft.slots) ? 2 : 0);
+        if (el && el[0] == '1') c->lens_kind = 0;
+        if (c->variant == 0) {
+            using L = FastLayout<kFPB>;
+            c->frames_per_unit = kFPB;
+            c->region_a = L::region_a(hop_size);
+            c->fast_lds = sizeof(float) * (c->ft.blob.size() + c->region_a + L::region_b() + L::region_max());
+        } else {
+            const bool staged = (c->variant % 2) == 0;
+            const int waves = c->variant <= 2 ? 4 : 8;
+            c->frames_per_unit = kFPW;
+            c->slice_floats = WaveLayout::slice_floats(hop_size, staged);
+            c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(waves) * c->slice_floats);
+        }
         if (c->fast_lds > kLdsLimit) c->fast = false;
     }
     if (c->fast) {
@@ -368,7 +445,7 @@ int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t 
         return fail(MELSPEC_ERR_INVALID_ARG, "clip_stride smaller than clip_len");
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? kFPB : 1);
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? c->frames_per_unit : 1);
     return launch_ctx(c, pl.desc, s);
 }
 
@@ -387,9 +464,34 @@ int melspec_compute_ragged_device(melspec_ctx *c, const float *d_pcm, const uint
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     BatchPlan pl;
     int rc = plan_ragged(c->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, c->n_mels,
-                         c->fast ? kFPB : 1, pl);
+                         c->fast ? c->frames_per_unit : 1, pl);
     if (rc) return rc;
     return launch_ctx(c, pl.desc, s);
+}
+
+int melspec_time_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                uint32_t n_clips, float *d_out, int warmup, int iters, float *avg_ms) {
+    if (!c || !avg_ms || iters < 1) return fail(MELSPEC_ERR_INVALID_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = MELSPEC_OK;
+    for (int i = 0; i < warmup && !rc; ++i)
+        rc = melspec_compute_uniform_device(c, d_pcm, clip_stride, clip_len, n_clips, d_out, c->stream);
+    if (!rc) {
+        (void)hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iters && !rc; ++i)
+            rc = melspec_compute_uniform_device(c, d_pcm, clip_stride, clip_len, n_clips, d_out, c->stream);
+        (void)hipEventRecord(e1, c->stream);
+        const hipError_t e = hipEventSynchronize(e1);
+        if (!rc && e != hipSuccess) rc = fail_hip(e, "hipEventSynchronize");
+        float ms = 0.0f;
+        if (!rc) { (void)hipEventElapsedTime(&ms, e0, e1); *avg_ms = ms / iters; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int melspec_synchronize(melspec_ctx *c, void *stream) {

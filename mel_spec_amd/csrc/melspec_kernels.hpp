@@ -10,6 +10,7 @@
 #include <cstdint>
 
 #include "whisper_fast.hpp"
+#include "whisper_wave.hpp"
 
 namespace melspec {
 
@@ -69,7 +70,8 @@ struct FastParams {
     int blob_len;      // floats, multiple of 4
     int hop;
     int n_mels;
-    int region_a;      // floats
+    int region_a;      // floats (block kernel)
+    int slice_floats;  // floats per wave (wave kernel)
     MelSlots slots;
 };
 
@@ -103,6 +105,49 @@ __global__ __launch_bounds__(NT) void whisper400_kernel(const FastParams p) {
         fast_phase3<FPB, NSLOTS>(tid, nv, p.n_mels, p.slots, blob, reg_a, pmax, vals);
         __syncthreads();
         fast_phase4<FPB, NSLOTS>(tid, nv, p.n_mels, pmax, vals, loc.out + f0 * (uint64_t)p.n_mels);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Wave-autonomous fused Whisper kernel (phases in whisper_wave.hpp).  A work unit is kFPW = 5
+// consecutive frames of one clip and belongs to one wavefront; the WAVES waves of a workgroup
+// share only the table blob.  LDS: [table blob][WAVES x private slice].  No barrier in the loop.
+// ------------------------------------------------------------------------------------
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1>
+__global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const FastParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *blob = lds;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    float *slice = blob + p.blob_len + wave * p.slice_floats;
+    const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+    const bool in = lane < kFPW * kMelJobs;
+
+    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * kFPW;
+        const uint64_t left = loc.frames - f0;
+        const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv;
+        if (!DIRECT) {
+            const int need = (nv - 1) * p.hop + 400;
+            for (int i = lane; i < need; i += 64) slice[i] = src[i];
+            __builtin_amdgcn_wave_barrier();
+        }
+        wave_phase1<DIRECT>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
+        __builtin_amdgcn_wave_barrier();
+        wave_phase2(fl, j, act, blob, slice);
+        __builtin_amdgcn_wave_barrier();
+        float vals[NSLOTS];
+        wave_phase3<NSLOTS, Lens>(fl, j, act, p.n_mels, p.slots, blob, slice, vals);
+        __builtin_amdgcn_wave_barrier();
+        wave_phase4<NSLOTS>(fl, j, act, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

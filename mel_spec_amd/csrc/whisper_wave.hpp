@@ -1,0 +1,209 @@
+// whisper_wave.hpp -- wave-autonomous form of the fused n_fft=400 log-mel pipeline.
+//
+// Same arithmetic and the same table blob as whisper_fast.hpp (see the derivation there),
+// but one 64-lane wavefront owns kFPW = 5 whole frames from PCM to mel rows: lane = 11*frame + j.
+// All exchanges go through the wave's private LDS slice, and because LDS operations of one
+// wave execute in program order no workgroup barrier is needed anywhere in the tile loop --
+// waves of a workgroup only share the read-only table blob.  The slice is reused in place:
+//   [PCM tile (optional staging)] -> [FFT exchange rows] -> [power rows | frame maxima]
+// which is safe for the same reason (every lane's reads of a stage are issued before any
+// lane's writes of the next stage).
+//
+// Reference steps: frame_windows src/stft.rs:147-169; FFT src/stft.rs:105-111; sparse mel +
+// log10 src/mel.rs:148-168; per-frame normalisation src/mel.rs:645-654.
+#pragma once
+#include "whisper_fast.hpp"
+
+namespace melspec {
+
+constexpr int kFPW = 5;   // frames per wavefront (5 * 11 = 55 of 64 lanes)
+
+struct WaveLayout {
+    static constexpr int kXRow = 20;
+    static constexpr int kXStride = 436;                 // == 20 (mod 32): conflict-free b64 row writes
+    static constexpr int kPStride = 201;
+    static constexpr int kPmaxStride = 12;               // 11 maxima + 1 pad, 48 B rows (16-byte aligned)
+    static constexpr int kPmaxOff = 1008;                // after the 5 power rows (5*201 = 1005)
+    static constexpr int slice_floats(int hop, bool staged) {
+        const int x = kFPW * kXStride;                   // 2180
+        const int pcm = staged ? (kFPW - 1) * hop + 400 : 0;
+        return ((x > pcm ? x : pcm) + 3) & ~3;
+    }
+};
+
+// Compile-time slot lengths for the two Whisper filterbanks (16 kHz, 80 / 128 mels); any
+// other (sr, n_mels) uses the runtime lengths in MelSlots.
+struct LensRuntime {
+    static constexpr bool kStatic = false;
+    static constexpr int kSlots = kMaxSlots;
+    MS_HD static int len(int) { return 0; }
+    MS_HD static int woff(int) { return 0; }
+};
+template <int... L>
+struct LensStatic {
+    static constexpr bool kStatic = true;
+    static constexpr int kSlots = sizeof...(L);
+    MS_HD static constexpr int len(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        return t[i];
+    }
+    MS_HD static constexpr int woff(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        int s = 0;
+        for (int k = 0; k < i; ++k) s += t[k];
+        return FastBlob::kMelW + kMelJobs * s;
+    }
+};
+using LensW80 = LensStatic<2, 2, 2, 4, 6, 8, 13, 14>;
+using LensW128 = LensStatic<2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 8, 9>;
+
+// 8-byte load from a pointer that is only 4-byte aligned (clip offsets are arbitrary).
+MS_DEV f2 load2_unaligned(const float *p) {
+#if defined(__HIPCC__)
+    typedef float v2u __attribute__((ext_vector_type(2), aligned(4)));
+    const v2u v = *reinterpret_cast<const v2u *>(p);
+    return f2{v.x, v.y};
+#else
+    return f2{p[0], p[1]};
+#endif
+}
+
+// ---- phase 1 -----------------------------------------------------------------------------
+// DIRECT: read the frame's samples straight from global memory (L1/L2 absorb the 2.5x frame
+// overlap); otherwise from the PCM tile staged at the start of the slice.
+template <bool DIRECT>
+MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, const float *gsrc /* tile's first sample */,
+                        float *slice) {
+    if (!active) return;
+    const float *w = blob + FastBlob::kWin + 2 * t;
+    cf x[20];
+    if (DIRECT) {
+        const float *s = gsrc + fl * hop + 2 * t;
+#pragma unroll
+        for (int n1 = 0; n1 < 20; ++n1) {
+            const f2 sv = load2_unaligned(s + 20 * n1);
+            const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
+            x[n1] = {sv.x * wv.x, sv.y * wv.y};
+        }
+    } else {
+        const float *s = slice + fl * hop + 2 * t;
+#pragma unroll
+        for (int n1 = 0; n1 < 20; ++n1) {
+            const f2 sv = *reinterpret_cast<const f2 *>(s + 20 * n1);
+            const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
+            x[n1] = {sv.x * wv.x, sv.y * wv.y};
+        }
+    }
+    fft20(x);
+    const float *tw = blob + FastBlob::kTw1 + t * FastBlob::kTw1Stride;
+    float *xo = slice + fl * WaveLayout::kXStride + 2 * t;
+    {
+        const f2 m = *reinterpret_cast<const f2 *>(blob + FastBlob::kMod + 2 * t);
+        const cf y = cmul(x[0], cf{m.x, m.y});
+        *reinterpret_cast<f2 *>(xo + 20 * WaveLayout::kXRow) = f2{y.re, y.im};
+        *reinterpret_cast<f2 *>(xo) = f2{x[0].re, x[0].im};
+    }
+#pragma unroll
+    for (int k1 = 1; k1 < 20; ++k1) {
+        const f2 wv = *reinterpret_cast<const f2 *>(tw + 2 * k1);
+        const cf y = cmul(x[k1], cf{wv.x, wv.y});
+        *reinterpret_cast<f2 *>(xo + k1 * WaveLayout::kXRow) = f2{y.re, y.im};
+    }
+}
+
+// ---- phase 2: reads the exchange rows, writes the power row over the same slice ----------
+MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *slice) {
+    if (!active) return;
+    const int brow = (j == 0) ? 20 : 20 - j;
+    const float *ua = slice + fl * WaveLayout::kXStride + j * WaveLayout::kXRow;
+    const float *va = slice + fl * WaveLayout::kXStride + brow * WaveLayout::kXRow;
+    cf u[10], v[10];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const f4 a = *reinterpret_cast<const f4 *>(ua + 4 * i);
+        const f4 b = *reinterpret_cast<const f4 *>(va + 4 * i);
+        u[2 * i] = {a.x, a.y};
+        u[2 * i + 1] = {a.z, a.w};
+        v[2 * i] = {b.x, b.y};
+        v[2 * i + 1] = {b.z, b.w};
+    }
+    fft10(u);
+    fft10(v);
+    const float *tw = blob + FastBlob::kTw2 + j * 20;
+    float *p = slice + fl * WaveLayout::kPStride;
+#pragma unroll
+    for (int q = 0; q < 10; q += 2) {
+        const f4 w2 = *reinterpret_cast<const f4 *>(tw + 2 * q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int qq = q + h;
+            const cf zk = u[qq], zm = v[9 - qq];
+            const cf S = {zk.re + zm.re, zk.im - zm.im};
+            const cf D = {zk.re - zm.re, zk.im + zm.im};
+            const cf W = h == 0 ? cf{w2.x, w2.y} : cf{w2.z, w2.w};
+            const cf wd = cmul(W, D);
+            const float ar = S.re + wd.im, ai = S.im - wd.re;
+            const float br = S.re - wd.im, bi = S.im + wd.re;
+            p[j + 20 * qq] = 0.25f * (ar * ar + ai * ai);
+            p[200 - j - 20 * qq] = 0.25f * (br * br + bi * bi);
+        }
+    }
+}
+
+// ---- phase 3: banded mel projection + log10, per-thread max to LDS ------------------------
+template <int NSLOTS, class Lens>
+MS_DEV void wave_phase3(int fl, int j, bool active, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+                        float (&vals)[NSLOTS]) {
+    if (!active) return;
+    const float *p = slice + fl * WaveLayout::kPStride;
+    const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        float acc = 0.0f;
+        if (Lens::kStatic) {
+            if (i < Lens::kSlots) {
+                const float *pp = p + starts[i * kMelJobs + j];
+                const float *wrow = blob + Lens::woff(i < Lens::kSlots ? i : 0) + j;
+#pragma unroll
+                for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) acc += wrow[r * kMelJobs] * pp[r];
+            }
+        } else if (i < ms.n_slots) {
+            const float *pp = p + starts[i * kMelJobs + j];
+            const float *wrow = blob + ms.woff[i] + j;
+            const int len = ms.len[i];
+            for (int r = 0; r < len; ++r) acc += wrow[r * kMelJobs] * pp[r];
+        }
+        const float v = acc > 1e-10f ? fast_log2(acc) * 0.30102999566398120f : -10.0f;
+        vals[i] = v;
+        if (j + kMelJobs * i < n_mels) mx = mx > v ? mx : v;
+    }
+    slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j] = mx;
+    if (j == 0) slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + 11] = -3.0e38f;
+}
+
+// ---- phase 4: frame max, clamp, scale, store ------------------------------------------------
+template <int NSLOTS>
+MS_DEV void wave_phase4(int fl, int j, bool active, int n_mels, const float *slice, const float (&vals)[NSLOTS],
+                        float *out_tile) {
+    if (!active) return;
+    const float *pm = slice + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
+    const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4),
+             c = *reinterpret_cast<const f4 *>(pm + 8);
+    float m0 = a.x > a.y ? a.x : a.y, m1 = a.z > a.w ? a.z : a.w, m2 = b.x > b.y ? b.x : b.y,
+          m3 = b.z > b.w ? b.z : b.w, m4 = c.x > c.y ? c.x : c.y, m5 = c.z > c.w ? c.z : c.w;
+    m0 = m0 > m1 ? m0 : m1; m2 = m2 > m3 ? m2 : m3; m4 = m4 > m5 ? m4 : m5;
+    m0 = m0 > m2 ? m0 : m2;
+    const float lo = (m0 > m4 ? m0 : m4) - 8.0f;
+    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const int m = j + kMelJobs * i;
+        if (m < n_mels) {
+            const float v = vals[i] > lo ? vals[i] : lo;
+            o[kMelJobs * i] = (v + 4.0f) * 0.25f;
+        }
+    }
+}
+
+}  // namespace melspec

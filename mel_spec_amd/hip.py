@@ -150,6 +150,14 @@ class HipMelSpectrogram:
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_synchronize(self._h, C.c_void_p(stream)))
 
+    def time_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
+                            warmup: int = 3, iters: int = 20) -> float:
+        """Average milliseconds per launch, HIP events on the context's stream."""
+        ms = C.c_float(0.0)
+        _check(lib().melspec_time_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
+                                                 C.c_void_p(d_out), warmup, iters, C.byref(ms)))
+        return float(ms.value)
+
     def compute_batch(self, clips) -> np.ndarray:
         """[n_clips, clip_len] host f32 -> [n_clips, frames, n_mels] host f32 in one launch."""
         x = _f32(clips)

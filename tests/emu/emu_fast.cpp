@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../mel_spec_amd/csrc/fast_tables.hpp"
+#include "../../mel_spec_amd/csrc/whisper_wave.hpp"
 
 using namespace melspec;
 
@@ -48,6 +49,88 @@ static long long run(const float *pcm, long long n, int hop, int n_mels, double 
 extern "C" long long emu_whisper_fast(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
     if (n_mels <= 88) return run<23, 8>(pcm, n, hop, n_mels, sr, out);
     return run<23, 12>(pcm, n, hop, n_mels, sr, out);
+}
+
+// Wave-autonomous kernel (whisper_wave.hpp): one 64-lane wave per 5-frame unit, one phase at a
+// time over all lanes, the slice poisoned where the kernel promises not to read.
+template <int NSLOTS, bool DIRECT, class Lens>
+static long long run_wave(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+    FastTables T;
+    if (!build_fast_tables(sr, n_mels, T)) return -1;
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / hop + 1;
+    std::vector<float> slice(WaveLayout::slice_floats(hop, !DIRECT));
+    std::vector<float> vals(static_cast<size_t>(64) * NSLOTS);
+    for (long long f0 = 0; f0 < frames; f0 += kFPW) {
+        const int nv = static_cast<int>(std::min<long long>(kFPW, frames - f0));
+        std::fill(slice.begin(), slice.end(), 1.0e30f);
+        const float *src = pcm + f0 * hop;
+        if (!DIRECT) {
+            const int need = (nv - 1) * hop + 400;
+            for (int i = 0; i < need; ++i) slice[i] = src[i];
+        }
+        // phase 1 reads every input before writing any exchange row: emulate with a snapshot
+        std::vector<float> snap(slice);
+        std::vector<float> next(slice);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            std::vector<float> tmp(snap);
+            wave_phase1<DIRECT>(fl, j, act && j < kFftJobs, hop, T.blob.data(), src, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            std::vector<float> tmp(snap);
+            wave_phase2(fl, j, act, T.blob.data(), tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            std::vector<float> tmp(snap);
+            wave_phase3<NSLOTS, Lens>(fl, j, act, n_mels, T.slots, T.blob.data(), tmp.data(),
+                                      *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            wave_phase4<NSLOTS>(fl, j, act, n_mels, slice.data(),
+                                *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+                                out + f0 * n_mels);
+        }
+    }
+    return frames;
+}
+
+template <class Lens>
+static bool lens_ok(const MelSlots &ms) {
+    if (ms.n_slots != Lens::kSlots) return false;
+    for (int i = 0; i < Lens::kSlots; ++i)
+        if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
+    return true;
+}
+
+// mode: 0 direct+runtime lens, 1 staged+runtime lens, 2 direct+static lens (only 16 kHz 80/128), 3 staged+static
+extern "C" long long emu_whisper_wave(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+    FastTables T;
+    if (!build_fast_tables(sr, n_mels, T)) return -1;
+    const bool direct = (mode % 2) == 0, stat = mode >= 2;
+    if (stat) {
+        if (lens_ok<LensW80>(T.slots))
+            return direct ? run_wave<8, true, LensW80>(pcm, n, hop, n_mels, sr, out) : run_wave<8, false, LensW80>(pcm, n, hop, n_mels, sr, out);
+        if (lens_ok<LensW128>(T.slots))
+            return direct ? run_wave<12, true, LensW128>(pcm, n, hop, n_mels, sr, out) : run_wave<12, false, LensW128>(pcm, n, hop, n_mels, sr, out);
+        return -2;
+    }
+    if (n_mels <= 88)
+        return direct ? run_wave<8, true, LensRuntime>(pcm, n, hop, n_mels, sr, out) : run_wave<8, false, LensRuntime>(pcm, n, hop, n_mels, sr, out);
+    return direct ? run_wave<12, true, LensRuntime>(pcm, n, hop, n_mels, sr, out) : run_wave<12, false, LensRuntime>(pcm, n, hop, n_mels, sr, out);
 }
 
 // power spectrum only (debug): |X[k]|^2, k in [0,200], for the first frame of pcm
