@@ -32,6 +32,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # no SLP packing: v_pk_*_f32 issues at half the rate of the plain op on gfx950 (measured,
+           # tools/valu_rate.hip) and pairing registers costs ~250 v_mov per kernel
+           "-fno-slp-vectorize",
            "-Wall", "-Wno-unused-function",
            "-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:

@@ -171,7 +171,7 @@ MS_DEV void fast_phase3(int tid, int n_valid, int n_mels, const MelSlots &ms, co
         // log10(max(E, 1e-10)); the floored case is exactly -10 like the reference's f64 log10(1e-10)
         const float v = acc > 1e-10f ? fast_log2(acc) * 0.30102999566398120f : -10.0f;
         vals[i] = v;
-        if (j + kMelJobs * i < n_mels) mx = mx > v ? mx : v;
+        if (j + kMelJobs * i < n_mels) mx = __builtin_fmaxf(mx, v);
     }
     pmax[fl * kMelJobs + j] = mx;
 }
@@ -196,7 +196,7 @@ MS_DEV void fast_phase4(int tid, int n_valid, int n_mels, const float *pmax, con
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
         if (m < n_mels) {
-            const float v = vals[i] > lo ? vals[i] : lo;
+            const float v = __builtin_fmaxf(vals[i], lo);
             o[kMelJobs * i] = (v + 4.0f) * 0.25f;
         }
     }

@@ -176,7 +176,7 @@ MS_DEV void wave_phase3(int fl, int j, bool active, int n_mels, const MelSlots &
         }
         const float v = acc > 1e-10f ? fast_log2(acc) * 0.30102999566398120f : -10.0f;
         vals[i] = v;
-        if (j + kMelJobs * i < n_mels) mx = mx > v ? mx : v;
+        if (j + kMelJobs * i < n_mels) mx = __builtin_fmaxf(mx, v);
     }
     slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j] = mx;
     if (j == 0) slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + 11] = -3.0e38f;
@@ -190,17 +190,16 @@ MS_DEV void wave_phase4(int fl, int j, bool active, int n_mels, const float *sli
     const float *pm = slice + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
     const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4),
              c = *reinterpret_cast<const f4 *>(pm + 8);
-    float m0 = a.x > a.y ? a.x : a.y, m1 = a.z > a.w ? a.z : a.w, m2 = b.x > b.y ? b.x : b.y,
-          m3 = b.z > b.w ? b.z : b.w, m4 = c.x > c.y ? c.x : c.y, m5 = c.z > c.w ? c.z : c.w;
-    m0 = m0 > m1 ? m0 : m1; m2 = m2 > m3 ? m2 : m3; m4 = m4 > m5 ? m4 : m5;
-    m0 = m0 > m2 ? m0 : m2;
-    const float lo = (m0 > m4 ? m0 : m4) - 8.0f;
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
+    const float m2 = __builtin_fmaxf(__builtin_fmaxf(c.x, c.y), __builtin_fmaxf(c.z, c.w));
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2) - 8.0f;
     float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
         if (m < n_mels) {
-            const float v = vals[i] > lo ? vals[i] : lo;
+            const float v = __builtin_fmaxf(vals[i], lo);
             o[kMelJobs * i] = (v + 4.0f) * 0.25f;
         }
     }
