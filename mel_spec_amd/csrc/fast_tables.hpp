@@ -14,10 +14,86 @@ struct FastTables {
     MelSlots slots{};
     int n_mels = 0;
     int nnz = 0;
+    bool interval = false;   // mel section holds the interval scheme (see build_interval_mel)
 };
 
+// Interval form of a triangular filterbank.  With edges e_0..e_{M+1}, bin k lies in exactly one
+// interval I_i = [e_i, e_{i+1}) and only filters i (rising there) and i-1 (falling there) can be
+// non-zero on it, so  mel[m] = sum_{k in I_m} w[m][k] P[k] + sum_{k in I_{m+1}} w[m][k] P[k]:
+// every bin is read once and feeds two running sums.  Lane j of a 12-lane frame group owns interval
+// i = j + 11*slot (j = 11 duplicates j = 0 of the next slot so that the "fall" sum a mel needs is
+// always in the next lane).  Weights are pre-scaled by 1/4 (phase 2 then stores 4*|X|^2).
+// Returns false if some non-zero weight violates the two-filters-per-bin structure.
+inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int bins, int bin_limit,
+                               std::vector<float> &b, MelSlots &slots) {
+    // interval of bin k = the filter whose rising part contains it = last row that is non-zero at k
+    // and whose peak is at or after k; derive it from the matrix itself: rows non-zero at k are
+    // {i-1, i} (or one of them); i is the larger one unless k sits on filter (i-1)'s falling side only.
+    std::vector<int> idx(bin_limit, -1);
+    for (int k = 0; k < bin_limit; ++k) {
+        int lo = -1, hi = -1;
+        for (int m = 0; m < n_mels; ++m)
+            if (dense[static_cast<size_t>(m) * bins + k] != 0.0) { if (lo < 0) lo = m; hi = m; }
+        if (lo < 0) continue;                 // bin used by no filter
+        if (hi - lo > 1) return false;
+        if (hi != lo) { idx[k] = hi; continue; }
+        // a single filter m: k is on its rising side (interval m) or falling side (interval m+1)
+        const double *row = &dense[static_cast<size_t>(lo) * bins];
+        int peak = 0;
+        for (int q = 1; q < bin_limit; ++q) if (row[q] > row[peak]) peak = q;
+        idx[k] = (k <= peak) ? lo : lo + 1;
+    }
+    // intervals must be contiguous, non-decreasing runs
+    int last = -1;
+    for (int k = 0; k < bin_limit; ++k) {
+        if (idx[k] < 0) continue;
+        if (idx[k] < last) return false;
+        last = idx[k];
+    }
+    const int n_int = n_mels + 1;
+    std::vector<int> first(n_int, 0), cnt(n_int, 0);
+    for (int k = 0; k < bin_limit; ++k) {
+        if (idx[k] < 0) continue;
+        if (cnt[idx[k]] == 0) first[idx[k]] = k;
+        else if (first[idx[k]] + cnt[idx[k]] != k) return false;   // hole inside an interval
+        ++cnt[idx[k]];
+    }
+    const int n_slots = (n_int + kMelJobs - 1) / kMelJobs;
+    if (n_slots > kMaxSlots) return false;
+    slots = MelSlots{};
+    slots.n_slots = n_slots;
+    for (int s = 0; s < n_slots; ++s) {
+        int L = 0;
+        for (int j = 0; j < 12; ++j) {
+            const int i = s * kMelJobs + j;
+            if (i < n_int && cnt[i] > L) L = cnt[i];
+        }
+        slots.len[s] = L;
+        slots.woff[s] = static_cast<int>(b.size());
+        b.resize(b.size() + static_cast<size_t>(L) * 24, 0.0f);
+        for (int j = 0; j < 12; ++j) {
+            const int i = s * kMelJobs + j;
+            int st = 0;
+            if (i < n_int && cnt[i] > 0) {
+                st = first[i];
+                if (st + L > bin_limit) st = bin_limit - L;
+                for (int r = 0; r < L; ++r) {
+                    const int k = st + r;
+                    if (idx[k] != i) continue;       // padding bins belong to a neighbour interval
+                    const double rise = i < n_mels ? dense[static_cast<size_t>(i) * bins + k] : 0.0;
+                    const double fall = i >= 1 ? dense[static_cast<size_t>(i - 1) * bins + k] : 0.0;
+                    b[slots.woff[s] + (r * 12 + j) * 2] = static_cast<float>(0.25 * rise);
+                    b[slots.woff[s] + (r * 12 + j) * 2 + 1] = static_cast<float>(0.25 * fall);
+                }
+            }
+            std::memcpy(&b[FastBlob::kMelStart + s * 12 + j], &st, sizeof(int));
+        }
+    }
+    return true;
+}
+
 // Returns false if the geometry is outside the fused kernel's coverage.
-inline bool build_fast_tables(double sr, int n_mels, FastTables &out) {
+inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_interval = false) {
     constexpr int N = 400, M = 200;
     const int n_slots = (n_mels + kMelJobs - 1) / kMelJobs;
     if (n_mels < 1 || n_slots > kMaxSlots) return false;
@@ -49,6 +125,13 @@ inline bool build_fast_tables(double sr, int n_mels, FastTables &out) {
     const BandedFilterbank fb = band_filterbank(dense, n_mels, bins, M);
     out.nnz = fb.nnz;
     out.n_mels = n_mels;
+    out.interval = false;
+    if (want_interval && build_interval_mel(dense, n_mels, bins, M, b, out.slots)) {
+        out.interval = true;
+        while (b.size() % 4) b.push_back(0.0f);
+        return true;
+    }
+    b.resize(FastBlob::kMelW);
     out.slots = MelSlots{};
     out.slots.n_slots = n_slots;
     for (int i = 0; i < n_slots; ++i) {

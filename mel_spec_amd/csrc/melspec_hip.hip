@@ -45,7 +45,7 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kFPB = 23;       // frames per workgroup tile (23*11 = 253 <= 256 threads)
 constexpr int kNT = 256;
 constexpr int kGenericNT = 256;
-constexpr int kDefaultVariant = 5;   // wave kernel, 8 waves/workgroup, direct global reads, <=128 VGPRs
+constexpr int kDefaultVariant = 8;   // wave kernel, 8 waves/workgroup, direct PCM reads, interval mel scheme
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
@@ -275,19 +275,19 @@ int launch_block_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     return MELSPEC_OK;
 }
 
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1>
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false>
 int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW>, "hipFuncSetAttribute(whisper400_wave_kernel)");
+        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL>, "hipFuncSetAttribute(whisper400_wave_kernel)");
         if (rc) return rc;
         attr_done = true;
     }
     const FastParams fp = fast_params(c, desc);
     const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
     const unsigned grid = grid_for(blocks, c->dev.cus, 16);
-    hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW>), dim3(grid), dim3(WAVES * 64),
-                       c->fast_lds, stream, fp);
+    hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL>), dim3(grid),
+                       dim3(WAVES * 64), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
@@ -317,10 +317,32 @@ int launch_wave_v(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, boo
     }
 }
 
+// interval-scheme variants: 7: 4 waves direct, 8: 8 waves direct (<=128 VGPRs), 9: 8 waves staged (<=128 VGPRs)
+template <int NSLOTS, class StaticLens>
+int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool static_ok) {
+    const int v = c->variant;
+    if (static_ok) {
+        switch (v) {
+            case 7: return launch_wave_t<NSLOTS, true, 4, StaticLens, 1, true>(c, desc, stream);
+            case 8: return launch_wave_t<NSLOTS, true, 8, StaticLens, 4, true>(c, desc, stream);
+            default: return launch_wave_t<NSLOTS, false, 8, StaticLens, 4, true>(c, desc, stream);
+        }
+    }
+    switch (v) {
+        case 7: return launch_wave_t<NSLOTS, true, 4, LensRuntime, 1, true>(c, desc, stream);
+        case 8: return launch_wave_t<NSLOTS, true, 8, LensRuntime, 4, true>(c, desc, stream);
+        default: return launch_wave_t<NSLOTS, false, 8, LensRuntime, 4, true>(c, desc, stream);
+    }
+}
+
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     if (desc.n_units == 0) return MELSPEC_OK;
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     const bool small = c->ft.slots.n_slots <= 8;
+    if (c->variant >= 7) {
+        if (small) return launch_wave_i<8, LensI80>(c, desc, stream, c->lens_kind == 1);
+        return launch_wave_i<12, LensI128>(c, desc, stream, c->lens_kind == 2);
+    }
     if (c->variant == 0) return small ? launch_block_t<8>(c, desc, stream) : launch_block_t<12>(c, desc, stream);
     if (small) return launch_wave_v<8, LensW80>(c, desc, stream, c->lens_kind == 1);
     return launch_wave_v<12, LensW128>(c, desc, stream, c->lens_kind == 2);
@@ -378,13 +400,18 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
 
     // fused kernel: n_fft == 400, even hop (8-byte aligned LDS reads), n_mels <= 132
-    c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft);
+    const char *ev = std::getenv("MELSPEC_VARIANT");
+    const char *el = std::getenv("MELSPEC_RUNTIME_LENS");
+    c->variant = ev ? std::atoi(ev) : kDefaultVariant;
+    if (c->variant < 0 || c->variant > 9) c->variant = kDefaultVariant;
+    c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) &&
+              build_fast_tables(sampling_rate, n_mels, c->ft, c->variant >= 7);
     if (c->fast) {
-        const char *ev = std::getenv("MELSPEC_VARIANT");
-        const char *el = std::getenv("MELSPEC_RUNTIME_LENS");
-        c->variant = ev ? std::atoi(ev) : kDefaultVariant;
-        if (c->variant < 0 || c->variant > 6) c->variant = kDefaultVariant;
-        c->lens_kind = lens_match<LensW80>(c->ft.slots) ? 1 : (lens_match<LensW128>(c->ft.slots) ? 2 : 0);
+        if (c->variant >= 7 && !c->ft.interval) c->variant = 5;   // filterbank is not two-filters-per-bin
+        if (c->variant >= 7)
+            c->lens_kind = lens_match<LensI80>(c->ft.slots) ? 1 : (lens_match<LensI128>(c->ft.slots) ? 2 : 0);
+        else
+            c->lens_kind = lens_match<LensW80>(c->ft.slots) ? 1 : (lens_match<LensW128>(c->ft.slots) ? 2 : 0);
         if (el && el[0] == '1') c->lens_kind = 0;
         if (c->variant == 0) {
             using L = FastLayout<kFPB>;
@@ -392,8 +419,8 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
             c->region_a = L::region_a(hop_size);
             c->fast_lds = sizeof(float) * (c->ft.blob.size() + c->region_a + L::region_b() + L::region_max());
         } else {
-            const bool staged = (c->variant % 2) == 0;
-            const int waves = c->variant <= 2 ? 4 : 8;
+            const bool staged = c->variant <= 6 ? (c->variant % 2) == 0 : c->variant == 9;
+            const int waves = (c->variant <= 2 || c->variant == 7) ? 4 : 8;
             c->frames_per_unit = kFPW;
             c->slice_floats = WaveLayout::slice_floats(hop_size, staged);
             c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(waves) * c->slice_floats);

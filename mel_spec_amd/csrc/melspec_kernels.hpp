@@ -113,7 +113,13 @@ __global__ __launch_bounds__(NT) void whisper400_kernel(const FastParams p) {
 // consecutive frames of one clip and belongs to one wavefront; the WAVES waves of a workgroup
 // share only the table blob.  LDS: [table blob][WAVES x private slice].  No barrier in the loop.
 // ------------------------------------------------------------------------------------
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1>
+// One-lane-down shift across the whole wave (lane l receives lane l+1's value).
+__device__ __forceinline__ float wave_shift_down1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */,
+                                                                 0xf, 0xf, false));
+}
+
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const FastParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
@@ -126,6 +132,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     float *slice = blob + p.blob_len + wave * p.slice_floats;
     const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
     const bool in = lane < kFPW * kMelJobs;
+    // interval scheme: 12 lanes per frame in phases 3-4
+    const int fl3 = INTERVAL ? lane / 12 : fl, j3 = INTERVAL ? lane - fl3 * 12 : j;
+    const bool in3 = INTERVAL ? lane < kFPW * 12 : in;
+    int st[NSLOTS];
+    if (INTERVAL) {
+        const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart);
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
+    }
 
     for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
@@ -134,6 +149,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
+        const bool act3 = in3 && fl3 < nv;
         if (!DIRECT) {
             const int need = (nv - 1) * p.hop + 400;
             for (int i = lane; i < need; i += 64) slice[i] = src[i];
@@ -141,12 +157,20 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         }
         wave_phase1<DIRECT>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
-        wave_phase2(fl, j, act, blob, slice);
+        wave_phase2<!INTERVAL>(fl, j, act, blob, slice);
         __builtin_amdgcn_wave_barrier();
         float vals[NSLOTS];
-        wave_phase3<NSLOTS, Lens>(fl, j, act, p.n_mels, p.slots, blob, slice, vals);
+        if (INTERVAL) {
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            wave_phase3i_finish<NSLOTS>(fl3, j3, act3, p.n_mels, rise, fnext, slice, vals);
+        } else {
+            wave_phase3<NSLOTS, Lens>(fl, j, act, p.n_mels, p.slots, blob, slice, vals);
+        }
         __builtin_amdgcn_wave_barrier();
-        wave_phase4<NSLOTS>(fl, j, act, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels);
+        wave_phase4<NSLOTS>(fl3, j3, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels);
         __builtin_amdgcn_wave_barrier();
     }
 }

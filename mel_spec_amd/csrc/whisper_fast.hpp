@@ -35,13 +35,14 @@ struct FastBlob {
     static constexpr int kTw1 = 400;                     // [10][44] W_200^{t*k1}
     static constexpr int kMod = kTw1 + 10 * kTw1Stride;  // [10] complex W_10^{n2}
     static constexpr int kTw2 = kMod + 20;               // [11][10] complex W_400^{j+20q}
-    static constexpr int kMelStart = kTw2 + kMelJobs * 20;   // [kMaxSlots*11] int bit patterns
-    static constexpr int kMelW = kMelStart + kMaxSlots * kMelJobs;  // padded weights [slot][r][11]
+    static constexpr int kMelStart = kTw2 + kMelJobs * 20;   // [kMaxSlots*12] int bit patterns
+    // banded scheme: padded weights [slot][r][11]; interval scheme: (rise, fall) pairs [slot][r][12][2]
+    static constexpr int kMelW = kMelStart + kMaxSlots * 12;
 };
 
 // Per-launch uniform parameters of the mel slots (scalar registers on the device).
 struct MelSlots {
-    int n_slots;               // ceil(n_mels / 11)
+    int n_slots;               // banded: ceil(n_mels / 11); interval: ceil((n_mels + 1) / 11)
     int len[kMaxSlots];        // padded span length of slot i
     int woff[kMaxSlots];       // float offset of slot i's weights inside the blob
 };

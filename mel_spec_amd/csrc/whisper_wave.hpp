@@ -57,6 +57,26 @@ struct LensStatic {
 using LensW80 = LensStatic<2, 2, 2, 4, 6, 8, 13, 14>;
 using LensW128 = LensStatic<2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 8, 9>;
 
+// Interval scheme (build_interval_mel): padded interval lengths per slot, weights are float pairs
+// over 12 lanes, so a slot of length L occupies 24*L floats.
+template <int... L>
+struct LensIntervalStatic {
+    static constexpr bool kStatic = true;
+    static constexpr int kSlots = sizeof...(L);
+    MS_HD static constexpr int len(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        return t[i];
+    }
+    MS_HD static constexpr int woff(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        int s = 0;
+        for (int k = 0; k < i; ++k) s += t[k];
+        return FastBlob::kMelW + 24 * s;
+    }
+};
+using LensI80 = LensIntervalStatic<1, 1, 1, 2, 3, 4, 7, 7>;
+using LensI128 = LensIntervalStatic<1, 1, 1, 1, 1, 1, 2, 2, 3, 3, 4, 5>;
+
 // 8-byte load from a pointer that is only 4-byte aligned (clip offsets are arbitrary).
 MS_DEV f2 load2_unaligned(const float *p) {
 #if defined(__HIPCC__)
@@ -112,6 +132,8 @@ MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, 
 }
 
 // ---- phase 2: reads the exchange rows, writes the power row over the same slice ----------
+// SCALED: store |X|^2 (x 1/4 applied here); otherwise store 4*|X|^2 (the interval mel weights carry the 1/4).
+template <bool SCALED = true>
 MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *slice) {
     if (!active) return;
     const int brow = (j == 0) ? 20 : 20 - j;
@@ -144,10 +166,68 @@ MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *sl
             const cf wd = cmul(W, D);
             const float ar = S.re + wd.im, ai = S.im - wd.re;
             const float br = S.re - wd.im, bi = S.im + wd.re;
-            p[j + 20 * qq] = 0.25f * (ar * ar + ai * ai);
-            p[200 - j - 20 * qq] = 0.25f * (br * br + bi * bi);
+            const float pk = ar * ar + ai * ai, pm = br * br + bi * bi;
+            p[j + 20 * qq] = SCALED ? 0.25f * pk : pk;
+            p[200 - j - 20 * qq] = SCALED ? 0.25f * pm : pm;
         }
     }
+}
+
+// ---- phase 3, interval scheme: lane (frame, j12) with j12 in [0,12) owns interval j12 + 11*slot ----
+// sums: rise[i] = sum_{k in I} w_rise*P[k] (mel i's rising part), fprev[i] = sum w_fall*P[k] (the
+// falling part of mel i-1).  The kernel then shifts fprev down one lane (DPP) so that lane j12 holds
+// the falling part of its own mel, and calls the finish step.
+template <int NSLOTS, class Lens>
+MS_DEV void wave_phase3i_sums(int fl, int j12, bool active, const MelSlots &ms, const float *blob, const float *slice,
+                              const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
+    if (!active) return;
+    const float *p = slice + fl * WaveLayout::kPStride;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        float ar = 0.0f, af = 0.0f;
+        if (Lens::kStatic) {
+            if (i < Lens::kSlots) {
+                const float *pp = p + st[i];
+                const float *w = blob + Lens::woff(i < Lens::kSlots ? i : 0) + 2 * j12;
+#pragma unroll
+                for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
+                    const f2 wv = *reinterpret_cast<const f2 *>(w + 24 * r);
+                    const float pv = pp[r];
+                    ar += wv.x * pv;
+                    af += wv.y * pv;
+                }
+            }
+        } else if (i < ms.n_slots) {
+            const float *pp = p + st[i];
+            const float *w = blob + ms.woff[i] + 2 * j12;
+            const int len = ms.len[i];
+            for (int r = 0; r < len; ++r) {
+                const f2 wv = *reinterpret_cast<const f2 *>(w + 24 * r);
+                const float pv = pp[r];
+                ar += wv.x * pv;
+                af += wv.y * pv;
+            }
+        }
+        rise[i] = ar;
+        fprev[i] = af;
+    }
+}
+
+template <int NSLOTS>
+MS_DEV void wave_phase3i_finish(int fl, int j12, bool active, int n_mels, const float (&rise)[NSLOTS],
+                                const float (&fnext)[NSLOTS] /* fprev of lane+1 */, float *slice, float (&vals)[NSLOTS]) {
+    if (!active) return;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const float e = rise[i] + fnext[i];
+        const float v = e > 1e-10f ? fast_log2(e) * 0.30102999566398120f : -10.0f;
+        vals[i] = v;
+        if (j12 < kMelJobs && j12 + kMelJobs * i < n_mels) mx = __builtin_fmaxf(mx, v);
+    }
+    slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j12] = mx;
 }
 
 // ---- phase 3: banded mel projection + log10, per-thread max to LDS ------------------------
@@ -198,7 +278,7 @@ MS_DEV void wave_phase4(int fl, int j, bool active, int n_mels, const float *sli
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
-        if (m < n_mels) {
+        if (j < kMelJobs && m < n_mels) {
             const float v = __builtin_fmaxf(vals[i], lo);
             o[kMelJobs * i] = (v + 4.0f) * 0.25f;
         }

@@ -53,10 +53,11 @@ extern "C" long long emu_whisper_fast(const float *pcm, long long n, int hop, in
 
 // Wave-autonomous kernel (whisper_wave.hpp): one 64-lane wave per 5-frame unit, one phase at a
 // time over all lanes, the slice poisoned where the kernel promises not to read.
-template <int NSLOTS, bool DIRECT, class Lens>
+template <int NSLOTS, bool DIRECT, class Lens, bool INTERVAL = false>
 static long long run_wave(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
     FastTables T;
-    if (!build_fast_tables(sr, n_mels, T)) return -1;
+    if (!build_fast_tables(sr, n_mels, T, INTERVAL)) return -1;
+    if (INTERVAL && !T.interval) return -3;
     if (n < 400) return 0;
     const long long frames = (n - 400) / hop + 1;
     std::vector<float> slice(WaveLayout::slice_floats(hop, !DIRECT));
@@ -84,22 +85,47 @@ static long long run_wave(const float *pcm, long long n, int hop, int n_mels, do
             const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
             const bool act = lane < kFPW * kMelJobs && fl < nv;
             std::vector<float> tmp(snap);
-            wave_phase2(fl, j, act, T.blob.data(), tmp.data());
+            wave_phase2<!INTERVAL>(fl, j, act, T.blob.data(), tmp.data());
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
-        for (int lane = 0; lane < 64; ++lane) {
-            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
-            const bool act = lane < kFPW * kMelJobs && fl < nv;
-            std::vector<float> tmp(snap);
-            wave_phase3<NSLOTS, Lens>(fl, j, act, n_mels, T.slots, T.blob.data(), tmp.data(),
-                                      *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
-            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        if (INTERVAL) {
+            std::vector<float> rise(64 * NSLOTS), fprev(64 * NSLOTS + NSLOTS, 0.0f);
+            const int *starts = reinterpret_cast<const int *>(T.blob.data() + FastBlob::kMelStart);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int fl = lane / 12, j = lane - fl * 12;
+                const bool act = lane < kFPW * 12 && fl < nv;
+                int st[NSLOTS];
+                for (int i = 0; i < NSLOTS; ++i) st[i] = lane < kFPW * 12 ? starts[i * 12 + j] : 0;
+                wave_phase3i_sums<NSLOTS, Lens>(fl, j, act, T.slots, T.blob.data(), snap.data(), st,
+                                                *reinterpret_cast<float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                                *reinterpret_cast<float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane) * NSLOTS]));
+            }
+            for (int lane = 0; lane < 64; ++lane) {     // wave_shl:1 -> lane l sees lane l+1
+                const int fl = lane / 12, j = lane - fl * 12;
+                const bool act = lane < kFPW * 12 && fl < nv;
+                std::vector<float> tmp(snap);
+                wave_phase3i_finish<NSLOTS>(fl, j, act, n_mels,
+                                            *reinterpret_cast<const float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                            *reinterpret_cast<const float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane + 1) * NSLOTS]),
+                                            tmp.data(), *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+                for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+            }
+        } else {
+            for (int lane = 0; lane < 64; ++lane) {
+                const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+                const bool act = lane < kFPW * kMelJobs && fl < nv;
+                std::vector<float> tmp(snap);
+                wave_phase3<NSLOTS, Lens>(fl, j, act, n_mels, T.slots, T.blob.data(), tmp.data(),
+                                          *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+                for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+            }
         }
         slice = next;
         for (int lane = 0; lane < 64; ++lane) {
-            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
-            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            const int G = INTERVAL ? 12 : kMelJobs;
+            const int fl = lane / G, j = lane - fl * G;
+            const bool act = lane < kFPW * G && fl < nv;
             wave_phase4<NSLOTS>(fl, j, act, n_mels, slice.data(),
                                 *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
                                 out + f0 * n_mels);
@@ -116,9 +142,21 @@ static bool lens_ok(const MelSlots &ms) {
     return true;
 }
 
-// mode: 0 direct+runtime lens, 1 staged+runtime lens, 2 direct+static lens (only 16 kHz 80/128), 3 staged+static
+// mode: 0 direct+runtime lens, 1 staged+runtime lens, 2 direct+static lens (only 16 kHz 80/128), 3 staged+static,
+//       4 interval scheme + runtime lens, 5 interval scheme + static lens
 extern "C" long long emu_whisper_wave(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
     FastTables T;
+    if (mode >= 4) {
+        if (!build_fast_tables(sr, n_mels, T, true)) return -1;
+        if (!T.interval) return -3;
+        if (mode == 5) {
+            if (lens_ok<LensI80>(T.slots)) return run_wave<8, true, LensI80, true>(pcm, n, hop, n_mels, sr, out);
+            if (lens_ok<LensI128>(T.slots)) return run_wave<12, true, LensI128, true>(pcm, n, hop, n_mels, sr, out);
+            return -2;
+        }
+        if (T.slots.n_slots <= 8) return run_wave<8, true, LensRuntime, true>(pcm, n, hop, n_mels, sr, out);
+        return run_wave<12, true, LensRuntime, true>(pcm, n, hop, n_mels, sr, out);
+    }
     if (!build_fast_tables(sr, n_mels, T)) return -1;
     const bool direct = (mode % 2) == 0, stat = mode >= 2;
     if (stat) {
