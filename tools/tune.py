@@ -33,7 +33,7 @@ for v in variants:
     assert worst <= 1e-4, (v, worst)
 for r in range(rounds):
     for v in variants:
-        res[v].append(ctxs[v].time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=2, iters=10))
+        res[v].append(ctxs[v].time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=int(os.environ.get("TUNE_WARMUP","2")), iters=int(os.environ.get("TUNE_ITERS","10"))))
 frames = n_clips * fpc
 for v in variants:
     ms = np.array(res[v])
