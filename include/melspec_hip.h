@@ -134,6 +134,8 @@ int melspec_fbank_create(melspec_fbank **out, int device, const melspec_fbank_co
 void melspec_fbank_destroy(melspec_fbank *fb);
 size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples); /* src/fbank.rs:147-151 */
 int melspec_fbank_num_mel_bins(const melspec_fbank *fb);
+/* 1 if this configuration runs on the fused 512-point kernel, 0 if on the generic f64 kernel. */
+int melspec_fbank_uses_fast_path(const melspec_fbank *fb);
 /* Fbank::compute(&self, samples) -> Array2<f32> (frames, num_mel_bins) (src/fbank.rs:141-236). */
 int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n_samples,
                                float *out, size_t out_capacity_floats, size_t *n_frames);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "melspec_fbank_destroy": (None, [_vp]),
     "melspec_fbank_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
     "melspec_fbank_num_mel_bins": (C.c_int, [_vp]),
+    "melspec_fbank_uses_fast_path": (C.c_int, [_vp]),
     "melspec_fbank_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_fbank_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "melspec_fbank_synchronize": (C.c_int, [_vp, _vp]),

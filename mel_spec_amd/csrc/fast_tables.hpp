@@ -25,7 +25,9 @@ struct FastTables {
 // always in the next lane).  Weights are pre-scaled by 1/4 (phase 2 then stores 4*|X|^2).
 // Returns false if some non-zero weight violates the two-filters-per-bin structure.
 inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int bins, int bin_limit,
-                               std::vector<float> &b, MelSlots &slots) {
+                               std::vector<float> &b, MelSlots &slots, int lanes = 12, double scale = 0.25,
+                               int starts_off = FastBlob::kMelStart) {
+    const int real = lanes - 1;   // intervals per slot (the last lane of a group is the ghost)
     // interval of bin k = the filter whose rising part contains it = last row that is non-zero at k
     // and whose peak is at or after k; derive it from the matrix itself: rows non-zero at k are
     // {i-1, i} (or one of them); i is the larger one unless k sits on filter (i-1)'s falling side only.
@@ -58,21 +60,21 @@ inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int
         else if (first[idx[k]] + cnt[idx[k]] != k) return false;   // hole inside an interval
         ++cnt[idx[k]];
     }
-    const int n_slots = (n_int + kMelJobs - 1) / kMelJobs;
+    const int n_slots = (n_int + real - 1) / real;
     if (n_slots > kMaxSlots) return false;
     slots = MelSlots{};
     slots.n_slots = n_slots;
     for (int s = 0; s < n_slots; ++s) {
         int L = 0;
-        for (int j = 0; j < 12; ++j) {
-            const int i = s * kMelJobs + j;
+        for (int j = 0; j < lanes; ++j) {
+            const int i = s * real + j;
             if (i < n_int && cnt[i] > L) L = cnt[i];
         }
         slots.len[s] = L;
         slots.woff[s] = static_cast<int>(b.size());
-        b.resize(b.size() + static_cast<size_t>(L) * 24, 0.0f);
-        for (int j = 0; j < 12; ++j) {
-            const int i = s * kMelJobs + j;
+        b.resize(b.size() + static_cast<size_t>(L) * lanes * 2, 0.0f);
+        for (int j = 0; j < lanes; ++j) {
+            const int i = s * real + j;
             int st = 0;
             if (i < n_int && cnt[i] > 0) {
                 st = first[i];
@@ -82,11 +84,11 @@ inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int
                     if (idx[k] != i) continue;       // padding bins belong to a neighbour interval
                     const double rise = i < n_mels ? dense[static_cast<size_t>(i) * bins + k] : 0.0;
                     const double fall = i >= 1 ? dense[static_cast<size_t>(i - 1) * bins + k] : 0.0;
-                    b[slots.woff[s] + (r * 12 + j) * 2] = static_cast<float>(0.25 * rise);
-                    b[slots.woff[s] + (r * 12 + j) * 2 + 1] = static_cast<float>(0.25 * fall);
+                    b[slots.woff[s] + (r * lanes + j) * 2] = static_cast<float>(scale * rise);
+                    b[slots.woff[s] + (r * lanes + j) * 2 + 1] = static_cast<float>(scale * fall);
                 }
             }
-            std::memcpy(&b[FastBlob::kMelStart + s * 12 + j], &st, sizeof(int));
+            std::memcpy(&b[starts_off + s * lanes + j], &st, sizeof(int));
         }
     }
     return true;

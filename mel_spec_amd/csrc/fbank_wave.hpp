@@ -1,0 +1,211 @@
+// fbank_wave.hpp -- fused Kaldi-fbank frame pipeline (default geometry: 400-sample frames, 512-point
+// FFT), wave-autonomous like whisper_wave.hpp: one wavefront owns kFbFPW = 7 whole frames,
+// lane = 9*frame + j.  Reference: Fbank::compute, src/fbank.rs:141-236.
+//
+// Arithmetic type T.  Unlike the Whisper path there is no per-frame clamp here: ln(E) of a mel band
+// 90 dB below the frame's strongest band is an output, and rounding the *windowed frame itself* to
+// f32 already puts a noise floor ~-149 dB per bin under the frame energy, i.e. ~2e-3 relative error on
+// such a band (measured on jfk_f32le.wav: 2.1e-3).  The reference computes in f64 (src/fbank.rs:154-158),
+// so the parity build is T = double from the window multiply to |X|^2; T = float is kept for
+// throughput experiments only.
+//
+//   DC removal + pre-emphasis + Povey window (src/fbank.rs:164-190)
+//       y[i] = (x[i]-m) - a*(x[i-1]-m) = x[i] - a*x[i-1] - (1-a)*m,   frame[i] = y[i]*w[i]
+//       (for the very first sample of a clip the reference applies no pre-emphasis: y[0] = x[0]-m,
+//        which is the same formula with x[-1] := m)
+//   zero-pad to 512, forward FFT (src/fbank.rs:184-194): real-512 as complex-256 = 16 x 16,
+//       z[n] = x[2n] + i*x[2n+1];  n = 16*n1 + n2,  k = k1 + 16*k2
+//       phase 1: lane t<8 does the 16-point DFTs over n1 for n2 = t and n2 = t+8 (inputs beyond
+//                sample 399 are literal zeros), multiplies by W_256^{n2*k1}, writes row k1
+//       phase 2: lane j<9 owns residues a=j and b=16-j (j=0: row 0 and its W_16^{n2}-modulated copy,
+//                j=8: row 8 twice), two 16-point DFTs, Hermitian split -> bins k=a+16q and 256-k
+//   power, bins 0..=256 (src/fbank.rs:197-203), stored as f32 (sums of non-negative terms from here on)
+//   sparse mel, floor, ln (src/fbank.rs:205-221): interval scheme, 9 lanes per frame
+//   CMN (src/fbank.rs:224-233) is a second kernel (cmn_kernel) because it is a per-clip reduction.
+#pragma once
+#include "whisper_wave.hpp"
+
+namespace melspec {
+
+constexpr int kFbFPW = 7;        // frames per wavefront (7 * 9 = 63 lanes)
+constexpr int kFbLanes = 9;      // lanes per frame: 8 workers + 1 (ghost in phase 3, 9th job in phase 2)
+constexpr int kFbSlots = 11;     // intervals j + 8*slot, up to 87 mel bins
+
+template <class T> struct PairOf;
+template <> struct PairOf<float> { using type = f2; };
+template <> struct PairOf<double> { using type = d2; };
+template <class T> MS_DEV cpx<T> ldc(const T *p) {
+    const typename PairOf<T>::type v = *reinterpret_cast<const typename PairOf<T>::type *>(p);
+    return {v.x, v.y};
+}
+template <class T> MS_DEV void stc(T *p, cpx<T> v) {
+    *reinterpret_cast<typename PairOf<T>::type *>(p) = typename PairOf<T>::type{v.re, v.im};
+}
+
+// Table blob: a T-typed part (offsets in units of T) followed by the f32/int mel section.
+struct FbankBlob {
+    static constexpr int kWin = 0;                         // [400] Povey window
+    static constexpr int kTw1Stride = 36;                  // 16 complex + 4 pad
+    static constexpr int kTw1 = 400;                       // [16 n2][36] W_256^{n2*k1}
+    static constexpr int kMod = kTw1 + 16 * kTw1Stride;    // [16] complex W_16^{n2}
+    static constexpr int kTw2Stride = 36;
+    static constexpr int kTw2 = kMod + 32;                 // [9][36] complex W_512^{j+16q}
+    static constexpr int kTCount = kTw2 + 9 * kTw2Stride;  // 1332 elements of T
+    // mel section, float offsets from its own base
+    static constexpr int kMelStart = 0;                                // [kFbSlots*9] ints
+    static constexpr int kMelW = (kFbSlots * kFbLanes + 3) & ~3;       // pairs [slot][r][9][2]
+};
+
+template <class T>
+struct FbankLayout {
+    // exchange rows, units of T; padded so that the 9 lanes of a frame reading 9 different rows hit
+    // different banks (f64: 16-byte complex reads, rows 68 words apart)
+    static constexpr int kXRow = sizeof(T) == 8 ? 34 : 32;
+    static constexpr int kXStride = sizeof(T) == 8 ? 17 * 34 + 2 : 17 * 32 + 16;
+    static constexpr int kPStride = 259;                   // f32 power rows (bins 0..256), aliased over the rows
+    static constexpr int kSumOff = kFbFPW * kXStride;      // 64 partial sums (units of T)
+    static constexpr int slice_elems() { return (kFbFPW * kXStride + 64 + 1) & ~1; }   // units of T
+};
+
+// frame-sum partial: lane (f,t<8) adds its 50 samples (pairs 32*n1 + 2t + {0,1} and +16)
+template <class T>
+MS_DEV T fb_partial_sum(const float *frame, int t) {
+    T s = 0;
+#pragma unroll
+    for (int n1 = 0; n1 < 13; ++n1) {
+        const f2 a = load2_unaligned(frame + 32 * n1 + 2 * t);
+        s += static_cast<T>(a.x) + static_cast<T>(a.y);
+        if (n1 < 12) {
+            const f2 b = load2_unaligned(frame + 32 * n1 + 16 + 2 * t);
+            s += static_cast<T>(b.x) + static_cast<T>(b.y);
+        }
+    }
+    return s;
+}
+
+// One 16-point column: samples frame[32*n1 + off + {0,1}], n1 < NV (the rest of the 512-point frame is
+// zero padding), pre-emphasis, DC removal, window, DFT over n1, twiddle by W_256^{n2*k1}, exchange rows.
+template <class T, int NV>
+MS_DEV void fb_column(const float *frame, int off, int n2, T preemph, T mean, bool patch_first, const T *tblob,
+                      T *xo /* &row[0][n2] */) {
+    using L = FbankLayout<T>;
+    cpx<T> x[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        if (n1 < NV) {
+            const int i = 32 * n1 + off;
+            // frame_buf[i] = x[i] - mean; frame_buf[i] -= preemph * frame_buf[i-1]  (src/fbank.rs:165-181);
+            // the first sample of a clip gets no pre-emphasis
+            const f2 s = load2_unaligned(frame + i);
+            const T b0 = static_cast<T>(s.x) - mean, b1 = static_cast<T>(s.y) - mean;
+            T y0 = b0;
+            if (!(n1 == 0 && patch_first)) y0 = b0 - preemph * (static_cast<T>(frame[i - 1]) - mean);
+            const T y1 = b1 - preemph * b0;
+            const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
+            x[n1] = {y0 * w.re, y1 * w.im};
+        } else {
+            x[n1] = {T(0), T(0)};
+        }
+    }
+    fft16(x);
+    const T *tw = tblob + FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride;
+    stc(xo, x[0]);
+    stc(xo + 16 * L::kXRow, cmul(x[0], ldc(tblob + FbankBlob::kMod + 2 * n2)));
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) stc(xo + k1 * L::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
+}
+
+// phase 1 (after the frame mean is known): lane t<8 does columns n2 = t (13 non-zero inputs) and
+// n2 = t+8 (12 non-zero inputs).
+template <class T>
+MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this frame's first sample */, bool clip_start,
+                      T mean, T preemph, const T *tblob, T *slice) {
+    if (!active) return;
+    T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
+    fb_column<T, 13>(frame, 2 * t, t, preemph, mean, clip_start && t == 0, tblob, xo);
+    fb_column<T, 12>(frame, 16 + 2 * t, t + 8, preemph, mean, false, tblob, xo + 16);
+}
+
+// phase 2: two 16-point DFTs, Hermitian split with W_512, 4*power (or 2*magnitude) as f32 to LDS.
+// The power rows (f32) are written over the exchange rows of the same wave.
+template <class T>
+MS_DEV void fb_phase2(int fl, int j, bool active, bool use_power, const T *tblob, T *slice) {
+    if (!active) return;
+    using L = FbankLayout<T>;
+    const int brow = (j == 0) ? 16 : 16 - j;
+    const T *ua = slice + fl * L::kXStride + j * L::kXRow;
+    const T *va = slice + fl * L::kXStride + brow * L::kXRow;
+    cpx<T> u[16], v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        u[i] = ldc(ua + 2 * i);
+        v[i] = ldc(va + 2 * i);
+    }
+    fft16(u);
+    fft16(v);
+    const T *tw = tblob + FbankBlob::kTw2 + j * FbankBlob::kTw2Stride;
+    float *p = reinterpret_cast<float *>(slice) + fl * L::kPStride;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const cpx<T> zk = u[q], zm = v[15 - q];
+        const cpx<T> S = {zk.re + zm.re, zk.im - zm.im};
+        const cpx<T> D = {zk.re - zm.re, zk.im + zm.im};
+        const cpx<T> wd = cmul(ldc(tw + 2 * q), D);
+        const T ar = S.re + wd.im, ai = S.im - wd.re;
+        const T br = S.re - wd.im, bi = S.im + wd.re;
+        float pk = static_cast<float>(ar * ar + ai * ai), pm = static_cast<float>(br * br + bi * bi);   // 4*|X|^2
+        if (!use_power) {                                                                         // 2*|X|
+            pk = __builtin_sqrtf(pk);
+            pm = __builtin_sqrtf(pm);
+        }
+        p[j + 16 * q] = pk;
+        p[256 - j - 16 * q] = pm;
+    }
+}
+
+// phase 3: interval sums over 9-lane groups (lane j<8 owns interval j + 8*slot, j=8 is the ghost)
+template <class T>
+MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *mel /* mel section base */,
+                           const T *slice, const int (&st)[kFbSlots], float (&rise)[kFbSlots], float (&fprev)[kFbSlots]) {
+#pragma unroll
+    for (int i = 0; i < kFbSlots; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
+    if (!active) return;
+    const float *p = reinterpret_cast<const float *>(slice) + fl * FbankLayout<T>::kPStride;
+#pragma unroll
+    for (int i = 0; i < kFbSlots; ++i) {
+        float ar = 0.0f, af = 0.0f;
+        if (i < ms.n_slots) {
+            const float *pp = p + st[i];
+            const float *w = mel + ms.woff[i] + 2 * j;
+            const int len = ms.len[i];
+            for (int r = 0; r < len; ++r) {
+                const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kFbLanes * r);
+                const float pv = pp[r];
+                ar += wv.x * pv;
+                af += wv.y * pv;
+            }
+        }
+        rise[i] = ar;
+        fprev[i] = af;
+    }
+}
+
+MS_DEV float fast_ln(float x) { return fast_log2(x) * 0.69314718055994531f; }
+
+// floor, ln, store (src/fbank.rs:207-221).  out_tile = &out[first frame of the tile][0]
+MS_DEV void fb_phase3_store(int fl, int j, bool active, int n_mels, float floor_v, bool use_log,
+                            const float (&rise)[kFbSlots], const float (&fnext)[kFbSlots], float *out_tile) {
+    if (!active || j >= 8) return;
+    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+#pragma unroll
+    for (int i = 0; i < kFbSlots; ++i) {
+        const int m = j + 8 * i;
+        if (m < n_mels) {
+            float e = rise[i] + fnext[i];
+            e = __builtin_fmaxf(e, floor_v);
+            o[8 * i] = use_log ? fast_ln(e) : e;
+        }
+    }
+}
+
+}  // namespace melspec

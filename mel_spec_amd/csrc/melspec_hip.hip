@@ -17,6 +17,7 @@
 
 #include "../../include/melspec_hip.h"
 #include "fast_tables.hpp"
+#include "fbank_tables.hpp"
 #include "melspec_kernels.hpp"
 #include "tables.hpp"
 
@@ -586,9 +587,17 @@ struct melspec_fbank {
     melspec_fbank_config cfg{};
     int frame_len = 0, frame_shift = 0, fft_size = 0;
     hipStream_t stream = nullptr;
+    bool fast = false;          // fused 512-point kernel (default Kaldi geometry) vs generic f64 kernel
+    FbankFastTables ft;
+    DevBuf d_blob;
+    size_t fast_lds = 0;
     GenericTables gt;
     DevBuf h2d, d2h;
 };
+
+namespace {
+constexpr int kFbWaves = 4;
+}  // namespace
 
 namespace {
 uint64_t fbank_frames(const melspec_fbank *fb, uint64_t n) {
@@ -630,6 +639,27 @@ int melspec_fbank_create(melspec_fbank **out, int device, const melspec_fbank_co
     if (hipStreamCreate(&fb->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
     const double high = cfg->high_freq == 0.0 ? cfg->sample_rate / 2.0 : cfg->high_freq;
     const int bins = fft_size / 2 + 1;
+    // MELSPEC_FBANK=generic forces the f64 direct-DFT kernel; =f32 selects the f32 build of the fused
+    // kernel (throughput experiments only: it cannot hold 1e-4 on quiet mel bands, see fbank_wave.hpp)
+    const char *eg = std::getenv("MELSPEC_FBANK");
+    const bool want_generic = eg && std::strcmp(eg, "generic") == 0;
+    const bool want_f32 = eg && std::strcmp(eg, "f32") == 0;
+    fb->fast = !want_generic && frame_len == 400 && fft_size == 512 &&
+               (want_f32 ? build_fbank_fast_tables<float>(cfg->sample_rate, cfg->num_mel_bins, cfg->low_freq, high,
+                                                          cfg->use_power != 0, fb->ft)
+                         : build_fbank_fast_tables<double>(cfg->sample_rate, cfg->num_mel_bins, cfg->low_freq, high,
+                                                           cfg->use_power != 0, fb->ft));
+    if (fb->fast) {
+        const size_t slice_bytes = fb->ft.f64 ? FbankLayout<double>::slice_elems() * sizeof(double)
+                                              : FbankLayout<float>::slice_elems() * sizeof(float);
+        fb->fast_lds = fb->ft.blob.size() * 4 + static_cast<size_t>(kFbWaves) * slice_bytes;
+        if (fb->fast_lds > kLdsLimit) fb->fast = false;
+    }
+    if (fb->fast) {
+        if ((rc = upload(fb->d_blob, fb->ft.blob))) return bail(rc);
+        if ((rc = allow_big_lds(&fbank512_wave_kernel<double, kFbWaves, 1>, "hipFuncSetAttribute(fbank512_wave_kernel<f64>)"))) return bail(rc);
+        if ((rc = allow_big_lds(&fbank512_wave_kernel<float, kFbWaves, 1>, "hipFuncSetAttribute(fbank512_wave_kernel<f32>)"))) return bail(rc);
+    }
     const std::vector<double> dense = kaldi_mel_filterbank(cfg->sample_rate, fft_size, cfg->num_mel_bins, cfg->low_freq, high);
     if ((rc = fb->gt.build(fft_size, frame_len, bins, povey_window(frame_len), dense, cfg->num_mel_bins, bins))) return bail(rc);
     if (fb->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
@@ -642,7 +672,7 @@ void melspec_fbank_destroy(melspec_fbank *fb) {
     if (!fb) return;
     if (fb->dev.device >= 0) (void)hipSetDevice(fb->dev.device);
     if (fb->stream) { (void)hipStreamSynchronize(fb->stream); (void)hipStreamDestroy(fb->stream); }
-    fb->gt.release(); fb->h2d.release(); fb->d2h.release();
+    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release();
     delete fb;
 }
 
@@ -650,6 +680,7 @@ size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples) {
     return fb ? static_cast<size_t>(fbank_frames(fb, n_samples)) : 0;
 }
 int melspec_fbank_num_mel_bins(const melspec_fbank *fb) { return fb ? fb->cfg.num_mel_bins : 0; }
+int melspec_fbank_uses_fast_path(const melspec_fbank *fb) { return fb && fb->fast ? 1 : 0; }
 
 int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                          uint32_t n_clips, float *d_out, void *stream) {
@@ -661,10 +692,34 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
     HIP_TRY(hipSetDevice(fb->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fb->stream;
     const int nm = fb->cfg.num_mel_bins;
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, nm, 1);
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, nm, fb->fast ? kFbFPW : 1);
     const double floor_v = fb->cfg.energy_floor > 0.0 ? fb->cfg.energy_floor : static_cast<double>(FLT_EPSILON);
-    int rc = launch_generic(fb->gt, pl.desc, fb->frame_shift, true, fb->cfg.use_log_fbank, fb->cfg.use_power,
+    int rc = MELSPEC_OK;
+    if (fb->fast) {
+        FbankFastParams fp{};
+        fp.b = pl.desc;
+        fp.d_blob = static_cast<const uint32_t *>(fb->d_blob.p);
+        fp.blob_words = static_cast<int>(fb->ft.blob.size());
+        fp.mel_off_words = fb->ft.mel_off_words;
+        fp.shift = fb->frame_shift;
+        fp.n_mels = nm;
+        fp.preemph = fb->cfg.preemphasis > 0.0 ? fb->cfg.preemphasis : 0.0;   // src/fbank.rs:172
+        fp.floor_v = static_cast<float>(floor_v);
+        fp.use_log = fb->cfg.use_log_fbank;
+        fp.use_power = fb->cfg.use_power;
+        fp.slots = fb->ft.slots;
+        const uint64_t blocks = (pl.desc.n_units + kFbWaves - 1) / kFbWaves;
+        const unsigned grid = grid_for(blocks, fb->dev.cus, 16);
+        if (fb->ft.f64)
+            hipLaunchKernelGGL((fbank512_wave_kernel<double, kFbWaves, 1>), dim3(grid), dim3(kFbWaves * 64), fb->fast_lds, s, fp);
+        else
+            hipLaunchKernelGGL((fbank512_wave_kernel<float, kFbWaves, 1>), dim3(grid), dim3(kFbWaves * 64), fb->fast_lds, s, fp);
+        HIP_TRY(hipGetLastError());
+        // the CMN pass below walks clips, not units
+    } else {
+        rc = launch_generic(fb->gt, pl.desc, fb->frame_shift, true, fb->cfg.use_log_fbank, fb->cfg.use_power,
                             fb->cfg.preemphasis, floor_v, fb->dev.cus, s);
+    }
     if (rc) return rc;
     if (fb->cfg.apply_cmn) {
         CmnParams cp{};

@@ -11,6 +11,7 @@
 
 #include "whisper_fast.hpp"
 #include "whisper_wave.hpp"
+#include "fbank_wave.hpp"
 
 namespace melspec {
 
@@ -171,6 +172,77 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         }
         __builtin_amdgcn_wave_barrier();
         wave_phase4<NSLOTS>(fl3, j3, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Fused Kaldi-fbank kernel (phases in fbank_wave.hpp): 7 frames per wavefront, no workgroup barrier
+// in the loop.  Writes un-normalised features; CMN is cmn_kernel.
+// ------------------------------------------------------------------------------------
+struct FbankFastParams {
+    BatchDesc b;            // units of kFbFPW frames
+    const uint32_t *d_blob;
+    int blob_words;         // 32-bit words, multiple of 4
+    int mel_off_words;      // mel section offset inside the blob
+    int shift;              // frame shift in samples
+    int n_mels;
+    double preemph;
+    float floor_v;
+    int use_log, use_power;
+    MelSlots slots;
+};
+
+template <class T, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const FbankFastParams p) {
+    using L = FbankLayout<T>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    __syncthreads();
+    const T *tblob = reinterpret_cast<const T *>(ldsw);
+    const float *mel = reinterpret_cast<const float *>(ldsw + p.mel_off_words);
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    T *slice = reinterpret_cast<T *>(ldsw + p.blob_words) + wave * L::slice_elems();
+    const int fl = lane / kFbLanes, j = lane - fl * kFbLanes;
+    const bool in = lane < kFbFPW * kFbLanes;
+    int st[kFbSlots];
+    {
+        const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+#pragma unroll
+        for (int i = 0; i < kFbSlots; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
+    }
+    const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
+    const T preemph = static_cast<T>(p.preemph);
+
+    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * kFbFPW;
+        const uint64_t left = loc.frames - f0;
+        const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
+        const bool act = in && fl < nv;
+        const bool act1 = act && j < 8;
+        const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
+        // frame mean (src/fbank.rs:165-166): 8 partial sums of 50 samples through LDS
+        slice[L::kSumOff + lane] = act1 ? fb_partial_sum<T>(frame, j) : T(0);
+        __builtin_amdgcn_wave_barrier();
+        T mean = 0;
+        if (act) {
+            const T *ps = slice + L::kSumOff + fl * kFbLanes;
+            mean = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / T(400);
+        }
+        __builtin_amdgcn_wave_barrier();
+        fb_phase1<T>(fl, j, act1, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+        __builtin_amdgcn_wave_barrier();
+        fb_phase2<T>(fl, j, act, use_power, tblob, slice);
+        __builtin_amdgcn_wave_barrier();
+        float rise[kFbSlots], fprev[kFbSlots], fnext[kFbSlots];
+        fb_phase3_sums<T>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
+#pragma unroll
+        for (int i = 0; i < kFbSlots; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+        fb_phase3_store(fl, j, act, p.n_mels, p.floor_v, use_log, rise, fnext, loc.out + f0 * (uint64_t)p.n_mels);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -259,6 +259,10 @@ class Fbank:
     def num_frames(self, n_samples: int) -> int:
         return int(lib().melspec_fbank_num_frames(self._h, n_samples))
 
+    @property
+    def uses_fast_path(self) -> bool:
+        return bool(lib().melspec_fbank_uses_fast_path(self._h))
+
     def compute(self, samples) -> np.ndarray:
         """&[f32] -> Array2<f32> (num_frames, num_mel_bins)."""
         x = _f32(samples).reshape(-1)

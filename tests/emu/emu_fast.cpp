@@ -11,6 +11,7 @@
 
 #include "../../mel_spec_amd/csrc/fast_tables.hpp"
 #include "../../mel_spec_amd/csrc/whisper_wave.hpp"
+#include "../../mel_spec_amd/csrc/fbank_tables.hpp"
 
 using namespace melspec;
 
@@ -169,6 +170,80 @@ extern "C" long long emu_whisper_wave(const float *pcm, long long n, int hop, in
     if (n_mels <= 88)
         return direct ? run_wave<8, true, LensRuntime>(pcm, n, hop, n_mels, sr, out) : run_wave<8, false, LensRuntime>(pcm, n, hop, n_mels, sr, out);
     return direct ? run_wave<12, true, LensRuntime>(pcm, n, hop, n_mels, sr, out) : run_wave<12, false, LensRuntime>(pcm, n, hop, n_mels, sr, out);
+}
+
+// Fused fbank kernel (fbank_wave.hpp), default geometry, no CMN.  out = [frames][n_mels].
+template <class T>
+static long long run_fbank(const float *pcm, long long n, int shift, int n_mels, double sr, double low, double high,
+                           double preemph, float floor_v, int use_log, int use_power, float *out) {
+    using L = FbankLayout<T>;
+    FbankFastTables F;
+    if (!build_fbank_fast_tables<T>(sr, n_mels, low, high, use_power != 0, F)) return -1;
+    const T *tblob = reinterpret_cast<const T *>(F.blob.data());
+    const float *mel = reinterpret_cast<const float *>(F.blob.data() + F.mel_off_words);
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / shift + 1;
+    std::vector<T> slice(L::slice_elems());
+    const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+    for (long long f0 = 0; f0 < frames; f0 += kFbFPW) {
+        const int nv = static_cast<int>(std::min<long long>(kFbFPW, frames - f0));
+        std::fill(slice.begin(), slice.end(), T(1.0e30));
+        auto lane_info = [&](int lane, int &fl, int &j, bool &act) {
+            fl = lane / kFbLanes; j = lane - fl * kFbLanes; act = lane < kFbFPW * kFbLanes && fl < nv;
+        };
+        std::vector<T> mean(64, T(0));
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            slice[L::kSumOff + lane] = (act && j < 8) ? fb_partial_sum<T>(pcm + (f0 + fl) * shift, j) : T(0);
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            if (!act) continue;
+            const T *ps = slice.data() + L::kSumOff + fl * kFbLanes;
+            mean[lane] = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / T(400);
+        }
+        std::vector<T> snap(slice), next(slice);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            std::vector<T> tmp(snap);
+            fb_phase1<T>(fl, j, act && j < 8, pcm + (f0 + (act ? fl : 0)) * shift, f0 + fl == 0, mean[lane], static_cast<T>(preemph), tblob, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            std::vector<T> tmp(snap);
+            fb_phase2<T>(fl, j, act, use_power != 0, tblob, tmp.data());
+            // power rows are f32 written into the T-typed slice: compare bytes
+            const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
+            uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
+            for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];
+        }
+        slice = next;
+        std::vector<float> rise(64 * kFbSlots), fprev(65 * kFbSlots, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            int st[kFbSlots];
+            for (int i = 0; i < kFbSlots; ++i) st[i] = lane < kFbFPW * kFbLanes ? starts[i * kFbLanes + j] : 0;
+            fb_phase3_sums<T>(fl, j, act, F.slots, mel, slice.data(), st,
+                              *reinterpret_cast<float(*)[kFbSlots]>(&rise[static_cast<size_t>(lane) * kFbSlots]),
+                              *reinterpret_cast<float(*)[kFbSlots]>(&fprev[static_cast<size_t>(lane) * kFbSlots]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            fb_phase3_store(fl, j, act, n_mels, floor_v, use_log != 0,
+                            *reinterpret_cast<const float(*)[kFbSlots]>(&rise[static_cast<size_t>(lane) * kFbSlots]),
+                            *reinterpret_cast<const float(*)[kFbSlots]>(&fprev[static_cast<size_t>(lane + 1) * kFbSlots]),
+                            out + f0 * n_mels);
+        }
+    }
+    return frames;
+}
+
+extern "C" long long emu_fbank_wave(const float *pcm, long long n, int shift, int n_mels, double sr, double low, double high,
+                                    double preemph, float floor_v, int use_log, int use_power, int f64, float *out) {
+    return f64 ? run_fbank<double>(pcm, n, shift, n_mels, sr, low, high, preemph, floor_v, use_log, use_power, out)
+               : run_fbank<float>(pcm, n, shift, n_mels, sr, low, high, preemph, floor_v, use_log, use_power, out);
 }
 
 // power spectrum only (debug): |X[k]|^2, k in [0,200], for the first frame of pcm

@@ -23,6 +23,11 @@ def emu():
     L.emu_whisper_fast.restype = C.c_longlong
     L.emu_whisper_fast.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
     L.emu_small_fft.argtypes = [C.c_int, f32p]
+    L.emu_whisper_wave.restype = C.c_longlong
+    L.emu_whisper_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
+    L.emu_fbank_wave.restype = C.c_longlong
+    L.emu_fbank_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                                 C.c_float, C.c_int, C.c_int, C.c_int, f32p]
 
     def run(x, hop=160, n_mels=80, sr=16000.0):
         x = np.ascontiguousarray(x, np.float32)
@@ -78,3 +83,85 @@ def test_edges(emu, oracle):
     # a loud click inside digital silence: 8 decades of per-frame dynamic range
     x = np.zeros(4000, np.float32); x[1234] = 1.0
     assert np.abs(emu(x) - oracle.compute_mel_spectrogram_cpu(x)).max() <= TOL
+
+
+# ---- wave-autonomous kernels (whisper_wave.hpp / fbank_wave.hpp) -------------------------------
+
+def _wave(emu, x, mode, hop=160, n_mels=80, sr=16000.0):
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 400 else (len(x) - 400) // hop + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    f32p = C.POINTER(C.c_float)
+    got = emu.lib.emu_whisper_wave(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, mode, out.ctypes.data_as(f32p))
+    return got, out
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])   # direct/staged x runtime/static slot lengths, interval scheme
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_wave_kernel_modes(emu, oracle, jfk, mode, n_mels):
+    x = jfk[8000:60000]
+    got, out = _wave(emu, x, mode, n_mels=n_mels)
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, n_mels)
+    assert got == want.shape[0] and np.abs(out - want).max() <= TOL
+
+
+@pytest.mark.parametrize("hop,n_mels,sr", [(160, 64, 16000.0), (128, 40, 8000.0), (320, 100, 22050.0), (160, 1, 16000.0),
+                                            (160, 131, 16000.0), (2, 80, 16000.0)])
+def test_wave_kernel_interval_scheme_other_filterbanks(emu, oracle, jfk, hop, n_mels, sr):
+    x = jfk[20000:20000 + (9000 if hop > 2 else 500)]
+    got, out = _wave(emu, x, 4, hop=hop, n_mels=n_mels, sr=sr)
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr)
+    assert got == want.shape[0] and np.abs(out - want).max() <= TOL
+
+
+def test_wave_kernel_edges(emu, oracle):
+    for n in (400, 559, 560, 400 + 4 * 160, 400 + 5 * 160, 400 + 11 * 160 + 1):
+        x = oracle.synth_pcm(1, n)
+        for mode in (2, 5):
+            got, out = _wave(emu, x, mode)
+            want = oracle.compute_mel_spectrogram_cpu(x)
+            assert got == want.shape[0] and np.abs(out - want).max() <= TOL
+    got, out = _wave(emu, np.zeros(4000, np.float32), 5)
+    assert np.all(out == np.float32(-1.5))
+
+
+def _fbank(emu, x, f64=1, shift=160, n_mels=80, sr=16000.0, low=20.0, high=8000.0, preemph=0.97, use_log=1, use_power=1,
+           floor_v=float(np.finfo(np.float32).eps)):
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 400 else (len(x) - 400) // shift + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    f32p = C.POINTER(C.c_float)
+    got = emu.lib.emu_fbank_wave(x.ctypes.data_as(f32p), len(x), shift, n_mels, sr, low, high, preemph, floor_v, use_log,
+                                 use_power, f64, out.ctypes.data_as(f32p))
+    return got, out
+
+
+def test_fbank_fused_f64_matches_oracle(emu, oracle, jfk):
+    cfg = oracle.fbank_default_config(); cfg.apply_cmn = 0
+    for x in (jfk, oracle.synth_pcm(3, 16000), oracle.synth_pcm(6, 400 + 7 * 160)):
+        got, out = _fbank(emu, x)
+        want = oracle.fbank_compute(x, cfg)
+        assert got == want.shape[0] and np.abs(out - want).max() <= 2e-5
+
+
+def test_fbank_fused_f32_cannot_hold_the_tolerance_on_speech(emu, oracle, jfk):
+    """Documents why the parity build of the fbank kernel is f64 (fbank_wave.hpp header)."""
+    cfg = oracle.fbank_default_config(); cfg.apply_cmn = 0
+    got, out = _fbank(emu, jfk, f64=0)
+    d = np.abs(out - oracle.fbank_compute(jfk, cfg))
+    assert d.max() > TOL and d.mean() < 1e-4
+
+
+def test_fbank_fused_variants(emu, oracle, jfk):
+    x = jfk[40000:56000]
+    for kw, args in ((dict(num_mel_bins=40), dict(n_mels=40)), (dict(preemphasis=0.0), dict(preemph=0.0)),
+                     (dict(use_power=0), dict(use_power=0)), (dict(use_log_fbank=0), dict(use_log=0)),
+                     (dict(low_freq=100.0, high_freq=7000.0), dict(low=100.0, high=7000.0)),
+                     (dict(frame_shift_ms=6.3125), dict(shift=101))):
+        cfg = oracle.fbank_default_config(); cfg.apply_cmn = 0
+        for k_, v in kw.items():
+            setattr(cfg, k_, type(getattr(cfg, k_))(v))
+        got, out = _fbank(emu, x, **args)
+        want = oracle.fbank_compute(x, cfg)
+        tol = 2e-5 if kw.get("use_log_fbank", 1) else 2e-5 * max(1.0, float(np.abs(want).max()))
+        assert got == want.shape[0] and np.abs(out - want).max() <= tol, kw

@@ -214,6 +214,7 @@ def test_sample_offsets_beyond_32_bits(gpu, w80, oracle):
 
 def test_fbank_jfk(gpu, oracle, jfk, golden):
     fb = gpu.Fbank(gpu.FbankConfig())
+    assert fb.uses_fast_path          # default Kaldi geometry -> fused 512-point kernel (f64 arithmetic)
     got = fb.compute(jfk)
     want = oracle.fbank_compute(jfk)
     assert got.shape == want.shape == (1098, 80)
@@ -227,16 +228,32 @@ def test_fbank_jfk(gpu, oracle, jfk, golden):
     assert abs(float(raw[0, 0]) - float(np.log(np.float64(np.finfo(np.float32).eps)))) < 1e-4
 
 
+def test_fbank_generic_kernel_agrees(gpu, oracle, jfk, monkeypatch):
+    """The f64 direct-DFT kernel and the fused kernel are two independent device paths."""
+    monkeypatch.setenv("MELSPEC_FBANK", "generic")
+    g = gpu.Fbank(gpu.FbankConfig())
+    assert not g.uses_fast_path
+    monkeypatch.delenv("MELSPEC_FBANK")
+    f = gpu.Fbank(gpu.FbankConfig())
+    x = jfk[:60000]
+    a, b, want = g.compute(x), f.compute(x), oracle.fbank_compute(x)
+    assert np.abs(a - want).max() <= 2e-6 and np.abs(b - want).max() <= 2e-5 and np.abs(a - b).max() <= 2e-5
+
+
 def test_fbank_variants_and_edges(gpu, oracle, jfk):
     x = jfk[40000:56000]
     for kw in (dict(num_mel_bins=40), dict(preemphasis=0.0), dict(use_log_fbank=False, apply_cmn=False),
                dict(use_power=False), dict(energy_floor=1e-3), dict(low_freq=100.0, high_freq=7000.0),
-               dict(frame_length_ms=20.0, frame_shift_ms=8.0), dict(sample_rate=8000.0)):
+               dict(frame_length_ms=20.0, frame_shift_ms=8.0), dict(sample_rate=8000.0), dict(frame_shift_ms=6.3125),
+               dict(num_mel_bins=87), dict(num_mel_bins=88), dict(num_mel_bins=23, high_freq=-400.0 + 8000.0)):
         cfg = gpu.FbankConfig(**kw)
         oc = oracle.fbank_default_config()
         for k_, v in kw.items():
             setattr(oc, k_, type(getattr(oc, k_))(v))
-        got = gpu.Fbank(cfg).compute(x)
+        fbk = gpu.Fbank(cfg)
+        default_geometry = cfg.frame_length_samples() == 400 and cfg.num_mel_bins <= 87
+        assert fbk.uses_fast_path == default_geometry, kw
+        got = fbk.compute(x)
         want = oracle.fbank_compute(x, oc)
         assert got.shape == want.shape and want.shape[0] > 0
         tol = TOL if kw.get("use_log_fbank", True) else 1e-4 * max(1.0, float(np.abs(want).max()))
@@ -244,18 +261,24 @@ def test_fbank_variants_and_edges(gpu, oracle, jfk):
     fb = gpu.Fbank()
     assert fb.compute(np.zeros(399, np.float32)).shape == (0, 80)
     assert fb.compute(np.zeros(16000, np.float32)).shape == (98, 80)
+    for n in (400, 559, 560, 400 + 6 * 160, 400 + 7 * 160, 400 + 8 * 160 + 3):   # around the 7-frame unit size
+        xx = oracle.synth_pcm(4, n)
+        assert np.abs(fb.compute(xx) - oracle.fbank_compute(xx)).max() <= TOL
+    # a DC offset 60 dB above the signal (DC removal happens before the FFT, in f64 like the reference)
+    xx = (oracle.synth_pcm(9, 8000) * np.float32(1e-3) + np.float32(0.75)).astype(np.float32)
+    assert np.abs(fb.compute(xx) - oracle.fbank_compute(xx)).max() <= TOL
 
 
 def test_fbank_batch_config3_sampled(gpu, oracle):
-    """BASELINE configs[2]: 80-bin fbank over a batch of 10 s clips (per-clip CMN), sampled vs the oracle."""
-    n_clips, clip_len, fpc = 64, 160000, 998
+    """BASELINE configs[2] at full size: 80-bin fbank over 1024 x 10 s clips (per-clip CMN), sampled vs the oracle."""
+    n_clips, clip_len, fpc = 1024, 160000, 998
     fb = gpu.Fbank()
     pcm = gpu.DeviceBuffer(n_clips * clip_len * 4)
     out = gpu.DeviceBuffer(n_clips * fpc * 80 * 4)
     gpu.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
     fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
     fb.synchronize()
-    for c in (0, 31, 63):
+    for c in (0, 511, 1023):
         got = out.download((fpc, 80), offset_bytes=c * fpc * 80 * 4)
         assert np.abs(got - oracle.fbank_compute(oracle.synth_pcm(c, clip_len))).max() <= TOL
         assert np.abs(got.mean(axis=0)).max() < 1e-4          # CMN leaves zero column means
