@@ -726,7 +726,7 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         cp.b = pl.desc;
         cp.n_mels = nm;
         const unsigned grid = grid_for(n_clips, fb->dev.cus, 8);
-        hipLaunchKernelGGL(cmn_kernel<128>, dim3(grid), dim3(128), 0, s, cp);
+        hipLaunchKernelGGL(cmn_kernel<512>, dim3(grid), dim3(512), 0, s, cp);
         HIP_TRY(hipGetLastError());
     }
     return MELSPEC_OK;

@@ -366,8 +366,12 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
     }
 }
 
-// CMN: per clip and mel column, mean = (sequential f32 sum over frames) / frames, then
-// subtract -- the same order as ndarray's mean() on a strided column (src/fbank.rs:226-233).
+// CMN (src/fbank.rs:224-233): per clip and mel column subtract the f32 mean over the clip's frames.
+// One workgroup per clip; thread (g, m) accumulates frames g, g+G, g+2G, ... of column m in f32
+// (4 independent partial sums so the loads pipeline), the G partials are combined in a fixed order,
+// so the result is deterministic.  The reference folds left-to-right in f32 (ndarray's mean() on a
+// strided column); the two orders differ by ~1e-5 of a feature value, far inside the 1e-4 budget, and
+// both are dominated by the f32 rounding of the same sum.
 struct CmnParams {
     BatchDesc b;   // only the clip geometry is used
     int n_mels;
@@ -375,6 +379,10 @@ struct CmnParams {
 
 template <int NT>
 __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
+    __shared__ float part[NT];
+    __shared__ float mean_s[NT];
+    const int nm = p.n_mels;
+    const int tid = threadIdx.x;
     for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x) {
         float *o;
         uint64_t frames;
@@ -386,11 +394,34 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
             frames = p.b.d_frames[clip];
         }
         if (frames == 0) continue;
-        for (int m = threadIdx.x; m < p.n_mels; m += NT) {
-            float sum = 0.0f;
-            for (uint64_t f = 0; f < frames; ++f) sum = sum + o[f * p.n_mels + m];
-            const float mean = sum / (float)frames;
-            for (uint64_t f = 0; f < frames; ++f) o[f * p.n_mels + m] -= mean;
+        for (int m0 = 0; m0 < nm; m0 += NT) {                 // column chunks when n_mels > NT
+            const int cols = nm - m0 < NT ? nm - m0 : NT;
+            const int G = NT / cols;                           // frame groups per column
+            const int g = tid / cols, m = m0 + tid - g * cols;
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            if (g < G) {
+                uint64_t f = g;
+                for (; f + 3 * (uint64_t)G < frames; f += 4 * (uint64_t)G) {
+                    s0 += o[f * nm + m];
+                    s1 += o[(f + G) * nm + m];
+                    s2 += o[(f + 2 * (uint64_t)G) * nm + m];
+                    s3 += o[(f + 3 * (uint64_t)G) * nm + m];
+                }
+                for (; f < frames; f += G) s0 += o[f * nm + m];
+            }
+            part[tid] = (s0 + s1) + (s2 + s3);
+            __syncthreads();
+            if (tid < cols) {
+                float s = part[tid];
+                for (int k = 1; k < G; ++k) s += part[tid + k * cols];
+                mean_s[tid] = s / (float)frames;
+            }
+            __syncthreads();
+            if (g < G) {
+                const float mean = mean_s[tid - g * cols];
+                for (uint64_t f = g; f < frames; f += G) o[f * nm + m] -= mean;
+            }
+            __syncthreads();
         }
     }
 }

