@@ -1,0 +1,122 @@
+// melspec_hip.hpp -- header-only C++ host mirror of the reference's plugin interface, over the C ABI
+// (melspec_hip.h).  Same names, argument order and error split as the reference's Rust types:
+//
+//   melspec::HipMelSpectrogram(fft_size, hop_size, sampling_rate, n_mels)   CudaMelSpectrogram::new   src/cuda.rs:39-82
+//   .compute_mel_spectrogram(samples) -> vector<vector<float>>              src/cuda.rs:88-101
+//   melspec::Fbank(FbankConfig{}).compute(samples) -> Array2f               Fbank::{new,compute}      src/fbank.rs:94,141
+//   melspec::mel(sr, n_fft, n_mels, f_min, f_max, htk, norm)                mel()                     src/mel.rs:547-589
+//
+// HipUnavailable == CudaError::Unavailable (construction; callers may skip), HipRuntimeError ==
+// CudaError::Runtime (per call).  Objects are move-only and single-threaded, like `&mut self`.
+#pragma once
+#include <cstddef>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "melspec_hip.h"
+
+namespace melspec {
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string &m) : std::runtime_error("[" + std::to_string(c) + "] " + m), code(c) {}
+};
+struct HipUnavailable : HipError { using HipError::HipError; };
+struct HipRuntimeError : HipError { using HipError::HipError; };
+
+namespace detail {
+inline void check(int rc, bool constructing) {
+    if (rc == MELSPEC_OK) return;
+    const char *m = melspec_last_error();
+    if (constructing || rc == MELSPEC_ERR_UNAVAILABLE) throw HipUnavailable(rc, m ? m : "");
+    throw HipRuntimeError(rc, m ? m : "");
+}
+}  // namespace detail
+
+class HipMelSpectrogram {
+public:
+    HipMelSpectrogram(std::size_t fft_size, std::size_t hop_size, double sampling_rate, std::size_t n_mels, int device = -1) {
+        detail::check(melspec_create(&ctx_, device, static_cast<int>(fft_size), static_cast<int>(hop_size), sampling_rate,
+                                     static_cast<int>(n_mels)), true);
+    }
+    ~HipMelSpectrogram() { melspec_destroy(ctx_); }
+    HipMelSpectrogram(HipMelSpectrogram &&o) noexcept : ctx_(std::exchange(o.ctx_, nullptr)) {}
+    HipMelSpectrogram &operator=(HipMelSpectrogram &&o) noexcept {
+        if (this != &o) { melspec_destroy(ctx_); ctx_ = std::exchange(o.ctx_, nullptr); }
+        return *this;
+    }
+    HipMelSpectrogram(const HipMelSpectrogram &) = delete;
+    HipMelSpectrogram &operator=(const HipMelSpectrogram &) = delete;
+
+    std::size_t n_mels() const { return static_cast<std::size_t>(melspec_n_mels(ctx_)); }
+    std::size_t num_frames(std::size_t n_samples) const { return melspec_num_frames(ctx_, n_samples); }
+
+    // frames x n_mels, row-major, one inner vector per frame like the reference's Vec<Vec<f32>>
+    std::vector<std::vector<float>> compute_mel_spectrogram(const std::vector<float> &samples) {
+        const std::size_t frames = num_frames(samples.size()), nm = n_mels();
+        std::vector<float> flat(frames * nm);
+        std::size_t got = 0;
+        detail::check(melspec_compute_host(ctx_, samples.data(), samples.size(), flat.data(), flat.size(), &got), false);
+        std::vector<std::vector<float>> out(got);
+        for (std::size_t f = 0; f < got; ++f) out[f].assign(flat.begin() + f * nm, flat.begin() + (f + 1) * nm);
+        return out;
+    }
+
+    // device-resident batch of equal-length clips (additive surface)
+    void compute_uniform_device(const float *d_pcm, std::uint64_t clip_stride, std::uint64_t clip_len, std::uint32_t n_clips,
+                                float *d_out, void *stream = nullptr) {
+        detail::check(melspec_compute_uniform_device(ctx_, d_pcm, clip_stride, clip_len, n_clips, d_out, stream), false);
+    }
+    void synchronize(void *stream = nullptr) { detail::check(melspec_synchronize(ctx_, stream), false); }
+    melspec_ctx *raw() { return ctx_; }
+
+private:
+    melspec_ctx *ctx_ = nullptr;
+};
+
+struct FbankConfig : melspec_fbank_config {
+    FbankConfig() { melspec_fbank_default_config(this); }   // FbankConfig::default, src/fbank.rs:46-64
+};
+
+struct Array2f {   // Array2<f32> (rows, cols), row-major
+    std::size_t rows = 0, cols = 0;
+    std::vector<float> data;
+    float operator()(std::size_t r, std::size_t c) const { return data[r * cols + c]; }
+};
+
+class Fbank {
+public:
+    explicit Fbank(const FbankConfig &cfg = FbankConfig(), int device = -1) {
+        detail::check(melspec_fbank_create(&fb_, device, &cfg), true);
+    }
+    ~Fbank() { melspec_fbank_destroy(fb_); }
+    Fbank(const Fbank &) = delete;
+    Fbank &operator=(const Fbank &) = delete;
+
+    Array2f compute(const std::vector<float> &samples) {
+        Array2f a;
+        a.cols = static_cast<std::size_t>(melspec_fbank_num_mel_bins(fb_));
+        a.rows = melspec_fbank_num_frames(fb_, samples.size());
+        a.data.assign(a.rows * a.cols, 0.0f);
+        std::size_t got = 0;
+        detail::check(melspec_fbank_compute_host(fb_, samples.data(), samples.size(), a.data.data(), a.data.size(), &got), false);
+        return a;
+    }
+
+private:
+    melspec_fbank *fb_ = nullptr;
+};
+
+// dense [n_mels][n_fft/2+1] row-major; std::nullopt == None
+inline std::vector<double> mel(double sr, std::size_t n_fft, std::size_t n_mels, std::optional<double> f_min = std::nullopt,
+                               std::optional<double> f_max = std::nullopt, bool htk = false, bool norm = true) {
+    std::vector<double> w(n_mels * (n_fft / 2 + 1));
+    detail::check(melspec_mel_filterbank(sr, static_cast<int>(n_fft), static_cast<int>(n_mels), f_min.value_or(-1.0),
+                                         f_max.value_or(-1.0), htk, norm, w.data()), false);
+    return w;
+}
+
+}  // namespace melspec

@@ -284,3 +284,18 @@ def test_fbank_batch_config3_sampled(gpu, oracle):
         assert np.abs(got - oracle.fbank_compute(oracle.synth_pcm(c, clip_len))).max() <= TOL
         assert np.abs(got.mean(axis=0)).max() < 1e-4          # CMN leaves zero column means
     pcm.free(); out.free()
+
+
+def test_cpp_host_mirror(gpu, oracle, tmp_path):
+    """include/melspec_hip.hpp (the C++ twin of HipMelSpectrogram / Fbank / mel) against the oracle."""
+    import subprocess
+    from conftest import ROOT
+    exe = tmp_path / "host_mirror"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp"),
+                           "-L", os.path.join(ROOT, "mel_spec_amd"), "-lmelspec_hip",
+                           "-L", os.path.join(ROOT, "oracle"), "-lmelspec_oracle",
+                           "-Wl,-rpath," + os.path.join(ROOT, "mel_spec_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
