@@ -71,11 +71,12 @@ def lib() -> C.CDLL:
     """Load libmelspec_hip.so (built in-tree by mel_spec_amd.build / __graft_entry__.build)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("MELSPEC_LIB", LIB_PATH)   # tuning builds of the same ABI
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                f"{path} is missing: the HIP extension has not been built "
                 "(run `python -m mel_spec_amd.build`). mel_spec_amd has no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)   # AttributeError if the ABI lost a symbol
             fn.restype = res

@@ -156,11 +156,22 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
             for (int i = lane; i < need; i += 64) slice[i] = src[i];
             __builtin_amdgcn_wave_barrier();
         }
+        // MELSPEC_ABLATE=n builds (tools/ablate.py) drop one phase to measure its marginal cost; results are
+        // then wrong by design and such builds are never shipped.
+#if !defined(MELSPEC_ABLATE) || (MELSPEC_ABLATE != 1 && MELSPEC_ABLATE != 12)
         wave_phase1<DIRECT>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
+#endif
         __builtin_amdgcn_wave_barrier();
+#if !defined(MELSPEC_ABLATE) || (MELSPEC_ABLATE != 2 && MELSPEC_ABLATE != 12)
         wave_phase2<!INTERVAL>(fl, j, act, blob, slice);
+#endif
         __builtin_amdgcn_wave_barrier();
         float vals[NSLOTS];
+#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 3
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) vals[i] = slice[fl * WaveLayout::kPStride + j3 + 12 * i];
+        if (act3) slice[WaveLayout::kPmaxOff + fl3 * WaveLayout::kPmaxStride + j3] = vals[0];
+#else
         if (INTERVAL) {
             float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
             wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
@@ -170,6 +181,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         } else {
             wave_phase3<NSLOTS, Lens>(fl, j, act, p.n_mels, p.slots, blob, slice, vals);
         }
+#endif
         __builtin_amdgcn_wave_barrier();
         wave_phase4<NSLOTS>(fl3, j3, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels);
         __builtin_amdgcn_wave_barrier();

@@ -98,7 +98,11 @@ MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, 
     const float *w = blob + FastBlob::kWin + 2 * t;
     cf x[20];
     if (DIRECT) {
+#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 4
+        const float *s = blob + FastBlob::kTw1 + fl + 2 * t;    // ablation: phase 1 without global loads
+#else
         const float *s = gsrc + fl * hop + 2 * t;
+#endif
 #pragma unroll
         for (int n1 = 0; n1 < 20; ++n1) {
             const f2 sv = load2_unaligned(s + 20 * n1);
