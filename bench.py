@@ -141,25 +141,23 @@ def main() -> None:
         if worst > 1e-4:
             raise SystemExit(f"parity check failed before timing: max|diff| = {worst}")
 
+    # timed region: barrier + synchronize on both sides, MAX over ranks (mel_spec_amd.parallel.timed_steps);
+    # HIP events on the launch stream bracket the same K launches for the kernel-side figure.
+    from mel_spec_amd.parallel import timed_steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+    state = {"n": 0}
 
+    def timed_step():
+        if state["n"] == 0:
+            ev0.record()
+        step()
+        state["n"] += 1
+        if state["n"] == args.steps:
+            ev1.record()
+
+    elapsed = timed_steps(timed_step, torch.cuda.synchronize, args.steps, 0, dist if distributed else None, dev)
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())

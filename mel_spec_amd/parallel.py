@@ -32,3 +32,31 @@ def shard_by_samples(lengths, world_size: int) -> list[tuple[int, int]]:
     while len(bounds) < world_size:
         bounds.append((len(lengths), len(lengths)))
     return bounds[:world_size]
+
+
+def timed_steps(step, synchronize, steps: int, warmup: int, dist=None, device=None):
+    """The bench protocol: `warmup` untimed steps, then exactly `steps` timed steps bracketed by a
+    barrier + synchronize on both sides; returns the MAX elapsed seconds over ranks.
+
+    `dist` is torch.distributed (initialised) or None for a single process; `device` is where the
+    reduction tensor lives (cuda device for nccl, None/cpu for gloo)."""
+    import time
+    for _ in range(warmup):
+        step()
+    synchronize()
+    if dist is not None:
+        dist.barrier()
+    synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed

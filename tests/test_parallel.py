@@ -49,6 +49,11 @@ dist.barrier(); t0 = time.perf_counter()
 outs = [O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len)) for c in range(lo, hi)]
 dist.barrier(); dt = time.perf_counter() - t0
 t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+# the bench protocol itself (bench.py uses this helper with nccl): rank 1 is slower, MAX must win
+from mel_spec_amd.parallel import timed_steps
+calls = []
+el = timed_steps(lambda: (calls.append(1), time.sleep(0.02 * (rank + 1))), lambda: None, 3, 2, dist, None)
+assert len(calls) == 5 and 0.11 <= el < 1.0, (len(calls), el)
 frames = torch.tensor([sum(o.shape[0] for o in outs)], dtype=torch.int64); dist.all_reduce(frames)
 chk = torch.tensor([float(sum(np.float64(o).sum() for o in outs))], dtype=torch.float64); dist.all_reduce(chk)
 if rank == 0:
