@@ -13,7 +13,9 @@ out = M.DeviceBuffer(n_clips*fpc*80*4)
 ts=[m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=30, iters=100) for _ in range(3)]
 print(os.environ.get("MELSPEC_LIB","default"), "ms", min(ts))
 ''' % ROOT
-for lib in [None] + [os.path.join(ROOT, "mel_spec_amd", f"libmelspec_abl{a}.so") for a in (1, 2, 3, 4, 12)]:
+libs = [os.path.join(ROOT, "mel_spec_amd", a) for a in sys.argv[1:]] or \
+       [os.path.join(ROOT, "mel_spec_amd", f"libmelspec_abl{a}.so") for a in (1, 2, 3, 4, 12)]
+for lib in [None] + libs + [None]:
     env = dict(os.environ)
     if lib: env["MELSPEC_LIB"] = lib
     subprocess.run([sys.executable, "-c", code], env=env)

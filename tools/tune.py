@@ -18,6 +18,8 @@ M.device_synchronize()
 ctxs = {}
 for v in variants:
     vv, rt = (v[:-1], "1") if v.endswith("r") else (v, "0")
+    vv, sg = (vv.split("s") + ["0"])[:2] if "s" in vv else (vv, "0")     # "8s64" = variant 8, stagger 64
+    os.environ["MELSPEC_STAGGER"] = sg
     os.environ["MELSPEC_VARIANT"] = vv
     os.environ["MELSPEC_RUNTIME_LENS"] = rt
     ctxs[v] = M.HipMelSpectrogram(400, 160, 16000.0, n_mels)
