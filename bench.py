@@ -71,8 +71,16 @@ def cpu_baseline(clip_len: int, n_mels: int, target_s: float) -> dict:
     t1 = time.perf_counter()
     o1 = O.compute_mel_batch(clips[:k], N_FFT, HOP, n_mels, SR, n_threads=1)
     dt1 = time.perf_counter() - t1
+    cpu_model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
-        "value": frames / dt, "unit": "mel frames/s", "cores": cores, "kind": "port",
+        "value": frames / dt, "unit": "mel frames/s", "cores": cores, "kind": "port", "cpu": cpu_model,
         "sample": f"{n} of the {CLIPS_PER_GPU} synthetic {clip_len / SR:.0f} s clips x {reps} passes ({frames} frames) in {dt:.2f} s, "
                   f"oracle/melspec_oracle.c (f64 restatement of Spectrogram::compute_mel_spectrogram_cpu), OpenMP over clips",
         "single_thread_frames_per_s": o1.shape[0] * o1.shape[1] / dt1,

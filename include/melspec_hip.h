@@ -81,6 +81,16 @@ int melspec_compute_host(melspec_ctx *ctx, const float *samples, size_t n_sample
 int melspec_compute_uniform_device(melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride,
                                    uint64_t clip_len, uint32_t n_clips, float *d_out, void *stream);
 
+/* interleave_frames(frames, major_column_order, min_width) (src/mel.rs:480-544) fused into the
+ * store: per clip the output is n_mels x W floats, W = melspec_interleaved_width(): the frame count,
+ * +1 zero column if it is odd and min_width > 0 (whisper.cpp needs an even width), then zero columns up
+ * to min_width (must be even).  major_column_order == 0 -> [mel][W] rows (what whisper.cpp's set_mel
+ * takes); != 0 -> [W][mel] rows.  Clips with no frame are an error, like the reference's assert. */
+size_t melspec_interleaved_width(const melspec_ctx *ctx, size_t n_samples, size_t min_width);
+int melspec_compute_uniform_device_interleaved(melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride,
+                                               uint64_t clip_len, uint32_t n_clips, float *d_out,
+                                               int major_column_order, uint64_t min_width, void *stream);
+
 /* Ragged batch: clip c = d_pcm[h_offsets[c] .. + h_lengths[c]) (sample units, host arrays).
  * Output of clip c starts at d_out + h_out_offsets[c] (float units); pass NULL to pack the
  * clips back to back in order.  Clips shorter than fft_size produce zero frames. */

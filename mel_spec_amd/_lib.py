@@ -41,6 +41,9 @@ SIGNATURES = {
     "melspec_uses_fast_path": (C.c_int, [_vp]),
     "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_interleaved_width": (C.c_size_t, [_vp, C.c_size_t, C.c_size_t]),
+    "melspec_compute_uniform_device_interleaved": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int,
+                                                             C.c_uint64, _vp]),
     "melspec_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
     "melspec_time_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _f32p]),
     "melspec_synchronize": (C.c_int, [_vp, _vp]),

@@ -151,14 +151,17 @@ struct BatchPlan {
 
 // Fill a BatchDesc for n_clips equal-length clips.
 BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, uint64_t frames_per_clip,
-                       uint32_t n_clips, int n_mels, int frames_per_unit) {
+                       uint32_t n_clips, int n_mels, int frames_per_unit, uint64_t out_width = 0, bool mel_major = false) {
     BatchPlan pl;
     BatchDesc &b = pl.desc;
+    if (out_width < frames_per_clip) out_width = frames_per_clip;
     b.pcm = d_pcm; b.out = d_out;
     b.clip_stride = clip_stride;
-    b.out_stride = frames_per_clip * static_cast<uint64_t>(n_mels);
+    b.out_stride = out_width * static_cast<uint64_t>(n_mels);
     b.frames_per_clip = frames_per_clip;
-    b.units_per_clip = static_cast<uint32_t>((frames_per_clip + frames_per_unit - 1) / frames_per_unit);
+    b.out_width = out_width;
+    b.mel_major = mel_major ? 1 : 0;
+    b.units_per_clip = static_cast<uint32_t>((out_width + frames_per_unit - 1) / frames_per_unit);
     b.n_clips = n_clips;
     b.n_units = static_cast<uint64_t>(b.units_per_clip) * n_clips;
     pl.total_frames = frames_per_clip * n_clips;
@@ -276,21 +279,28 @@ int launch_block_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     return MELSPEC_OK;
 }
 
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false>
-int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW, bool INTERVAL, bool LAYOUT>
+int launch_wave_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL>, "hipFuncSetAttribute(whisper400_wave_kernel)");
+        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>, "hipFuncSetAttribute(whisper400_wave_kernel)");
         if (rc) return rc;
         attr_done = true;
     }
     const FastParams fp = fast_params(c, desc);
     const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
     const unsigned grid = grid_for(blocks, c->dev.cus, 16);
-    hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL>), dim3(grid),
+    hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>), dim3(grid),
                        dim3(WAVES * 64), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
+}
+
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false>
+int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+    if (layout) return launch_wave_l<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, true>(c, desc, stream);
+    return launch_wave_l<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, false>(c, desc, stream);
 }
 
 template <int NSLOTS, class StaticLens>
@@ -474,6 +484,36 @@ int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t 
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? c->frames_per_unit : 1);
+    return launch_ctx(c, pl.desc, s);
+}
+
+// interleave_frames' width rule (src/mel.rs:497-516)
+static uint64_t interleaved_width(uint64_t frames, uint64_t min_width) {
+    uint64_t nf = frames;
+    if (min_width > 0 && (nf & 1)) nf += 1;
+    return nf > min_width ? nf : min_width;
+}
+
+size_t melspec_interleaved_width(const melspec_ctx *c, size_t n_samples, size_t min_width) {
+    if (!c) return 0;
+    uint64_t f; ctx_num_frames(c, n_samples, f);
+    return f == 0 ? 0 : static_cast<size_t>(interleaved_width(f, min_width));
+}
+
+int melspec_compute_uniform_device_interleaved(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                               uint32_t n_clips, float *d_out, int major_column_order, uint64_t min_width,
+                                               void *stream) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (min_width % 2 != 0) return fail(MELSPEC_ERR_INVALID_ARG, "min_width must be even");   // src/mel.rs:488
+    if (n_clips == 0) return MELSPEC_OK;
+    uint64_t fpc; ctx_num_frames(c, clip_len, fpc);
+    if (fpc == 0) return fail(MELSPEC_ERR_INVALID_ARG, "frames is empty");                      // src/mel.rs:487
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (c->fast && c->variant == 0) return fail(MELSPEC_ERR_UNSUPPORTED, "the block kernel (MELSPEC_VARIANT=0) has no layout option");
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? c->frames_per_unit : 1,
+                                      interleaved_width(fpc, min_width), major_column_order == 0);
     return launch_ctx(c, pl.desc, s);
 }
 

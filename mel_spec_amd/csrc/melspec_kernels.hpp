@@ -26,6 +26,8 @@ struct BatchDesc {
     uint32_t units_per_clip;   // uniform
     uint32_t n_clips;
     uint64_t n_units;
+    uint64_t out_width;        // uniform: output columns per clip (>= frames_per_clip; the excess is zero-filled)
+    int mel_major;             // uniform: 0 = [frame][mel] rows, 1 = [mel][out_width] rows (interleave_frames, src/mel.rs:480-544)
     const uint64_t *d_off;       // ragged (device): first sample of clip c
     const uint64_t *d_frames;    // ragged: frames in clip c
     const uint64_t *d_out_off;   // ragged: first output float of clip c
@@ -120,7 +122,9 @@ __device__ __forceinline__ float wave_shift_down1(float v) {
                                                                  0xf, 0xf, false));
 }
 
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false>
+// LAYOUT = false: plain [clip][frame][mel] output (the hot configuration, no padding logic compiled in);
+// LAYOUT = true: padded and/or mel-major output (interleave_frames, BatchDesc::out_width / mel_major).
+template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false, bool LAYOUT = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const FastParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
@@ -146,8 +150,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = loc.frames - f0;
+        const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
+        const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
+        const uint64_t wleft = width - f0;
+        const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
         const bool act3 = in3 && fl3 < nv;
@@ -183,7 +191,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         }
 #endif
         __builtin_amdgcn_wave_barrier();
-        wave_phase4<NSLOTS>(fl3, j3, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels);
+        if (LAYOUT && p.b.mel_major)
+            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0, (long long)width);
+        else
+            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -314,6 +325,12 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
 
     for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
         const UnitLoc loc = locate_unit(p.b, unit);
+        if (loc.unit >= loc.frames) {       // zero column of a padded layout (uniform batches only)
+            float *z = p.b.mel_major ? loc.out + loc.unit : loc.out + loc.unit * (uint64_t)p.n_mels;
+            const uint64_t zstep = p.b.mel_major ? p.b.out_width : 1;
+            for (int m = tid; m < p.n_mels; m += NT) z[m * zstep] = 0.0f;
+            continue;
+        }
         const uint64_t start = loc.unit * (uint64_t)p.hop;
         const float *x = loc.pcm + start;
         __syncthreads();
@@ -365,12 +382,14 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
             mv[m] = v;
             mx = mx > v ? mx : v;
         }
-        float *o = loc.out + loc.unit * (uint64_t)p.n_mels;
+        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+        float *o = p.b.mel_major ? loc.out + loc.unit : loc.out + loc.unit * (uint64_t)p.n_mels;
+        const uint64_t ostep = p.b.mel_major ? width : 1;
         if (!p.fbank) {
             const double lo = block_reduce<NT>(mx, red, true) - 8.0;   // src/mel.rs:645-654
             for (int m = tid; m < p.n_mels; m += NT) {
                 const double v = mv[m] > lo ? mv[m] : lo;
-                o[m] = (float)((v + 4.0) / 4.0);
+                o[m * ostep] = (float)((v + 4.0) / 4.0);
             }
         } else {
             for (int m = tid; m < p.n_mels; m += NT) o[m] = (float)mv[m];

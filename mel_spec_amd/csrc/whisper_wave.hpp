@@ -267,25 +267,29 @@ MS_DEV void wave_phase3(int fl, int j, bool active, int n_mels, const MelSlots &
 }
 
 // ---- phase 4: frame max, clamp, scale, store ------------------------------------------------
-template <int NSLOTS>
-MS_DEV void wave_phase4(int fl, int j, bool active, int n_mels, const float *slice, const float (&vals)[NSLOTS],
-                        float *out_tile) {
-    if (!active) return;
-    const float *pm = slice + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
-    const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4),
-             c = *reinterpret_cast<const f4 *>(pm + 8);
-    const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
-    const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
-    const float m2 = __builtin_fmaxf(__builtin_fmaxf(c.x, c.y), __builtin_fmaxf(c.z, c.w));
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2) - 8.0f;
-    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+// store: this lane's frame column exists in the output; valid: it is a real frame (otherwise a zero
+// column of a padded layout).  row_w == 0: [frame][mel] rows; row_w > 0: [mel][row_w] rows.
+template <int NSLOTS, bool LAYOUT = true>
+MS_DEV void wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
+                        float *out_tile, long long row_w) {
+    if (!LAYOUT) { valid = true; row_w = 0; }     // plain output: every stored column is a real frame
+    if (!store || j >= kMelJobs) return;
+    float lo = 0.0f;
+    if (valid) {
+        const float *pm = slice + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
+        const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4),
+                 c = *reinterpret_cast<const f4 *>(pm + 8);
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
+        const float m2 = __builtin_fmaxf(__builtin_fmaxf(c.x, c.y), __builtin_fmaxf(c.z, c.w));
+        lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2) - 8.0f;
+    }
+    float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
+    const long long step = row_w ? kMelJobs * row_w : kMelJobs;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
-        if (j < kMelJobs && m < n_mels) {
-            const float v = __builtin_fmaxf(vals[i], lo);
-            o[kMelJobs * i] = (v + 4.0f) * 0.25f;
-        }
+        if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
     }
 }
 

@@ -138,6 +138,31 @@ class HipMelSpectrogram:
         _check(lib().melspec_compute_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
                                                     C.c_void_p(d_out), C.c_void_p(stream)))
 
+    def interleaved_width(self, n_samples: int, min_width: int = 0) -> int:
+        return int(lib().melspec_interleaved_width(self._h, n_samples, min_width))
+
+    def compute_uniform_device_interleaved(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
+                                           major_column_order: bool = False, min_width: int = 0, stream: int = 0) -> None:
+        """interleave_frames (src/mel.rs:480-544) fused into the store; see melspec_hip.h."""
+        _check(lib().melspec_compute_uniform_device_interleaved(
+            self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips, C.c_void_p(d_out), int(major_column_order),
+            min_width, C.c_void_p(stream)))
+
+    def compute_batch_interleaved(self, clips, major_column_order: bool = False, min_width: int = 0) -> np.ndarray:
+        """[n_clips, clip_len] -> [n_clips, n_mels, W] (or [n_clips, W, n_mels]) in one launch."""
+        x = _f32(clips)
+        n_clips, clip_len = x.shape
+        W = self.interleaved_width(clip_len, min_width)
+        shape = (n_clips, W, self.n_mels) if major_column_order else (n_clips, self.n_mels, W)
+        din, dout = DeviceBuffer(x.nbytes), DeviceBuffer(max(16, n_clips * W * self.n_mels * 4))
+        try:
+            din.upload(x)
+            self.compute_uniform_device_interleaved(din.ptr, clip_len, clip_len, n_clips, dout.ptr, major_column_order, min_width)
+            self.synchronize()
+            return dout.download(shape)
+        finally:
+            din.free(); dout.free()
+
     def compute_ragged_device(self, d_pcm: int, offsets, lengths, d_out: int, out_offsets=None, stream: int = 0) -> None:
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         ln = np.ascontiguousarray(lengths, dtype=np.uint64)

@@ -292,6 +292,28 @@ int64_t oracle_compute_mel_spectrogram_cpu(const float *samples, int64_t len, in
     return frames;
 }
 
+/* src/mel.rs:480-544 interleave_frames on single-column frames ([n_frames][n_mels] f32 in).
+ * Returns the output width W (columns per mel row); out must hold n_mels * W floats.
+ *   min_width > 0 and n_frames odd -> one zero frame appended (whisper.cpp needs an even count);
+ *   then zero columns are appended up to min_width.
+ *   major_column_order != 0 -> [frame][mel] (waterfall); 0 -> [mel][frame] (what whisper.cpp expects). */
+int64_t oracle_interleave_frames(const float *frames, int64_t n_frames, int n_mels, int major_column_order,
+                                 int64_t min_width, float *out) {
+    if (n_frames <= 0 || (min_width % 2) != 0) return -1;          /* the reference asserts both */
+    int64_t nf = n_frames;
+    if (min_width > 0 && (nf % 2) != 0) nf += 1;
+    const int64_t padding = min_width > nf ? min_width - nf : 0;
+    const int64_t W = nf + padding;
+    if (!out) return W;
+    for (int64_t i = 0; i < W * n_mels; ++i) out[i] = 0.0f;
+    for (int64_t f = 0; f < n_frames; ++f)
+        for (int m = 0; m < n_mels; ++m) {
+            if (major_column_order) out[f * n_mels + m] = frames[f * n_mels + m];
+            else out[(int64_t)m * W + f] = frames[f * n_mels + m];
+        }
+    return W;
+}
+
 /* Many clips, clips split across OpenMP threads (the all-cores CPU baseline of
  * bench.py).  Clip c is samples[c*clip_stride .. +clip_len); out is
  * [clip][frame][mel].  Same arithmetic as the function above. */

@@ -60,6 +60,8 @@ def lib():
         L.oracle_compute_mel_spectrogram_cpu.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p]
         L.oracle_compute_mel_batch.restype = C.c_int64
         L.oracle_compute_mel_batch.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
+        L.oracle_interleave_frames.restype = C.c_int64
+        L.oracle_interleave_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int64, f32p]
         L.oracle_max_threads.restype = C.c_int
         L.oracle_stream_mel.restype = C.c_int64
         L.oracle_stream_mel.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int64]
@@ -150,6 +152,18 @@ def compute_mel_batch(clips, fft_size=400, hop_size=160, n_mels=80, sampling_rat
     if nf and x.shape[0]:
         lib().oracle_compute_mel_batch(_p(x, C.c_float), x.shape[1], x.shape[1], x.shape[0], fft_size, hop_size,
                                        n_mels, sampling_rate, _p(out, C.c_float), n_threads)
+    return out
+
+
+def interleave_frames(frames, major_column_order=False, min_width=0) -> np.ndarray:
+    """interleave_frames (src/mel.rs:480-544) on [n_frames, n_mels] -> [n_mels, W] (or [W, n_mels])."""
+    x = _f32(frames)
+    nf, nm = x.shape
+    W = lib().oracle_interleave_frames(_p(x, C.c_float), nf, nm, int(major_column_order), min_width, None)
+    if W < 0:
+        raise ValueError("frames is empty or min_width is odd")
+    out = np.empty((W, nm) if major_column_order else (nm, W), np.float32)
+    lib().oracle_interleave_frames(_p(x, C.c_float), nf, nm, int(major_column_order), min_width, _p(out, C.c_float))
     return out
 
 

@@ -127,9 +127,9 @@ static long long run_wave(const float *pcm, long long n, int hop, int n_mels, do
             const int G = INTERVAL ? 12 : kMelJobs;
             const int fl = lane / G, j = lane - fl * G;
             const bool act = lane < kFPW * G && fl < nv;
-            wave_phase4<NSLOTS>(fl, j, act, n_mels, slice.data(),
+            wave_phase4<NSLOTS>(fl, j, act, act, n_mels, slice.data(),
                                 *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
-                                out + f0 * n_mels);
+                                out + f0 * n_mels, 0);
         }
     }
     return frames;

@@ -128,6 +128,29 @@ def test_ragged_batch_with_empty_and_short_clips(w80, oracle, jfk):
             assert np.abs(g - want).max() <= TOL
 
 
+@pytest.mark.parametrize("n,min_width", [(16000, 0), (16000, 3000), (16160, 0), (16160, 2), (16160, 100), (16160, 200), (560, 3000)])
+def test_interleaved_layouts(gpu, w80, oracle, n, min_width):
+    """interleave_frames (src/mel.rs:480-544) fused into the store: mel-major for whisper.cpp, even width, zero padding."""
+    clips = np.stack([oracle.synth_pcm(c, n) for c in range(3)])
+    for col_major in (False, True):
+        got = w80.compute_batch_interleaved(clips, major_column_order=col_major, min_width=min_width)
+        for c in range(3):
+            frames = oracle.compute_mel_spectrogram_cpu(clips[c], 400, 160, 80, SR)
+            want = oracle.interleave_frames(frames, col_major, min_width)
+            assert got[c].shape == want.shape, (got[c].shape, want.shape)
+            assert np.abs(got[c] - want).max() <= TOL
+            pad = want == 0.0
+            assert np.array_equal(got[c][pad], want[pad])          # the padding is exact zeros
+    g = gpu.HipMelSpectrogram(512, 160, SR, 80)                    # generic kernel honours the layout too
+    got = g.compute_batch_interleaved(clips, False, min_width)
+    want = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(clips[1], 512, 160, 80, SR), False, min_width)
+    assert got[1].shape == want.shape and np.abs(got[1] - want).max() <= 2e-6
+    with pytest.raises(gpu.HipRuntimeError):
+        w80.compute_batch_interleaved(clips, False, 3)             # odd min_width (src/mel.rs:488)
+    with pytest.raises(gpu.HipRuntimeError):
+        w80.compute_batch_interleaved(np.zeros((1, 399), np.float32))   # "frames is empty" (src/mel.rs:487)
+
+
 def test_device_synth_is_bit_identical_to_cpu_twin(gpu, oracle):
     n_clips, n = 11, 5000
     buf = gpu.DeviceBuffer(n_clips * n * 4)
@@ -158,7 +181,11 @@ def test_config2_full_size_1024x10s(gpu, w80, oracle):
     w80.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
     w80.synchronize()
     a = out.download((n_clips, fpc, 80))
-    _sampled_parity(oracle, a, 0, clip_len, 80, [0, 1, 7, 255, 256, 511, 777, 1023])
+    # >= 64 clips spread over the batch (first, last, boundaries, strided) against the oracle
+    picks = sorted(set([0, 1, 7, 255, 256, 511, 512, 777, 1022, 1023] + list(range(3, 1024, 19))))
+    assert len(picks) >= 64
+    want = oracle.compute_mel_batch(np.stack([oracle.synth_pcm(c, clip_len) for c in picks]), 400, 160, 80, SR)
+    assert np.abs(a[picks] - want).max() <= TOL
     # properties: finite; per-frame normalisation puts every frame's max-min within 2.0 exactly
     assert np.all(np.isfinite(a))
     fmax, fmin = a.max(axis=2), a.min(axis=2)

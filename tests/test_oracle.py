@@ -103,3 +103,20 @@ def test_synth_pcm_is_deterministic_and_bounded(oracle):
     a, b = oracle.synth_pcm(5, 4096), oracle.synth_pcm(5, 4096)
     assert np.array_equal(a, b) and np.abs(a).max() < 2.0 ** -5 + 1e-9 and a.std() > 0
     assert np.abs(oracle.synth_pcm(8, 4096)).max() <= 1.0
+
+
+def test_interleave_frames_rules(oracle):
+    # src/mel.rs:480-544 and tests/readme_examples.rs:60-71 (one 80-mel frame, min_width 2 -> 80 x 2)
+    fr = np.arange(80, dtype=np.float32).reshape(1, 80) / 80
+    out = oracle.interleave_frames(fr, False, 2)
+    assert out.shape == (80, 2) and np.array_equal(out[:, 0], fr[0]) and not out[:, 1].any()
+    f3 = np.arange(3 * 4, dtype=np.float32).reshape(3, 4) + 1
+    assert oracle.interleave_frames(f3, False, 0).shape == (4, 3)              # no evening when min_width == 0
+    assert oracle.interleave_frames(f3, False, 2).shape == (4, 4)              # odd count -> one zero frame
+    assert oracle.interleave_frames(f3, False, 10).shape == (4, 10)
+    assert np.array_equal(oracle.interleave_frames(f3, False, 0), f3.T)
+    cm = oracle.interleave_frames(f3, True, 6)
+    assert cm.shape == (6, 4) and np.array_equal(cm[:3], f3) and not cm[3:].any()
+    import pytest
+    with pytest.raises(ValueError):
+        oracle.interleave_frames(f3, False, 3)
