@@ -154,6 +154,44 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
                                          uint64_t clip_len, uint32_t n_clips, float *d_out, void *stream);
 int melspec_fbank_synchronize(melspec_fbank *fb, void *stream);
 
+/* ---- NeMo/Parakeet log-mel frontend: replaces BatchLogMelSpectrogram (src/mel.rs:171-418) ------- */
+
+/* BatchLogMelConfig (src/mel.rs:171-208). */
+typedef struct melspec_blm_config {
+    int32_t sample_rate;            /* 16000 */
+    int32_t n_fft;                  /* 512 */
+    int32_t win_length;             /* 400 */
+    int32_t hop_length;             /* 160 */
+    int32_t n_mels;                 /* 80 */
+    double f_min;                   /* 0.0 */
+    double f_max;                   /* <= 0 == None (sample_rate / 2) */
+    int32_t htk;                    /* 0 */
+    int32_t norm;                   /* 1 */
+    float preemphasis;              /* 0.0 (NeMo: 0.97) */
+    int32_t center;                 /* 1 */
+    float log_zero_guard;           /* f32::EPSILON (NeMo: 2^-24) */
+    int32_t pad_to;                 /* 0 */
+    int32_t normalize_per_feature;  /* 0 */
+} melspec_blm_config;
+
+typedef struct melspec_blm melspec_blm;
+void melspec_blm_default_config(melspec_blm_config *cfg);                 /* BatchLogMelConfig::default (src/mel.rs:189-208) */
+/* BatchLogMelSpectrogram::new (src/mel.rs:248-280); validate_batch_config's messages (src/mel.rs:656-683) come
+ * back through melspec_last_error with MELSPEC_ERR_INVALID_ARG (== BatchLogMelError::InvalidConfig).
+ * Only n_fft = 512 / win_length = 400 (the NeMo/Parakeet geometry) is covered: else MELSPEC_ERR_UNSUPPORTED. */
+int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *cfg);
+void melspec_blm_destroy(melspec_blm *b);
+size_t melspec_blm_num_frames(const melspec_blm *b, size_t n_samples);    /* valid frames (src/mel.rs:387-395) */
+size_t melspec_blm_padded_frames(const melspec_blm *b, size_t n_samples); /* cols = pad_len(valid, pad_to) (src/mel.rs:751-756) */
+/* compute_flat (src/mel.rs:304-385): feature-major [n_mels][cols] f32; *rows = n_mels, *cols = padded frames.
+ * Empty input -> cols = 0 (src/mel.rs:326-332). */
+int melspec_blm_compute_host(melspec_blm *b, const float *samples, size_t n_samples, float *out,
+                             size_t out_capacity_floats, size_t *rows, size_t *cols);
+/* Many equal-length clips resident in HBM; d_out = [clip][n_mels][cols]. */
+int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                       uint32_t n_clips, float *d_out, void *stream);
+int melspec_blm_synchronize(melspec_blm *b, void *stream);
+
 /* ---- device memory helpers for hosts with no HIP binding of their own --------------- */
 /* (what the cudaMalloc/cudaMemcpyAsync externs of src/cuda.rs:185-199 give the Rust side) */
 int melspec_malloc(void **dptr, size_t bytes);

@@ -1,10 +1,10 @@
 """mel_spec_amd -- MI355X (gfx950) log-mel spectrogram frontend behind the API of
 wavey-ai/mel-spec's GPU plugin slot.  All compute runs in hand-written HIP kernels
 (csrc/) reached through the C ABI of libmelspec_hip.so (include/melspec_hip.h)."""
-from .hip import (DeviceBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable,
+from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, DeviceBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable,
                   device_count, device_synchronize, hann_window, kaldi_mel_filterbank, mel, synth_pcm_device)
 from .parallel import shard_range
 
-__all__ = ["DeviceBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError",
+__all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError",
            "HipUnavailable", "device_count", "device_synchronize", "hann_window", "kaldi_mel_filterbank", "mel",
            "synth_pcm_device", "shard_range"]

@@ -26,6 +26,16 @@ class FbankConfigC(C.Structure):
     ]
 
 
+class BlmConfigC(C.Structure):
+    """melspec_blm_config (include/melspec_hip.h) == BatchLogMelConfig (src/mel.rs:171-208)."""
+    _fields_ = [
+        ("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("win_length", C.c_int32), ("hop_length", C.c_int32),
+        ("n_mels", C.c_int32), ("f_min", C.c_double), ("f_max", C.c_double), ("htk", C.c_int32), ("norm", C.c_int32),
+        ("preemphasis", C.c_float), ("center", C.c_int32), ("log_zero_guard", C.c_float), ("pad_to", C.c_int32),
+        ("normalize_per_feature", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); must list every symbol include/melspec_hip.h declares
 _vp, _f32p, _f64p, _u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)
 SIGNATURES = {
@@ -59,6 +69,14 @@ SIGNATURES = {
     "melspec_fbank_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_fbank_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "melspec_fbank_synchronize": (C.c_int, [_vp, _vp]),
+    "melspec_blm_default_config": (None, [C.POINTER(BlmConfigC)]),
+    "melspec_blm_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(BlmConfigC)]),
+    "melspec_blm_destroy": (None, [_vp]),
+    "melspec_blm_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
+    "melspec_blm_padded_frames": (C.c_size_t, [_vp, C.c_size_t]),
+    "melspec_blm_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "melspec_blm_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_blm_synchronize": (C.c_int, [_vp, _vp]),
     "melspec_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "melspec_free": (C.c_int, [_vp]),
     "melspec_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),

@@ -26,7 +26,7 @@ struct FastTables {
 // Returns false if some non-zero weight violates the two-filters-per-bin structure.
 inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int bins, int bin_limit,
                                std::vector<float> &b, MelSlots &slots, int lanes = 12, double scale = 0.25,
-                               int starts_off = FastBlob::kMelStart) {
+                               int starts_off = FastBlob::kMelStart, int max_slots = kMaxSlots) {
     const int real = lanes - 1;   // intervals per slot (the last lane of a group is the ghost)
     // interval of bin k = the filter whose rising part contains it = last row that is non-zero at k
     // and whose peak is at or after k; derive it from the matrix itself: rows non-zero at k are
@@ -61,7 +61,7 @@ inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int
         ++cnt[idx[k]];
     }
     const int n_slots = (n_int + real - 1) / real;
-    if (n_slots > kMaxSlots) return false;
+    if (n_slots > max_slots || n_slots > kSlotCap) return false;
     slots = MelSlots{};
     slots.n_slots = n_slots;
     for (int s = 0; s < n_slots; ++s) {

@@ -15,16 +15,16 @@ struct FbankFastTables {
     bool f64 = true;
 };
 
-// Default Kaldi geometry only (400-sample frames, 512-point FFT).  Returns false when the filterbank
-// lacks the two-filters-per-bin structure or needs more than kFbSlots slots.
+// Tables of the fused 512-point kernels: `window` = the 400 taps applied to the frame, `dense` = the
+// filterbank [n_mels][257].  Returns false when the filterbank lacks the two-filters-per-bin structure or
+// needs more than `max_slots` slots of 8 intervals.
 template <class T>
-inline bool build_fbank_fast_tables(double sample_rate, int num_mel_bins, double low_freq, double high_freq,
-                                    bool use_power, FbankFastTables &out) {
+inline bool build_fused512_tables(const std::vector<double> &window, const std::vector<double> &dense, int n_mels,
+                                  double scale, int max_slots, FbankFastTables &out) {
     constexpr int N = 512, FL = 400;
-    if (num_mel_bins < 1 || num_mel_bins > 8 * kFbSlots - 1) return false;
+    if (n_mels < 1 || n_mels > 8 * max_slots - 1 || static_cast<int>(window.size()) != FL) return false;
     std::vector<T> t(FbankBlob::kTCount, T(0));
-    const std::vector<double> win = povey_window(FL);              // src/fbank.rs:98-105
-    for (int i = 0; i < FL; ++i) t[FbankBlob::kWin + i] = static_cast<T>(win[i]);
+    for (int i = 0; i < FL; ++i) t[FbankBlob::kWin + i] = static_cast<T>(window[i]);
     for (int n2 = 0; n2 < 16; ++n2)
         for (int k1 = 0; k1 < 16; ++k1) {
             const double a = -2.0 * kPi * ((n2 * k1) % 256) / 256.0;
@@ -43,13 +43,9 @@ inline bool build_fbank_fast_tables(double sample_rate, int num_mel_bins, double
             t[FbankBlob::kTw2 + j * FbankBlob::kTw2Stride + 2 * q + 1] = static_cast<T>(std::sin(a));
         }
     const int bins = N / 2 + 1;
-    const std::vector<double> dense = kaldi_mel_filterbank(sample_rate, N, num_mel_bins, low_freq, high_freq);
-    // phase 2 stores 4*|X|^2 (or 2*|X|): the weights carry the 1/4 (1/2)
     std::vector<float> mel(FbankBlob::kMelW, 0.0f);
-    if (!build_interval_mel(dense, num_mel_bins, bins, bins, mel, out.slots, kFbLanes, use_power ? 0.25 : 0.5,
-                            FbankBlob::kMelStart))
+    if (!build_interval_mel(dense, n_mels, bins, bins, mel, out.slots, kFbLanes, scale, FbankBlob::kMelStart, max_slots))
         return false;
-    if (out.slots.n_slots > kFbSlots) return false;
     while (mel.size() % 4) mel.push_back(0.0f);
     const size_t t_words = t.size() * sizeof(T) / 4;
     out.mel_off_words = static_cast<int>(t_words);
@@ -58,6 +54,33 @@ inline bool build_fbank_fast_tables(double sample_rate, int num_mel_bins, double
     std::memcpy(out.blob.data() + t_words, mel.data(), mel.size() * sizeof(float));
     out.f64 = sizeof(T) == 8;
     return true;
+}
+
+// Kaldi fbank, default geometry (400-sample frames, 512-point FFT): Povey window (src/fbank.rs:98-105),
+// un-normalised Kaldi triangles (src/fbank.rs:253-301).  Phase 2 stores 4*|X|^2 (or 2*|X|), so the
+// weights carry the 1/4 (1/2).
+template <class T>
+inline bool build_fbank_fast_tables(double sample_rate, int num_mel_bins, double low_freq, double high_freq,
+                                    bool use_power, FbankFastTables &out) {
+    const std::vector<double> dense = kaldi_mel_filterbank(sample_rate, 512, num_mel_bins, low_freq, high_freq);
+    return build_fused512_tables<T>(povey_window(400), dense, num_mel_bins, use_power ? 0.25 : 0.5, kFbSlots, out);
+}
+
+// NeMo/Parakeet frontend (BatchLogMelSpectrogram::new, src/mel.rs:248-280): symmetric Hann(400) computed in
+// f32 exactly like centered_hann_window_f32 (src/mel.rs:708-719), Slaney/HTK mel() with explicit f_min/f_max,
+// weights rounded to f32 like project_power_f32 (src/mel.rs:139-145).
+template <class T>
+inline bool build_blm_fast_tables(int sample_rate, int n_mels, double f_min, double f_max, bool htk, bool norm,
+                                  FbankFastTables &out) {
+    std::vector<double> win(400);
+    const float pi_f32 = 3.14159265358979323846f;
+    for (int i = 0; i < 400; ++i) {
+        const float phase = (2.0f * pi_f32 * static_cast<float>(i)) / (400.0f - 1.0f);
+        win[i] = static_cast<double>(0.5f - (0.5f * std::cos(phase)));
+    }
+    std::vector<double> dense = mel_filterbank(static_cast<double>(sample_rate), 512, n_mels, f_min > 0.0 ? f_min : -1.0, f_max, htk, norm);
+    for (double &w : dense) w = static_cast<double>(static_cast<float>(w));
+    return build_fused512_tables<T>(win, dense, n_mels, 0.25, kBlmSlots, out);
 }
 
 }  // namespace melspec

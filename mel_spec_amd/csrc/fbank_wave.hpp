@@ -29,7 +29,8 @@ namespace melspec {
 
 constexpr int kFbFPW = 7;        // frames per wavefront (7 * 9 = 63 lanes)
 constexpr int kFbLanes = 9;      // lanes per frame: 8 workers + 1 (ghost in phase 3, 9th job in phase 2)
-constexpr int kFbSlots = 11;     // intervals j + 8*slot, up to 87 mel bins
+constexpr int kFbSlots = 11;     // intervals j + 8*slot, up to 87 mel bins (Kaldi fbank)
+constexpr int kBlmSlots = 17;    // up to 135 mel bins (NeMo/Parakeet uses 80 or 128)
 
 template <class T> struct PairOf;
 template <> struct PairOf<float> { using type = f2; };
@@ -52,8 +53,8 @@ struct FbankBlob {
     static constexpr int kTw2 = kMod + 32;                 // [9][36] complex W_512^{j+16q}
     static constexpr int kTCount = kTw2 + 9 * kTw2Stride;  // 1332 elements of T
     // mel section, float offsets from its own base
-    static constexpr int kMelStart = 0;                                // [kFbSlots*9] ints
-    static constexpr int kMelW = (kFbSlots * kFbLanes + 3) & ~3;       // pairs [slot][r][9][2]
+    static constexpr int kMelStart = 0;                                // [kBlmSlots*9] ints
+    static constexpr int kMelW = (kBlmSlots * kFbLanes + 3) & ~3;      // pairs [slot][r][9][2]
 };
 
 template <class T>
@@ -83,12 +84,24 @@ MS_DEV T fb_partial_sum(const float *frame, int t) {
     return s;
 }
 
+// DFT over n1 of one column, twiddle by W_256^{n2*k1}, write the 16 exchange rows (+ the W_16-modulated
+// copy of row 0 that lane 0 of phase 2 pairs row 0 with).
+template <class T>
+MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *tblob, T *xo /* &row[0][n2] */) {
+    using L = FbankLayout<T>;
+    fft16(x);
+    const T *tw = tblob + FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride;
+    stc(xo, x[0]);
+    stc(xo + 16 * L::kXRow, cmul(x[0], ldc(tblob + FbankBlob::kMod + 2 * n2)));
+#pragma unroll
+    for (int k1 = 1; k1 < 16; ++k1) stc(xo + k1 * L::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
+}
+
 // One 16-point column: samples frame[32*n1 + off + {0,1}], n1 < NV (the rest of the 512-point frame is
 // zero padding), pre-emphasis, DC removal, window, DFT over n1, twiddle by W_256^{n2*k1}, exchange rows.
 template <class T, int NV>
 MS_DEV void fb_column(const float *frame, int off, int n2, T preemph, T mean, bool patch_first, const T *tblob,
                       T *xo /* &row[0][n2] */) {
-    using L = FbankLayout<T>;
     cpx<T> x[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
@@ -107,12 +120,7 @@ MS_DEV void fb_column(const float *frame, int off, int n2, T preemph, T mean, bo
             x[n1] = {T(0), T(0)};
         }
     }
-    fft16(x);
-    const T *tw = tblob + FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride;
-    stc(xo, x[0]);
-    stc(xo + 16 * L::kXRow, cmul(x[0], ldc(tblob + FbankBlob::kMod + 2 * n2)));
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) stc(xo + k1 * L::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
+    fb_column_finish<T>(x, n2, tblob, xo);
 }
 
 // phase 1 (after the frame mean is known): lane t<8 does columns n2 = t (13 non-zero inputs) and
@@ -124,6 +132,57 @@ MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this fra
     T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
     fb_column<T, 13>(frame, 2 * t, t, preemph, mean, clip_start && t == 0, tblob, xo);
     fb_column<T, 12>(frame, 16 + 2 * t, t + 8, preemph, mean, false, tblob, xo + 16);
+}
+
+// ---- NeMo/Parakeet flavour (BatchLogMelSpectrogram, src/mel.rs:299-385) --------------------------
+// The 400 window taps sit at positions 56..455 of the 512-point frame; a circular shift does not change
+// |X|, so they are processed at positions 0..399 exactly like the Kaldi frame.  Sample `s` of the clip is
+// the pre-emphasised waveform (f32, two roundings like `current - (coeff * prev)`, src/mel.rs:696-706),
+// zero outside [0, len) (centre padding, src/mel.rs:685-694).
+// a*b rounded to f32 on its own: the product must not be contracted into an FMA with the following
+// subtraction (HIP's __fmul_rn is a plain multiply and does get contracted), because the reference's
+// two roundings are visible in the weakest bins of loud frames (up to 7e-2 of a bin on jfk_f32le.wav).
+MS_DEV float f32_mul_rn(float a, float b) {
+#if defined(__HIPCC__)
+    float p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+#else
+    volatile float p = a * b;
+    return p;
+#endif
+}
+MS_DEV float nemo_sample(const float *clip, long long s, long long len, float coeff) {
+    if (s < 0 || s >= len) return 0.0f;
+    const float cur = clip[s];
+    if (coeff == 0.0f || s == 0) return cur;
+    return cur - f32_mul_rn(coeff, clip[s - 1]);
+}
+
+template <class T, int NV>
+MS_DEV void nemo_column(const float *clip, long long org, long long len, int off, int n2, float coeff, const T *tblob, T *xo) {
+    cpx<T> x[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        if (n1 < NV) {
+            const int i = 32 * n1 + off;
+            const float y0 = nemo_sample(clip, org + i, len, coeff), y1 = nemo_sample(clip, org + i + 1, len, coeff);
+            const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
+            x[n1] = {static_cast<T>(y0) * w.re, static_cast<T>(y1) * w.im};
+        } else {
+            x[n1] = {T(0), T(0)};
+        }
+    }
+    fb_column_finish<T>(x, n2, tblob, xo);
+}
+
+template <class T>
+MS_DEV void nemo_phase1(int fl, int t, bool active, const float *clip, long long org, long long len, float coeff,
+                        const T *tblob, T *slice) {
+    if (!active) return;
+    T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
+    nemo_column<T, 13>(clip, org, len, 2 * t, t, coeff, tblob, xo);
+    nemo_column<T, 12>(clip, org, len, 16 + 2 * t, t + 8, coeff, tblob, xo + 16);
 }
 
 // phase 2: two 16-point DFTs, Hermitian split with W_512, 4*power (or 2*magnitude) as f32 to LDS.
@@ -164,15 +223,15 @@ MS_DEV void fb_phase2(int fl, int j, bool active, bool use_power, const T *tblob
 }
 
 // phase 3: interval sums over 9-lane groups (lane j<8 owns interval j + 8*slot, j=8 is the ghost)
-template <class T>
+template <class T, int NSLOTS = kFbSlots>
 MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *mel /* mel section base */,
-                           const T *slice, const int (&st)[kFbSlots], float (&rise)[kFbSlots], float (&fprev)[kFbSlots]) {
+                           const T *slice, const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
 #pragma unroll
-    for (int i = 0; i < kFbSlots; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
+    for (int i = 0; i < NSLOTS; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
     if (!active) return;
     const float *p = reinterpret_cast<const float *>(slice) + fl * FbankLayout<T>::kPStride;
 #pragma unroll
-    for (int i = 0; i < kFbSlots; ++i) {
+    for (int i = 0; i < NSLOTS; ++i) {
         float ar = 0.0f, af = 0.0f;
         if (i < ms.n_slots) {
             const float *pp = p + st[i];
@@ -193,18 +252,34 @@ MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const
 MS_DEV float fast_ln(float x) { return fast_log2(x) * 0.69314718055994531f; }
 
 // floor, ln, store (src/fbank.rs:207-221).  out_tile = &out[first frame of the tile][0]
+template <int NSLOTS = kFbSlots>
 MS_DEV void fb_phase3_store(int fl, int j, bool active, int n_mels, float floor_v, bool use_log,
-                            const float (&rise)[kFbSlots], const float (&fnext)[kFbSlots], float *out_tile) {
+                            const float (&rise)[NSLOTS], const float (&fnext)[NSLOTS], float *out_tile) {
     if (!active || j >= 8) return;
     float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
 #pragma unroll
-    for (int i = 0; i < kFbSlots; ++i) {
+    for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + 8 * i;
         if (m < n_mels) {
             float e = rise[i] + fnext[i];
             e = __builtin_fmaxf(e, floor_v);
             o[8 * i] = use_log ? fast_ln(e) : e;
         }
+    }
+}
+
+// NeMo epilogue: ln(E + guard) (src/mel.rs:365-368), feature-major rows of `row_w` columns
+// (src/mel.rs:366); columns past the valid frames are zero (the reference zero-initialises `features`).
+template <int NSLOTS>
+MS_DEV void nemo_phase3_store(int fl, int j, bool store, bool valid, int n_mels, float guard, const float (&rise)[NSLOTS],
+                              const float (&fnext)[NSLOTS], float *out_col /* &out[0][first frame of the tile] */,
+                              long long row_w) {
+    if (!store || j >= 8) return;
+    float *o = out_col + static_cast<long long>(j) * row_w + fl;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const int m = j + 8 * i;
+        if (m < n_mels) o[static_cast<long long>(8 * i) * row_w] = valid ? fast_ln((rise[i] + fnext[i]) + guard) : 0.0f;
     }
 }
 

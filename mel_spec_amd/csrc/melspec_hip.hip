@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -799,6 +800,165 @@ int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n
     HIP_TRY(hipMemcpyAsync(out, fb->d2h.p, need * sizeof(float), hipMemcpyDeviceToHost, fb->stream));
     HIP_TRY(hipStreamSynchronize(fb->stream));
     if (n_frames) *n_frames = static_cast<size_t>(frames);
+    return MELSPEC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// NeMo / Parakeet frontend context (BatchLogMelSpectrogram, src/mel.rs:239-396)
+// ------------------------------------------------------------------------------------
+struct melspec_blm {
+    DeviceInfo dev;
+    melspec_blm_config cfg{};
+    hipStream_t stream = nullptr;
+    FbankFastTables ft;
+    DevBuf d_blob;
+    size_t fast_lds = 0;
+    DevBuf h2d, d2h;
+};
+
+namespace {
+uint64_t blm_valid_frames(const melspec_blm *b, uint64_t n) {       // src/mel.rs:326-332,387-395
+    if (n == 0) return 0;
+    if (b->cfg.center) return n / b->cfg.hop_length + 1;
+    if (n < static_cast<uint64_t>(b->cfg.n_fft)) return 0;
+    return (n - b->cfg.n_fft) / b->cfg.hop_length + 1;
+}
+uint64_t blm_padded(const melspec_blm *b, uint64_t frames) {         // pad_len, src/mel.rs:751-756
+    const uint64_t p = b->cfg.pad_to;
+    return p == 0 ? frames : (frames + p - 1) / p * p;
+}
+}  // namespace
+
+extern "C" {
+
+void melspec_blm_default_config(melspec_blm_config *c) {
+    if (!c) return;
+    c->sample_rate = 16000; c->n_fft = 512; c->win_length = 400; c->hop_length = 160; c->n_mels = 80;
+    c->f_min = 0.0; c->f_max = -1.0; c->htk = 0; c->norm = 1; c->preemphasis = 0.0f; c->center = 1;
+    c->log_zero_guard = FLT_EPSILON; c->pad_to = 0; c->normalize_per_feature = 0;
+}
+
+int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *cfg) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!cfg) return fail(MELSPEC_ERR_INVALID_ARG, "cfg is NULL");
+    // validate_batch_config (src/mel.rs:656-683), same order and messages
+    if (cfg->sample_rate <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: sample_rate must be > 0");
+    if (cfg->n_fft <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: n_fft must be > 0");
+    if (cfg->win_length <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: win_length must be > 0");
+    if (cfg->win_length > cfg->n_fft) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: win_length must be <= n_fft");
+    if (cfg->hop_length <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: hop_length must be > 0");
+    if (cfg->n_mels <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: n_mels must be > 0");
+    if (!std::isfinite(cfg->log_zero_guard) || cfg->log_zero_guard <= 0.0f)
+        return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: log_zero_guard must be finite and > 0");
+    if (cfg->pad_to < 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: pad_to must be >= 0");
+    if (cfg->n_fft != 512 || cfg->win_length != 400)
+        return fail(MELSPEC_ERR_UNSUPPORTED, "only n_fft = 512 with win_length = 400 is covered by the fused kernel");
+    DeviceInfo info;
+    int rc = pick_device(device, info);
+    if (rc) return rc;
+    melspec_blm *b = new (std::nothrow) melspec_blm();
+    if (!b) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    b->dev = info; b->cfg = *cfg;
+    auto bail = [&](int code) { melspec_blm_destroy(b); return code; };
+    if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
+    if (hipStreamCreate(&b->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
+    const double f_max = cfg->f_max > 0.0 ? cfg->f_max : cfg->sample_rate / 2.0;   // src/mel.rs:254
+    if (!build_blm_fast_tables<double>(cfg->sample_rate, cfg->n_mels, cfg->f_min, f_max, cfg->htk != 0, cfg->norm != 0, b->ft))
+        return bail(fail(MELSPEC_ERR_UNSUPPORTED, "filterbank outside the fused kernel's coverage (n_mels <= 135, triangular bank)"));
+    b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(kFbWaves) * FbankLayout<double>::slice_elems() * sizeof(double);
+    if (b->fast_lds > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "tables do not fit in LDS"));
+    if ((rc = upload(b->d_blob, b->ft.blob))) return bail(rc);
+    if ((rc = allow_big_lds(&fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kFbSlots>, "hipFuncSetAttribute(nemo kernel)"))) return bail(rc);
+    if ((rc = allow_big_lds(&fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kBlmSlots>, "hipFuncSetAttribute(nemo kernel)"))) return bail(rc);
+    *out = b;
+    return MELSPEC_OK;
+}
+
+void melspec_blm_destroy(melspec_blm *b) {
+    if (!b) return;
+    if (b->dev.device >= 0) (void)hipSetDevice(b->dev.device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    b->d_blob.release(); b->h2d.release(); b->d2h.release();
+    delete b;
+}
+
+size_t melspec_blm_num_frames(const melspec_blm *b, size_t n) { return b ? static_cast<size_t>(blm_valid_frames(b, n)) : 0; }
+size_t melspec_blm_padded_frames(const melspec_blm *b, size_t n) { return b ? static_cast<size_t>(blm_padded(b, blm_valid_frames(b, n))) : 0; }
+
+int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                       uint32_t n_clips, float *d_out, void *stream) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    if (n_clips == 0) return MELSPEC_OK;
+    const uint64_t valid = blm_valid_frames(b, clip_len), cols = blm_padded(b, valid);
+    if (cols == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
+    const int nm = b->cfg.n_mels;
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, valid, n_clips, nm, kFbFPW, cols, true);
+    FbankFastParams fp{};
+    fp.b = pl.desc;
+    fp.d_blob = static_cast<const uint32_t *>(b->d_blob.p);
+    fp.blob_words = static_cast<int>(b->ft.blob.size());
+    fp.mel_off_words = b->ft.mel_off_words;
+    fp.shift = b->cfg.hop_length;
+    fp.n_mels = nm;
+    fp.preemph = b->cfg.preemphasis;
+    fp.floor_v = b->cfg.log_zero_guard;
+    fp.use_log = 1; fp.use_power = 1;
+    fp.clip_len = static_cast<long long>(clip_len);
+    fp.org0 = b->cfg.center ? -200 : 56;      // tap 0 of the window sits at position (512-400)/2 of the frame
+    fp.slots = b->ft.slots;
+    const uint64_t blocks = (pl.desc.n_units + kFbWaves - 1) / kFbWaves;
+    const unsigned grid = grid_for(blocks, b->dev.cus, 16);
+    if (b->ft.slots.n_slots <= kFbSlots)
+        hipLaunchKernelGGL((fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kFbSlots>), dim3(grid), dim3(kFbWaves * 64), b->fast_lds, s, fp);
+    else
+        hipLaunchKernelGGL((fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kBlmSlots>), dim3(grid), dim3(kFbWaves * 64), b->fast_lds, s, fp);
+    HIP_TRY(hipGetLastError());
+    if (b->cfg.normalize_per_feature && valid > 0) {
+        BlmNormParams np{};
+        np.out = d_out; np.clip_stride = cols * static_cast<uint64_t>(nm); np.row_w = cols; np.valid = valid;
+        np.n_clips = n_clips; np.n_mels = nm;
+        const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
+        const unsigned g2 = grid_for((rows + 3) / 4, b->dev.cus, 16);
+        hipLaunchKernelGGL(blm_normalize_kernel<4>, dim3(g2), dim3(256), 0, s, np);
+        HIP_TRY(hipGetLastError());
+    }
+    return MELSPEC_OK;
+}
+
+int melspec_blm_synchronize(melspec_blm *b, void *stream) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    HIP_TRY(hipStreamSynchronize(stream ? static_cast<hipStream_t>(stream) : b->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_blm_compute_host(melspec_blm *b, const float *samples, size_t n_samples, float *out, size_t out_capacity_floats,
+                             size_t *rows, size_t *cols) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    if (rows) *rows = static_cast<size_t>(b->cfg.n_mels);
+    if (cols) *cols = 0;
+    const uint64_t c = blm_padded(b, blm_valid_frames(b, n_samples));
+    if (c == 0) return MELSPEC_OK;
+    if (!samples || !out) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+    const uint64_t need = c * static_cast<uint64_t>(b->cfg.n_mels);
+    if (out_capacity_floats < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    int rc;
+    if ((rc = b->h2d.ensure(n_samples * sizeof(float)))) return rc;
+    if ((rc = b->d2h.ensure(need * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h2d.p, samples, n_samples * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    rc = melspec_blm_compute_uniform_device(b, static_cast<const float *>(b->h2d.p), n_samples, n_samples, 1,
+                                            static_cast<float *>(b->d2h.p), b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, b->d2h.p, need * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (cols) *cols = static_cast<size_t>(c);
     return MELSPEC_OK;
 }
 

@@ -208,15 +208,22 @@ struct FbankFastParams {
     const uint32_t *d_blob;
     int blob_words;         // 32-bit words, multiple of 4
     int mel_off_words;      // mel section offset inside the blob
-    int shift;              // frame shift in samples
+    int shift;              // frame shift (hop) in samples
     int n_mels;
     double preemph;
-    float floor_v;
+    float floor_v;          // Kaldi: energy floor; NeMo: log_zero_guard
     int use_log, use_power;
+    long long clip_len;     // NeMo (uniform batches): samples per clip, for the centre padding
+    int org0;               // NeMo: clip index of tap 0 of frame 0 (-200 centred, +56 not centred)
     MelSlots slots;
 };
 
-template <class T, int WAVES, int MINW>
+constexpr int kFlavorKaldi = 0, kFlavorNemo = 1;
+
+// FLAVOR = Kaldi: Fbank::compute (src/fbank.rs:141-236), frame-major output, CMN by cmn_kernel.
+// FLAVOR = NeMo:  BatchLogMelSpectrogram::compute (src/mel.rs:321-385), feature-major output of
+//                 b.out_width columns per mel row (columns past the valid frames are zero).
+template <class T, int WAVES, int MINW, int FLAVOR = kFlavorKaldi, int NSLOTS = kFbSlots>
 __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const FbankFastParams p) {
     using L = FbankLayout<T>;
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
@@ -231,11 +238,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     T *slice = reinterpret_cast<T *>(ldsw + p.blob_words) + wave * L::slice_elems();
     const int fl = lane / kFbLanes, j = lane - fl * kFbLanes;
     const bool in = lane < kFbFPW * kFbLanes;
-    int st[kFbSlots];
+    int st[NSLOTS];
     {
         const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
 #pragma unroll
-        for (int i = 0; i < kFbSlots; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
+        for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
     }
     const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
     const T preemph = static_cast<T>(p.preemph);
@@ -243,30 +250,79 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFbFPW;
-        const uint64_t left = loc.frames - f0;
+        const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
         const bool act = in && fl < nv;
         const bool act1 = act && j < 8;
-        const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-        // frame mean (src/fbank.rs:165-166): 8 partial sums of 50 samples through LDS
-        slice[L::kSumOff + lane] = act1 ? fb_partial_sum<T>(frame, j) : T(0);
-        __builtin_amdgcn_wave_barrier();
-        T mean = 0;
-        if (act) {
-            const T *ps = slice + L::kSumOff + fl * kFbLanes;
-            mean = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / T(400);
+        if (FLAVOR == kFlavorKaldi) {
+            const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
+            // frame mean (src/fbank.rs:165-166): 8 partial sums of 50 samples through LDS
+            slice[L::kSumOff + lane] = act1 ? fb_partial_sum<T>(frame, j) : T(0);
+            __builtin_amdgcn_wave_barrier();
+            T mean = 0;
+            if (act) {
+                const T *ps = slice + L::kSumOff + fl * kFbLanes;
+                mean = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / T(400);
+            }
+            __builtin_amdgcn_wave_barrier();
+            fb_phase1<T>(fl, j, act1, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+        } else {
+            const long long org = (long long)(f0 + (uint64_t)fl) * p.shift + p.org0;
+            nemo_phase1<T>(fl, j, act1, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
         }
-        __builtin_amdgcn_wave_barrier();
-        fb_phase1<T>(fl, j, act1, frame, f0 + fl == 0, mean, preemph, tblob, slice);
         __builtin_amdgcn_wave_barrier();
         fb_phase2<T>(fl, j, act, use_power, tblob, slice);
         __builtin_amdgcn_wave_barrier();
-        float rise[kFbSlots], fprev[kFbSlots], fnext[kFbSlots];
-        fb_phase3_sums<T>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
+        float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+        fb_phase3_sums<T, NSLOTS>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
 #pragma unroll
-        for (int i = 0; i < kFbSlots; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-        fb_phase3_store(fl, j, act, p.n_mels, p.floor_v, use_log, rise, fnext, loc.out + f0 * (uint64_t)p.n_mels);
+        for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+        if (FLAVOR == kFlavorKaldi) {
+            fb_phase3_store<NSLOTS>(fl, j, act, p.n_mels, p.floor_v, use_log, rise, fnext, loc.out + f0 * (uint64_t)p.n_mels);
+        } else {
+            const uint64_t wleft = p.b.out_width - f0;
+            const int ns = wleft < (uint64_t)kFbFPW ? (int)wleft : kFbFPW;
+            nemo_phase3_store<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, p.floor_v, rise, fnext, loc.out + f0,
+                                      (long long)p.b.out_width);
+        }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Per-feature normalisation of the NeMo frontend (normalize_per_feature, src/mel.rs:721-749): for every
+// (clip, mel) row: mean over the valid frames, unbiased variance, (v - mean) / (sqrt(var) + 1e-5).
+// One wavefront per row, fixed summation order (lane-strided partials, then a fixed tree).
+struct BlmNormParams {
+    float *out;
+    uint64_t clip_stride;   // floats between clips = n_mels * row_w
+    uint64_t row_w;         // columns per row (padded frames)
+    uint64_t valid;         // valid frames
+    uint32_t n_clips;
+    int n_mels;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void blm_normalize_kernel(const BlmNormParams p) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
+    for (uint64_t row = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6); row < rows; row += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
+        float *r = p.out + clip * p.clip_stride + m * p.row_w;
+        float s = 0.0f;
+        for (uint64_t f = lane; f < p.valid; f += 64) s += r[f];
+        const float mean = wave_sum(s) / (float)p.valid;
+        float q = 0.0f;
+        for (uint64_t f = lane; f < p.valid; f += 64) { const float d = r[f] - mean; q += d * d; }
+        float denom = (float)p.valid - 1.0f;
+        denom = denom < 1.0f ? 1.0f : denom;
+        const float sd = sqrtf(wave_sum(q) / denom) + 1e-5f;
+        for (uint64_t f = lane; f < p.valid; f += 64) r[f] = (r[f] - mean) / sd;
     }
 }
 

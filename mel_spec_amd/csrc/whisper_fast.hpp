@@ -26,7 +26,8 @@ namespace melspec {
 
 constexpr int kMelJobs = 11;        // threads per frame in phases 2-4
 constexpr int kFftJobs = 10;        // threads per frame in phase 1
-constexpr int kMaxSlots = 12;       // mel slots per thread (n_mels <= 132)
+constexpr int kMaxSlots = 12;       // mel slots per thread of the Whisper kernels (n_mels <= 131)
+constexpr int kSlotCap = 17;        // capacity of MelSlots (the NeMo frontend uses up to 17 slots of 8)
 
 // LDS layout of the constant table blob (float offsets).  Built by build_fast_tables().
 struct FastBlob {
@@ -43,8 +44,8 @@ struct FastBlob {
 // Per-launch uniform parameters of the mel slots (scalar registers on the device).
 struct MelSlots {
     int n_slots;               // banded: ceil(n_mels / 11); interval: ceil((n_mels + 1) / 11)
-    int len[kMaxSlots];        // padded span length of slot i
-    int woff[kMaxSlots];       // float offset of slot i's weights inside the blob
+    int len[kSlotCap];         // padded span length of slot i
+    int woff[kSlotCap];        // float offset of slot i's weights inside the blob
 };
 
 template <int FPB>

@@ -19,7 +19,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import FbankConfigC, lib
+from ._lib import BlmConfigC, FbankConfigC, lib
 
 
 class HipError(RuntimeError):
@@ -326,6 +326,99 @@ class Fbank:
     def close(self) -> None:
         if self._h is not None:
             lib().melspec_fbank_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchLogMelError(HipError):
+    """BatchLogMelError::InvalidConfig (src/mel.rs:210-225)."""
+
+
+@dataclass
+class BatchLogMelConfig:
+    """BatchLogMelConfig::default (src/mel.rs:189-208)."""
+    sample_rate: int = 16000
+    n_fft: int = 512
+    win_length: int = 400
+    hop_length: int = 160
+    n_mels: int = 80
+    f_min: float = 0.0
+    f_max: float | None = None
+    htk: bool = False
+    norm: bool = True
+    preemphasis: float = 0.0
+    center: bool = True
+    log_zero_guard: float = float(np.finfo(np.float32).eps)
+    pad_to: int = 0
+    normalize_per_feature: bool = False
+
+    def to_c(self) -> BlmConfigC:
+        return BlmConfigC(self.sample_rate, self.n_fft, self.win_length, self.hop_length, self.n_mels, self.f_min,
+                          -1.0 if self.f_max is None else self.f_max, int(self.htk), int(self.norm), self.preemphasis,
+                          int(self.center), self.log_zero_guard, self.pad_to, int(self.normalize_per_feature))
+
+
+class BatchLogMelSpectrogram:
+    """MI355X twin of BatchLogMelSpectrogram (src/mel.rs:239-396): NeMo/Parakeet-style frontend."""
+
+    def __init__(self, config: BatchLogMelConfig | None = None, device: int = -1):
+        self._h = None
+        self.config = config or BatchLogMelConfig()
+        h = C.c_void_p()
+        cc = self.config.to_c()
+        rc = lib().melspec_blm_create(C.byref(h), device, C.byref(cc))
+        if rc == _lib.ERR_INVALID_ARG:
+            raise BatchLogMelError(rc, _lib.last_error())
+        _check(rc, construct=True)
+        self._h = h
+
+    def num_frames(self, n_samples: int) -> int:
+        return int(lib().melspec_blm_num_frames(self._h, n_samples))
+
+    def padded_frames(self, n_samples: int) -> int:
+        return int(lib().melspec_blm_padded_frames(self._h, n_samples))
+
+    def compute(self, samples) -> np.ndarray:
+        """&[f32] -> Array2<f32> (n_mels, cols), feature-major (src/mel.rs:299-302)."""
+        x = _f32(samples).reshape(-1)
+        cols = self.padded_frames(x.shape[0])
+        out = np.zeros((self.config.n_mels, cols), np.float32)
+        r, c = C.c_size_t(0), C.c_size_t(0)
+        _check(lib().melspec_blm_compute_host(self._h, _fp(x), x.shape[0], _fp(out), out.size, C.byref(r), C.byref(c)))
+        assert r.value == self.config.n_mels and c.value == cols
+        return out
+
+    def compute_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int, stream: int = 0) -> None:
+        _check(lib().melspec_blm_compute_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
+                                                        C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def synchronize(self, stream: int = 0) -> None:
+        _check(lib().melspec_blm_synchronize(self._h, C.c_void_p(stream)))
+
+    def compute_batch(self, clips) -> np.ndarray:
+        x = _f32(clips)
+        n_clips, clip_len = x.shape
+        cols = self.padded_frames(clip_len)
+        shape = (n_clips, self.config.n_mels, cols)
+        if cols == 0:
+            return np.zeros(shape, np.float32)
+        din, dout = DeviceBuffer(x.nbytes), DeviceBuffer(int(np.prod(shape)) * 4)
+        try:
+            din.upload(x)
+            self.compute_uniform_device(din.ptr, clip_len, clip_len, n_clips, dout.ptr)
+            self.synchronize()
+            return dout.download(shape)
+        finally:
+            din.free(); dout.free()
+
+    def close(self) -> None:
+        if self._h is not None:
+            lib().melspec_blm_destroy(self._h)
             self._h = None
 
     def __del__(self):

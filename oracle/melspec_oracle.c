@@ -526,6 +526,184 @@ int64_t oracle_fbank_batch(const oracle_fbank_config *cfg, const float *samples,
 }
 
 /* ------------------------------------------------------------------------- */
+/* BatchLogMelSpectrogram (NeMo/Parakeet-style frontend): src/mel.rs:171-418,   */
+/* 656-756.  The reference computes this path in f32 (rustfft f32, f32 window,  */
+/* f32 projection); `oracle_blm_compute_f32` restates it literally in f32 with  */
+/* this file's own FFT, `oracle_blm_compute_f64` evaluates the same definition  */
+/* in f64 (only the f32-rounded inputs the reference also has -- window table,  */
+/* pre-emphasised waveform, f32 weights -- are kept) and is what the GPU path   */
+/* is gated against.  The reference's tests pin only the output shape           */
+/* (src/mel.rs:943-961): values are PARITY UNPINNED for this path.              */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int sample_rate, n_fft, win_length, hop_length, n_mels;   /* BatchLogMelConfig, src/mel.rs:171-208 */
+    double f_min, f_max;                                      /* f_max <= 0 == None (sample_rate/2)     */
+    int htk, norm;
+    float preemphasis;
+    int center;
+    float log_zero_guard;
+    int pad_to;
+    int normalize_per_feature;
+} oracle_blm_config;
+
+void oracle_blm_default_config(oracle_blm_config *c) {   /* src/mel.rs:189-208 */
+    c->sample_rate = 16000; c->n_fft = 512; c->win_length = 400; c->hop_length = 160; c->n_mels = 80;
+    c->f_min = 0.0; c->f_max = -1.0; c->htk = 0; c->norm = 1; c->preemphasis = 0.0f; c->center = 1;
+    c->log_zero_guard = FLT_EPSILON; c->pad_to = 0; c->normalize_per_feature = 0;
+}
+int64_t oracle_blm_num_frames(const oracle_blm_config *c, int64_t len) {   /* src/mel.rs:387-395 */
+    if (len == 0) return 0;                                                  /* src/mel.rs:326-332 */
+    if (c->center) return len / c->hop_length + 1;
+    if (len < c->n_fft) return 0;
+    return (len - c->n_fft) / c->hop_length + 1;
+}
+int64_t oracle_blm_padded_frames(const oracle_blm_config *c, int64_t frames) {   /* pad_len, src/mel.rs:751-756 */
+    if (c->pad_to == 0) return frames;
+    return ((frames + c->pad_to - 1) / c->pad_to) * c->pad_to;
+}
+
+typedef struct { float re, im; } cplxf;
+typedef struct { int n; cplxf *tw; cplxf *scratch; } fft_planf;
+static void fft_planf_init(fft_planf *p, int n) {
+    p->n = n; p->tw = (cplxf *)malloc(sizeof(cplxf) * (size_t)n); p->scratch = (cplxf *)malloc(sizeof(cplxf) * (size_t)n);
+    for (int j = 0; j < n; ++j) { double a = -2.0 * M_PI * (double)j / (double)n; p->tw[j].re = (float)cos(a); p->tw[j].im = (float)sin(a); }
+}
+static void fft_planf_free(fft_planf *p) { free(p->tw); free(p->scratch); }
+static inline cplxf cmulf(cplxf a, cplxf b) { cplxf r = { a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re }; return r; }
+static inline cplxf caddf(cplxf a, cplxf b) { cplxf r = { a.re + b.re, a.im + b.im }; return r; }
+static inline cplxf csubf(cplxf a, cplxf b) { cplxf r = { a.re - b.re, a.im - b.im }; return r; }
+static void fft_recf(const fft_planf *pl, int n, int stride, const cplxf *in, cplxf *out) {
+    if (n == 1) { out[0] = in[0]; return; }
+    const int N = pl->n, p = pick_radix(n), m = n / p;
+    for (int q = 0; q < p; ++q) fft_recf(pl, m, stride * p, in + (size_t)q * stride, out + (size_t)q * m);
+    const int tstep = N / n, pstep = N / p;
+    cplxf t[64];
+    for (int k = 0; k < m; ++k) {
+        for (int q = 0; q < p; ++q) t[q] = q ? cmulf(out[q * m + k], pl->tw[(q * k) * tstep]) : out[k];
+        for (int r = 0; r < p; ++r) {
+            cplxf acc = t[0];
+            for (int q = 1; q < p; ++q) acc = caddf(acc, cmulf(t[q], pl->tw[((q * r) % p) * pstep]));
+            out[r * m + k] = acc;
+        }
+    }
+    (void)csubf;
+}
+
+/* shared front part: pre-emphasised waveform (f32, src/mel.rs:696-706), f32 window (708-719), f32 weights */
+static void blm_prepare(const oracle_blm_config *c, const float *samples, int64_t len, float *wave, float *window,
+                        sparse_fb *fb, double **dense_out) {
+    memcpy(wave, samples, sizeof(float) * (size_t)len);
+    if (len > 0 && c->preemphasis != 0.0f) {
+        float prev = wave[0];
+        for (int64_t i = 1; i < len; ++i) { float cur = wave[i]; wave[i] = cur - (c->preemphasis * prev); prev = cur; }
+    }
+    for (int i = 0; i < c->n_fft; ++i) window[i] = 0.0f;
+    if (c->win_length > 1) {
+        const int offset = (c->n_fft - c->win_length) / 2;
+        const float pi_f32 = 3.14159265358979323846f;
+        for (int i = 0; i < c->win_length; ++i) {
+            float phase = (2.0f * pi_f32 * (float)i) / ((float)c->win_length - 1.0f);
+            window[offset + i] = 0.5f - (0.5f * cosf(phase));
+        }
+    }
+    const int bins = c->n_fft / 2 + 1;
+    const double fmax_ = c->f_max > 0.0 ? c->f_max : (double)c->sample_rate / 2.0;
+    double *dense = (double *)malloc(sizeof(double) * (size_t)c->n_mels * bins);
+    /* SparseMelFilterbank::from_mel(sr, n_fft, n_mels, Some(f_min), Some(f_max), htk, norm), src/mel.rs:254-263 */
+    {
+        /* mel() with explicit f_min (may be 0.0 exactly, which the None-encoding of oracle_mel_filterbank also means) */
+        oracle_mel_filterbank((double)c->sample_rate, c->n_fft, c->n_mels, c->f_min > 0.0 ? c->f_min : -1.0, fmax_, c->htk, c->norm, dense);
+    }
+    sparse_from_dense(fb, dense, c->n_mels, bins);
+    *dense_out = dense;
+}
+
+static void blm_normalize(float *features, int n_mels, int64_t valid, int64_t padded) {   /* src/mel.rs:721-749 */
+    if (valid == 0) return;
+    for (int m = 0; m < n_mels; ++m) {
+        float *row = features + (int64_t)m * padded;
+        float sum = 0.0f;
+        for (int64_t f = 0; f < valid; ++f) sum += row[f];
+        const float mean = sum / (float)valid;
+        float denom = (float)valid - 1.0f; if (denom < 1.0f) denom = 1.0f;
+        float var = 0.0f;
+        for (int64_t f = 0; f < valid; ++f) { float d = row[f] - mean; var += d * d; }
+        var = var / denom;
+        const float sd = sqrtf(var) + 1e-5f;
+        for (int64_t f = 0; f < valid; ++f) row[f] = (row[f] - mean) / sd;
+    }
+}
+
+/* out: [n_mels][padded_frames] f32.  Returns padded_frames (cols); *valid_out = valid frames. */
+int64_t oracle_blm_compute_f32(const oracle_blm_config *c, const float *samples, int64_t len, float *out, int64_t *valid_out) {
+    const int64_t valid = oracle_blm_num_frames(c, len), padded = oracle_blm_padded_frames(c, valid);
+    if (valid_out) *valid_out = valid;
+    if (len == 0 || !out) return padded;
+    const int N = c->n_fft, bins = N / 2 + 1, pad = c->center ? N / 2 : 0;
+    float *wave = (float *)malloc(sizeof(float) * (size_t)len), *window = (float *)malloc(sizeof(float) * (size_t)N);
+    float *power = (float *)malloc(sizeof(float) * (size_t)bins);
+    cplxf *buf = (cplxf *)malloc(sizeof(cplxf) * (size_t)N);
+    sparse_fb fb; double *dense;
+    blm_prepare(c, samples, len, wave, window, &fb, &dense);
+    fft_planf pl; fft_planf_init(&pl, N);
+    for (int64_t i = 0; i < (int64_t)c->n_mels * padded; ++i) out[i] = 0.0f;
+    for (int64_t f = 0; f < valid; ++f) {
+        const int64_t start = f * c->hop_length;
+        for (int i = 0; i < N; ++i) {
+            const int64_t s = start + i - pad;                 /* index into the un-padded waveform */
+            const float v = (s >= 0 && s < len) ? wave[s] : 0.0f;
+            buf[i].re = v * window[i]; buf[i].im = 0.0f;
+        }
+        memcpy(pl.scratch, buf, sizeof(cplxf) * (size_t)N);
+        fft_recf(&pl, N, 1, pl.scratch, buf);
+        for (int b = 0; b < bins; ++b) power[b] = buf[b].re * buf[b].re + buf[b].im * buf[b].im;
+        for (int m = 0; m < c->n_mels; ++m) {                  /* project_power_f32, src/mel.rs:127-146 */
+            float e = 0.0f;
+            for (int j = fb.row_ptr[m]; j < fb.row_ptr[m + 1]; ++j) e += (float)fb.w[j] * power[fb.bin[j]];
+            out[(int64_t)m * padded + f] = logf(e + c->log_zero_guard);
+        }
+    }
+    if (c->normalize_per_feature) blm_normalize(out, c->n_mels, valid, padded);
+    fft_planf_free(&pl); sparse_free(&fb);
+    free(dense); free(wave); free(window); free(power); free(buf);
+    return padded;
+}
+
+/* Same definition with f64 FFT / power / projection / ln; keeps the f32-rounded inputs of the reference. */
+int64_t oracle_blm_compute_f64(const oracle_blm_config *c, const float *samples, int64_t len, float *out, int64_t *valid_out) {
+    const int64_t valid = oracle_blm_num_frames(c, len), padded = oracle_blm_padded_frames(c, valid);
+    if (valid_out) *valid_out = valid;
+    if (len == 0 || !out) return padded;
+    const int N = c->n_fft, bins = N / 2 + 1, pad = c->center ? N / 2 : 0;
+    float *wave = (float *)malloc(sizeof(float) * (size_t)len), *window = (float *)malloc(sizeof(float) * (size_t)N);
+    double *power = (double *)malloc(sizeof(double) * (size_t)bins);
+    cplx *buf = (cplx *)malloc(sizeof(cplx) * (size_t)N);
+    sparse_fb fb; double *dense;
+    blm_prepare(c, samples, len, wave, window, &fb, &dense);
+    fft_plan pl; fft_plan_init(&pl, N);
+    for (int64_t i = 0; i < (int64_t)c->n_mels * padded; ++i) out[i] = 0.0f;
+    for (int64_t f = 0; f < valid; ++f) {
+        const int64_t start = f * c->hop_length;
+        for (int i = 0; i < N; ++i) {
+            const int64_t s = start + i - pad;
+            const double v = (s >= 0 && s < len) ? (double)wave[s] : 0.0;
+            buf[i].re = v * (double)window[i]; buf[i].im = 0.0;
+        }
+        fft_forward_inplace(&pl, buf);
+        for (int b = 0; b < bins; ++b) power[b] = buf[b].re * buf[b].re + buf[b].im * buf[b].im;
+        for (int m = 0; m < c->n_mels; ++m) {
+            double e = 0.0;
+            for (int j = fb.row_ptr[m]; j < fb.row_ptr[m + 1]; ++j) e += (double)(float)fb.w[j] * power[fb.bin[j]];
+            out[(int64_t)m * padded + f] = (float)log(e + (double)c->log_zero_guard);
+        }
+    }
+    if (c->normalize_per_feature) blm_normalize(out, c->n_mels, valid, padded);
+    fft_plan_free(&pl); sparse_free(&fb);
+    free(dense); free(wave); free(window); free(power); free(buf);
+    return padded;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Synthetic PCM generator of SURVEY.md §8(d): bit-identical on CPU and GPU,    */
 /* no libm.  x[clip][i] = u * 2^-(clip & 7), u in [-1,1).                       */
 /* ------------------------------------------------------------------------- */

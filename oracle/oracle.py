@@ -34,6 +34,15 @@ class FbankConfig(C.Structure):
     ]
 
 
+class BlmConfig(C.Structure):
+    """Mirror of oracle_blm_config (BatchLogMelConfig, src/mel.rs:171-208)."""
+    _fields_ = [
+        ("sample_rate", C.c_int), ("n_fft", C.c_int), ("win_length", C.c_int), ("hop_length", C.c_int), ("n_mels", C.c_int),
+        ("f_min", C.c_double), ("f_max", C.c_double), ("htk", C.c_int), ("norm", C.c_int), ("preemphasis", C.c_float),
+        ("center", C.c_int), ("log_zero_guard", C.c_float), ("pad_to", C.c_int), ("normalize_per_feature", C.c_int),
+    ]
+
+
 _lib = None
 
 
@@ -75,6 +84,11 @@ def lib():
         L.oracle_fbank_batch.restype = C.c_int64
         L.oracle_fbank_batch.argtypes = [C.POINTER(FbankConfig), f32p, C.c_int64, C.c_int64, C.c_int, f32p, C.c_int]
         L.oracle_synth_pcm.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, f32p]
+        L.oracle_blm_default_config.argtypes = [C.POINTER(BlmConfig)]
+        for name in ("oracle_blm_compute_f32", "oracle_blm_compute_f64"):
+            fn = getattr(L, name)
+            fn.restype = C.c_int64
+            fn.argtypes = [C.POINTER(BlmConfig), f32p, C.c_int64, f32p, C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -218,6 +232,28 @@ def fbank_batch(clips, cfg: FbankConfig | None = None, n_threads=0) -> np.ndarra
         lib().oracle_fbank_batch(C.byref(cfg), _p(x, C.c_float), x.shape[1], x.shape[1], x.shape[0],
                                  _p(out, C.c_float), n_threads)
     return out
+
+
+def blm_default_config(**kw) -> BlmConfig:
+    c = BlmConfig()
+    lib().oracle_blm_default_config(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, type(getattr(c, k))(v))
+    return c
+
+
+def blm_compute(samples, cfg: BlmConfig | None = None, f64: bool = True):
+    """BatchLogMelSpectrogram::compute (src/mel.rs:299-385) -> (features [n_mels, cols] f32, valid_frames).
+    f64=False is the literal f32 restatement, f64=True the same definition evaluated in f64."""
+    cfg = cfg or blm_default_config()
+    x = _f32(samples).reshape(-1)
+    fn = lib().oracle_blm_compute_f64 if f64 else lib().oracle_blm_compute_f32
+    valid = C.c_int64(0)
+    cols = fn(C.byref(cfg), _p(x, C.c_float), x.shape[0], None, C.byref(valid))
+    out = np.zeros((cfg.n_mels, cols), np.float32)
+    if x.shape[0]:
+        fn(C.byref(cfg), _p(x, C.c_float), x.shape[0], _p(out, C.c_float), C.byref(valid))
+    return out, int(valid.value)
 
 
 SYNTH_SEED = 0x4D454C53

@@ -246,6 +246,64 @@ extern "C" long long emu_fbank_wave(const float *pcm, long long n, int shift, in
                : run_fbank<float>(pcm, n, shift, n_mels, sr, low, high, preemph, floor_v, use_log, use_power, out);
 }
 
+// NeMo flavour of the fused 512 kernel (nemo_phase1 / nemo_phase3_store), f64 arithmetic.  out = [n_mels][cols].
+extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_mels, int sample_rate, double f_min, double f_max,
+                                  int htk, int norm, float preemph, int center, float guard, long long cols, float *out) {
+    using T = double;
+    using L = FbankLayout<T>;
+    constexpr int NS = kBlmSlots;
+    FbankFastTables F;
+    if (!build_blm_fast_tables<T>(sample_rate, n_mels, f_min, f_max > 0 ? f_max : sample_rate / 2.0, htk != 0, norm != 0, F)) return -1;
+    const T *tblob = reinterpret_cast<const T *>(F.blob.data());
+    const float *mel = reinterpret_cast<const float *>(F.blob.data() + F.mel_off_words);
+    const long long valid = n == 0 ? 0 : (center ? n / hop + 1 : (n < 512 ? 0 : (n - 512) / hop + 1));
+    const int org0 = center ? -200 : 56;
+    std::vector<T> slice(L::slice_elems());
+    const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+    for (long long f0 = 0; f0 < cols; f0 += kFbFPW) {
+        const int nv = static_cast<int>(std::max<long long>(0, std::min<long long>(kFbFPW, valid - f0)));
+        const int ns = static_cast<int>(std::min<long long>(kFbFPW, cols - f0));
+        std::fill(slice.begin(), slice.end(), T(1.0e30));
+        auto lane_info = [&](int lane, int &fl, int &j, bool &act) {
+            fl = lane / kFbLanes; j = lane - fl * kFbLanes; act = lane < kFbFPW * kFbLanes && fl < nv;
+        };
+        std::vector<T> snap(slice), next(slice);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            std::vector<T> tmp(snap);
+            nemo_phase1<T>(fl, j, act && j < 8, pcm, (f0 + fl) * hop + org0, n, preemph, tblob, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            std::vector<T> tmp(snap);
+            fb_phase2<T>(fl, j, act, true, tblob, tmp.data());
+            const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
+            uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
+            for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];
+        }
+        slice = next;
+        std::vector<float> rise(64 * NS), fprev(65 * NS, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            int st[NS];
+            for (int i = 0; i < NS; ++i) st[i] = lane < kFbFPW * kFbLanes ? starts[i * kFbLanes + j] : 0;
+            fb_phase3_sums<T, NS>(fl, j, act, F.slots, mel, slice.data(), st,
+                                  *reinterpret_cast<float(*)[NS]>(&rise[static_cast<size_t>(lane) * NS]),
+                                  *reinterpret_cast<float(*)[NS]>(&fprev[static_cast<size_t>(lane) * NS]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            nemo_phase3_store<NS>(fl, j, lane < kFbFPW * kFbLanes && fl < ns, act, n_mels, guard,
+                                  *reinterpret_cast<const float(*)[NS]>(&rise[static_cast<size_t>(lane) * NS]),
+                                  *reinterpret_cast<const float(*)[NS]>(&fprev[static_cast<size_t>(lane + 1) * NS]),
+                                  out + f0, cols);
+        }
+    }
+    return valid;
+}
+
 // power spectrum only (debug): |X[k]|^2, k in [0,200], for the first frame of pcm
 extern "C" int emu_fast_power(const float *pcm, double sr, float *pw201) {
     using L = FastLayout<1>;

@@ -25,6 +25,9 @@ def emu():
     L.emu_small_fft.argtypes = [C.c_int, f32p]
     L.emu_whisper_wave.restype = C.c_longlong
     L.emu_whisper_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
+    L.emu_blm_wave.restype = C.c_longlong
+    L.emu_blm_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
+                               C.c_float, C.c_int, C.c_float, C.c_longlong, f32p]
     L.emu_fbank_wave.restype = C.c_longlong
     L.emu_fbank_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_float, C.c_int, C.c_int, C.c_int, f32p]
@@ -165,3 +168,23 @@ def test_fbank_fused_variants(emu, oracle, jfk):
         want = oracle.fbank_compute(x, cfg)
         tol = 2e-5 if kw.get("use_log_fbank", 1) else 2e-5 * max(1.0, float(np.abs(want).max()))
         assert got == want.shape[0] and np.abs(out - want).max() <= tol, kw
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), dict(center=0, n_mels=64),
+                                dict(pad_to=16, preemphasis=0.5), dict(htk=1, norm=0, f_min=50.0, f_max=7000.0)])
+def test_nemo_frontend_fused_f64_matches_oracle(emu, oracle, jfk, kw):
+    """BatchLogMelSpectrogram (src/mel.rs:299-385) on the fused 512-point kernel, against the f64 evaluation of the
+    reference's definition; the literal f32 restatement is reported like the reference reports its NeMo distance."""
+    cfg = oracle.blm_default_config(**kw)
+    f32p = C.POINTER(C.c_float)
+    for x in (jfk[30000:70000], oracle.synth_pcm(2, 16007), oracle.synth_pcm(4, 300)):
+        want, valid = oracle.blm_compute(x, cfg, True)
+        if want.size == 0:
+            continue
+        out = np.full_like(want, np.nan)
+        got = emu.lib.emu_blm_wave(x.ctypes.data_as(f32p), len(x), cfg.hop_length, cfg.n_mels, cfg.sample_rate, cfg.f_min,
+                                   cfg.f_max, cfg.htk, cfg.norm, cfg.preemphasis, cfg.center, cfg.log_zero_guard,
+                                   want.shape[1], out.ctypes.data_as(f32p))
+        assert got == valid and np.abs(out - want).max() <= 2e-5
+        lit, _ = oracle.blm_compute(x, cfg, False)
+        assert np.abs(out - lit).max() < 5e-3 and np.abs(out - lit).mean() < 1e-5

@@ -326,3 +326,49 @@ def test_cpp_host_mirror(gpu, oracle, tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and p.stdout.strip().endswith("OK"), p.stdout + p.stderr
+
+
+# ---- NeMo / Parakeet frontend (BatchLogMelSpectrogram, src/mel.rs:239-396) -------------------------------
+
+@pytest.mark.parametrize("kw", [dict(), dict(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), dict(center=False, n_mels=64),
+                                dict(pad_to=16, preemphasis=0.5), dict(htk=True, norm=False, f_min=50.0, f_max=7000.0),
+                                dict(n_mels=128, preemphasis=0.97, normalize_per_feature=True)])
+def test_nemo_frontend(gpu, oracle, jfk, kw):
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    cfg = oracle.blm_default_config(**okw)
+    for x in (jfk, oracle.synth_pcm(2, 16007), oracle.synth_pcm(4, 300), np.zeros(0, np.float32)):
+        got = fe.compute(x)
+        want, valid = oracle.blm_compute(x, cfg, True)
+        assert got.shape == want.shape and fe.num_frames(len(x)) == valid
+        if want.size:
+            tol = 2e-3 if kw.get("normalize_per_feature") else TOL      # the division by std amplifies 1e-6 differences
+            assert np.abs(got - want).max() <= tol, kw
+            lit, _ = oracle.blm_compute(x, cfg, False)                   # informational, like src/fbank.rs:522-526
+            assert np.abs(got - lit).mean() < 1e-4
+    if not kw:
+        assert fe.compute(jfk).shape == (80, 1101)
+
+
+def test_nemo_frontend_reference_shape_and_errors(gpu):
+    # src/mel.rs:943-961
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24,
+                                                          normalize_per_feature=True))
+    out = fe.compute(np.zeros(16000, np.float32))
+    assert out.shape == (128, 101) and np.all(np.isfinite(out))
+    for bad, msg in ((dict(sample_rate=0), "sample_rate must be > 0"), (dict(win_length=600), "win_length must be <= n_fft"),
+                     (dict(hop_length=0), "hop_length must be > 0"), (dict(log_zero_guard=0.0), "log_zero_guard must be finite and > 0")):
+        with pytest.raises(gpu.BatchLogMelError, match=msg):      # validate_batch_config, src/mel.rs:656-683
+            gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**bad))
+    with pytest.raises(gpu.HipUnavailable):
+        gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_fft=1024, win_length=800))   # outside the fused kernel
+
+
+def test_nemo_frontend_batch(gpu, oracle):
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24))
+    clips = np.stack([oracle.synth_pcm(c, 48000) for c in range(16)])
+    got = fe.compute_batch(clips)
+    cfg = oracle.blm_default_config(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24)
+    assert got.shape == (16, 128, 301)
+    for c in (0, 7, 15):
+        assert np.abs(got[c] - oracle.blm_compute(clips[c], cfg, True)[0]).max() <= TOL

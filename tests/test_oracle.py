@@ -120,3 +120,19 @@ def test_interleave_frames_rules(oracle):
     import pytest
     with pytest.raises(ValueError):
         oracle.interleave_frames(f3, False, 3)
+
+
+def test_batch_log_mel_shape_pins(oracle, jfk):
+    # src/mel.rs:943-961: 128 mels, preemphasis 0.97, guard 2^-24, per-feature normalisation, 1 s of zeros -> (128, 101)
+    cfg = oracle.blm_default_config(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24, normalize_per_feature=1)
+    out, valid = oracle.blm_compute(np.zeros(16000, np.float32), cfg, f64=False)
+    assert out.shape == (128, 101) and valid == 101 and np.all(np.isfinite(out))
+    # README.md:146-149: the Parakeet frontend on jfk gives 128 x 1101
+    cfg = oracle.blm_default_config(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24)
+    a, _ = oracle.blm_compute(jfk, cfg, f64=False)
+    b, _ = oracle.blm_compute(jfk, cfg, f64=True)
+    assert a.shape == b.shape == (128, 1101)
+    d = np.abs(a - b)          # the reference's own f32 noise against the exact definition
+    assert d.max() < 2e-3 and d.mean() < 1e-5
+    assert oracle.blm_compute(np.zeros(0, np.float32))[0].shape == (80, 0)       # src/mel.rs:326-332
+    assert oracle.blm_compute(np.zeros(1000, np.float32), oracle.blm_default_config(pad_to=8))[0].shape == (80, 8)
