@@ -49,6 +49,8 @@ SIGNATURES = {
     "melspec_hop_size": (C.c_int, [_vp]),
     "melspec_n_mels": (C.c_int, [_vp]),
     "melspec_uses_fast_path": (C.c_int, [_vp]),
+    "melspec_set_precise": (C.c_int, [_vp, C.c_int]),
+    "melspec_is_precise": (C.c_int, [_vp]),
     "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "melspec_interleaved_width": (C.c_size_t, [_vp, C.c_size_t, C.c_size_t]),

@@ -38,6 +38,18 @@ struct alignas(16) d2 {
     double x, y;
 };
 
+// one complex value as one 8-byte (f32) / 16-byte (f64) access
+template <class T> struct PairOf;
+template <> struct PairOf<float> { using type = f2; };
+template <> struct PairOf<double> { using type = d2; };
+template <class T> MS_DEV cpx<T> ldc(const T *p) {
+    const typename PairOf<T>::type v = *reinterpret_cast<const typename PairOf<T>::type *>(p);
+    return {v.x, v.y};
+}
+template <class T> MS_DEV void stc(T *p, cpx<T> v) {
+    *reinterpret_cast<typename PairOf<T>::type *>(p) = typename PairOf<T>::type{v.re, v.im};
+}
+
 template <class T> MS_DEV cpx<T> operator+(cpx<T> a, cpx<T> b) { return {a.re + b.re, a.im + b.im}; }
 template <class T> MS_DEV cpx<T> operator-(cpx<T> a, cpx<T> b) { return {a.re - b.re, a.im - b.im}; }
 template <class T> MS_DEV cpx<T> cmul(cpx<T> a, cpx<T> b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }

@@ -1,6 +1,7 @@
 // fast_tables.hpp -- host builder of the constant blob the n_fft=400 kernel keeps in LDS
 // (layout: FastBlob in whisper_fast.hpp).  All values are computed in f64 and rounded once.
 #pragma once
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -159,6 +160,51 @@ inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_
         }
     }
     while (b.size() % 4) b.push_back(0.0f);
+    return true;
+}
+
+}  // namespace melspec
+
+#include "whisper_wave_f64.hpp"
+
+namespace melspec {
+
+// Blob of the precise kernel: [PreciseBlob tables in f64][the mel section of an interval-scheme f32 blob].
+struct PreciseTables {
+    std::vector<uint32_t> blob;
+    int mel_off_words = 0;
+};
+
+inline bool build_precise_tables(const FastTables &ft, PreciseTables &out) {
+    if (!ft.interval) return false;
+    constexpr int N = 400, M = 200;
+    std::vector<double> t(PreciseBlob::kCount, 0.0);
+    const std::vector<double> win = hann_window(N);
+    for (int i = 0; i < N; ++i) t[PreciseBlob::kWin + i] = win[i];
+    for (int tt = 0; tt < 10; ++tt)
+        for (int k1 = 0; k1 < 20; ++k1) {
+            const double a = -2.0 * kPi * ((tt * k1) % M) / M;
+            t[PreciseBlob::kTw1 + tt * PreciseBlob::kTw1Stride + 2 * k1] = std::cos(a);
+            t[PreciseBlob::kTw1 + tt * PreciseBlob::kTw1Stride + 2 * k1 + 1] = std::sin(a);
+        }
+    for (int n2 = 0; n2 < 10; ++n2) {
+        const double a = -2.0 * kPi * n2 / 10.0;
+        t[PreciseBlob::kMod + 2 * n2] = std::cos(a);
+        t[PreciseBlob::kMod + 2 * n2 + 1] = std::sin(a);
+    }
+    for (int j = 0; j < kMelJobs; ++j)
+        for (int q = 0; q < 10; ++q) {
+            const double a = -2.0 * kPi * (j + 20 * q) / N;
+            t[PreciseBlob::kTw2 + j * 20 + 2 * q] = std::cos(a);
+            t[PreciseBlob::kTw2 + j * 20 + 2 * q + 1] = std::sin(a);
+        }
+    const size_t t_words = t.size() * 2;
+    const size_t mel_floats = ft.blob.size() - FastBlob::kMelStart;
+    out.mel_off_words = static_cast<int>(t_words);
+    out.blob.assign(t_words + mel_floats, 0u);
+    std::memcpy(out.blob.data(), t.data(), t.size() * sizeof(double));
+    std::memcpy(out.blob.data() + t_words, ft.blob.data() + FastBlob::kMelStart, mel_floats * sizeof(float));
+    while (out.blob.size() % 4) out.blob.push_back(0u);
     return true;
 }
 

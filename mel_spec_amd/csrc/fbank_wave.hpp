@@ -32,17 +32,6 @@ constexpr int kFbLanes = 9;      // lanes per frame: 8 workers + 1 (ghost in pha
 constexpr int kFbSlots = 11;     // intervals j + 8*slot, up to 87 mel bins (Kaldi fbank)
 constexpr int kBlmSlots = 17;    // up to 135 mel bins (NeMo/Parakeet uses 80 or 128)
 
-template <class T> struct PairOf;
-template <> struct PairOf<float> { using type = f2; };
-template <> struct PairOf<double> { using type = d2; };
-template <class T> MS_DEV cpx<T> ldc(const T *p) {
-    const typename PairOf<T>::type v = *reinterpret_cast<const typename PairOf<T>::type *>(p);
-    return {v.x, v.y};
-}
-template <class T> MS_DEV void stc(T *p, cpx<T> v) {
-    *reinterpret_cast<typename PairOf<T>::type *>(p) = typename PairOf<T>::type{v.re, v.im};
-}
-
 // Table blob: a T-typed part (offsets in units of T) followed by the f32/int mel section.
 struct FbankBlob {
     static constexpr int kWin = 0;                         // [400] Povey window

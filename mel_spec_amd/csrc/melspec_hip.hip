@@ -244,6 +244,11 @@ struct melspec_ctx {
     int lens_kind = 0;      // 0 runtime slot lengths, 1 static Whisper-80, 2 static Whisper-128
     int slice_floats = 0;
     int frames_per_unit = 1;
+    // precise (f64 FFT) build of the fused kernel, melspec_set_precise
+    bool precise = false;
+    PreciseTables pt;
+    DevBuf d_blob64;
+    size_t precise_lds = 0;
     // generic path
     GenericTables gt;
     // scratch
@@ -347,9 +352,42 @@ int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, boo
     }
 }
 
+constexpr int kPreciseWaves = 8;
+
+template <int NSLOTS, class Lens>
+int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves>, "hipFuncSetAttribute(whisper400_precise_kernel)");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    PreciseParams pp{};
+    pp.b = desc;
+    pp.d_blob = static_cast<const uint32_t *>(c->d_blob64.p);
+    pp.blob_words = static_cast<int>(c->pt.blob.size());
+    pp.mel_off_words = c->pt.mel_off_words;
+    pp.hop = c->hop_size;
+    pp.n_mels = c->n_mels;
+    pp.slots = c->ft.slots;
+    const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
+    const unsigned grid = grid_for(blocks, c->dev.cus, 8);
+    hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves>), dim3(grid), dim3(kPreciseWaves * 64),
+                       c->precise_lds, stream, pp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     if (desc.n_units == 0) return MELSPEC_OK;
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
+    if (c->precise) {
+        if (desc.mel_major || desc.out_width != desc.frames_per_clip)
+            return fail(MELSPEC_ERR_UNSUPPORTED, "the precise build has no padded / mel-major layout yet");
+        if (c->ft.slots.n_slots <= 8)
+            return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stream) : launch_precise_t<8, LensRuntime>(c, desc, stream);
+        return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stream) : launch_precise_t<12, LensRuntime>(c, desc, stream);
+    }
     const bool small = c->ft.slots.n_slots <= 8;
     if (c->variant >= 7) {
         if (small) return launch_wave_i<8, LensI80>(c, desc, stream, c->lens_kind == 1);
@@ -451,6 +489,8 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
         if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
     }
+    const char *ep = std::getenv("MELSPEC_PRECISE");
+    if (ep && ep[0] == '1' && c->fast && (rc = melspec_set_precise(c, 1))) return bail(rc);
     *out = c;
     return MELSPEC_OK;
 }
@@ -459,7 +499,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
+    c->d_blob.release(); c->d_blob64.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
     delete c;
 }
 
@@ -472,6 +512,24 @@ int melspec_fft_size(const melspec_ctx *c) { return c ? c->fft_size : 0; }
 int melspec_hop_size(const melspec_ctx *c) { return c ? c->hop_size : 0; }
 int melspec_n_mels(const melspec_ctx *c) { return c ? c->n_mels : 0; }
 int melspec_uses_fast_path(const melspec_ctx *c) { return c && c->fast ? 1 : 0; }
+
+int melspec_set_precise(melspec_ctx *c, int on) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (!on) { c->precise = false; return MELSPEC_OK; }
+    if (!c->fast) return MELSPEC_OK;          // the generic kernel is f64 already
+    if (c->variant < 7 || !c->ft.interval) return fail(MELSPEC_ERR_UNSUPPORTED, "the precise build needs the interval mel scheme");
+    if (c->pt.blob.empty()) {
+        if (!build_precise_tables(c->ft, c->pt)) return fail(MELSPEC_ERR_INTERNAL, "precise tables");
+        c->precise_lds = c->pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double);
+        if (c->precise_lds > kLdsLimit) return fail(MELSPEC_ERR_UNSUPPORTED, "precise tables do not fit in LDS");
+        HIP_TRY(hipSetDevice(c->dev.device));
+        int rc = upload(c->d_blob64, c->pt.blob);
+        if (rc) return rc;
+    }
+    c->precise = true;
+    return MELSPEC_OK;
+}
+int melspec_is_precise(const melspec_ctx *c) { return c && (c->precise || !c->fast) ? 1 : 0; }
 
 int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                    uint32_t n_clips, float *d_out, void *stream) {

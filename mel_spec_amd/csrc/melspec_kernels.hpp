@@ -12,6 +12,7 @@
 #include "whisper_fast.hpp"
 #include "whisper_wave.hpp"
 #include "fbank_wave.hpp"
+#include "whisper_wave_f64.hpp"
 
 namespace melspec {
 
@@ -195,6 +196,66 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
             wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0, (long long)width);
         else
             wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// "Precise" fused Whisper kernel: f64 FFT (whisper_wave_f64.hpp), f32 interval mel + normalisation.
+// LDS words: [f64 tables][f32 mel section][WAVES x slice of 2320 doubles].  Plain [frame][mel] output.
+// ------------------------------------------------------------------------------------
+struct PreciseParams {
+    BatchDesc b;
+    const uint32_t *d_blob;
+    int blob_words;       // multiple of 4
+    int mel_off_words;    // where the f32 mel section (FastBlob::kMelStart.. of the f32 blob) starts
+    int hop;
+    int n_mels;
+    MelSlots slots;       // woff[] as in the f32 blob (float offsets from FastBlob's base)
+};
+
+template <int NSLOTS, class Lens, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const PreciseParams p) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    __syncthreads();
+    const double *tb = reinterpret_cast<const double *>(ldsw);
+    // the shared phase-3 code addresses the mel tables as offsets from the base of the f32 blob
+    const float *fblob = reinterpret_cast<const float *>(ldsw + p.mel_off_words) - FastBlob::kMelStart;
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    double *rows = reinterpret_cast<double *>(ldsw + p.blob_words) + wave * PreciseLayout::slice_doubles();
+    float *slice = reinterpret_cast<float *>(rows);
+    const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+    const bool in = lane < kFPW * kMelJobs;
+    const int fl3 = lane / 12, j3 = lane - fl3 * 12;
+    const bool in3 = lane < kFPW * 12;
+    int st[NSLOTS];
+    {
+        const int *starts = reinterpret_cast<const int *>(fblob + FastBlob::kMelStart);
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
+    }
+    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * kFPW;
+        const uint64_t left = loc.frames - f0;
+        const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
+        precise_phase1(fl, j, act && j < kFftJobs, p.hop, tb, src, rows);
+        __builtin_amdgcn_wave_barrier();
+        precise_phase2(fl, j, act, tb, rows);
+        __builtin_amdgcn_wave_barrier();
+        float vals[NSLOTS], rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+        wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, fblob, slice, st, rise, fprev);
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+        wave_phase3i_finish<NSLOTS>(fl3, j3, act3, p.n_mels, rise, fnext, slice, vals);
+        __builtin_amdgcn_wave_barrier();
+        wave_phase4<NSLOTS, false>(fl3, j3, act3, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         __builtin_amdgcn_wave_barrier();
     }
 }

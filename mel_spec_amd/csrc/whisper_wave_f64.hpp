@@ -1,0 +1,80 @@
+// whisper_wave_f64.hpp -- "precise" build of the fused Whisper kernel: phases 1-2 (window, 400-point
+// real FFT, Hermitian split, power) in f64, everything after the power rows shared with the f32 kernel
+// (whisper_wave.hpp: interval mel sums, log10, per-frame normalisation).
+//
+// Why it exists: the f32 kernel is within ~3e-5 of the f64 reference on speech and noise, but the
+// per-frame clamp at max-8 lets mel bands 80 dB under the frame maximum through, and for a strong pure
+// tone plus broadband content ~70 dB down the f32 rounding of the windowed frame reaches 9e-5 (measured,
+// tests/test_emu.py), i.e. the 1e-4 bound is met but not with margin on such signals.  This build holds
+// ~1e-6 on everything at roughly a third of the throughput; it is selected per context
+// (melspec_set_precise).
+#pragma once
+#include "whisper_wave.hpp"
+
+namespace melspec {
+
+// f64 table part, offsets in doubles (same logical tables as FastBlob's first four)
+struct PreciseBlob {
+    static constexpr int kWin = 0;                        // [400]
+    static constexpr int kTw1Stride = 44;
+    static constexpr int kTw1 = 400;                      // [10][44]  W_200^{t*k1}
+    static constexpr int kMod = kTw1 + 10 * kTw1Stride;   // [10] complex W_10^{n2}
+    static constexpr int kTw2 = kMod + 20;                // [11][10] complex W_400^{j+20q}
+    static constexpr int kCount = kTw2 + kMelJobs * 20;   // 1080 doubles
+};
+
+struct PreciseLayout {
+    static constexpr int kXRow = 22;                      // 10 complex + 1 pad: 44-word row pitch, 11 rows hit 11 bank slots
+    static constexpr int kXStride = 21 * kXRow + 2;       // 464 doubles per frame
+    static constexpr int slice_doubles() { return kFPW * kXStride; }   // 2320 doubles; power rows / maxima alias its head
+};
+
+MS_DEV void precise_phase1(int fl, int t, bool active, int hop, const double *tb, const float *gsrc, double *rows) {
+    if (!active) return;
+    const float *s = gsrc + fl * hop + 2 * t;
+    cd x[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) {
+        const f2 sv = load2_unaligned(s + 20 * n1);
+        const cd w = ldc(tb + PreciseBlob::kWin + 20 * n1 + 2 * t);
+        x[n1] = {static_cast<double>(sv.x) * w.re, static_cast<double>(sv.y) * w.im};   // src/stft.rs:163
+    }
+    fft20(x);
+    const double *tw = tb + PreciseBlob::kTw1 + t * PreciseBlob::kTw1Stride;
+    double *xo = rows + fl * PreciseLayout::kXStride + 2 * t;
+    stc(xo, x[0]);
+    stc(xo + 20 * PreciseLayout::kXRow, cmul(x[0], ldc(tb + PreciseBlob::kMod + 2 * t)));
+#pragma unroll
+    for (int k1 = 1; k1 < 20; ++k1) stc(xo + k1 * PreciseLayout::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
+}
+
+// writes 4*|X|^2 as f32 power rows (stride WaveLayout::kPStride) over the head of the same slice
+MS_DEV void precise_phase2(int fl, int j, bool active, const double *tb, double *rows) {
+    if (!active) return;
+    const int brow = (j == 0) ? 20 : 20 - j;
+    const double *ua = rows + fl * PreciseLayout::kXStride + j * PreciseLayout::kXRow;
+    const double *va = rows + fl * PreciseLayout::kXStride + brow * PreciseLayout::kXRow;
+    cd u[10], v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        u[i] = ldc(ua + 2 * i);
+        v[i] = ldc(va + 2 * i);
+    }
+    fft10(u);
+    fft10(v);
+    const double *tw = tb + PreciseBlob::kTw2 + j * 20;
+    float *p = reinterpret_cast<float *>(rows) + fl * WaveLayout::kPStride;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const cd zk = u[q], zm = v[9 - q];
+        const cd S = {zk.re + zm.re, zk.im - zm.im};
+        const cd D = {zk.re - zm.re, zk.im + zm.im};
+        const cd wd = cmul(ldc(tw + 2 * q), D);
+        const double ar = S.re + wd.im, ai = S.im - wd.re;
+        const double br = S.re - wd.im, bi = S.im + wd.re;
+        p[j + 20 * q] = static_cast<float>(ar * ar + ai * ai);
+        p[200 - j - 20 * q] = static_cast<float>(br * br + bi * bi);
+    }
+}
+
+}  // namespace melspec

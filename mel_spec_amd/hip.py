@@ -132,6 +132,14 @@ class HipMelSpectrogram:
     def uses_fast_path(self) -> bool:
         return bool(lib().melspec_uses_fast_path(self._h))
 
+    def set_precise(self, on: bool = True) -> None:
+        """f64 FFT build of the fused kernel (melspec_set_precise)."""
+        _check(lib().melspec_set_precise(self._h, int(on)))
+
+    @property
+    def precise(self) -> bool:
+        return bool(lib().melspec_is_precise(self._h))
+
     def compute_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
                                stream: int = 0) -> None:
         """Device pointers in, device pointers out, asynchronous on `stream`."""

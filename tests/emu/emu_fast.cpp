@@ -304,6 +304,80 @@ extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_
     return valid;
 }
 
+// Precise kernel (whisper_wave_f64.hpp): f64 phases 1-2, shared f32 interval mel phases.
+extern "C" long long emu_whisper_precise(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+    FastTables T;
+    if (!build_fast_tables(sr, n_mels, T, true) || !T.interval) return -1;
+    PreciseTables P;
+    if (!build_precise_tables(T, P)) return -2;
+    const double *tb = reinterpret_cast<const double *>(P.blob.data());
+    const float *fblob = reinterpret_cast<const float *>(P.blob.data() + P.mel_off_words) - FastBlob::kMelStart;
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / hop + 1;
+    constexpr int NS = 12;
+    std::vector<double> rows(PreciseLayout::slice_doubles());
+    std::vector<float> vals(64 * NS);
+    const int *starts = reinterpret_cast<const int *>(fblob + FastBlob::kMelStart);
+    for (long long f0 = 0; f0 < frames; f0 += kFPW) {
+        const int nv = static_cast<int>(std::min<long long>(kFPW, frames - f0));
+        std::fill(rows.begin(), rows.end(), 1.0e30);
+        std::vector<double> snap(rows), next(rows);
+        auto merge = [&](const std::vector<double> &tmp) {
+            const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
+            uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
+            for (size_t i = 0; i < tmp.size() * 2; ++i) if (a[i] != b0[i]) d[i] = a[i];
+        };
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            std::vector<double> tmp(snap);
+            precise_phase1(fl, j, act && j < kFftJobs, hop, tb, pcm + f0 * hop, tmp.data());
+            merge(tmp);
+        }
+        rows = next; snap = rows;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            std::vector<double> tmp(snap);
+            precise_phase2(fl, j, act, tb, tmp.data());
+            merge(tmp);
+        }
+        rows = next; snap = rows;
+        float *slice = reinterpret_cast<float *>(rows.data());
+        std::vector<float> rise(64 * NS), fprev(65 * NS, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / 12, j = lane - fl * 12;
+            const bool act = lane < kFPW * 12 && fl < nv;
+            int st[NS];
+            for (int i = 0; i < NS; ++i) st[i] = lane < kFPW * 12 ? starts[i * 12 + j] : 0;
+            wave_phase3i_sums<NS, LensRuntime>(fl, j, act, T.slots, fblob, slice, st,
+                                               *reinterpret_cast<float(*)[NS]>(&rise[static_cast<size_t>(lane) * NS]),
+                                               *reinterpret_cast<float(*)[NS]>(&fprev[static_cast<size_t>(lane) * NS]));
+        }
+        std::vector<float> pm(64, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / 12, j = lane - fl * 12;
+            const bool act = lane < kFPW * 12 && fl < nv;
+            std::vector<double> tmp(rows);
+            wave_phase3i_finish<NS>(fl, j, act, n_mels, *reinterpret_cast<const float(*)[NS]>(&rise[static_cast<size_t>(lane) * NS]),
+                                    *reinterpret_cast<const float(*)[NS]>(&fprev[static_cast<size_t>(lane + 1) * NS]),
+                                    reinterpret_cast<float *>(tmp.data()), *reinterpret_cast<float(*)[NS]>(&vals[static_cast<size_t>(lane) * NS]));
+            if (act) pm[lane] = reinterpret_cast<float *>(tmp.data())[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j];
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / 12, j = lane - fl * 12;
+            if (lane < kFPW * 12 && fl < nv) slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j] = pm[lane];
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / 12, j = lane - fl * 12;
+            const bool act = lane < kFPW * 12 && fl < nv;
+            wave_phase4<NS, false>(fl, j, act, act, n_mels, slice, *reinterpret_cast<const float(*)[NS]>(&vals[static_cast<size_t>(lane) * NS]),
+                                   out + f0 * n_mels, 0);
+        }
+    }
+    return frames;
+}
+
 // power spectrum only (debug): |X[k]|^2, k in [0,200], for the first frame of pcm
 extern "C" int emu_fast_power(const float *pcm, double sr, float *pw201) {
     using L = FastLayout<1>;

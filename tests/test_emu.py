@@ -25,6 +25,8 @@ def emu():
     L.emu_small_fft.argtypes = [C.c_int, f32p]
     L.emu_whisper_wave.restype = C.c_longlong
     L.emu_whisper_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
+    L.emu_whisper_precise.restype = C.c_longlong
+    L.emu_whisper_precise.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
     L.emu_blm_wave.restype = C.c_longlong
     L.emu_blm_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                C.c_float, C.c_int, C.c_float, C.c_longlong, f32p]
@@ -126,6 +128,52 @@ def test_wave_kernel_edges(emu, oracle):
             assert got == want.shape[0] and np.abs(out - want).max() <= TOL
     got, out = _wave(emu, np.zeros(4000, np.float32), 5)
     assert np.all(out == np.float32(-1.5))
+
+
+def tone_over_noise_floor(n=32000, level_db=-70.0, f=3333.3, seed=0):
+    """Worst case for f32 spectra: a near-full-scale tone puts the per-frame clamp (max - 8) right at the
+    level of the noise-only bands, whose f32 FFT error is set by the tone's rounding noise."""
+    t = np.arange(n) / 16000.0
+    rng = np.random.default_rng(seed)
+    return (0.9 * np.sin(2 * np.pi * f * t) + 10 ** (level_db / 20) * rng.standard_normal(n)).astype(np.float32)
+
+
+def _precise(emu, x, hop=160, n_mels=80, sr=16000.0):
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 400 else (len(x) - 400) // hop + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    f32p = C.POINTER(C.c_float)
+    assert emu.lib.emu_whisper_precise(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, out.ctypes.data_as(f32p)) == nf
+    return out
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_precise_kernel_is_f64_accurate(emu, oracle, jfk, n_mels):
+    want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels)
+    assert np.abs(_precise(emu, jfk, n_mels=n_mels) - want).max() <= 2e-6
+
+
+def test_precise_kernel_on_the_f32_worst_case(emu, oracle):
+    """A near-full-scale tone over a noise floor ~80 dB below it in the mel domain: every f32 FFT (pocketfft's
+    too) leaves the tone's rounding noise in the noise-only bins, and the bands just above the per-frame clamp
+    miss 1e-4 (7 kHz: up to ~4e-4).  Speech and noise stay within ~3e-5 (tests above).  The f64 build does not
+    care.  This is why melspec_set_precise exists; the reference's CUDA back-end also runs a Z2Z (f64) FFT,
+    src/cuda.rs:204-219."""
+    for f, lo, hi in ((3333.3, 2e-5, 1.5e-4), (7000.0, 1e-4, 6e-4)):
+        x = tone_over_noise_floor(f=f)
+        want = oracle.compute_mel_spectrogram_cpu(x)
+        d32 = np.abs(_wave(emu, x, 5)[1] - want).max()
+        d64 = np.abs(_precise(emu, x) - want).max()
+        assert lo < d32 < hi, (f, d32)
+        assert d64 <= 2e-6
+
+
+@pytest.mark.parametrize("hop,n_mels,n", [(128, 40, 3000), (320, 100, 5000), (160, 80, 400), (160, 80, 400 + 5 * 160 + 3)])
+def test_precise_kernel_geometries_and_edges(emu, oracle, jfk, hop, n_mels, n):
+    x = jfk[20000:20000 + n]
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels)
+    got = _precise(emu, x, hop=hop, n_mels=n_mels)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
 
 
 def _fbank(emu, x, f64=1, shift=160, n_mels=80, sr=16000.0, low=20.0, high=8000.0, preemph=0.97, use_log=1, use_power=1,

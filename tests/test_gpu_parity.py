@@ -62,6 +62,50 @@ def test_reference_gpu_parity_signal(w80, oracle, four_tone, golden):
     assert np.abs(got - golden["tone_w80"]).max() <= TOL
 
 
+def _tone_over_noise_floor(n=32000, level_db=-70.0, f=3333.3, seed=0):
+    t = np.arange(n) / 16000.0
+    rng = np.random.default_rng(seed)
+    return (0.9 * np.sin(2 * np.pi * f * t) + 10 ** (level_db / 20) * rng.standard_normal(n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_precise_mode(gpu, oracle, jfk, n_mels):
+    """melspec_set_precise: f64 window/FFT/power (the reference's arithmetic, src/stft.rs:98-111)."""
+    m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+    assert m.uses_fast_path and not m.precise
+    m.set_precise(True)
+    assert m.precise
+    want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels, SR)
+    got = m.compute_mel_spectrogram(jfk)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    x = _tone_over_noise_floor()
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, n_mels, SR)
+    assert np.abs(m.compute_mel_spectrogram(x) - want).max() <= 2e-6
+    for n in (0, 399, 400, 400 + 4 * 160, 400 + 5 * 160, 400 + 45 * 160 + 7):
+        y = oracle.synth_pcm(9, n)
+        assert np.array_equal(m.compute_mel_spectrogram(y).shape, (max(0, (n - 400) // 160 + 1) if n >= 400 else 0, n_mels))
+        if n >= 400:
+            assert np.abs(m.compute_mel_spectrogram(y) - oracle.compute_mel_spectrogram_cpu(y, 400, 160, n_mels, SR)).max() <= 2e-6
+    m.set_precise(False)
+    assert not m.precise
+    d32 = np.abs(m.compute_mel_spectrogram(x) - want).max()
+    assert 2e-5 < d32 < 2e-4      # the f32 FFT's known worst case (tests/test_emu.py::test_precise_kernel_on_the_f32_worst_case)
+    m.close()
+
+
+def test_precise_mode_batch_and_other_geometry(gpu, oracle):
+    m = gpu.HipMelSpectrogram(400, 128, 8000.0, 40)
+    m.set_precise(True)
+    clips = np.stack([oracle.synth_pcm(c, 8000) for c in range(37)])
+    got = m.compute_batch(clips)
+    for c in (0, 17, 36):
+        assert np.abs(got[c] - oracle.compute_mel_spectrogram_cpu(clips[c], 400, 128, 40, 8000.0)).max() <= 2e-6
+    g = gpu.HipMelSpectrogram(512, 160, SR, 80)     # generic kernel: always f64
+    assert g.precise
+    g.set_precise(True)
+    m.close(); g.close()
+
+
 def test_generic_kernel_agrees_with_fused_kernel(gpu, w80, oracle, jfk):
     """hop=161 is odd, so that geometry takes the f64 generic kernel; on the same frames the two
     device paths and the oracle must agree."""

@@ -17,12 +17,15 @@ M.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
 M.device_synchronize()
 ctxs = {}
 for v in variants:
-    vv, rt = (v[:-1], "1") if v.endswith("r") else (v, "0")
+    vp, prec = (v[:-1], True) if v.endswith("p") else (v, False)           # "8p" = variant 8, precise (f64 FFT) build
+    vv, rt = (vp[:-1], "1") if vp.endswith("r") else (vp, "0")
     vv, sg = (vv.split("s") + ["0"])[:2] if "s" in vv else (vv, "0")     # "8s64" = variant 8, stagger 64
     os.environ["MELSPEC_STAGGER"] = sg
     os.environ["MELSPEC_VARIANT"] = vv
     os.environ["MELSPEC_RUNTIME_LENS"] = rt
     ctxs[v] = M.HipMelSpectrogram(400, 160, 16000.0, n_mels)
+    if prec:
+        ctxs[v].set_precise(True)
 fpc = ctxs[variants[0]].num_frames(clip_len)
 out = M.DeviceBuffer(n_clips * fpc * n_mels * 4)
 want = {c: O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), 400, 160, n_mels) for c in (0, n_clips // 2 + 1, n_clips - 1)}
