@@ -199,6 +199,49 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
                                        uint32_t n_clips, float *d_out, void *stream);
 int melspec_blm_synchronize(melspec_blm *b, void *stream);
 
+/* ---- 8-bit quantisation + TGA container: replaces src/quant.rs ------------------------ */
+/* The reference's wire/disk format right after the mel path: a mel-major interleaved image
+ * ([n_mels][width] f32, what melspec_compute_uniform_device_interleaved(.., major_column_order = 0, ..)
+ * writes) is quantised to u8 with its own {min,max} and wrapped in an 18-byte TARGA header plus an 8-byte
+ * ID field holding {min,max} as little-endian f32 (tga_8bit_data, src/quant.rs:38-64).  Bytes are
+ * identical to the CPU's: the arithmetic is the reference's f32 sequence (quantize, src/quant.rs:140-153:
+ * f32::min/max folds that skip NaN, scale = 255/(max-min), round half away from zero, clamp). */
+typedef struct melspec_tga melspec_tga;
+
+int melspec_tga_create(melspec_tga **out, int device);
+void melspec_tga_destroy(melspec_tga *q);
+
+/* tga_8bit (src/quant.rs:29-36) cuts an image into chunks of <= 65535 columns
+ * (chunk_frames_into_strides, :100-136), one TGA each.  Layout used by this library for the
+ * Vec<Vec<u8>> it returns: chunk c of an image starts at byte c * chunk_stride (a multiple of 4);
+ * every chunk but the last holds 26 + n_mels*65535 bytes, the last one last_chunk_bytes.
+ * width == 0 -> 0 chunks. */
+int melspec_tga_layout(int n_mels, size_t width, uint32_t *n_chunks, size_t *chunk_stride, size_t *last_chunk_bytes);
+
+/* n_images images, image i at d_images + i*image_stride floats -> blobs at d_blobs + i*blob_stride bytes
+ * (blob_stride a multiple of 4, >= n_chunks*chunk_stride; d_blobs 4-byte aligned).  Asynchronous on
+ * `stream` (NULL -> the handle's stream).  save_tga_8bit (src/quant.rs:15-27) is this plus a file write. */
+int melspec_tga_encode_device(melspec_tga *q, const float *d_images, size_t image_stride, int n_mels, size_t width,
+                              uint32_t n_images, uint8_t *d_blobs, size_t blob_stride, void *stream);
+/* parse_tga_8bit / load_tga_8bit (src/quant.rs:66-98) for the same layout: reads {min,max} from bytes
+ * 18..25 of every chunk and dequantises (dequantize, :156-165: u8 * ((max-min)/255) + min, two roundings). */
+int melspec_tga_decode_device(melspec_tga *q, const uint8_t *d_blobs, size_t blob_stride, int n_mels, size_t width,
+                              uint32_t n_images, float *d_images, size_t image_stride, void *stream);
+/* tga_8bit(data, n_mels) on host memory; n_chunks blobs laid out as melspec_tga_layout says. */
+int melspec_tga_encode_host(melspec_tga *q, const float *data, size_t len, int n_mels, uint8_t *out, size_t out_capacity,
+                            uint32_t *n_chunks);
+/* parse_tga_8bit(blob): skips the 18 header bytes without looking at them, like the reference;
+ * n_bytes < 26 -> MELSPEC_ERR_INVALID_ARG ("failed to fill whole buffer"). */
+int melspec_tga_decode_host(melspec_tga *q, const uint8_t *blob, size_t n_bytes, float *out, size_t out_capacity, size_t *n_values);
+
+/* quantize / dequantize without the container (src/quant.rs:140-165; src/wasm.rs:113 uses it per frame).
+ * range = {min, max}.  Device variants: d_out needs n rounded up to a multiple of 4 bytes. */
+int melspec_quantize_device(melspec_tga *q, const float *d_frame, size_t n, uint8_t *d_out, float *d_range, void *stream);
+int melspec_dequantize_device(melspec_tga *q, const uint8_t *d_data, size_t n, const float *d_range, float *d_out, void *stream);
+int melspec_quantize_host(melspec_tga *q, const float *frame, size_t n, uint8_t *out, float *range);
+int melspec_dequantize_host(melspec_tga *q, const uint8_t *data, size_t n, const float *range, float *out);
+int melspec_tga_synchronize(melspec_tga *q);
+
 /* ---- device memory helpers for hosts with no HIP binding of their own --------------- */
 /* (what the cudaMalloc/cudaMemcpyAsync externs of src/cuda.rs:185-199 give the Rust side) */
 int melspec_malloc(void **dptr, size_t bytes);

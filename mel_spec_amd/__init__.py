@@ -4,7 +4,8 @@ wavey-ai/mel-spec's GPU plugin slot.  All compute runs in hand-written HIP kerne
 from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, DeviceBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable,
                   device_count, device_synchronize, hann_window, kaldi_mel_filterbank, mel, synth_pcm_device)
 from .parallel import shard_range
+from .quant import QuantizationRange, TgaCodec, to_array2
 
 __all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError",
            "HipUnavailable", "device_count", "device_synchronize", "hann_window", "kaldi_mel_filterbank", "mel",
-           "synth_pcm_device", "shard_range"]
+           "synth_pcm_device", "shard_range", "QuantizationRange", "TgaCodec", "to_array2"]

@@ -85,6 +85,18 @@ SIGNATURES = {
     "melspec_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "melspec_device_synchronize": (C.c_int, []),
     "melspec_synth_pcm_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
+    "melspec_tga_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "melspec_tga_destroy": (None, [_vp]),
+    "melspec_tga_layout": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "melspec_tga_encode_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "melspec_tga_decode_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "melspec_tga_encode_host": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
+    "melspec_tga_decode_host": (C.c_int, [_vp, _vp, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "melspec_quantize_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "melspec_dequantize_device": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "melspec_quantize_host": (C.c_int, [_vp, _f32p, C.c_size_t, _vp, _f32p]),
+    "melspec_dequantize_host": (C.c_int, [_vp, _vp, C.c_size_t, _f32p, _f32p]),
+    "melspec_tga_synchronize": (C.c_int, [_vp]),
 }
 
 _lib = None

@@ -128,19 +128,6 @@ MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this fra
 // |X|, so they are processed at positions 0..399 exactly like the Kaldi frame.  Sample `s` of the clip is
 // the pre-emphasised waveform (f32, two roundings like `current - (coeff * prev)`, src/mel.rs:696-706),
 // zero outside [0, len) (centre padding, src/mel.rs:685-694).
-// a*b rounded to f32 on its own: the product must not be contracted into an FMA with the following
-// subtraction (HIP's __fmul_rn is a plain multiply and does get contracted), because the reference's
-// two roundings are visible in the weakest bins of loud frames (up to 7e-2 of a bin on jfk_f32le.wav).
-MS_DEV float f32_mul_rn(float a, float b) {
-#if defined(__HIPCC__)
-    float p = a * b;
-    asm volatile("" : "+v"(p));
-    return p;
-#else
-    volatile float p = a * b;
-    return p;
-#endif
-}
 MS_DEV float nemo_sample(const float *clip, long long s, long long len, float coeff) {
     if (s < 0 || s >= len) return 0.0f;
     const float cur = clip[s];

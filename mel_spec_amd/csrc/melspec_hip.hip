@@ -20,6 +20,7 @@
 #include "fast_tables.hpp"
 #include "fbank_tables.hpp"
 #include "melspec_kernels.hpp"
+#include "tga_quant.hpp"
 #include "tables.hpp"
 
 using namespace melspec;
@@ -858,6 +859,260 @@ int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n
     HIP_TRY(hipMemcpyAsync(out, fb->d2h.p, need * sizeof(float), hipMemcpyDeviceToHost, fb->stream));
     HIP_TRY(hipStreamSynchronize(fb->stream));
     if (n_frames) *n_frames = static_cast<size_t>(frames);
+    return MELSPEC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// 8-bit quantisation + TGA container (src/quant.rs)
+// ------------------------------------------------------------------------------------
+struct melspec_tga {
+    DeviceInfo dev;
+    hipStream_t stream = nullptr;
+    DevBuf keys, ranges, h2d, d2h;
+};
+
+namespace {
+size_t round_up4(size_t v) { return (v + 3) & ~static_cast<size_t>(3); }
+
+struct TgaLayout { uint32_t chunks; uint32_t chunk_w; size_t chunk_stride; size_t last_bytes; };
+TgaLayout tga_layout(uint32_t rows, uint64_t width) {
+    TgaLayout l{};
+    if (width == 0) return l;
+    l.chunks = static_cast<uint32_t>((width + kTgaMaxWidth - 1) / kTgaMaxWidth);
+    l.chunk_w = static_cast<uint32_t>(width < kTgaMaxWidth ? width : kTgaMaxWidth);
+    l.chunk_stride = round_up4(kTgaHeader + static_cast<size_t>(rows) * l.chunk_w);
+    l.last_bytes = kTgaHeader + static_cast<size_t>(rows) * (width - static_cast<uint64_t>(l.chunks - 1) * l.chunk_w);
+    return l;
+}
+
+// fills the descriptor and the launch shape shared by encode and decode
+int quant_plan(melspec_tga *q, QuantDesc &d, const void *img, size_t image_stride, uint32_t rows, uint64_t width, uint32_t n_images,
+               const void *blob, size_t blob_stride, bool header, uint32_t &items, uint32_t &bpi_px, uint32_t &bpi_dw) {
+    if (width > 0xffffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "image wider than 2^32-1 columns");
+    d = QuantDesc{};
+    d.rows = rows; d.width = static_cast<uint32_t>(width); d.n_images = n_images;
+    d.img_stride = image_stride; d.blob_stride = blob_stride;
+    d.header = header ? kTgaHeader : 0;
+    if (header) {
+        const TgaLayout l = tga_layout(rows, width);
+        d.chunks = l.chunks; d.chunk_w = l.chunk_w; d.chunk_stride = l.chunk_stride;
+        if (blob_stride % 4 || blob_stride < l.chunk_stride * l.chunks)
+            return fail(MELSPEC_ERR_INVALID_ARG, "blob_stride must be a multiple of 4 and >= n_chunks * chunk_stride (melspec_tga_layout)");
+    } else {
+        d.chunks = 1; d.chunk_w = d.width; d.chunk_stride = 0;
+        if (blob_stride % 4) return fail(MELSPEC_ERR_INVALID_ARG, "blob_stride must be a multiple of 4");
+    }
+    if (reinterpret_cast<uintptr_t>(blob) % 4) return fail(MELSPEC_ERR_INVALID_ARG, "blob pointer must be 4-byte aligned");
+    if (reinterpret_cast<uintptr_t>(img) % 4) return fail(MELSPEC_ERR_INVALID_ARG, "image pointer must be 4-byte aligned");
+    d.vec = d.chunks == 1 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && (n_images == 1 || image_stride % 4 == 0);
+    const uint64_t items64 = static_cast<uint64_t>(n_images) * d.chunks;
+    const uint64_t npx = static_cast<uint64_t>(rows) * d.chunk_w;
+    const uint64_t bpx = (npx + kQuantPxPerBlock - 1) / kQuantPxPerBlock;
+    const uint64_t bdw = ((d.header + npx + 3) / 4 + kQuantDwPerBlock - 1) / kQuantDwPerBlock;
+    if (items64 * bpx > 0x7fffffffull || items64 * bdw > 0x7fffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "batch too large for one launch");
+    items = static_cast<uint32_t>(items64); bpi_px = static_cast<uint32_t>(bpx); bpi_dw = static_cast<uint32_t>(bdw);
+    int rc = q->keys.ensure(items64 * 2 * sizeof(uint32_t) + 16);
+    if (rc) return rc;
+    d.keys = static_cast<uint32_t *>(q->keys.p);
+    return MELSPEC_OK;
+}
+
+int quant_encode(melspec_tga *q, const float *d_img, size_t image_stride, uint32_t rows, uint64_t width, uint32_t n_images,
+                 uint8_t *d_blob, size_t blob_stride, bool header, float *d_ranges, hipStream_t stream) {
+    if (n_images == 0 || width == 0 || rows == 0) return MELSPEC_OK;
+    if (!d_img || !d_blob) return fail(MELSPEC_ERR_INVALID_ARG, "image/blob pointer is NULL");
+    HIP_TRY(hipSetDevice(q->dev.device));
+    QuantDesc d;
+    uint32_t items, bpx, bdw;
+    int rc = quant_plan(q, d, d_img, image_stride, rows, width, n_images, d_blob, blob_stride, header, items, bpx, bdw);
+    if (rc) return rc;
+    d.img = d_img; d.blob = d_blob; d.ranges = d_ranges;
+    hipLaunchKernelGGL(quant_init_keys_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, d.keys, items);
+    hipLaunchKernelGGL(quant_minmax_kernel, dim3(items * bpx), dim3(kQuantThreads), 0, stream, d, bpx);
+    hipLaunchKernelGGL(quant_encode_kernel, dim3(items * bdw), dim3(kQuantThreads), 0, stream, d, bdw);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int quant_decode(melspec_tga *q, const uint8_t *d_blob, size_t blob_stride, uint32_t rows, uint64_t width, uint32_t n_images,
+                 float *d_img, size_t image_stride, bool header, const float *d_ranges, hipStream_t stream) {
+    if (n_images == 0 || width == 0 || rows == 0) return MELSPEC_OK;
+    if (!d_img || !d_blob) return fail(MELSPEC_ERR_INVALID_ARG, "image/blob pointer is NULL");
+    if (!header && !d_ranges) return fail(MELSPEC_ERR_INVALID_ARG, "range pointer is NULL");
+    HIP_TRY(hipSetDevice(q->dev.device));
+    QuantDesc d;
+    uint32_t items, bpx, bdw;
+    int rc = quant_plan(q, d, d_img, image_stride, rows, width, n_images, d_blob, blob_stride, header, items, bpx, bdw);
+    if (rc) return rc;
+    d.img_out = d_img; d.blob = const_cast<uint8_t *>(d_blob); d.ranges = const_cast<float *>(d_ranges);
+    hipLaunchKernelGGL(quant_decode_kernel, dim3(items * bdw), dim3(kQuantThreads), 0, stream, d, bdw);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int melspec_tga_create(melspec_tga **out, int device) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    DeviceInfo info;
+    int rc = pick_device(device, info);
+    if (rc) return rc;
+    melspec_tga *q = new (std::nothrow) melspec_tga();
+    if (!q) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    q->dev = info;
+    if (hipSetDevice(info.device) != hipSuccess || hipStreamCreate(&q->stream) != hipSuccess) {
+        delete q;
+        return fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed");
+    }
+    *out = q;
+    return MELSPEC_OK;
+}
+
+void melspec_tga_destroy(melspec_tga *q) {
+    if (!q) return;
+    if (q->dev.device >= 0) (void)hipSetDevice(q->dev.device);
+    if (q->stream) { (void)hipStreamSynchronize(q->stream); (void)hipStreamDestroy(q->stream); }
+    q->keys.release(); q->ranges.release(); q->h2d.release(); q->d2h.release();
+    delete q;
+}
+
+int melspec_tga_layout(int n_mels, size_t width, uint32_t *n_chunks, size_t *chunk_stride, size_t *last_chunk_bytes) {
+    if (n_mels <= 0 || n_mels > 65535) return fail(MELSPEC_ERR_INVALID_ARG, "n_mels must be in 1..65535");
+    const TgaLayout l = tga_layout(static_cast<uint32_t>(n_mels), width);
+    if (n_chunks) *n_chunks = l.chunks;
+    if (chunk_stride) *chunk_stride = l.chunk_stride;
+    if (last_chunk_bytes) *last_chunk_bytes = l.last_bytes;
+    return MELSPEC_OK;
+}
+
+int melspec_tga_encode_device(melspec_tga *q, const float *d_images, size_t image_stride, int n_mels, size_t width,
+                              uint32_t n_images, uint8_t *d_blobs, size_t blob_stride, void *stream) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (n_mels <= 0 || n_mels > 65535) return fail(MELSPEC_ERR_INVALID_ARG, "n_mels must be in 1..65535");
+    if (image_stride < static_cast<size_t>(n_mels) * width) return fail(MELSPEC_ERR_INVALID_ARG, "image_stride < n_mels * width");
+    return quant_encode(q, d_images, image_stride, static_cast<uint32_t>(n_mels), width, n_images, d_blobs, blob_stride, true, nullptr,
+                        stream ? static_cast<hipStream_t>(stream) : q->stream);
+}
+
+int melspec_tga_decode_device(melspec_tga *q, const uint8_t *d_blobs, size_t blob_stride, int n_mels, size_t width,
+                              uint32_t n_images, float *d_images, size_t image_stride, void *stream) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (n_mels <= 0 || n_mels > 65535) return fail(MELSPEC_ERR_INVALID_ARG, "n_mels must be in 1..65535");
+    if (image_stride < static_cast<size_t>(n_mels) * width) return fail(MELSPEC_ERR_INVALID_ARG, "image_stride < n_mels * width");
+    return quant_decode(q, d_blobs, blob_stride, static_cast<uint32_t>(n_mels), width, n_images, d_images, image_stride, true, nullptr,
+                        stream ? static_cast<hipStream_t>(stream) : q->stream);
+}
+
+int melspec_quantize_device(melspec_tga *q, const float *d_frame, size_t n, uint8_t *d_out, float *d_range, void *stream) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (!d_range) return fail(MELSPEC_ERR_INVALID_ARG, "range pointer is NULL");
+    return quant_encode(q, d_frame, n, 1, n, 1, d_out, round_up4(n), false, d_range, stream ? static_cast<hipStream_t>(stream) : q->stream);
+}
+
+int melspec_dequantize_device(melspec_tga *q, const uint8_t *d_data, size_t n, const float *d_range, float *d_out, void *stream) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    return quant_decode(q, d_data, round_up4(n), 1, n, 1, d_out, n, false, d_range, stream ? static_cast<hipStream_t>(stream) : q->stream);
+}
+
+int melspec_tga_synchronize(melspec_tga *q) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_quantize_host(melspec_tga *q, const float *frame, size_t n, uint8_t *out, float *range) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (!range) return fail(MELSPEC_ERR_INVALID_ARG, "range pointer is NULL");
+    if (n == 0) { range[0] = INFINITY; range[1] = -INFINITY; return MELSPEC_OK; }       // the folds' start values
+    if (!frame || !out) return fail(MELSPEC_ERR_INVALID_ARG, "frame/out is NULL");
+    HIP_TRY(hipSetDevice(q->dev.device));
+    int rc;
+    if ((rc = q->h2d.ensure(n * sizeof(float)))) return rc;
+    if ((rc = q->d2h.ensure(round_up4(n) + 16))) return rc;
+    if ((rc = q->ranges.ensure(16))) return rc;
+    HIP_TRY(hipMemcpyAsync(q->h2d.p, frame, n * sizeof(float), hipMemcpyHostToDevice, q->stream));
+    if ((rc = melspec_quantize_device(q, static_cast<const float *>(q->h2d.p), n, static_cast<uint8_t *>(q->d2h.p),
+                                      static_cast<float *>(q->ranges.p), q->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, q->d2h.p, n, hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(hipMemcpyAsync(range, q->ranges.p, 2 * sizeof(float), hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_dequantize_host(melspec_tga *q, const uint8_t *data, size_t n, const float *range, float *out) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (n == 0) return MELSPEC_OK;
+    if (!data || !range || !out) return fail(MELSPEC_ERR_INVALID_ARG, "data/range/out is NULL");
+    HIP_TRY(hipSetDevice(q->dev.device));
+    int rc;
+    if ((rc = q->h2d.ensure(round_up4(n) + 16))) return rc;
+    if ((rc = q->d2h.ensure(n * sizeof(float)))) return rc;
+    if ((rc = q->ranges.ensure(16))) return rc;
+    HIP_TRY(hipMemcpyAsync(q->h2d.p, data, n, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(hipMemcpyAsync(q->ranges.p, range, 2 * sizeof(float), hipMemcpyHostToDevice, q->stream));
+    if ((rc = melspec_dequantize_device(q, static_cast<const uint8_t *>(q->h2d.p), n, static_cast<const float *>(q->ranges.p),
+                                        static_cast<float *>(q->d2h.p), q->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, q->d2h.p, n * sizeof(float), hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_tga_encode_host(melspec_tga *q, const float *data, size_t len, int n_mels, uint8_t *out, size_t out_capacity,
+                            uint32_t *n_chunks) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (n_chunks) *n_chunks = 0;
+    if (n_mels <= 0 || n_mels > 65535) return fail(MELSPEC_ERR_INVALID_ARG, "n_mels must be in 1..65535");
+    if (len % static_cast<size_t>(n_mels)) return fail(MELSPEC_ERR_INVALID_ARG, "data length is not a multiple of n_mels");
+    const size_t width = len / n_mels;
+    if (width == 0) return MELSPEC_OK;
+    if (!data || !out) return fail(MELSPEC_ERR_INVALID_ARG, "data/out is NULL");
+    const TgaLayout l = tga_layout(static_cast<uint32_t>(n_mels), width);
+    const size_t region = l.chunk_stride * l.chunks;
+    if (out_capacity < region - l.chunk_stride + l.last_bytes) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    HIP_TRY(hipSetDevice(q->dev.device));
+    int rc;
+    if ((rc = q->h2d.ensure(len * sizeof(float)))) return rc;
+    if ((rc = q->d2h.ensure(region))) return rc;
+    HIP_TRY(hipMemcpyAsync(q->h2d.p, data, len * sizeof(float), hipMemcpyHostToDevice, q->stream));
+    if ((rc = melspec_tga_encode_device(q, static_cast<const float *>(q->h2d.p), len, n_mels, width, 1,
+                                        static_cast<uint8_t *>(q->d2h.p), region, q->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, q->d2h.p, region - l.chunk_stride + l.last_bytes, hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    if (n_chunks) *n_chunks = l.chunks;
+    return MELSPEC_OK;
+}
+
+int melspec_tga_decode_host(melspec_tga *q, const uint8_t *blob, size_t n_bytes, float *out, size_t out_capacity, size_t *n_values) {
+    if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");
+    if (n_values) *n_values = 0;
+    if (!blob || n_bytes < kTgaHeader) return fail(MELSPEC_ERR_INVALID_ARG, "failed to fill whole buffer");   // read_exact, src/quant.rs:74-75
+    const size_t npx = n_bytes - kTgaHeader;
+    if (npx == 0) return MELSPEC_OK;
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    if (out_capacity < npx) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    if (npx > 0xffffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "more than 2^32-1 pixels");
+    HIP_TRY(hipSetDevice(q->dev.device));
+    int rc;
+    if ((rc = q->h2d.ensure(round_up4(n_bytes) + 16))) return rc;
+    if ((rc = q->d2h.ensure(npx * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpyAsync(q->h2d.p, blob, n_bytes, hipMemcpyHostToDevice, q->stream));
+    // the header's width/height are ignored by the reference too: everything after byte 26 is one row of pixels
+    QuantDesc d;
+    uint32_t items, bpx, bdw;
+    d = QuantDesc{};
+    d.rows = 1; d.width = static_cast<uint32_t>(npx); d.n_images = 1; d.chunks = 1; d.chunk_w = d.width;
+    d.header = kTgaHeader; d.vec = 1; d.img_out = static_cast<float *>(q->d2h.p); d.blob = static_cast<uint8_t *>(q->h2d.p);
+    items = 1; bpx = 0; (void)bpx;
+    bdw = static_cast<uint32_t>(((kTgaHeader + npx + 3) / 4 + kQuantDwPerBlock - 1) / kQuantDwPerBlock);
+    hipLaunchKernelGGL(quant_decode_kernel, dim3(items * bdw), dim3(kQuantThreads), 0, q->stream, d, bdw);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, q->d2h.p, npx * sizeof(float), hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(hipStreamSynchronize(q->stream));
+    if (n_values) *n_values = npx;
     return MELSPEC_OK;
 }
 

@@ -314,6 +314,50 @@ int64_t oracle_interleave_frames(const float *frames, int64_t n_frames, int n_me
     return W;
 }
 
+/* ---- src/quant.rs: 8-bit quantisation and the TGA container ----------------------------------------
+ * quantize (src/quant.rs:140-153): min/max by f32::min/f32::max folds from +/-inf (a NaN operand is
+ * ignored), scale = 255/(max-min) in f32, pixel = round_half_away((v-min)*scale) clamped to [0,255]
+ * (f32::max(NaN,0)=0, so NaN -> 0; max==min gives scale=inf and 0*inf=NaN -> 0). */
+void oracle_quantize(const float *frame, int64_t n, uint8_t *out, float *range) {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int64_t i = 0; i < n; ++i) { mn = fminf(mn, frame[i]); mx = fmaxf(mx, frame[i]); }
+    const float scale = 255.0f / (mx - mn);
+    for (int64_t i = 0; i < n; ++i) {
+        const float d = frame[i] - mn;
+        const float p = d * scale;
+        const float r = fminf(fmaxf(roundf(p), 0.0f), 255.0f);
+        out[i] = (uint8_t)r;
+    }
+    range[0] = mn; range[1] = mx;
+}
+
+/* dequantize (src/quant.rs:156-165): scale = (max-min)/255 in f32; value = u8 as f32 * scale + min,
+ * the product rounded before the sum (Rust does not contract; this file is built with -ffp-contract=off). */
+void oracle_dequantize(const uint8_t *data, int64_t n, const float *range, float *out) {
+    const float scale = (range[1] - range[0]) / 255.0f;
+    for (int64_t i = 0; i < n; ++i) {
+        const float p = (float)data[i] * scale;
+        out[i] = p + range[0];
+    }
+}
+
+/* tga_8bit_data (src/quant.rs:38-64): 18-byte TARGA header (ID length 8, type 3 = uncompressed grey,
+ * width = len/n_mels and height = n_mels as little-endian u16, 8 bpp), the 8-byte ID field {min,max} as
+ * little-endian f32, then the pixels.  out must hold 26 + n bytes; returns that size. */
+int64_t oracle_tga_8bit_data(const float *data, int64_t n, int n_mels, uint8_t *out) {
+    float range[2];
+    oracle_quantize(data, n, out + 26, range);
+    const uint16_t width = (uint16_t)(n / n_mels), height = (uint16_t)n_mels;
+    memset(out, 0, 18);
+    out[0] = 8; out[2] = 3;
+    out[12] = (uint8_t)(width & 0xff); out[13] = (uint8_t)(width >> 8);
+    out[14] = (uint8_t)(height & 0xff); out[15] = (uint8_t)(height >> 8);
+    out[16] = 8;
+    memcpy(out + 18, &range[0], 4);       /* x86-64 / gfx950 hosts are little-endian */
+    memcpy(out + 22, &range[1], 4);
+    return 26 + n;
+}
+
 /* Many clips, clips split across OpenMP threads (the all-cores CPU baseline of
  * bench.py).  Clip c is samples[c*clip_stride .. +clip_len); out is
  * [clip][frame][mel].  Same arithmetic as the function above. */

@@ -71,6 +71,13 @@ def lib():
         L.oracle_compute_mel_batch.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
         L.oracle_interleave_frames.restype = C.c_int64
         L.oracle_interleave_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int64, f32p]
+        u8p = C.POINTER(C.c_uint8)
+        L.oracle_quantize.restype = None
+        L.oracle_quantize.argtypes = [f32p, C.c_int64, u8p, f32p]
+        L.oracle_dequantize.restype = None
+        L.oracle_dequantize.argtypes = [u8p, C.c_int64, f32p, f32p]
+        L.oracle_tga_8bit_data.restype = C.c_int64
+        L.oracle_tga_8bit_data.argtypes = [f32p, C.c_int64, C.c_int, u8p]
         L.oracle_max_threads.restype = C.c_int
         L.oracle_stream_mel.restype = C.c_int64
         L.oracle_stream_mel.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int64]
@@ -179,6 +186,58 @@ def interleave_frames(frames, major_column_order=False, min_width=0) -> np.ndarr
     out = np.empty((W, nm) if major_column_order else (nm, W), np.float32)
     lib().oracle_interleave_frames(_p(x, C.c_float), nf, nm, int(major_column_order), min_width, _p(out, C.c_float))
     return out
+
+
+# ---- src/quant.rs ---------------------------------------------------------------------------------
+
+def quantize(frame):
+    """quantize (src/quant.rs:140-153) -> (u8 array, (min, max))."""
+    x = _f32(frame).ravel()
+    out = np.empty(x.shape[0], np.uint8)
+    rng = np.empty(2, np.float32)
+    lib().oracle_quantize(_p(x, C.c_float), x.shape[0], _p(out, C.c_uint8), _p(rng, C.c_float))
+    return out, (rng[0], rng[1])
+
+
+def dequantize(data, rng) -> np.ndarray:
+    """dequantize (src/quant.rs:156-165)."""
+    d = np.ascontiguousarray(data, np.uint8).ravel()
+    r = np.asarray(rng, np.float32).copy()
+    out = np.empty(d.shape[0], np.float32)
+    lib().oracle_dequantize(_p(d, C.c_uint8), d.shape[0], _p(r, C.c_float), _p(out, C.c_float))
+    return out
+
+
+def tga_8bit_data(data, n_mels: int) -> bytes:
+    """tga_8bit_data (src/quant.rs:38-64) on a major-row-order interleaved image."""
+    x = _f32(data).ravel()
+    out = np.empty(26 + x.shape[0], np.uint8)
+    lib().oracle_tga_8bit_data(_p(x, C.c_float), x.shape[0], n_mels, _p(out, C.c_uint8))
+    return out.tobytes()
+
+
+def chunk_frames_into_strides(frames, n_mels: int, stride_size: int):
+    """chunk_frames_into_strides (src/quant.rs:100-136): [n_mels][width] cut into stride x stride tiles, row-major each."""
+    x = _f32(frames).ravel()
+    width = x.shape[0] // n_mels
+    if stride_size == width:
+        return [x]
+    img = x.reshape(n_mels, width)
+    return [np.ascontiguousarray(img[y:y + stride_size, c:c + stride_size]).ravel()
+            for y in range(0, n_mels, stride_size) for c in range(0, width, stride_size)]
+
+
+def tga_8bit(data, n_mels: int):
+    """tga_8bit (src/quant.rs:29-36): one TGA per <= 65535-column chunk."""
+    return [tga_8bit_data(c, n_mels) for c in chunk_frames_into_strides(data, n_mels, 65535)]
+
+
+def parse_tga_8bit(blob: bytes) -> np.ndarray:
+    """parse_tga_8bit (src/quant.rs:66-88): skip 18 bytes, read {min,max}, dequantise the rest."""
+    if len(blob) < 26:
+        raise ValueError("failed to fill whole buffer")
+    rng = np.frombuffer(blob[18:26], "<f4")
+    return dequantize(np.frombuffer(blob[26:], np.uint8), rng)
 
 
 def max_threads() -> int:

@@ -12,6 +12,7 @@
 #include "../../mel_spec_amd/csrc/fast_tables.hpp"
 #include "../../mel_spec_amd/csrc/whisper_wave.hpp"
 #include "../../mel_spec_amd/csrc/fbank_tables.hpp"
+#include "../../mel_spec_amd/csrc/tga_quant.hpp"
 
 using namespace melspec;
 
@@ -397,4 +398,75 @@ extern "C" void emu_small_fft(int n, float *interleaved) {
     if (n == 20) { cf x[20]; std::memcpy(x, interleaved, sizeof x); fft20(x); std::memcpy(interleaved, x, sizeof x); }
     if (n == 8)  { cf x[8];  std::memcpy(x, interleaved, sizeof x); fft8(x);  std::memcpy(interleaved, x, sizeof x); }
     if (n == 16) { cf x[16]; std::memcpy(x, interleaved, sizeof x); fft16(x); std::memcpy(interleaved, x, sizeof x); }
+}
+
+// ---- tga_quant.hpp: the three kernels of the quantiser, thread by thread ---------------------------
+static void emu_quant_fill(QuantDesc &d, uint32_t rows, uint64_t width, uint32_t n_images, uint64_t img_stride, uint64_t blob_stride,
+                           int header, const void *img) {
+    d = QuantDesc{};
+    d.rows = rows; d.width = static_cast<uint32_t>(width); d.n_images = n_images; d.img_stride = img_stride; d.blob_stride = blob_stride;
+    d.header = header ? kTgaHeader : 0;
+    if (header) {
+        d.chunks = static_cast<uint32_t>((width + kTgaMaxWidth - 1) / kTgaMaxWidth);
+        d.chunk_w = static_cast<uint32_t>(width < kTgaMaxWidth ? width : kTgaMaxWidth);
+        d.chunk_stride = (kTgaHeader + static_cast<uint64_t>(rows) * d.chunk_w + 3) & ~3ull;
+    } else {
+        d.chunks = 1; d.chunk_w = d.width;
+    }
+    d.vec = d.chunks == 1 && reinterpret_cast<uintptr_t>(img) % 16 == 0 && (n_images == 1 || img_stride % 4 == 0);
+}
+
+extern "C" int emu_tga_encode(const float *img, uint32_t rows, uint64_t width, uint32_t n_images, uint64_t img_stride, uint8_t *blob,
+                              uint64_t blob_stride, int header, float *ranges) {
+    QuantDesc d;
+    emu_quant_fill(d, rows, width, n_images, img_stride, blob_stride, header, img);
+    const uint32_t items = n_images * d.chunks;
+    std::vector<uint32_t> keys(2 * static_cast<size_t>(items));
+    for (uint32_t i = 0; i < items; ++i) { keys[2 * i] = kKeyPosInf; keys[2 * i + 1] = kKeyNegInf; }
+    for (uint32_t item = 0; item < items; ++item) {
+        const uint32_t image = item / d.chunks, c = item - image * d.chunks, cw = chunk_cols(d, c);
+        const uint64_t npx = static_cast<uint64_t>(rows) * cw;
+        const float *im = img + image * img_stride;
+        // min/max pass: per-thread partial folds merged through the ordered keys, in a scrambled order
+        for (uint64_t t = 0; t < (npx + 3) / 4; ++t) {
+            const uint64_t tt = ((npx + 3) / 4) - 1 - t;             // any order gives the same keys; run it backwards
+            float mn = INFINITY, mx = -INFINITY;
+            for (uint64_t i = 4 * tt; i < 4 * tt + 4 && i < npx; ++i) {
+                const float v = im[image_index(d, c, cw, i)];
+                mn = fminf(mn, v); mx = fmaxf(mx, v);
+            }
+            keys[2 * item] = std::min(keys[2 * item], ordered_key(mn));
+            keys[2 * item + 1] = std::max(keys[2 * item + 1], ordered_key(mx));
+        }
+        const float mn = key_to_float(keys[2 * item]), mx = key_to_float(keys[2 * item + 1]);
+        const float scale = f32_div_rn(255.0f, mx - mn);
+        if (ranges) { ranges[2 * item] = mn; ranges[2 * item + 1] = mx; }
+        uint32_t *out = reinterpret_cast<uint32_t *>(blob + image * blob_stride + c * d.chunk_stride);
+        const uint64_t ndw = (d.header + npx + 3) / 4;
+        for (uint64_t dw = 0; dw < ndw; ++dw) out[dw] = encode_dword(d, im, c, cw, npx, dw, mn, mx, scale);
+    }
+    return static_cast<int>(items);
+}
+
+extern "C" int emu_tga_decode(const uint8_t *blob, uint64_t blob_stride, uint32_t rows, uint64_t width, uint32_t n_images, float *img,
+                              uint64_t img_stride, int header, const float *ranges) {
+    QuantDesc d;
+    emu_quant_fill(d, rows, width, n_images, img_stride, blob_stride, header, img);
+    const uint32_t items = n_images * d.chunks;
+    for (uint32_t item = 0; item < items; ++item) {
+        const uint32_t image = item / d.chunks, c = item - image * d.chunks, cw = chunk_cols(d, c);
+        const uint64_t npx = static_cast<uint64_t>(rows) * cw;
+        const uint8_t *b = blob + image * blob_stride + c * d.chunk_stride;
+        float mn, mx;
+        if (header) { std::memcpy(&mn, b + 18, 4); std::memcpy(&mx, b + 22, 4); }
+        else { mn = ranges[2 * item]; mx = ranges[2 * item + 1]; }
+        const float scale = f32_div_rn(mx - mn, 255.0f);
+        const uint64_t ndw = (d.header + npx + 3) / 4;
+        for (uint64_t dw = 0; dw < ndw; ++dw) {
+            uint32_t w = 0;
+            std::memcpy(&w, b + 4 * dw, 4);
+            decode_dword(d, img + image * img_stride, c, cw, npx, dw, w, mn, scale);
+        }
+    }
+    return static_cast<int>(items);
 }
