@@ -13,6 +13,8 @@
  *   - mel(n_fft=512)      vs testdata/nemo_mel_filters.npz @1e-7  (src/mel.rs:853-871)
  *   - streaming 512/160/80 on jfk_f32le.wav vs testdata/rust_jfk_golden.npy @1e-6
  *                                                          (src/rb.rs:134-179)
+ *   - Whisper 400/160/80 on jfk_f32le.wav[80:] -> tga_8bit_data vs testdata/quantized_mel_golden.tga:
+ *     all 88026 bytes equal (tests/test_quant.py; the file is loaded by src/vad.rs:684-744)
  *   - librosa scalar known-answers                         (src/mel.rs:787-835)
  *   - fbank frame count 1098 on JFK; values informational  (src/fbank.rs:484-490)
  * The FFT itself lives in a third-party crate (rustfft ^6.2.0, Cargo.toml:18, no
