@@ -199,6 +199,42 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
                                        uint32_t n_clips, float *d_out, void *stream);
 int melspec_blm_synchronize(melspec_blm *b, void *stream);
 
+/* ---- streaming: Spectrogram::add + RingBuffer::maybe_mel (src/stft.rs:48-86, src/rb.rs:60-121) ---- */
+/* A bank of n_streams independent live streams over one melspec_ctx (its geometry, tables and
+ * kernels).  Per stream the device keeps what the reference keeps on the host: hop_buf's history (the
+ * last n_fft - hop samples) and the samples accumulated towards the next hop (RingBuffer's
+ * accumulated_samples); the host side of the handle keeps Spectrogram::idx.  A push appends a chunk of
+ * any length <= max_chunk to each named stream and emits, per stream, exactly the frames the reference's
+ * add_frame()/maybe_mel() loop would: one per completed hop once idx >= n_fft, so the first frame of a
+ * stream starts at sample ceil(n_fft/hop)*hop - n_fft (80 for 400/160, 128 for 512/160) -- the alignment
+ * testdata/rust_jfk_golden.npy pins (src/rb.rs:134-179).  Frames are computed in place on carry ++ chunk
+ * by the batch kernels (no staging copy of the history), then the tail becomes the new carry.
+ * The ctx must outlive the bank; one bank per host thread, like the ctx. */
+typedef struct melspec_stream melspec_stream;
+
+int melspec_stream_create(melspec_stream **out, melspec_ctx *ctx, uint32_t n_streams, uint32_t max_chunk);
+void melspec_stream_destroy(melspec_stream *st);
+/* Spectrogram::new state (zero history, idx = 0) for the listed streams; ids == NULL -> all. */
+int melspec_stream_reset(melspec_stream *st, const uint32_t *ids, uint32_t n);
+/* frames a push of n_new samples to stream id would emit now */
+size_t melspec_stream_frames_after(const melspec_stream *st, uint32_t id, uint32_t n_new);
+
+/* Host chunks: samples holds the n chunks back to back (lens[i] samples for stream ids[i], each id at most
+ * once per call); out receives the emitted frames back to back in entry order ([frame][mel] each),
+ * frames_out[i] how many entry i emitted.  Synchronous. */
+int melspec_stream_push_host(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                             float *out, size_t out_capacity_floats, uint32_t *frames_out);
+/* Spectrogram::add with fewer than hop samples (src/stft.rs:57-60): the pending samples of each listed
+ * stream are zero-padded to a hop, idx advances by the real samples only, at most one frame each. */
+int melspec_stream_flush_host(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,
+                              uint32_t *frames_out);
+/* Device producers write the next chunk of stream id at melspec_stream_input_ptr(st, id) (fixed per
+ * stream, 16-byte aligned, room for max_chunk samples) and then push lengths only.  Output goes to
+ * d_out + out_offsets[i] floats (NULL -> back to back).  Returns after the launches have completed. */
+float *melspec_stream_input_ptr(melspec_stream *st, uint32_t id);
+int melspec_stream_push_device(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
+                               const uint64_t *out_offsets, uint32_t *frames_out, void *stream);
+
 /* ---- 8-bit quantisation + TGA container: replaces src/quant.rs ------------------------ */
 /* The reference's wire/disk format right after the mel path: a mel-major interleaved image
  * ([n_mels][width] f32, what melspec_compute_uniform_device_interleaved(.., major_column_order = 0, ..)
@@ -254,6 +290,9 @@ int melspec_device_synchronize(void);
  * d_out[c*clip_stride + i] = hashnoise(seed, first_clip + c, i), c < n_clips, i < clip_len. */
 int melspec_synth_pcm_device(float *d_out, uint64_t clip_stride, uint64_t clip_len,
                              uint64_t first_clip, uint32_t n_clips, uint32_t seed, void *stream);
+/* samples [first_sample, first_sample + n_samples) of the same clips (a live producer for the streaming bank) */
+int melspec_synth_pcm_window_device(float *d_out, uint64_t clip_stride, uint64_t first_sample, uint64_t n_samples,
+                                    uint64_t first_clip, uint32_t n_clips, uint32_t seed, void *stream);
 
 #ifdef __cplusplus
 }

@@ -2,10 +2,11 @@
 wavey-ai/mel-spec's GPU plugin slot.  All compute runs in hand-written HIP kernels
 (csrc/) reached through the C ABI of libmelspec_hip.so (include/melspec_hip.h)."""
 from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, DeviceBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable,
-                  device_count, device_synchronize, hann_window, kaldi_mel_filterbank, mel, synth_pcm_device)
+                  device_count, device_synchronize, hann_window, kaldi_mel_filterbank, mel, synth_pcm_device, synth_pcm_window)
 from .parallel import shard_range
 from .quant import QuantizationRange, TgaCodec, to_array2
+from .stream import RingBuffer, StreamBank
 
 __all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError",
            "HipUnavailable", "device_count", "device_synchronize", "hann_window", "kaldi_mel_filterbank", "mel",
-           "synth_pcm_device", "shard_range", "QuantizationRange", "TgaCodec", "to_array2"]
+           "synth_pcm_device", "synth_pcm_window", "shard_range", "QuantizationRange", "TgaCodec", "to_array2", "RingBuffer", "StreamBank"]

@@ -38,6 +38,7 @@ class BlmConfigC(C.Structure):
 
 # name -> (restype, argtypes); must list every symbol include/melspec_hip.h declares
 _vp, _f32p, _f64p, _u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
 SIGNATURES = {
     "melspec_abi_version": (C.c_int, []),
     "melspec_device_count": (C.c_int, []),
@@ -85,6 +86,15 @@ SIGNATURES = {
     "melspec_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "melspec_device_synchronize": (C.c_int, []),
     "melspec_synth_pcm_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
+    "melspec_synth_pcm_window_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
+    "melspec_stream_create": (C.c_int, [C.POINTER(_vp), _vp, C.c_uint32, C.c_uint32]),
+    "melspec_stream_destroy": (None, [_vp]),
+    "melspec_stream_reset": (C.c_int, [_vp, _u32p, C.c_uint32]),
+    "melspec_stream_frames_after": (C.c_size_t, [_vp, C.c_uint32, C.c_uint32]),
+    "melspec_stream_push_host": (C.c_int, [_vp, _u32p, _f32p, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p]),
+    "melspec_stream_flush_host": (C.c_int, [_vp, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p]),
+    "melspec_stream_input_ptr": (_vp, [_vp, C.c_uint32]),
+    "melspec_stream_push_device": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, _vp, _u64p, _u32p, _vp]),
     "melspec_tga_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "melspec_tga_destroy": (None, [_vp]),
     "melspec_tga_layout": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

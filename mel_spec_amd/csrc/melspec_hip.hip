@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -20,6 +21,7 @@
 #include "fast_tables.hpp"
 #include "fbank_tables.hpp"
 #include "melspec_kernels.hpp"
+#include "stream_plan.hpp"
 #include "tga_quant.hpp"
 #include "tables.hpp"
 
@@ -865,6 +867,169 @@ int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------
+// Streaming: a bank of live streams with device-side overlap-save state
+// (Spectrogram::add src/stft.rs:48-86 driven by RingBuffer::maybe_mel src/rb.rs:86-121)
+// ------------------------------------------------------------------------------------
+struct melspec_stream {
+    melspec_ctx *ctx = nullptr;          // geometry, tables, kernels; not owned
+    StreamGeom geom{};
+    StreamBook book;                     // pending / idx per stream (host side of the state)
+    DevBuf state, entries, staging, out;
+};
+
+namespace {
+int stream_plan(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, bool flush, StreamPlan &pl) {
+    const char *err = nullptr;
+    const int rc = stream_plan_push(st->geom, st->book, ids, lens, n, flush, pl, &err);
+    if (rc == 1) return fail(MELSPEC_ERR_INVALID_ARG, err);
+    if (rc == 2) return fail(MELSPEC_ERR_CAPACITY, err);
+    return MELSPEC_OK;
+}
+void stream_commit(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, bool flush) {
+    stream_commit_push(st->geom, st->book, ids, lens, n, flush);
+}
+
+// scatter (optional) -> frames -> carry update, all on one stream
+int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float *d_src, float *d_out, const uint64_t *h_out_off,
+               hipStream_t s) {
+    melspec_ctx *c = st->ctx;
+    HIP_TRY(hipSetDevice(c->dev.device));
+    int rc = st->entries.ensure(static_cast<size_t>(n) * sizeof(StreamEntry));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(st->entries.p, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry), hipMemcpyHostToDevice, s));
+    const StreamEntry *d_e = static_cast<const StreamEntry *>(st->entries.p);
+    float *state = static_cast<float *>(st->state.p);
+    bool any_fill = d_src != nullptr;
+    for (uint32_t i = 0; i < n && !any_fill; ++i) any_fill = pl.entries[i].zero_fill != 0;
+    if (any_fill) hipLaunchKernelGGL(stream_scatter_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e, d_src);
+    if (pl.total_frames) {
+        if (!d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");
+        rc = melspec_compute_ragged_device(c, state, pl.off.data(), pl.len.data(), n, d_out, h_out_off ? h_out_off : pl.out_off.data(), s);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(stream_carry_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e);
+    HIP_TRY(hipGetLastError());
+    // pl.entries is pageable host memory that dies with the caller's frame
+    HIP_TRY(hipStreamSynchronize(s));
+    return MELSPEC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int melspec_stream_create(melspec_stream **out, melspec_ctx *ctx, uint32_t n_streams, uint32_t max_chunk) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!ctx) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (n_streams == 0 || max_chunk == 0) return fail(MELSPEC_ERR_INVALID_ARG, "n_streams and max_chunk must be > 0");
+    if (ctx->hop_size > ctx->fft_size) return fail(MELSPEC_ERR_UNSUPPORTED, "streaming needs hop_size <= fft_size");
+    melspec_stream *st = new (std::nothrow) melspec_stream();
+    if (!st) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    st->ctx = ctx;
+    st->geom = stream_geometry(static_cast<uint32_t>(ctx->fft_size), static_cast<uint32_t>(ctx->hop_size), static_cast<uint32_t>(ctx->n_mels),
+                               n_streams, max_chunk);
+    st->book.reset(n_streams);
+    if (hipSetDevice(ctx->dev.device) != hipSuccess) { delete st; return fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"); }
+    const size_t bytes = static_cast<size_t>(n_streams) * st->geom.stride * sizeof(float) + 64;
+    int rc = st->state.ensure(bytes);
+    if (rc) { delete st; return rc; }
+    if (hipMemset(st->state.p, 0, bytes) != hipSuccess) { st->state.release(); delete st; return fail(MELSPEC_ERR_INTERNAL, "hipMemset failed"); }
+    *out = st;
+    return MELSPEC_OK;
+}
+
+void melspec_stream_destroy(melspec_stream *st) {
+    if (!st) return;
+    if (st->ctx) { (void)hipSetDevice(st->ctx->dev.device); (void)hipStreamSynchronize(st->ctx->stream); }
+    st->state.release(); st->entries.release(); st->staging.release(); st->out.release();
+    delete st;
+}
+
+int melspec_stream_reset(melspec_stream *st, const uint32_t *ids, uint32_t n) {
+    if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    HIP_TRY(hipSetDevice(st->ctx->dev.device));
+    if (!ids) {
+        HIP_TRY(hipMemsetAsync(st->state.p, 0, static_cast<size_t>(st->geom.n_streams) * st->geom.stride * sizeof(float), st->ctx->stream));
+        st->book.reset(st->geom.n_streams);
+    } else {
+        for (uint32_t i = 0; i < n; ++i) {
+            if (ids[i] >= st->geom.n_streams) return fail(MELSPEC_ERR_INVALID_ARG, "stream id out of range");
+            HIP_TRY(hipMemsetAsync(static_cast<float *>(st->state.p) + ids[i] * st->geom.stride, 0, st->geom.in_off * sizeof(float), st->ctx->stream));
+            st->book.pending[ids[i]] = 0; st->book.idx[ids[i]] = 0;
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st->ctx->stream));
+    return MELSPEC_OK;
+}
+
+size_t melspec_stream_frames_after(const melspec_stream *st, uint32_t id, uint32_t n_new) {
+    if (!st || id >= st->geom.n_streams) return 0;
+    return stream_frames_after(st->geom, st->book, id, n_new);
+}
+
+float *melspec_stream_input_ptr(melspec_stream *st, uint32_t id) {
+    if (!st || id >= st->geom.n_streams) return nullptr;
+    return static_cast<float *>(st->state.p) + id * st->geom.stride + st->geom.in_off;
+}
+
+int melspec_stream_push_device(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
+                               const uint64_t *h_out_offsets, uint32_t *h_frames, void *stream) {
+    if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    if (n == 0) return MELSPEC_OK;
+    if (!ids || !lens) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
+    StreamPlan pl;
+    int rc = stream_plan(st, ids, lens, n, false, pl);
+    if (rc) return rc;
+    rc = stream_run(st, pl, n, nullptr, d_out, h_out_offsets, stream ? static_cast<hipStream_t>(stream) : st->ctx->stream);
+    if (rc) return rc;
+    stream_commit(st, ids, lens, n, false);
+    if (h_frames) std::memcpy(h_frames, pl.frames.data(), static_cast<size_t>(n) * sizeof(uint32_t));
+    return MELSPEC_OK;
+}
+
+static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                                 bool flush, float *out, size_t out_capacity_floats, uint32_t *h_frames) {
+    if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    if (n == 0) return MELSPEC_OK;
+    if (!ids || (!flush && !lens)) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
+    StreamPlan pl;
+    int rc = stream_plan(st, ids, lens, n, flush, pl);
+    if (rc) return rc;
+    const uint64_t need = pl.total_frames * st->ctx->n_mels;
+    if (need > out_capacity_floats) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    if (need && !out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += pl.entries[i].len;
+    if (total && !samples) return fail(MELSPEC_ERR_INVALID_ARG, "samples is NULL");
+    hipStream_t s = st->ctx->stream;
+    HIP_TRY(hipSetDevice(st->ctx->dev.device));
+    if ((rc = st->staging.ensure(total * sizeof(float) + 16))) return rc;
+    if ((rc = st->out.ensure(need * sizeof(float) + 16))) return rc;
+    if (total) HIP_TRY(hipMemcpyAsync(st->staging.p, samples, total * sizeof(float), hipMemcpyHostToDevice, s));
+    rc = stream_run(st, pl, n, total ? static_cast<const float *>(st->staging.p) : nullptr, static_cast<float *>(st->out.p), nullptr, s);
+    if (rc) return rc;
+    if (need) {
+        HIP_TRY(hipMemcpyAsync(out, st->out.p, need * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    stream_commit(st, ids, lens, n, flush);
+    if (h_frames) std::memcpy(h_frames, pl.frames.data(), static_cast<size_t>(n) * sizeof(uint32_t));
+    return MELSPEC_OK;
+}
+
+int melspec_stream_push_host(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                             float *out, size_t out_capacity_floats, uint32_t *h_frames) {
+    return stream_push_host_impl(st, ids, samples, lens, n, false, out, out_capacity_floats, h_frames);
+}
+
+int melspec_stream_flush_host(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,
+                              uint32_t *h_frames) {
+    return stream_push_host_impl(st, ids, nullptr, nullptr, n, true, out, out_capacity_floats, h_frames);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
 // 8-bit quantisation + TGA container (src/quant.rs)
 // ------------------------------------------------------------------------------------
 struct melspec_tga {
@@ -1300,17 +1465,27 @@ int melspec_device_synchronize(void) {
     return MELSPEC_OK;
 }
 
-int melspec_synth_pcm_device(float *d_out, uint64_t clip_stride, uint64_t clip_len, uint64_t first_clip,
-                             uint32_t n_clips, uint32_t seed, void *stream) {
-    if (n_clips == 0 || clip_len == 0) return MELSPEC_OK;
+static int synth_launch(float *d_out, uint64_t clip_stride, uint64_t first_sample, uint64_t n_samples, uint64_t first_clip,
+                        uint32_t n_clips, uint32_t seed, void *stream) {
+    if (n_clips == 0 || n_samples == 0) return MELSPEC_OK;
     if (!d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");
-    const uint64_t total = static_cast<uint64_t>(n_clips) * clip_len;
+    const uint64_t total = static_cast<uint64_t>(n_clips) * n_samples;
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(synth_pcm_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       d_out, clip_stride, clip_len, first_clip, n_clips, seed);
+                       d_out, clip_stride, n_samples, first_clip, n_clips, seed, first_sample);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
+}
+
+int melspec_synth_pcm_device(float *d_out, uint64_t clip_stride, uint64_t clip_len, uint64_t first_clip,
+                             uint32_t n_clips, uint32_t seed, void *stream) {
+    return synth_launch(d_out, clip_stride, 0, clip_len, first_clip, n_clips, seed, stream);
+}
+
+int melspec_synth_pcm_window_device(float *d_out, uint64_t clip_stride, uint64_t first_sample, uint64_t n_samples,
+                                    uint64_t first_clip, uint32_t n_clips, uint32_t seed, void *stream) {
+    return synth_launch(d_out, clip_stride, first_sample, n_samples, first_clip, n_clips, seed, stream);
 }
 
 }  // extern "C"

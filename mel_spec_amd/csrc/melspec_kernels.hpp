@@ -13,6 +13,7 @@
 #include "whisper_wave.hpp"
 #include "fbank_wave.hpp"
 #include "whisper_wave_f64.hpp"
+#include "stream_plan.hpp"
 
 namespace melspec {
 
@@ -574,6 +575,40 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
     }
 }
 
+// ---- streaming state (Spectrogram::add, src/stft.rs:48-86; RingBuffer::maybe_mel, src/rb.rs:86-121) ----
+// Every live stream owns a slot of `stride` floats: [carry, right-aligned so that it ends at `in_off`]
+// [the next chunk, always at in_off].  The carry is the reference's hop_buf history (n_fft - hop samples)
+// plus the samples RingBuffer has accumulated towards the next hop (< hop).  Frames are computed in place
+// by the batch kernels on carry ++ chunk; afterwards the tail of that span becomes the new carry.
+// copies host-pushed chunks (one flat staging buffer) into the slots; optionally zero-pads (flush)
+__global__ __launch_bounds__(256) void stream_scatter_kernel(float *state, uint64_t stride, uint32_t in_off, const StreamEntry *entries,
+                                                             const float *src) {
+    const StreamEntry e = entries[blockIdx.x];
+    float *dst = state + e.stream * stride + in_off;
+    if (src)
+        for (uint32_t i = threadIdx.x; i < e.len; i += 256) dst[i] = src[e.src_off + i];
+    for (uint32_t i = threadIdx.x; i < e.zero_fill; i += 256) dst[e.len + i] = 0.0f;
+}
+
+// new carry = the last `keep` samples before in_off + len (+ zero_fill), moved so that they end at in_off:
+// a shift to lower addresses by the chunk length.  Ascending 256-sample pieces, each read completely
+// before it is written, never touch the source of a later piece.
+__global__ __launch_bounds__(256) void stream_carry_kernel(float *state, uint64_t stride, uint32_t in_off, const StreamEntry *entries) {
+    const StreamEntry e = entries[blockIdx.x];
+    const uint32_t n = e.len + e.zero_fill;
+    if (n == 0) return;
+    float *slot = state + e.stream * stride;
+    const float *src = slot + in_off + n - e.keep;
+    float *dst = slot + in_off - e.keep;
+    for (uint32_t base = 0; base < e.keep; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const float v = i < e.keep ? src[i] : 0.0f;
+        __syncthreads();
+        if (i < e.keep) dst[i] = v;
+        __syncthreads();
+    }
+}
+
 // Hash-noise PCM (murmur3 finaliser) of SURVEY.md §8(d); the CPU tests regenerate the same bits.
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -581,12 +616,12 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
 }
 
 __global__ __launch_bounds__(256) void synth_pcm_kernel(float *out, uint64_t clip_stride, uint64_t clip_len,
-                                                        uint64_t first_clip, uint32_t n_clips, uint32_t seed) {
+                                                        uint64_t first_clip, uint32_t n_clips, uint32_t seed, uint64_t first_sample) {
     const uint64_t total = (uint64_t)n_clips * clip_len;
     for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (uint64_t)gridDim.x * 256) {
         const uint64_t c = g / clip_len, i = g - c * clip_len;
         const uint64_t clip = first_clip + c;
-        const uint32_t h = fmix32(seed ^ ((uint32_t)clip * 0x9E3779B1u) ^ ((uint32_t)i * 0x85EBCA6Bu));
+        const uint32_t h = fmix32(seed ^ ((uint32_t)clip * 0x9E3779B1u) ^ ((uint32_t)(first_sample + i) * 0x85EBCA6Bu));
         const float u = (float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
         out[c * clip_stride + i] = u * (1.0f / (float)(1u << (clip & 7u)));
     }

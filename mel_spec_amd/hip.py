@@ -97,6 +97,13 @@ def synth_pcm_device(buf_ptr: int, clip_stride: int, clip_len: int, first_clip: 
                                           C.c_void_p(stream)))
 
 
+def synth_pcm_window(buf_ptr: int, clip_stride: int, n_samples: int, first_sample: int, n_clips: int, first_clip: int = 0,
+                     seed: int = 0x4D454C53, stream: int = 0) -> None:
+    """Samples [first_sample, first_sample + n_samples) of the synthetic clips, clip c at buf + c*clip_stride floats."""
+    _check(lib().melspec_synth_pcm_window_device(C.c_void_p(buf_ptr), clip_stride, first_sample, n_samples, first_clip, n_clips, seed,
+                                                 C.c_void_p(stream)))
+
+
 def device_synchronize() -> None:
     _check(lib().melspec_device_synchronize())
 

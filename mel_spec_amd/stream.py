@@ -1,0 +1,133 @@
+"""Streaming side of the reference over the C ABI (melspec_stream_*): a bank of live streams whose
+overlap-save state lives in HBM, and a single-stream `RingBuffer` with the reference's method names
+(src/rb.rs:18-121: add_frame / add / maybe_mel)."""
+import ctypes as C
+from collections import deque
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from ._lib import lib
+from .hip import HipMelSpectrogram, _check, _f32, _fp
+
+_u32p = C.POINTER(C.c_uint32)
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+class StreamBank:
+    """n_streams independent Spectrogram::add states (src/stft.rs:48-86) on one HipMelSpectrogram's geometry."""
+
+    def __init__(self, mel: HipMelSpectrogram, n_streams: int, max_chunk: int):
+        self._mel = mel                      # keeps the ctx alive
+        self.n_streams, self.max_chunk, self.n_mels = int(n_streams), int(max_chunk), mel.n_mels
+        h = C.c_void_p()
+        _check(lib().melspec_stream_create(C.byref(h), mel._h, self.n_streams, self.max_chunk), construct=True)
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().melspec_stream_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset(self, ids: Optional[Sequence[int]] = None) -> None:
+        if ids is None:
+            _check(lib().melspec_stream_reset(self._h, None, 0))
+        else:
+            a = _u32(ids)
+            _check(lib().melspec_stream_reset(self._h, a.ctypes.data_as(_u32p), a.shape[0]))
+
+    def frames_after(self, stream: int, n_new: int) -> int:
+        return int(lib().melspec_stream_frames_after(self._h, stream, n_new))
+
+    def _collect(self, out: np.ndarray, frames: np.ndarray) -> List[np.ndarray]:
+        res, cur = [], 0
+        for f in frames:
+            res.append(out[cur:cur + int(f)])
+            cur += int(f)
+        return res
+
+    def push(self, ids: Sequence[int], chunks: Sequence) -> List[np.ndarray]:
+        """Append chunks[i] (any length <= max_chunk) to stream ids[i]; returns the frames each stream emitted, [k_i, n_mels]."""
+        a = _u32(ids)
+        xs = [_f32(c).ravel() for c in chunks]
+        assert len(xs) == a.shape[0]
+        lens = _u32([x.shape[0] for x in xs])
+        flat = np.concatenate(xs) if xs else np.zeros(0, np.float32)
+        cap = sum(self.frames_after(int(s), int(n)) for s, n in zip(a, lens))
+        out = np.empty((cap, self.n_mels), np.float32)
+        frames = np.zeros(a.shape[0], np.uint32)
+        _check(lib().melspec_stream_push_host(self._h, a.ctypes.data_as(_u32p), _fp(flat), lens.ctypes.data_as(_u32p), a.shape[0],
+                                              _fp(out), out.size, frames.ctypes.data_as(_u32p)))
+        assert int(frames.sum()) == cap
+        return self._collect(out, frames)
+
+    def flush(self, ids: Sequence[int]) -> List[np.ndarray]:
+        """Spectrogram::add with the pending (< hop) samples: zero-padded, at most one more frame per stream."""
+        a = _u32(ids)
+        out = np.empty((a.shape[0], self.n_mels), np.float32)
+        frames = np.zeros(a.shape[0], np.uint32)
+        _check(lib().melspec_stream_flush_host(self._h, a.ctypes.data_as(_u32p), a.shape[0], _fp(out), out.size, frames.ctypes.data_as(_u32p)))
+        return self._collect(out, frames)
+
+    # ---- device producers -----------------------------------------------------------------
+    def input_ptr(self, stream: int) -> int:
+        return int(lib().melspec_stream_input_ptr(self._h, stream) or 0)
+
+    def push_device(self, ids: Sequence[int], lens: Sequence[int], d_out: int, out_offsets=None, stream: int = 0) -> np.ndarray:
+        a, ln = _u32(ids), _u32(lens)
+        frames = np.zeros(a.shape[0], np.uint32)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, np.uint64)
+        _check(lib().melspec_stream_push_device(self._h, a.ctypes.data_as(_u32p), ln.ctypes.data_as(_u32p), a.shape[0], C.c_void_p(d_out),
+                                                None if oo is None else oo.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                frames.ctypes.data_as(_u32p), C.c_void_p(stream)))
+        return frames
+
+
+class RingBuffer:
+    """One stream with the reference's interface (src/rb.rs:18-121): add_frame / add feed samples, maybe_mel
+    returns one (n_mels, 1) column per completed hop or None.  Frames are computed on the device in batches
+    whenever maybe_mel runs dry, so calling it in the reference's `while let Some(mel) = rb.maybe_mel()` loop
+    costs one launch per add_frame, not one per hop."""
+
+    def __init__(self, mel: HipMelSpectrogram, capacity: int = 16384):
+        self._bank = StreamBank(mel, 1, max(int(capacity), mel.hop_size))
+        self._buf = deque()
+        self._n = 0
+        self._capacity = max(int(capacity), mel.hop_size)
+        self._ready = deque()
+
+    def add_frame(self, samples) -> None:
+        x = _f32(samples).ravel()
+        # src/rb.rs:60-68: when full, the oldest samples are dropped
+        over = self._n + x.shape[0] - self._capacity
+        while over > 0 and self._buf:
+            head = self._buf[0]
+            if head.shape[0] <= over:
+                self._buf.popleft(); self._n -= head.shape[0]; over -= head.shape[0]
+            else:
+                self._buf[0] = head[over:]; self._n -= over; over = 0
+        if x.shape[0] > self._capacity:
+            x = x[-self._capacity:]
+        self._buf.append(x)
+        self._n += x.shape[0]
+
+    def add(self, sample: float) -> None:
+        self.add_frame(np.array([sample], np.float32))
+
+    def maybe_mel(self) -> Optional[np.ndarray]:
+        if not self._ready and self._n:
+            x = np.concatenate(list(self._buf))
+            self._buf.clear(); self._n = 0
+            for f in self._bank.push([0], [x])[0]:
+                self._ready.append(f)
+        if not self._ready:
+            return None
+        return self._ready.popleft().astype(np.float64).reshape(-1, 1)
+
+    def close(self) -> None:
+        self._bank.close()

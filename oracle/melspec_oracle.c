@@ -394,8 +394,10 @@ int oracle_max_threads(void) {
 /* out: [emitted][n_mels]; returns frames emitted.  This is what                */
 /* testdata/rust_jfk_golden.npy pins (src/rb.rs:134-179, 512/160/80).           */
 /* ------------------------------------------------------------------------- */
-int64_t oracle_stream_mel(const float *samples, int64_t len, int fft_size, int hop_size, int n_mels,
-                          double sampling_rate, float *out, int64_t out_cap_frames) {
+/* flush_tail != 0: after the full hops, the remaining (< hop) samples go through one more add(), which
+ * zero-pads them and advances idx by their count only (src/stft.rs:55-66). */
+int64_t oracle_stream_mel_ex(const float *samples, int64_t len, int fft_size, int hop_size, int n_mels,
+                             double sampling_rate, float *out, int64_t out_cap_frames, int flush_tail) {
     const int bins = fft_size / 2 + 1;
     double *window = (double *)malloc(sizeof(double) * (size_t)fft_size);
     double *hop_buf = (double *)calloc((size_t)fft_size, sizeof(double));
@@ -409,10 +411,12 @@ int64_t oracle_stream_mel(const float *samples, int64_t len, int fft_size, int h
     uint64_t idx = 0;
     int64_t emitted = 0;
     /* RingBuffer::maybe_mel only calls Spectrogram::add with exactly hop_size samples. */
-    for (int64_t pos = 0; pos + hop_size <= len; pos += hop_size) {
+    for (int64_t pos = 0; pos < len; pos += hop_size) {
+        const int64_t got = len - pos < hop_size ? len - pos : hop_size;
+        if (got < hop_size && !flush_tail) break;
         memmove(hop_buf, hop_buf + hop_size, sizeof(double) * (size_t)(fft_size - hop_size));
-        for (int i = 0; i < hop_size; ++i) hop_buf[fft_size - hop_size + i] = (double)samples[pos + i];
-        idx += (uint64_t)hop_size;
+        for (int i = 0; i < hop_size; ++i) hop_buf[fft_size - hop_size + i] = i < got ? (double)samples[pos + i] : 0.0;
+        idx += (uint64_t)got;
         if (idx >= (uint64_t)fft_size) {
             if (emitted >= out_cap_frames) break;
             for (int j = 0; j < fft_size; ++j) { buf[j].re = hop_buf[j] * window[j]; buf[j].im = 0.0; }
@@ -424,6 +428,11 @@ int64_t oracle_stream_mel(const float *samples, int64_t len, int fft_size, int h
     fft_plan_free(&pl); sparse_free(&fb);
     free(window); free(hop_buf); free(dense); free(mel_buf); free(buf);
     return emitted;
+}
+
+int64_t oracle_stream_mel(const float *samples, int64_t len, int fft_size, int hop_size, int n_mels,
+                          double sampling_rate, float *out, int64_t out_cap_frames) {
+    return oracle_stream_mel_ex(samples, len, fft_size, hop_size, n_mels, sampling_rate, out, out_cap_frames, 0);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -69,6 +69,8 @@ def lib():
         L.oracle_compute_mel_spectrogram_cpu.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p]
         L.oracle_compute_mel_batch.restype = C.c_int64
         L.oracle_compute_mel_batch.argtypes = [f32p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int]
+        L.oracle_stream_mel_ex.restype = C.c_int64
+        L.oracle_stream_mel_ex.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int64, C.c_int]
         L.oracle_interleave_frames.restype = C.c_int64
         L.oracle_interleave_frames.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int64, f32p]
         u8p = C.POINTER(C.c_uint8)
@@ -244,13 +246,14 @@ def max_threads() -> int:
     return int(lib().oracle_max_threads())
 
 
-def stream_mel(samples, fft_size=512, hop_size=160, n_mels=80, sampling_rate=16000.0) -> np.ndarray:
-    """Streaming Spectrogram::add + MelSpectrogram::add (src/stft.rs:48-86, src/rb.rs:86-121)."""
+def stream_mel(samples, fft_size=512, hop_size=160, n_mels=80, sampling_rate=16000.0, flush_tail=False) -> np.ndarray:
+    """Streaming Spectrogram::add + MelSpectrogram::add (src/stft.rs:48-86, src/rb.rs:86-121); flush_tail pushes
+    the last (< hop) samples through add() too, zero-padded as src/stft.rs:55-60 does."""
     x = _f32(samples)
-    cap = x.shape[0] // hop_size + 1
+    cap = x.shape[0] // hop_size + 2
     out = np.empty((cap, n_mels), np.float32)
-    n = lib().oracle_stream_mel(_p(x, C.c_float), x.shape[0], fft_size, hop_size, n_mels, sampling_rate,
-                                _p(out, C.c_float), cap)
+    n = lib().oracle_stream_mel_ex(_p(x, C.c_float), x.shape[0], fft_size, hop_size, n_mels, sampling_rate,
+                                   _p(out, C.c_float), cap, int(flush_tail))
     return out[:n].copy()
 
 

@@ -470,3 +470,57 @@ extern "C" int emu_tga_decode(const uint8_t *blob, uint64_t blob_stride, uint32_
     }
     return static_cast<int>(items);
 }
+
+// ---- stream_plan.hpp: the streaming bank's bookkeeping with host stand-ins for the three kernels --------
+#include "../../mel_spec_amd/csrc/stream_plan.hpp"
+extern "C" long long emu_whisper_wave(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out);
+struct EmuStream {
+    StreamGeom g;
+    StreamBook bk;
+    std::vector<float> state;
+    double sr;
+};
+extern "C" void *emu_stream_create(int hop, int n_mels, double sr, uint32_t n_streams, uint32_t max_chunk) {
+    EmuStream *s = new EmuStream();
+    s->g = stream_geometry(400, static_cast<uint32_t>(hop), static_cast<uint32_t>(n_mels), n_streams, max_chunk);
+    s->bk.reset(n_streams);
+    s->state.assign(static_cast<size_t>(n_streams) * s->g.stride + 16, 0.0f);
+    s->sr = sr;
+    return s;
+}
+extern "C" void emu_stream_destroy(void *p) { delete static_cast<EmuStream *>(p); }
+extern "C" long long emu_stream_frames_after(void *p, uint32_t id, uint32_t n_new) {
+    EmuStream *s = static_cast<EmuStream *>(p);
+    return static_cast<long long>(stream_frames_after(s->g, s->bk, id, n_new));
+}
+// returns total frames (>= 0) or -(error code)
+extern "C" long long emu_stream_push(void *p, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n, int flush,
+                                     float *out, uint32_t *frames_out) {
+    EmuStream *s = static_cast<EmuStream *>(p);
+    StreamPlan pl;
+    const char *err = nullptr;
+    const int rc = stream_plan_push(s->g, s->bk, ids, lens, n, flush != 0, pl, &err);
+    if (rc) return -rc;
+    for (uint32_t i = 0; i < n; ++i) {                                  // stream_scatter_kernel
+        const StreamEntry &e = pl.entries[i];
+        float *dst = s->state.data() + e.stream * s->g.stride + s->g.in_off;
+        for (uint32_t k = 0; k < e.len; ++k) dst[k] = samples[e.src_off + k];
+        for (uint32_t k = 0; k < e.zero_fill; ++k) dst[e.len + k] = 0.0f;
+    }
+    for (uint32_t i = 0; i < n; ++i) {                                  // the batch kernel on carry ++ chunk
+        if (!pl.frames[i]) continue;
+        const long long got = emu_whisper_wave(s->state.data() + pl.off[i], static_cast<long long>(pl.len[i]), static_cast<int>(s->g.hop),
+                                               static_cast<int>(s->g.n_mels), s->sr, 4, out + pl.out_off[i]);
+        if (got != pl.frames[i]) return -100;
+    }
+    for (uint32_t i = 0; i < n; ++i) {                                  // stream_carry_kernel
+        const StreamEntry &e = pl.entries[i];
+        const uint32_t nn = e.len + e.zero_fill;
+        if (!nn) continue;
+        float *slot = s->state.data() + e.stream * s->g.stride;
+        std::memmove(slot + s->g.in_off - e.keep, slot + s->g.in_off + nn - e.keep, e.keep * sizeof(float));
+    }
+    stream_commit_push(s->g, s->bk, ids, lens, n, flush != 0);
+    if (frames_out) for (uint32_t i = 0; i < n; ++i) frames_out[i] = pl.frames[i];
+    return static_cast<long long>(pl.total_frames);
+}

@@ -1,0 +1,225 @@
+"""Streaming bank (melspec_stream_*): Spectrogram::add + RingBuffer::maybe_mel semantics (src/stft.rs:48-86,
+src/rb.rs:60-121) with the overlap-save state on the device.  The CPU part drives the bank's bookkeeping
+(csrc/stream_plan.hpp) with host stand-ins for the kernels; the GPU part drives the real thing.  Reference:
+the oracle's hop-by-hop streaming loop, which testdata/rust_jfk_golden.npy pins (tests/test_oracle.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+TOL = 1e-4
+SR = 16000.0
+
+
+class EmuBank:
+    def __init__(self, hop, n_mels, n_streams, max_chunk, sr=SR):
+        d = os.path.join(ROOT, "tests", "emu")
+        subprocess.check_call(["make", "-C", d, "-s"])
+        L = C.CDLL(os.path.join(d, "libmelspec_emu.so"))
+        L.emu_stream_create.restype = C.c_void_p
+        L.emu_stream_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint32, C.c_uint32]
+        L.emu_stream_destroy.argtypes = [C.c_void_p]
+        L.emu_stream_frames_after.restype = C.c_longlong
+        L.emu_stream_frames_after.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.emu_stream_push.restype = C.c_longlong
+        L.emu_stream_push.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p]
+        self.L, self.n_mels = L, n_mels
+        self.h = L.emu_stream_create(hop, n_mels, sr, n_streams, max_chunk)
+
+    def frames_after(self, s, n):
+        return int(self.L.emu_stream_frames_after(self.h, s, n))
+
+    def _run(self, ids, chunks, flush):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        xs = [np.ascontiguousarray(c, np.float32).ravel() for c in chunks]
+        lens = np.ascontiguousarray([x.shape[0] for x in xs], np.uint32)
+        flat = np.concatenate(xs + [np.zeros(1, np.float32)])
+        out = np.full((sum((int(n) // 1) for n in lens) // 1 + 2 * len(ids) + 8, self.n_mels), np.nan, np.float32)
+        fr = np.zeros(len(ids), np.uint32)
+        tot = self.L.emu_stream_push(self.h, ids.ctypes.data, flat.ctypes.data, lens.ctypes.data, len(ids), int(flush), out.ctypes.data, fr.ctypes.data)
+        if tot < 0:
+            raise ValueError(int(tot))
+        res, cur = [], 0
+        for f in fr:
+            res.append(out[cur:cur + int(f)].copy()); cur += int(f)
+        assert cur == tot
+        return res
+
+    def push(self, ids, chunks):
+        return self._run(ids, chunks, False)
+
+    def flush(self, ids):
+        return self._run(ids, [np.zeros(0, np.float32)] * len(ids), True)
+
+    def close(self):
+        self.L.emu_stream_destroy(self.h)
+
+
+def _drive(bank, oracle, jfk, hop, n_mels, n_streams, max_chunk, seed, sr=SR, flush=True, fft=400):
+    """Random-sized chunks (0 .. max_chunk, incl. sizes below, at and above a hop) to a random subset of the
+    streams per push; every stream's concatenated output must be what the reference's loop emits for its
+    concatenated input."""
+    rng = np.random.default_rng(seed)
+    src = [np.ascontiguousarray(jfk[(7919 * s) % 60000:][:24000] * (1.0 + 0.1 * s)) for s in range(n_streams)]
+    pos = [0] * n_streams
+    got = [[] for _ in range(n_streams)]
+    sizes = [0, 1, hop - 1, hop, hop + 1, 2 * hop, 399, 400, 401, max_chunk]
+    live = set(range(n_streams))
+    while live:
+        ids = [s for s in sorted(live) if rng.random() < 0.7]
+        if not ids:
+            continue
+        chunks = []
+        for s in ids:
+            n = int(rng.choice(sizes)) if rng.random() < 0.5 else int(rng.integers(0, max_chunk + 1))
+            n = min(n, max_chunk, len(src[s]) - pos[s])
+            assert bank.frames_after(s, n) >= 0
+            chunks.append(src[s][pos[s]:pos[s] + n]); pos[s] += n
+        want_counts = [bank.frames_after(s, len(c)) for s, c in zip(ids, chunks)]
+        res = bank.push(ids, chunks)
+        assert [len(r) for r in res] == want_counts
+        for s, r in zip(ids, res):
+            got[s].append(r)
+            if pos[s] >= len(src[s]):
+                live.discard(s)
+    tails = bank.flush(list(range(n_streams))) if flush else [np.zeros((0, n_mels), np.float32)] * n_streams
+    worst = 0.0
+    for s in range(n_streams):
+        mine = np.concatenate(got[s] + [tails[s]])
+        want = oracle.stream_mel(src[s], fft, hop, n_mels, sr, flush_tail=flush)
+        assert mine.shape == want.shape, (s, mine.shape, want.shape)
+        worst = max(worst, float(np.abs(mine - want).max()))
+    return worst
+
+
+# ---- CPU: bookkeeping + host stand-ins ----------------------------------------------------------------
+
+@pytest.mark.parametrize("hop,n_mels,max_chunk,seed", [(160, 80, 1000, 1), (160, 80, 160, 2), (128, 40, 517, 3), (320, 100, 2000, 4),
+                                                       (400, 80, 900, 5), (2, 80, 50, 6)])
+def test_bank_bookkeeping_on_the_host(oracle, jfk, hop, n_mels, max_chunk, seed):
+    bank = EmuBank(hop, n_mels, 5 if hop > 2 else 2, max_chunk)
+    src = jfk if hop > 2 else jfk[:3000]
+    if hop == 2:
+        rng = np.random.default_rng(seed)
+        x = np.ascontiguousarray(src[1000:1900])
+        out = []
+        p = 0
+        while p < len(x):
+            n = int(rng.integers(0, max_chunk + 1)); n = min(n, len(x) - p)
+            out.append(bank.push([1], [x[p:p + n]])[0]); p += n
+        mine = np.concatenate(out)
+        want = oracle.stream_mel(x, 400, hop, n_mels, SR)
+        assert mine.shape == want.shape and np.abs(mine - want).max() <= TOL
+    else:
+        assert _drive(bank, oracle, src, hop, n_mels, 5, max_chunk, seed) <= TOL
+    bank.close()
+
+
+def test_first_frame_alignment_and_golden_pin(oracle, jfk):
+    """off = ceil(n_fft/hop)*hop - n_fft: 80 for 400/160; hop-sized pushes emit nothing twice, then
+    one frame per push.  The streaming output equals the batch path on samples[80:], which is what the
+    reference's quantized_mel_golden.tga holds (tests/test_quant.py)."""
+    bank = EmuBank(160, 80, 1, 160)
+    counts = [len(bank.push([0], [jfk[i * 160:(i + 1) * 160]])[0]) for i in range(6)]
+    assert counts == [0, 0, 1, 1, 1, 1]
+    bank.close()
+    bank = EmuBank(160, 80, 1, 176000)
+    got = bank.push([0], [jfk])[0]
+    want = oracle.compute_mel_spectrogram_cpu(jfk[80:], 400, 160, 80)
+    assert got.shape == (1098, 80) and np.abs(got - want[:1098]).max() <= TOL
+    assert bank.flush([0])[0].shape == (0, 80)           # 176000 is a whole number of hops: nothing pending
+    bank.close()
+
+
+def test_push_errors_on_the_host():
+    bank = EmuBank(160, 80, 3, 100)
+    z = np.zeros(10, np.float32)
+    with pytest.raises(ValueError, match="-1"):
+        bank.push([3], [z])                      # id out of range
+    with pytest.raises(ValueError, match="-1"):
+        bank.push([1, 1], [z, z])                # twice in one push
+    with pytest.raises(ValueError, match="-2"):
+        bank.push([0], [np.zeros(101, np.float32)])
+    bank.close()
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fft,hop,n_mels,max_chunk,seed", [(400, 160, 80, 1000, 1), (400, 160, 128, 160, 2), (400, 128, 40, 517, 3),
+                                                           (512, 160, 80, 700, 4), (400, 161, 80, 333, 5)])
+def test_gpu_bank_random_chunks(gpu, oracle, jfk, fft, hop, n_mels, max_chunk, seed):
+    """fused f32 kernel (400/even hop), and the generic f64 kernel (512, odd hop) behind the same bank"""
+    m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
+    bank = gpu.StreamBank(m, 7, max_chunk)
+    assert _drive(bank, oracle, jfk, hop, n_mels, 7, max_chunk, seed, fft=fft) <= TOL
+    # a reset stream starts over (zero history, idx = 0); its neighbours keep their state
+    n = min(1000, max_chunk)
+    bank.reset([2])
+    before3 = bank.frames_after(3, n)
+    a = bank.push([2, 3], [jfk[:n], jfk[:n]])
+    assert len(a[0]) == bank_frames(fft, hop, n) and len(a[1]) == before3
+    if len(a[0]):
+        want = oracle.stream_mel(jfk[:n], fft, hop, n_mels, SR)
+        assert np.abs(a[0] - want).max() <= TOL
+    bank.close(); m.close()
+
+
+def bank_frames(fft, hop, n):
+    h = n // hop
+    skip = 0
+    for j in range(h):
+        if (j + 1) * hop < fft:
+            skip += 1
+    return h - skip
+
+
+@pytest.mark.gpu
+def test_gpu_streaming_reproduces_reference_golden(gpu, jfk):
+    """rust_jfk_golden.npy (src/rb.rs:134-179): RingBuffer fed the whole file, 512/160/80, @1e-6 in the reference."""
+    want = np.load(os.path.join(GOLDEN, "rust_jfk_golden.npy"))            # (80, 1097)
+    m = gpu.HipMelSpectrogram(512, 160, SR, 80)
+    rb = gpu.RingBuffer(m, capacity=len(jfk))
+    cols = []
+    for p in range(0, len(jfk), 4000):                                       # the test's wav reader hands over blocks
+        rb.add_frame(jfk[p:p + 4000])
+        while True:
+            c = rb.maybe_mel()
+            if c is None:
+                break
+            assert c.shape == (80, 1) and c.dtype == np.float64
+            cols.append(c)
+    got = np.concatenate(cols, axis=1)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    rb.close(); m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_device_producer_path_and_many_streams(gpu, oracle):
+    """4096 live streams, one hop per push, chunks written straight into the slots by a device producer."""
+    n_streams, hop = 4096, 160
+    m = gpu.HipMelSpectrogram(400, hop, SR, 80)
+    bank = gpu.StreamBank(m, n_streams, hop)
+    ids = np.arange(n_streams, dtype=np.uint32)
+    out = gpu.DeviceBuffer(n_streams * 80 * 4)
+    pushes = 6
+    got = []
+    p0 = bank.input_ptr(0)
+    slot = bank.input_ptr(1) - p0
+    assert slot > 0 and p0 % 16 == 0 and slot % 16 == 0
+    for k in range(pushes):
+        # synth clip c, samples [k*hop, (k+1)*hop): generate the whole clip prefix once per push into a scratch and copy the window
+        gpu.synth_pcm_window(p0, slot // 4, hop, k * hop, n_streams)
+        fr = bank.push_device(ids, np.full(n_streams, hop, np.uint32), out.ptr)
+        assert (fr == (1 if k >= 2 else 0)).all()
+        if k >= 2:
+            got.append(out.download((n_streams, 80)))
+    for s in (0, 1, 7, 2049, 4095):
+        want = oracle.stream_mel(oracle.synth_pcm(s, pushes * hop), 400, hop, 80, SR)
+        mine = np.stack([g[s] for g in got])
+        assert mine.shape == want.shape == (4, 80) and np.abs(mine - want).max() <= TOL
+    out.free(); bank.close(); m.close()
