@@ -247,6 +247,8 @@ struct melspec_ctx {
     int lens_kind = 0;      // 0 runtime slot lengths, 1 static Whisper-80, 2 static Whisper-128
     int slice_floats = 0;
     int frames_per_unit = 1;
+    int chunked = 0;        // MELSPEC_CHUNKED: contiguous runs of units per wave
+    int grid_per_cu = 16;   // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops
     // precise (f64 FFT) build of the fused kernel, melspec_set_precise
     bool precise = false;
     PreciseTables pt;
@@ -276,6 +278,7 @@ FastParams fast_params(melspec_ctx *c, const BatchDesc &desc) {
     fp.region_a = c->region_a;
     fp.slice_floats = c->slice_floats;
     fp.slots = c->ft.slots;
+    fp.chunked = c->chunked;
     return fp;
 }
 
@@ -298,7 +301,7 @@ int launch_wave_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     }
     const FastParams fp = fast_params(c, desc);
     const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
-    const unsigned grid = grid_for(blocks, c->dev.cus, 16);
+    const unsigned grid = grid_for(blocks, c->dev.cus, c->grid_per_cu);
     hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>), dim3(grid),
                        dim3(WAVES * 64), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
@@ -492,6 +495,8 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
         if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
     }
+    if (const char *e = std::getenv("MELSPEC_CHUNKED")) c->chunked = e[0] == '1';
+    if (const char *e = std::getenv("MELSPEC_GRID_PER_CU")) { const int g = std::atoi(e); if (g > 0 && g <= 64) c->grid_per_cu = g; }
     const char *ep = std::getenv("MELSPEC_PRECISE");
     if (ep && ep[0] == '1' && c->fast && (rc = melspec_set_precise(c, 1))) return bail(rc);
     *out = c;

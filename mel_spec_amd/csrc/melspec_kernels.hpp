@@ -77,6 +77,7 @@ struct FastParams {
     int n_mels;
     int region_a;      // floats (block kernel)
     int slice_floats;  // floats per wave (wave kernel)
+    int chunked;       // wave kernel: 1 = every wave walks a contiguous run of units instead of a grid-strided set
     MelSlots slots;
 };
 
@@ -149,7 +150,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
 
-    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+    // unit -> wave mapping: grid-strided (neighbouring waves take neighbouring units), or contiguous runs per wave
+    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES, wid = (uint64_t)blockIdx.x * WAVES + wave;
+    const uint64_t per = (p.b.n_units + n_waves - 1) / n_waves;
+    const uint64_t u_begin = p.chunked ? wid * per : wid;
+    const uint64_t u_end = p.chunked ? (u_begin + per < p.b.n_units ? u_begin + per : p.b.n_units) : p.b.n_units;
+    const uint64_t u_step = p.chunked ? 1 : n_waves;
+    for (uint64_t unit = u_begin; unit < u_end; unit += u_step) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
@@ -158,7 +165,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
         const uint64_t wleft = width - f0;
         const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
+#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 10
+#ifndef MELSPEC_ABL_MASK
+#define MELSPEC_ABL_MASK 255
+#endif
+        const float *src = p.b.pcm + (unit & MELSPEC_ABL_MASK) * 800;     // ablation: same loads over a smaller footprint (L2 / MALL resident)
+#else
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
+#endif
         const bool act = in && fl < nv;
         const bool act3 = in3 && fl3 < nv;
         if (!DIRECT) {

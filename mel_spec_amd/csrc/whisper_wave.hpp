@@ -286,11 +286,19 @@ MS_DEV void wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kMelJobs * row_w : kMelJobs;
+#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 8
+    // ablation: no global stores (one impossible store keeps the values alive)
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) acc += (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f;
+    if (acc == 12345.678f) o[0] = acc;
+#else
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
         if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
     }
+#endif
 }
 
 }  // namespace melspec
