@@ -17,12 +17,12 @@ struct FbankFastTables {
 
 // Tables of the fused 512-point kernels: `window` = the 400 taps applied to the frame, `dense` = the
 // filterbank [n_mels][257].  Returns false when the filterbank lacks the two-filters-per-bin structure or
-// needs more than `max_slots` slots of 8 intervals.
+// needs more than `max_slots` slots of 15 intervals.
 template <class T>
 inline bool build_fused512_tables(const std::vector<double> &window, const std::vector<double> &dense, int n_mels,
                                   double scale, int max_slots, FbankFastTables &out) {
     constexpr int N = 512, FL = 400;
-    if (n_mels < 1 || n_mels > 8 * max_slots - 1 || static_cast<int>(window.size()) != FL) return false;
+    if (n_mels < 1 || n_mels > kFbOwn * max_slots - 1 || static_cast<int>(window.size()) != FL) return false;
     std::vector<T> t(FbankBlob::kTCount, T(0));
     for (int i = 0; i < FL; ++i) t[FbankBlob::kWin + i] = static_cast<T>(window[i]);
     for (int n2 = 0; n2 < 16; ++n2)
@@ -36,7 +36,7 @@ inline bool build_fused512_tables(const std::vector<double> &window, const std::
         t[FbankBlob::kMod + 2 * n2] = static_cast<T>(std::cos(a));
         t[FbankBlob::kMod + 2 * n2 + 1] = static_cast<T>(std::sin(a));
     }
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < kFbJobs; ++j)
         for (int q = 0; q < 16; ++q) {
             const double a = -2.0 * kPi * (j + 16 * q) / N;
             t[FbankBlob::kTw2 + j * FbankBlob::kTw2Stride + 2 * q] = static_cast<T>(std::cos(a));

@@ -1,6 +1,12 @@
 // fbank_wave.hpp -- fused Kaldi-fbank frame pipeline (default geometry: 400-sample frames, 512-point
-// FFT), wave-autonomous like whisper_wave.hpp: one wavefront owns kFbFPW = 7 whole frames,
-// lane = 9*frame + j.  Reference: Fbank::compute, src/fbank.rs:141-236.
+// FFT), wave-autonomous like whisper_wave.hpp: one wavefront owns kFbFPW = 4 whole frames,
+// lane = 16*frame + j (one DPP row per frame).  Reference: Fbank::compute, src/fbank.rs:141-236.
+//
+// Shape: the exchange rows are f64, 4.6 KB per frame, so frames per wave decide the occupancy.  An earlier
+// build ran 7 frames x 9 lanes per wave (each lane two columns in phase 1): 32.5 KB of LDS per wave, 4
+// waves per CU, one per SIMD, and the lone wave spent 2/3 of its time waiting on its own LDS/global
+// latencies.  4 frames x 16 lanes gives every lane one column in phase 1, 18.6 KB per wave and two waves
+// per SIMD; phase 2 has 9 jobs per frame, so 7 of 16 lanes idle there.
 //
 // Arithmetic type T.  Unlike the Whisper path there is no per-frame clamp here: ln(E) of a mel band
 // 90 dB below the frame's strongest band is an output, and rounding the *windowed frame itself* to
@@ -15,22 +21,24 @@
 //        which is the same formula with x[-1] := m)
 //   zero-pad to 512, forward FFT (src/fbank.rs:184-194): real-512 as complex-256 = 16 x 16,
 //       z[n] = x[2n] + i*x[2n+1];  n = 16*n1 + n2,  k = k1 + 16*k2
-//       phase 1: lane t<8 does the 16-point DFTs over n1 for n2 = t and n2 = t+8 (inputs beyond
-//                sample 399 are literal zeros), multiplies by W_256^{n2*k1}, writes row k1
+//       phase 1: lane t does the 16-point DFT over n1 for column n2 = t (inputs beyond sample 399 are
+//                literal zeros), multiplies by W_256^{n2*k1}, writes row k1
 //       phase 2: lane j<9 owns residues a=j and b=16-j (j=0: row 0 and its W_16^{n2}-modulated copy,
 //                j=8: row 8 twice), two 16-point DFTs, Hermitian split -> bins k=a+16q and 256-k
 //   power, bins 0..=256 (src/fbank.rs:197-203), stored as f32 (sums of non-negative terms from here on)
-//   sparse mel, floor, ln (src/fbank.rs:205-221): interval scheme, 9 lanes per frame
+//   sparse mel, floor, ln (src/fbank.rs:205-221): interval scheme, 16 lanes per frame (15 intervals + ghost)
 //   CMN (src/fbank.rs:224-233) is a second kernel (cmn_kernel) because it is a per-clip reduction.
 #pragma once
 #include "whisper_wave.hpp"
 
 namespace melspec {
 
-constexpr int kFbFPW = 7;        // frames per wavefront (7 * 9 = 63 lanes)
-constexpr int kFbLanes = 9;      // lanes per frame: 8 workers + 1 (ghost in phase 3, 9th job in phase 2)
-constexpr int kFbSlots = 11;     // intervals j + 8*slot, up to 87 mel bins (Kaldi fbank)
-constexpr int kBlmSlots = 17;    // up to 135 mel bins (NeMo/Parakeet uses 80 or 128)
+constexpr int kFbFPW = 4;        // frames per wavefront
+constexpr int kFbLanes = 16;     // lanes per frame: one column each in phase 1; lane 15 is the ghost in phase 3
+constexpr int kFbJobs = 9;       // phase-2 jobs per frame (residue pairs j / 16-j)
+constexpr int kFbOwn = kFbLanes - 1;   // intervals a 16-lane group owns per slot
+constexpr int kFbSlots = 6;      // intervals j + 15*slot, up to 89 mel bins (Kaldi fbank)
+constexpr int kBlmSlots = 10;    // up to 149 mel bins (NeMo/Parakeet uses 80 or 128)
 
 // Table blob: a T-typed part (offsets in units of T) followed by the f32/int mel section.
 struct FbankBlob {
@@ -42,32 +50,30 @@ struct FbankBlob {
     static constexpr int kTw2 = kMod + 32;                 // [9][36] complex W_512^{j+16q}
     static constexpr int kTCount = kTw2 + 9 * kTw2Stride;  // 1332 elements of T
     // mel section, float offsets from its own base
-    static constexpr int kMelStart = 0;                                // [kBlmSlots*9] ints
-    static constexpr int kMelW = (kBlmSlots * kFbLanes + 3) & ~3;      // pairs [slot][r][9][2]
+    static constexpr int kMelStart = 0;                                // [kBlmSlots*16] ints
+    static constexpr int kMelW = (kBlmSlots * kFbLanes + 3) & ~3;      // pairs [slot][r][16][2]
 };
 
 template <class T>
 struct FbankLayout {
-    // exchange rows, units of T; padded so that the 9 lanes of a frame reading 9 different rows hit
+    // exchange rows, units of T; padded so that the 9 job lanes of a frame reading 9 different rows hit
     // different banks (f64: 16-byte complex reads, rows 68 words apart)
     static constexpr int kXRow = sizeof(T) == 8 ? 34 : 32;
-    static constexpr int kXStride = sizeof(T) == 8 ? 17 * 34 + 2 : 17 * 32 + 16;
+    static constexpr int kXStride = 17 * kXRow;            // lanes of different frames never share an LDS access group
     static constexpr int kPStride = 259;                   // f32 power rows (bins 0..256), aliased over the rows
-    static constexpr int kSumOff = kFbFPW * kXStride;      // 64 partial sums (units of T)
-    static constexpr int slice_elems() { return (kFbFPW * kXStride + 64 + 1) & ~1; }   // units of T
+    static constexpr int kSumOff = 0;                      // 64 partial sums (units of T): dead before phase 1 writes the rows
+    static constexpr int slice_elems() { return (kFbFPW * kXStride + 1) & ~1; }   // units of T
 };
 
-// frame-sum partial: lane (f,t<8) adds its 50 samples (pairs 32*n1 + 2t + {0,1} and +16)
+// frame-sum partial: lane (f,t) adds the samples of its own column, pairs 32*n1 + 2t + {0,1} below 400
 template <class T>
 MS_DEV T fb_partial_sum(const float *frame, int t) {
     T s = 0;
 #pragma unroll
     for (int n1 = 0; n1 < 13; ++n1) {
-        const f2 a = load2_unaligned(frame + 32 * n1 + 2 * t);
-        s += static_cast<T>(a.x) + static_cast<T>(a.y);
-        if (n1 < 12) {
-            const f2 b = load2_unaligned(frame + 32 * n1 + 16 + 2 * t);
-            s += static_cast<T>(b.x) + static_cast<T>(b.y);
+        if (n1 < 12 || t < 8) {
+            const f2 a = load2_unaligned(frame + 32 * n1 + 2 * t);
+            s += static_cast<T>(a.x) + static_cast<T>(a.y);
         }
     }
     return s;
@@ -86,16 +92,16 @@ MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *tblob, T *xo /* &
     for (int k1 = 1; k1 < 16; ++k1) stc(xo + k1 * L::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
 }
 
-// One 16-point column: samples frame[32*n1 + off + {0,1}], n1 < NV (the rest of the 512-point frame is
+// One 16-point column n2: samples frame[32*n1 + 2*n2 + {0,1}] below 400 (the rest of the 512-point frame is
 // zero padding), pre-emphasis, DC removal, window, DFT over n1, twiddle by W_256^{n2*k1}, exchange rows.
-template <class T, int NV>
-MS_DEV void fb_column(const float *frame, int off, int n2, T preemph, T mean, bool patch_first, const T *tblob,
-                      T *xo /* &row[0][n2] */) {
+template <class T>
+MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_first, const T *tblob, T *xo /* &row[0][n2] */) {
     cpx<T> x[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
-        if (n1 < NV) {
-            const int i = 32 * n1 + off;
+        x[n1] = {T(0), T(0)};
+        if (n1 < 12 || (n1 == 12 && n2 < 8)) {
+            const int i = 32 * n1 + 2 * n2;
             // frame_buf[i] = x[i] - mean; frame_buf[i] -= preemph * frame_buf[i-1]  (src/fbank.rs:165-181);
             // the first sample of a clip gets no pre-emphasis
             const f2 s = load2_unaligned(frame + i);
@@ -105,22 +111,17 @@ MS_DEV void fb_column(const float *frame, int off, int n2, T preemph, T mean, bo
             const T y1 = b1 - preemph * b0;
             const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
             x[n1] = {y0 * w.re, y1 * w.im};
-        } else {
-            x[n1] = {T(0), T(0)};
         }
     }
     fb_column_finish<T>(x, n2, tblob, xo);
 }
 
-// phase 1 (after the frame mean is known): lane t<8 does columns n2 = t (13 non-zero inputs) and
-// n2 = t+8 (12 non-zero inputs).
+// phase 1 (after the frame mean is known): lane t does column n2 = t (13 non-zero inputs for t < 8, else 12).
 template <class T>
 MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this frame's first sample */, bool clip_start,
                       T mean, T preemph, const T *tblob, T *slice) {
     if (!active) return;
-    T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
-    fb_column<T, 13>(frame, 2 * t, t, preemph, mean, clip_start && t == 0, tblob, xo);
-    fb_column<T, 12>(frame, 16 + 2 * t, t + 8, preemph, mean, false, tblob, xo + 16);
+    fb_column<T>(frame, t, preemph, mean, clip_start && t == 0, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
 }
 
 // ---- NeMo/Parakeet flavour (BatchLogMelSpectrogram, src/mel.rs:299-385) --------------------------
@@ -135,18 +136,17 @@ MS_DEV float nemo_sample(const float *clip, long long s, long long len, float co
     return cur - f32_mul_rn(coeff, clip[s - 1]);
 }
 
-template <class T, int NV>
-MS_DEV void nemo_column(const float *clip, long long org, long long len, int off, int n2, float coeff, const T *tblob, T *xo) {
+template <class T>
+MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2, float coeff, const T *tblob, T *xo) {
     cpx<T> x[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
-        if (n1 < NV) {
-            const int i = 32 * n1 + off;
+        x[n1] = {T(0), T(0)};
+        if (n1 < 12 || (n1 == 12 && n2 < 8)) {
+            const int i = 32 * n1 + 2 * n2;
             const float y0 = nemo_sample(clip, org + i, len, coeff), y1 = nemo_sample(clip, org + i + 1, len, coeff);
             const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
             x[n1] = {static_cast<T>(y0) * w.re, static_cast<T>(y1) * w.im};
-        } else {
-            x[n1] = {T(0), T(0)};
         }
     }
     fb_column_finish<T>(x, n2, tblob, xo);
@@ -156,9 +156,7 @@ template <class T>
 MS_DEV void nemo_phase1(int fl, int t, bool active, const float *clip, long long org, long long len, float coeff,
                         const T *tblob, T *slice) {
     if (!active) return;
-    T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
-    nemo_column<T, 13>(clip, org, len, 2 * t, t, coeff, tblob, xo);
-    nemo_column<T, 12>(clip, org, len, 16 + 2 * t, t + 8, coeff, tblob, xo + 16);
+    nemo_column<T>(clip, org, len, t, coeff, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
 }
 
 // phase 2: two 16-point DFTs, Hermitian split with W_512, 4*power (or 2*magnitude) as f32 to LDS.
@@ -198,7 +196,7 @@ MS_DEV void fb_phase2(int fl, int j, bool active, bool use_power, const T *tblob
     }
 }
 
-// phase 3: interval sums over 9-lane groups (lane j<8 owns interval j + 8*slot, j=8 is the ghost)
+// phase 3: interval sums over 16-lane groups (lane j<15 owns interval j + 15*slot, j=15 is the ghost)
 template <class T, int NSLOTS = kFbSlots>
 MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *mel /* mel section base */,
                            const T *slice, const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
@@ -231,15 +229,15 @@ MS_DEV float fast_ln(float x) { return fast_log2(x) * 0.69314718055994531f; }
 template <int NSLOTS = kFbSlots>
 MS_DEV void fb_phase3_store(int fl, int j, bool active, int n_mels, float floor_v, bool use_log,
                             const float (&rise)[NSLOTS], const float (&fnext)[NSLOTS], float *out_tile) {
-    if (!active || j >= 8) return;
+    if (!active || j >= kFbOwn) return;
     float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
-        const int m = j + 8 * i;
+        const int m = j + kFbOwn * i;
         if (m < n_mels) {
             float e = rise[i] + fnext[i];
             e = __builtin_fmaxf(e, floor_v);
-            o[8 * i] = use_log ? fast_ln(e) : e;
+            o[kFbOwn * i] = use_log ? fast_ln(e) : e;
         }
     }
 }
@@ -250,12 +248,12 @@ template <int NSLOTS>
 MS_DEV void nemo_phase3_store(int fl, int j, bool store, bool valid, int n_mels, float guard, const float (&rise)[NSLOTS],
                               const float (&fnext)[NSLOTS], float *out_col /* &out[0][first frame of the tile] */,
                               long long row_w) {
-    if (!store || j >= 8) return;
+    if (!store || j >= kFbOwn) return;
     float *o = out_col + static_cast<long long>(j) * row_w + fl;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
-        const int m = j + 8 * i;
-        if (m < n_mels) o[static_cast<long long>(8 * i) * row_w] = valid ? fast_ln((rise[i] + fnext[i]) + guard) : 0.0f;
+        const int m = j + kFbOwn * i;
+        if (m < n_mels) o[static_cast<long long>(kFbOwn * i) * row_w] = valid ? fast_ln((rise[i] + fnext[i]) + guard) : 0.0f;
     }
 }
 

@@ -247,8 +247,7 @@ struct melspec_ctx {
     int lens_kind = 0;      // 0 runtime slot lengths, 1 static Whisper-80, 2 static Whisper-128
     int slice_floats = 0;
     int frames_per_unit = 1;
-    int chunked = 0;        // MELSPEC_CHUNKED: contiguous runs of units per wave
-    int grid_per_cu = 16;   // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops
+    int grid_per_cu = 4;    // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops (2 are resident; 4 measured best)
     // precise (f64 FFT) build of the fused kernel, melspec_set_precise
     bool precise = false;
     PreciseTables pt;
@@ -278,7 +277,6 @@ FastParams fast_params(melspec_ctx *c, const BatchDesc &desc) {
     fp.region_a = c->region_a;
     fp.slice_floats = c->slice_floats;
     fp.slots = c->ft.slots;
-    fp.chunked = c->chunked;
     return fp;
 }
 
@@ -495,7 +493,6 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
         if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
     }
-    if (const char *e = std::getenv("MELSPEC_CHUNKED")) c->chunked = e[0] == '1';
     if (const char *e = std::getenv("MELSPEC_GRID_PER_CU")) { const int g = std::atoi(e); if (g > 0 && g <= 64) c->grid_per_cu = g; }
     const char *ep = std::getenv("MELSPEC_PRECISE");
     if (ep && ep[0] == '1' && c->fast && (rc = melspec_set_precise(c, 1))) return bail(rc);
@@ -698,12 +695,38 @@ struct melspec_fbank {
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
+    int waves = 4;
     GenericTables gt;
     DevBuf h2d, d2h;
 };
 
 namespace {
-constexpr int kFbWaves = 4;
+// Waves per workgroup of the fused 512-point kernels: 8 (two per SIMD, one workgroup per CU) when the tables
+// and eight 18.5 KB slices fit in LDS, else 4.  MELSPEC_FB_WAVES=4 forces the small shape.
+int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
+    const char *e = std::getenv("MELSPEC_FB_WAVES");
+    if (e && std::atoi(e) == 4) return 4;
+    return blob_bytes + 8 * slice_bytes <= kLdsLimit ? 8 : 4;
+}
+
+template <class T, int FLAVOR, int NSLOTS>
+int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
+        if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
+        if (rc) return rc;
+        attr_done = true;
+    }
+    const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
+    const unsigned grid = grid_for(blocks, cus, 8);
+    if (waves == 8)
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(512), lds, s, fp);
+    else
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(256), lds, s, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
 }  // namespace
 
 namespace {
@@ -759,14 +782,11 @@ int melspec_fbank_create(melspec_fbank **out, int device, const melspec_fbank_co
     if (fb->fast) {
         const size_t slice_bytes = fb->ft.f64 ? FbankLayout<double>::slice_elems() * sizeof(double)
                                               : FbankLayout<float>::slice_elems() * sizeof(float);
-        fb->fast_lds = fb->ft.blob.size() * 4 + static_cast<size_t>(kFbWaves) * slice_bytes;
+        fb->waves = fused512_waves(fb->ft.blob.size() * 4, slice_bytes);
+        fb->fast_lds = fb->ft.blob.size() * 4 + static_cast<size_t>(fb->waves) * slice_bytes;
         if (fb->fast_lds > kLdsLimit) fb->fast = false;
     }
-    if (fb->fast) {
-        if ((rc = upload(fb->d_blob, fb->ft.blob))) return bail(rc);
-        if ((rc = allow_big_lds(&fbank512_wave_kernel<double, kFbWaves, 1>, "hipFuncSetAttribute(fbank512_wave_kernel<f64>)"))) return bail(rc);
-        if ((rc = allow_big_lds(&fbank512_wave_kernel<float, kFbWaves, 1>, "hipFuncSetAttribute(fbank512_wave_kernel<f32>)"))) return bail(rc);
-    }
+    if (fb->fast && (rc = upload(fb->d_blob, fb->ft.blob))) return bail(rc);
     const std::vector<double> dense = kaldi_mel_filterbank(cfg->sample_rate, fft_size, cfg->num_mel_bins, cfg->low_freq, high);
     if ((rc = fb->gt.build(fft_size, frame_len, bins, povey_window(frame_len), dense, cfg->num_mel_bins, bins))) return bail(rc);
     if (fb->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
@@ -815,13 +835,9 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         fp.use_log = fb->cfg.use_log_fbank;
         fp.use_power = fb->cfg.use_power;
         fp.slots = fb->ft.slots;
-        const uint64_t blocks = (pl.desc.n_units + kFbWaves - 1) / kFbWaves;
-        const unsigned grid = grid_for(blocks, fb->dev.cus, 16);
-        if (fb->ft.f64)
-            hipLaunchKernelGGL((fbank512_wave_kernel<double, kFbWaves, 1>), dim3(grid), dim3(kFbWaves * 64), fb->fast_lds, s, fp);
-        else
-            hipLaunchKernelGGL((fbank512_wave_kernel<float, kFbWaves, 1>), dim3(grid), dim3(kFbWaves * 64), fb->fast_lds, s, fp);
-        HIP_TRY(hipGetLastError());
+        rc = fb->ft.f64 ? launch_fused512<double, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s)
+                        : launch_fused512<float, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
+        if (rc) return rc;
         // the CMN pass below walks clips, not units
     } else {
         rc = launch_generic(fb->gt, pl.desc, fb->frame_shift, true, fb->cfg.use_log_fbank, fb->cfg.use_power,
@@ -1298,6 +1314,7 @@ struct melspec_blm {
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
+    int waves = 4;
     DevBuf h2d, d2h;
 };
 
@@ -1350,12 +1367,12 @@ int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *
     if (hipStreamCreate(&b->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
     const double f_max = cfg->f_max > 0.0 ? cfg->f_max : cfg->sample_rate / 2.0;   // src/mel.rs:254
     if (!build_blm_fast_tables<double>(cfg->sample_rate, cfg->n_mels, cfg->f_min, f_max, cfg->htk != 0, cfg->norm != 0, b->ft))
-        return bail(fail(MELSPEC_ERR_UNSUPPORTED, "filterbank outside the fused kernel's coverage (n_mels <= 135, triangular bank)"));
-    b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(kFbWaves) * FbankLayout<double>::slice_elems() * sizeof(double);
+        return bail(fail(MELSPEC_ERR_UNSUPPORTED, "filterbank outside the fused kernel's coverage (n_mels <= 149, triangular bank)"));
+    const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double);
+    b->waves = fused512_waves(b->ft.blob.size() * 4, slice_bytes);
+    b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(b->waves) * slice_bytes;
     if (b->fast_lds > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "tables do not fit in LDS"));
     if ((rc = upload(b->d_blob, b->ft.blob))) return bail(rc);
-    if ((rc = allow_big_lds(&fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kFbSlots>, "hipFuncSetAttribute(nemo kernel)"))) return bail(rc);
-    if ((rc = allow_big_lds(&fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kBlmSlots>, "hipFuncSetAttribute(nemo kernel)"))) return bail(rc);
     *out = b;
     return MELSPEC_OK;
 }
@@ -1395,13 +1412,9 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
     fp.clip_len = static_cast<long long>(clip_len);
     fp.org0 = b->cfg.center ? -200 : 56;      // tap 0 of the window sits at position (512-400)/2 of the frame
     fp.slots = b->ft.slots;
-    const uint64_t blocks = (pl.desc.n_units + kFbWaves - 1) / kFbWaves;
-    const unsigned grid = grid_for(blocks, b->dev.cus, 16);
-    if (b->ft.slots.n_slots <= kFbSlots)
-        hipLaunchKernelGGL((fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kFbSlots>), dim3(grid), dim3(kFbWaves * 64), b->fast_lds, s, fp);
-    else
-        hipLaunchKernelGGL((fbank512_wave_kernel<double, kFbWaves, 1, kFlavorNemo, kBlmSlots>), dim3(grid), dim3(kFbWaves * 64), b->fast_lds, s, fp);
-    HIP_TRY(hipGetLastError());
+    int rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
+                                             : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+    if (rc) return rc;
     if (b->cfg.normalize_per_feature && valid > 0) {
         BlmNormParams np{};
         np.out = d_out; np.clip_stride = cols * static_cast<uint64_t>(nm); np.row_w = cols; np.valid = valid;

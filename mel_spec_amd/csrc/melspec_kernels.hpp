@@ -77,7 +77,6 @@ struct FastParams {
     int n_mels;
     int region_a;      // floats (block kernel)
     int slice_floats;  // floats per wave (wave kernel)
-    int chunked;       // wave kernel: 1 = every wave walks a contiguous run of units instead of a grid-strided set
     MelSlots slots;
 };
 
@@ -150,13 +149,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
 
-    // unit -> wave mapping: grid-strided (neighbouring waves take neighbouring units), or contiguous runs per wave
-    const uint64_t n_waves = (uint64_t)gridDim.x * WAVES, wid = (uint64_t)blockIdx.x * WAVES + wave;
-    const uint64_t per = (p.b.n_units + n_waves - 1) / n_waves;
-    const uint64_t u_begin = p.chunked ? wid * per : wid;
-    const uint64_t u_end = p.chunked ? (u_begin + per < p.b.n_units ? u_begin + per : p.b.n_units) : p.b.n_units;
-    const uint64_t u_step = p.chunked ? 1 : n_waves;
-    for (uint64_t unit = u_begin; unit < u_end; unit += u_step) {
+    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
@@ -329,25 +322,26 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
         const bool act = in && fl < nv;
-        const bool act1 = act && j < 8;
         if (FLAVOR == kFlavorKaldi) {
             const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            // frame mean (src/fbank.rs:165-166): 8 partial sums of 50 samples through LDS
-            slice[L::kSumOff + lane] = act1 ? fb_partial_sum<T>(frame, j) : T(0);
+            // frame mean (src/fbank.rs:165-166): 16 partial sums of 24-26 samples through LDS, fixed tree
+            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
             __builtin_amdgcn_wave_barrier();
             T mean = 0;
             if (act) {
                 const T *ps = slice + L::kSumOff + fl * kFbLanes;
-                mean = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / T(400);
+                const T a = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+                const T b = ((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15]));
+                mean = (a + b) / T(400);
             }
             __builtin_amdgcn_wave_barrier();
-            fb_phase1<T>(fl, j, act1, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
         } else {
             const long long org = (long long)(f0 + (uint64_t)fl) * p.shift + p.org0;
-            nemo_phase1<T>(fl, j, act1, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
+            nemo_phase1<T>(fl, j, act, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
         }
         __builtin_amdgcn_wave_barrier();
-        fb_phase2<T>(fl, j, act, use_power, tblob, slice);
+        fb_phase2<T>(fl, j, act && j < kFbJobs, use_power, tblob, slice);
         __builtin_amdgcn_wave_barrier();
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
         fb_phase3_sums<T, NSLOTS>(fl, j, act, p.slots, mel, slice, st, rise, fprev);

@@ -195,26 +195,28 @@ static long long run_fbank(const float *pcm, long long n, int shift, int n_mels,
         std::vector<T> mean(64, T(0));
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
-            slice[L::kSumOff + lane] = (act && j < 8) ? fb_partial_sum<T>(pcm + (f0 + fl) * shift, j) : T(0);
+            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(pcm + (f0 + fl) * shift, j) : T(0);
         }
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             if (!act) continue;
             const T *ps = slice.data() + L::kSumOff + fl * kFbLanes;
-            mean[lane] = (((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]))) / T(400);
+            const T a = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
+            const T b = ((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15]));
+            mean[lane] = (a + b) / T(400);
         }
         std::vector<T> snap(slice), next(slice);
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            fb_phase1<T>(fl, j, act && j < 8, pcm + (f0 + (act ? fl : 0)) * shift, f0 + fl == 0, mean[lane], static_cast<T>(preemph), tblob, tmp.data());
+            fb_phase1<T>(fl, j, act, pcm + (f0 + (act ? fl : 0)) * shift, f0 + fl == 0, mean[lane], static_cast<T>(preemph), tblob, tmp.data());
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            fb_phase2<T>(fl, j, act, use_power != 0, tblob, tmp.data());
+            fb_phase2<T>(fl, j, act && j < kFbJobs, use_power != 0, tblob, tmp.data());
             // power rows are f32 written into the T-typed slice: compare bytes
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
@@ -272,14 +274,14 @@ extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            nemo_phase1<T>(fl, j, act && j < 8, pcm, (f0 + fl) * hop + org0, n, preemph, tblob, tmp.data());
+            nemo_phase1<T>(fl, j, act, pcm, (f0 + fl) * hop + org0, n, preemph, tblob, tmp.data());
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            fb_phase2<T>(fl, j, act, true, tblob, tmp.data());
+            fb_phase2<T>(fl, j, act && j < kFbJobs, true, tblob, tmp.data());
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
             for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];

@@ -317,13 +317,13 @@ def test_fbank_variants_and_edges(gpu, oracle, jfk):
     for kw in (dict(num_mel_bins=40), dict(preemphasis=0.0), dict(use_log_fbank=False, apply_cmn=False),
                dict(use_power=False), dict(energy_floor=1e-3), dict(low_freq=100.0, high_freq=7000.0),
                dict(frame_length_ms=20.0, frame_shift_ms=8.0), dict(sample_rate=8000.0), dict(frame_shift_ms=6.3125),
-               dict(num_mel_bins=87), dict(num_mel_bins=88), dict(num_mel_bins=23, high_freq=-400.0 + 8000.0)):
+               dict(num_mel_bins=88), dict(num_mel_bins=89), dict(num_mel_bins=90), dict(num_mel_bins=23, high_freq=-400.0 + 8000.0)):
         cfg = gpu.FbankConfig(**kw)
         oc = oracle.fbank_default_config()
         for k_, v in kw.items():
             setattr(oc, k_, type(getattr(oc, k_))(v))
         fbk = gpu.Fbank(cfg)
-        default_geometry = cfg.frame_length_samples() == 400 and cfg.num_mel_bins <= 87
+        default_geometry = cfg.frame_length_samples() == 400 and cfg.num_mel_bins <= 89     # 6 slots of 15 intervals
         assert fbk.uses_fast_path == default_geometry, kw
         got = fbk.compute(x)
         want = oracle.fbank_compute(x, oc)
@@ -333,7 +333,7 @@ def test_fbank_variants_and_edges(gpu, oracle, jfk):
     fb = gpu.Fbank()
     assert fb.compute(np.zeros(399, np.float32)).shape == (0, 80)
     assert fb.compute(np.zeros(16000, np.float32)).shape == (98, 80)
-    for n in (400, 559, 560, 400 + 6 * 160, 400 + 7 * 160, 400 + 8 * 160 + 3):   # around the 7-frame unit size
+    for n in (400, 559, 560, 400 + 3 * 160, 400 + 4 * 160, 400 + 5 * 160 + 3, 400 + 8 * 160):   # around the 4-frame unit size
         xx = oracle.synth_pcm(4, n)
         assert np.abs(fb.compute(xx) - oracle.fbank_compute(xx)).max() <= TOL
     # a DC offset 60 dB above the signal (DC removal happens before the FFT, in f64 like the reference)

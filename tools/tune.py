@@ -17,13 +17,11 @@ M.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips)
 M.device_synchronize()
 ctxs = {}
 for v in variants:
-    # "8p" = variant 8 precise build; "8c" = contiguous units per wave; "8g2" = at most 2 workgroups per CU in the grid
+    # "8p" = variant 8 precise build; "8g2" = at most 2 workgroups per CU in the grid
     v0 = v
-    os.environ["MELSPEC_GRID_PER_CU"] = "16"
+    os.environ["MELSPEC_GRID_PER_CU"] = "4"
     if "g" in v0:
         v0, g = v0.split("g"); os.environ["MELSPEC_GRID_PER_CU"] = g
-    os.environ["MELSPEC_CHUNKED"] = "1" if v0.endswith("c") else "0"
-    v0 = v0[:-1] if v0.endswith("c") else v0
     vp, prec = (v0[:-1], True) if v0.endswith("p") else (v0, False)
     vv, rt = (vp[:-1], "1") if vp.endswith("r") else (vp, "0")
     vv, sg = (vv.split("s") + ["0"])[:2] if "s" in vv else (vv, "0")     # "8s64" = variant 8, stagger 64
