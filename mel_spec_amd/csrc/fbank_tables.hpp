@@ -31,16 +31,11 @@ inline bool build_fused512_tables(const std::vector<double> &window, const std::
             t[FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride + 2 * k1] = static_cast<T>(std::cos(a));
             t[FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride + 2 * k1 + 1] = static_cast<T>(std::sin(a));
         }
-    for (int n2 = 0; n2 < 16; ++n2) {
-        const double a = -2.0 * kPi * n2 / 16.0;
-        t[FbankBlob::kMod + 2 * n2] = static_cast<T>(std::cos(a));
-        t[FbankBlob::kMod + 2 * n2 + 1] = static_cast<T>(std::sin(a));
-    }
-    for (int j = 0; j < kFbJobs; ++j)
-        for (int q = 0; q < 16; ++q) {
-            const double a = -2.0 * kPi * (j + 16 * q) / N;
-            t[FbankBlob::kTw2 + j * FbankBlob::kTw2Stride + 2 * q] = static_cast<T>(std::cos(a));
-            t[FbankBlob::kTw2 + j * FbankBlob::kTw2Stride + 2 * q + 1] = static_cast<T>(std::sin(a));
+    for (int r = 0; r < 16; ++r)
+        for (int q = 0; q < 9; ++q) {
+            const double a = -2.0 * kPi * (r + 16 * q) / N;
+            t[FbankBlob::kTw2 + r * FbankBlob::kTw2Stride + 2 * q] = static_cast<T>(std::cos(a));
+            t[FbankBlob::kTw2 + r * FbankBlob::kTw2Stride + 2 * q + 1] = static_cast<T>(std::sin(a));
         }
     const int bins = N / 2 + 1;
     std::vector<float> mel(FbankBlob::kMelW, 0.0f);

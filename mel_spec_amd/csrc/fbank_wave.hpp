@@ -23,8 +23,10 @@
 //       z[n] = x[2n] + i*x[2n+1];  n = 16*n1 + n2,  k = k1 + 16*k2
 //       phase 1: lane t does the 16-point DFT over n1 for column n2 = t (inputs beyond sample 399 are
 //                literal zeros), multiplies by W_256^{n2*k1}, writes row k1
-//       phase 2: lane j<9 owns residues a=j and b=16-j (j=0: row 0 and its W_16^{n2}-modulated copy,
-//                j=8: row 8 twice), two 16-point DFTs, Hermitian split -> bins k=a+16q and 256-k
+//       phase 2: lane r does the 16-point DFT over n2 of row r (Z[r + 16*k2]), fetches the upper half of
+//                its Hermitian partner's DFT (row 16-r, lane (16-r)&15 of the same DPP row) with two DPP
+//                moves per dword, and splits 8 pairs -> bins k = r+16s and 256-k, s < 8 (lanes 0 and 8
+//                are their own partners; lane 0 pairs Z[16s] with Z[256-16s] and does a 9th split)
 //   power, bins 0..=256 (src/fbank.rs:197-203), stored as f32 (sums of non-negative terms from here on)
 //   sparse mel, floor, ln (src/fbank.rs:205-221): interval scheme, 16 lanes per frame (15 intervals + ghost)
 //   CMN (src/fbank.rs:224-233) is a second kernel (cmn_kernel) because it is a per-clip reduction.
@@ -35,7 +37,6 @@ namespace melspec {
 
 constexpr int kFbFPW = 4;        // frames per wavefront
 constexpr int kFbLanes = 16;     // lanes per frame: one column each in phase 1; lane 15 is the ghost in phase 3
-constexpr int kFbJobs = 9;       // phase-2 jobs per frame (residue pairs j / 16-j)
 constexpr int kFbOwn = kFbLanes - 1;   // intervals a 16-lane group owns per slot
 constexpr int kFbSlots = 6;      // intervals j + 15*slot, up to 89 mel bins (Kaldi fbank)
 constexpr int kBlmSlots = 10;    // up to 149 mel bins (NeMo/Parakeet uses 80 or 128)
@@ -45,10 +46,9 @@ struct FbankBlob {
     static constexpr int kWin = 0;                         // [400] Povey window
     static constexpr int kTw1Stride = 36;                  // 16 complex + 4 pad
     static constexpr int kTw1 = 400;                       // [16 n2][36] W_256^{n2*k1}
-    static constexpr int kMod = kTw1 + 16 * kTw1Stride;    // [16] complex W_16^{n2}
-    static constexpr int kTw2Stride = 36;
-    static constexpr int kTw2 = kMod + 32;                 // [9][36] complex W_512^{j+16q}
-    static constexpr int kTCount = kTw2 + 9 * kTw2Stride;  // 1332 elements of T
+    static constexpr int kTw2Stride = 20;                  // 9 complex + 2 pad: conflict-free 16-byte reads over a row's lanes
+    static constexpr int kTw2 = kTw1 + 16 * kTw1Stride;    // [16 r][20] complex W_512^{r+16s}, s = 0..8
+    static constexpr int kTCount = kTw2 + 16 * kTw2Stride; // 1296 elements of T
     // mel section, float offsets from its own base
     static constexpr int kMelStart = 0;                                // [kBlmSlots*16] ints
     static constexpr int kMelW = (kBlmSlots * kFbLanes + 3) & ~3;      // pairs [slot][r][16][2]
@@ -59,7 +59,7 @@ struct FbankLayout {
     // exchange rows, units of T; padded so that the 9 job lanes of a frame reading 9 different rows hit
     // different banks (f64: 16-byte complex reads, rows 68 words apart)
     static constexpr int kXRow = sizeof(T) == 8 ? 34 : 32;
-    static constexpr int kXStride = 17 * kXRow;            // lanes of different frames never share an LDS access group
+    static constexpr int kXStride = 16 * kXRow;            // lanes of different frames never share an LDS access group
     static constexpr int kPStride = 259;                   // f32 power rows (bins 0..256), aliased over the rows
     static constexpr int kSumOff = 0;                      // 64 partial sums (units of T): dead before phase 1 writes the rows
     static constexpr int slice_elems() { return (kFbFPW * kXStride + 1) & ~1; }   // units of T
@@ -79,15 +79,13 @@ MS_DEV T fb_partial_sum(const float *frame, int t) {
     return s;
 }
 
-// DFT over n1 of one column, twiddle by W_256^{n2*k1}, write the 16 exchange rows (+ the W_16-modulated
-// copy of row 0 that lane 0 of phase 2 pairs row 0 with).
+// DFT over n1 of one column, twiddle by W_256^{n2*k1}, write the 16 exchange rows.
 template <class T>
 MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *tblob, T *xo /* &row[0][n2] */) {
     using L = FbankLayout<T>;
     fft16(x);
     const T *tw = tblob + FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride;
     stc(xo, x[0]);
-    stc(xo + 16 * L::kXRow, cmul(x[0], ldc(tblob + FbankBlob::kMod + 2 * n2)));
 #pragma unroll
     for (int k1 = 1; k1 < 16; ++k1) stc(xo + k1 * L::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
 }
@@ -159,31 +157,47 @@ MS_DEV void nemo_phase1(int fl, int t, bool active, const float *clip, long long
     nemo_column<T>(clip, org, len, t, coeff, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
 }
 
-// phase 2: two 16-point DFTs, Hermitian split with W_512, 4*power (or 2*magnitude) as f32 to LDS.
-// The power rows (f32) are written over the exchange rows of the same wave.
+// Value held by lane (16 - r) & 15 of the caller's 16-lane row (r = lane & 15): row_mirror (lane i <- 15-i)
+// followed by row_ror:1 (lane i <- i-1).  Frames occupy whole rows, so source and destination lanes always
+// share their EXEC state.
+#if defined(__HIP_DEVICE_COMPILE__)
+MS_DEV int dpp_partner16(int x) {
+    const int m = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, m, 0x121, 0xf, 0xf, false);
+}
+MS_DEV float partner16(float v) { return __int_as_float(dpp_partner16(__float_as_int(v))); }
+MS_DEV double partner16(double v) {
+    return __hiloint2double(dpp_partner16(__double2hiint(v)), dpp_partner16(__double2loint(v)));
+}
+#else
+template <class T> MS_DEV T partner16(T v) { return v; }      // host pass of the kernel source only; tests/emu exchanges explicitly
+#endif
+
+// phase 2a: this lane's row of the exchange buffer through a 16-point DFT: own[k2] = Z[r + 16*k2]
 template <class T>
-MS_DEV void fb_phase2(int fl, int j, bool active, bool use_power, const T *tblob, T *slice) {
+MS_DEV void fb_phase2_dft(int fl, int r, bool active, const T *slice, cpx<T> (&own)[16]) {
     if (!active) return;
-    using L = FbankLayout<T>;
-    const int brow = (j == 0) ? 16 : 16 - j;
-    const T *ua = slice + fl * L::kXStride + j * L::kXRow;
-    const T *va = slice + fl * L::kXStride + brow * L::kXRow;
-    cpx<T> u[16], v[16];
+    const T *row = slice + fl * FbankLayout<T>::kXStride + r * FbankLayout<T>::kXRow;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        u[i] = ldc(ua + 2 * i);
-        v[i] = ldc(va + 2 * i);
-    }
-    fft16(u);
-    fft16(v);
-    const T *tw = tblob + FbankBlob::kTw2 + j * FbankBlob::kTw2Stride;
-    float *p = reinterpret_cast<float *>(slice) + fl * L::kPStride;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const cpx<T> zk = u[q], zm = v[15 - q];
+    for (int i = 0; i < 16; ++i) own[i] = ldc(row + 2 * i);
+    fft16(own);
+}
+
+// phase 2b: Hermitian split with W_512, 4*power (or 2*magnitude) as f32 to LDS (the power rows are written
+// over the exchange rows of the same wave).  part[i] = the partner lane's own[8 + i].
+//   pair s: Z[k], k = r + 16s, with Z[256-k] = partner[15 - s]; for r == 0 the partner index is 16 - s
+//   (mod 16: Z[256 - 16s]), i.e. own[0] for s = 0 and part[8 - s] for s = 1..8.
+template <class T>
+MS_DEV void fb_phase2_split(int fl, int r, bool active, bool use_power, const T *tblob, const cpx<T> (&own)[16],
+                            const cpx<T> (&part)[8], T *slice) {
+    if (!active) return;
+    const T *tw = tblob + FbankBlob::kTw2 + r * FbankBlob::kTw2Stride;
+    float *p = reinterpret_cast<float *>(slice) + fl * FbankLayout<T>::kPStride;
+    const bool lane0 = r == 0;
+    auto pair = [&](int s, cpx<T> zk, cpx<T> zm) {
         const cpx<T> S = {zk.re + zm.re, zk.im - zm.im};
         const cpx<T> D = {zk.re - zm.re, zk.im + zm.im};
-        const cpx<T> wd = cmul(ldc(tw + 2 * q), D);
+        const cpx<T> wd = cmul(ldc(tw + 2 * s), D);
         const T ar = S.re + wd.im, ai = S.im - wd.re;
         const T br = S.re - wd.im, bi = S.im + wd.re;
         float pk = static_cast<float>(ar * ar + ai * ai), pm = static_cast<float>(br * br + bi * bi);   // 4*|X|^2
@@ -191,9 +205,19 @@ MS_DEV void fb_phase2(int fl, int j, bool active, bool use_power, const T *tblob
             pk = __builtin_sqrtf(pk);
             pm = __builtin_sqrtf(pm);
         }
-        p[j + 16 * q] = pk;
-        p[256 - j - 16 * q] = pm;
+        p[r + 16 * s] = pk;
+        p[256 - r - 16 * s] = pm;
+    };
+    {
+        const cpx<T> zm = {lane0 ? own[0].re : part[7].re, lane0 ? own[0].im : part[7].im};
+        pair(0, own[0], zm);
     }
+#pragma unroll
+    for (int s = 1; s < 8; ++s) {
+        const cpx<T> zm = {lane0 ? part[8 - s].re : part[7 - s].re, lane0 ? part[8 - s].im : part[7 - s].im};
+        pair(s, own[s], zm);
+    }
+    if (lane0) pair(8, own[8], part[0]);
 }
 
 // phase 3: interval sums over 16-lane groups (lane j<15 owns interval j + 15*slot, j=15 is the ghost)

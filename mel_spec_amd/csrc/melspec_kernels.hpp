@@ -341,7 +341,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             nemo_phase1<T>(fl, j, act, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
         }
         __builtin_amdgcn_wave_barrier();
-        fb_phase2<T>(fl, j, act && j < kFbJobs, use_power, tblob, slice);
+        {
+            cpx<T> own[16], part[8];
+            fb_phase2_dft<T>(fl, j, act, slice, own);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
+            fb_phase2_split<T>(fl, j, act, use_power, tblob, own, part, slice);
+        }
         __builtin_amdgcn_wave_barrier();
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
         fb_phase3_sums<T, NSLOTS>(fl, j, act, p.slots, mel, slice, st, rise, fprev);

@@ -213,10 +213,19 @@ static long long run_fbank(const float *pcm, long long n, int shift, int n_mels,
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
+        std::vector<cpx<T>> own(64 * 16);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            fb_phase2_dft<T>(fl, j, act, snap.data(), *reinterpret_cast<cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]));
+        }
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            fb_phase2<T>(fl, j, act && j < kFbJobs, use_power != 0, tblob, tmp.data());
+            cpx<T> part[8];
+            const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);          // what partner16() fetches on the device
+            for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
+            fb_phase2_split<T>(fl, j, act, use_power != 0, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]),
+                               part, tmp.data());
             // power rows are f32 written into the T-typed slice: compare bytes
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
@@ -278,10 +287,19 @@ extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
+        std::vector<cpx<T>> own(64 * 16);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            fb_phase2_dft<T>(fl, j, act, snap.data(), *reinterpret_cast<cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]));
+        }
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            fb_phase2<T>(fl, j, act && j < kFbJobs, true, tblob, tmp.data());
+            cpx<T> part[8];
+            const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);          // what partner16() fetches on the device
+            for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
+            fb_phase2_split<T>(fl, j, act, true, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]),
+                               part, tmp.data());
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
             for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];
