@@ -134,15 +134,28 @@ MS_DEV float nemo_sample(const float *clip, long long s, long long len, float co
     return cur - f32_mul_rn(coeff, clip[s - 1]);
 }
 
+// `inside`: every sample this frame touches, and the one before its first, lies inside the clip (all frames
+// but the first two and last two of a centred clip), so the guards and the clip-start special case drop out
+// and the pair comes from one 8-byte load.
 template <class T>
-MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2, float coeff, const T *tblob, T *xo) {
+MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2, float coeff, bool inside, const T *tblob, T *xo) {
     cpx<T> x[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         x[n1] = {T(0), T(0)};
         if (n1 < 12 || (n1 == 12 && n2 < 8)) {
             const int i = 32 * n1 + 2 * n2;
-            const float y0 = nemo_sample(clip, org + i, len, coeff), y1 = nemo_sample(clip, org + i + 1, len, coeff);
+            float y0, y1;
+            if (inside) {
+                const float *s = clip + org + i;
+                const f2 c = load2_unaligned(s);
+                const float prev = s[-1];
+                y0 = coeff == 0.0f ? c.x : c.x - f32_mul_rn(coeff, prev);
+                y1 = coeff == 0.0f ? c.y : c.y - f32_mul_rn(coeff, c.x);
+            } else {
+                y0 = nemo_sample(clip, org + i, len, coeff);
+                y1 = nemo_sample(clip, org + i + 1, len, coeff);
+            }
             const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
             x[n1] = {static_cast<T>(y0) * w.re, static_cast<T>(y1) * w.im};
         }
@@ -154,7 +167,8 @@ template <class T>
 MS_DEV void nemo_phase1(int fl, int t, bool active, const float *clip, long long org, long long len, float coeff,
                         const T *tblob, T *slice) {
     if (!active) return;
-    nemo_column<T>(clip, org, len, t, coeff, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
+    const bool inside = org >= 1 && org + 400 <= len;
+    nemo_column<T>(clip, org, len, t, coeff, inside, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
 }
 
 // Value held by lane (16 - r) & 15 of the caller's 16-lane row (r = lane & 15): row_mirror (lane i <- 15-i)

@@ -1421,7 +1421,9 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         np.n_clips = n_clips; np.n_mels = nm;
         const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
         const unsigned g2 = grid_for((rows + 3) / 4, b->dev.cus, 16);
-        hipLaunchKernelGGL(blm_normalize_kernel<4>, dim3(g2), dim3(256), 0, s, np);
+        if (valid <= 64 * 16) hipLaunchKernelGGL((blm_normalize_kernel<4, 16>), dim3(g2), dim3(256), 0, s, np);
+        else if (valid <= 64 * 48) hipLaunchKernelGGL((blm_normalize_kernel<4, 48>), dim3(g2), dim3(256), 0, s, np);
+        else hipLaunchKernelGGL((blm_normalize_kernel<4, 0>), dim3(g2), dim3(256), 0, s, np);
         HIP_TRY(hipGetLastError());
     }
     return MELSPEC_OK;

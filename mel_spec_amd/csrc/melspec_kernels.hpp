@@ -383,22 +383,49 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <int WAVES>
+// ITEMS > 0: the row (<= 64*ITEMS valid frames) is read once into registers, and mean, variance and the
+// normalised values all come from there (one read + one write of the row instead of three reads + one write;
+// same values, same summation order).  ITEMS == 0: any length, three passes over the row.
+template <int WAVES, int ITEMS>
 __global__ __launch_bounds__(WAVES * 64) void blm_normalize_kernel(const BlmNormParams p) {
     const int lane = threadIdx.x & 63;
     const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
     for (uint64_t row = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6); row < rows; row += (uint64_t)gridDim.x * WAVES) {
         const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
         float *r = p.out + clip * p.clip_stride + m * p.row_w;
-        float s = 0.0f;
-        for (uint64_t f = lane; f < p.valid; f += 64) s += r[f];
-        const float mean = wave_sum(s) / (float)p.valid;
-        float q = 0.0f;
-        for (uint64_t f = lane; f < p.valid; f += 64) { const float d = r[f] - mean; q += d * d; }
         float denom = (float)p.valid - 1.0f;
         denom = denom < 1.0f ? 1.0f : denom;
-        const float sd = sqrtf(wave_sum(q) / denom) + 1e-5f;
-        for (uint64_t f = lane; f < p.valid; f += 64) r[f] = (r[f] - mean) / sd;
+        if (ITEMS > 0) {
+            float v[ITEMS > 0 ? ITEMS : 1];
+            float s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint64_t f = (uint64_t)k * 64 + lane;
+                v[k] = f < p.valid ? r[f] : 0.0f;
+                if (f < p.valid) s += v[k];
+            }
+            const float mean = wave_sum(s) / (float)p.valid;
+            float q = 0.0f;
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint64_t f = (uint64_t)k * 64 + lane;
+                if (f < p.valid) { const float d = v[k] - mean; q += d * d; }
+            }
+            const float sd = sqrtf(wave_sum(q) / denom) + 1e-5f;
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                const uint64_t f = (uint64_t)k * 64 + lane;
+                if (f < p.valid) r[f] = (v[k] - mean) / sd;
+            }
+        } else {
+            float s = 0.0f;
+            for (uint64_t f = lane; f < p.valid; f += 64) s += r[f];
+            const float mean = wave_sum(s) / (float)p.valid;
+            float q = 0.0f;
+            for (uint64_t f = lane; f < p.valid; f += 64) { const float d = r[f] - mean; q += d * d; }
+            const float sd = sqrtf(wave_sum(q) / denom) + 1e-5f;
+            for (uint64_t f = lane; f < p.valid; f += 64) r[f] = (r[f] - mean) / sd;
+        }
     }
 }
 

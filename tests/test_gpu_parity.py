@@ -416,3 +416,17 @@ def test_nemo_frontend_batch(gpu, oracle):
     assert got.shape == (16, 128, 301)
     for c in (0, 7, 15):
         assert np.abs(got[c] - oracle.blm_compute(clips[c], cfg, True)[0]).max() <= TOL
+
+
+@pytest.mark.parametrize("seconds,frames", [(3, 301), (30, 3001), (50, 5001)])
+def test_nemo_per_feature_normalisation_row_lengths(gpu, oracle, seconds, frames):
+    """normalize_per_feature (src/mel.rs:721-749) through the three builds of the row kernel: rows held in
+    16 or 48 registers per lane, and the three-pass fallback for longer clips."""
+    kw = dict(n_mels=80, preemphasis=0.97, normalize_per_feature=True)
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+    x = oracle.synth_pcm(3, seconds * 16000)
+    got = fe.compute(x)
+    want, wvalid = oracle.blm_compute(x, oracle.blm_default_config(**kw), True)
+    assert wvalid == frames and got.shape == want.shape
+    assert np.abs(got - want).max() <= TOL
+    fe.close()
