@@ -71,6 +71,9 @@ public:
         detail::check(melspec_compute_uniform_device(ctx_, d_pcm, clip_stride, clip_len, n_clips, d_out, stream), false);
     }
     void synchronize(void *stream = nullptr) { detail::check(melspec_synchronize(ctx_, stream), false); }
+    // f64 window/FFT/power like the reference's CPU and CUDA paths (melspec_set_precise)
+    void set_precise(bool on) { detail::check(melspec_set_precise(ctx_, on ? 1 : 0), false); }
+    bool precise() const { return melspec_is_precise(ctx_) != 0; }
     melspec_ctx *raw() { return ctx_; }
 
 private:
@@ -108,6 +111,93 @@ public:
 
 private:
     melspec_fbank *fb_ = nullptr;
+};
+
+// src/quant.rs: quantize / dequantize / tga_8bit / parse_tga_8bit, same names and return shapes
+struct QuantizationRange { float min, max; };
+
+class TgaCodec {
+public:
+    explicit TgaCodec(int device = -1) { detail::check(melspec_tga_create(&q_, device), true); }
+    ~TgaCodec() { melspec_tga_destroy(q_); }
+    TgaCodec(const TgaCodec &) = delete;
+    TgaCodec &operator=(const TgaCodec &) = delete;
+
+    std::pair<std::vector<std::uint8_t>, QuantizationRange> quantize(const std::vector<float> &frame) {
+        std::vector<std::uint8_t> out(frame.size());
+        float r[2] = {0.0f, 0.0f};
+        detail::check(melspec_quantize_host(q_, frame.data(), frame.size(), out.data(), r), false);
+        return {std::move(out), QuantizationRange{r[0], r[1]}};
+    }
+    std::vector<float> dequantize(const std::vector<std::uint8_t> &data, const QuantizationRange &range) {
+        std::vector<float> out(data.size());
+        const float r[2] = {range.min, range.max};
+        detail::check(melspec_dequantize_host(q_, data.data(), data.size(), r, out.data()), false);
+        return out;
+    }
+    // one TGA per <= 65535-column chunk of the major-row-order [n_mels][width] image
+    std::vector<std::vector<std::uint8_t>> tga_8bit(const std::vector<float> &data, std::size_t n_mels) {
+        std::uint32_t n = 0;
+        std::size_t stride = 0, last = 0;
+        detail::check(melspec_tga_layout(static_cast<int>(n_mels), n_mels ? data.size() / n_mels : 0, &n, &stride, &last), false);
+        std::vector<std::vector<std::uint8_t>> res;
+        if (n == 0) return res;
+        std::vector<std::uint8_t> flat(stride * (n - 1) + last);
+        std::uint32_t got = 0;
+        detail::check(melspec_tga_encode_host(q_, data.data(), data.size(), static_cast<int>(n_mels), flat.data(), flat.size(), &got), false);
+        const std::size_t full = 26 + n_mels * 65535;
+        for (std::uint32_t c = 0; c < n; ++c)
+            res.emplace_back(flat.begin() + c * stride, flat.begin() + c * stride + (c + 1 < n ? full : last));
+        return res;
+    }
+    std::vector<float> parse_tga_8bit(const std::vector<std::uint8_t> &blob) {
+        std::vector<float> out(blob.size() > 26 ? blob.size() - 26 : 0);
+        std::size_t n = 0;
+        detail::check(melspec_tga_decode_host(q_, blob.data(), blob.size(), out.data(), out.size(), &n), false);
+        out.resize(n);
+        return out;
+    }
+
+private:
+    melspec_tga *q_ = nullptr;
+};
+
+// One live stream with the reference's RingBuffer interface (src/rb.rs:18-121) over a 1-stream bank:
+// add_frame() feeds samples, maybe_mel() hands out one (n_mels) column per completed hop.
+class RingBuffer {
+public:
+    RingBuffer(HipMelSpectrogram &mel, std::size_t capacity = 16384) : n_mels_(mel.n_mels()), cap_(capacity) {
+        detail::check(melspec_stream_create(&st_, mel.raw(), 1, static_cast<std::uint32_t>(capacity)), true);
+    }
+    ~RingBuffer() { melspec_stream_destroy(st_); }
+    RingBuffer(const RingBuffer &) = delete;
+    RingBuffer &operator=(const RingBuffer &) = delete;
+
+    void add_frame(const std::vector<float> &samples) {
+        pending_.insert(pending_.end(), samples.begin(), samples.end());
+        if (pending_.size() > cap_) pending_.erase(pending_.begin(), pending_.begin() + (pending_.size() - cap_));   // src/rb.rs:60-68
+    }
+    void add(float sample) { add_frame(std::vector<float>(1, sample)); }
+    std::optional<std::vector<float>> maybe_mel() {
+        if (next_ == ready_.size() / (n_mels_ ? n_mels_ : 1) && !pending_.empty()) {
+            const std::uint32_t id = 0, len = static_cast<std::uint32_t>(pending_.size());
+            std::uint32_t frames = 0;
+            ready_.assign(melspec_stream_frames_after(st_, 0, len) * n_mels_, 0.0f);
+            next_ = 0;
+            detail::check(melspec_stream_push_host(st_, &id, pending_.data(), &len, 1, ready_.data(), ready_.size(), &frames), false);
+            ready_.resize(static_cast<std::size_t>(frames) * n_mels_);
+            pending_.clear();
+        }
+        if (next_ * n_mels_ >= ready_.size()) return std::nullopt;
+        std::vector<float> col(ready_.begin() + next_ * n_mels_, ready_.begin() + (next_ + 1) * n_mels_);
+        ++next_;
+        return col;
+    }
+
+private:
+    melspec_stream *st_ = nullptr;
+    std::size_t n_mels_, cap_, next_ = 0;
+    std::vector<float> pending_, ready_;
 };
 
 // dense [n_mels][n_fft/2+1] row-major; std::nullopt == None

@@ -2,6 +2,7 @@
 // (tests/readme_examples.rs:12-29), written against include/melspec_hip.hpp.  Expected values come
 // from the CPU oracle library, linked only into this test binary.
 //   build: g++ -std=c++17 -Iinclude tests/cpp/test_host_mirror.cpp -Lmel_spec_amd -lmelspec_hip -Loracle -lmelspec_oracle
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <vector>
@@ -9,6 +10,9 @@
 #include "melspec_hip.hpp"
 
 extern "C" long oracle_compute_mel_spectrogram_cpu(const float *, long, int, int, int, double, float *);
+extern "C" long oracle_stream_mel(const float *, long, int, int, int, double, float *, long);
+extern "C" void oracle_quantize(const float *, long, unsigned char *, float *);
+extern "C" long oracle_tga_8bit_data(const float *, long, int, unsigned char *);
 
 int main() {
     const double sr = 16000.0;
@@ -52,6 +56,47 @@ int main() {
     if (feats.cols != 80 || feats.rows != 98) { std::puts("FAIL: fbank shape"); return 1; }
     const std::vector<double> w = melspec::mel(sr, 400, 80);
     if (w.size() != 80 * 201) { std::puts("FAIL: mel shape"); return 1; }
+    // precise build, streaming mirror and the quantiser through the same header
+    {
+        melspec::HipMelSpectrogram hip(400, 160, sr, 80);
+        hip.set_precise(true);
+        if (!hip.precise()) { std::puts("FAIL: precise flag"); return 1; }
+        const auto pg = hip.compute_mel_spectrogram(samples);
+        float md = 0.0f;
+        for (size_t f = 0; f < 98; ++f)
+            for (size_t m = 0; m < 80; ++m) md = std::fmax(md, std::fabs(pg[f][m] - cpu[f * 80 + m]));
+        std::printf("precise max delta %.3g\n", md);
+        if (!(md <= 2e-6f)) { std::puts("FAIL: precise tolerance"); return 1; }
+        hip.set_precise(false);
+
+        melspec::RingBuffer rb(hip, 16000);
+        std::vector<float> want(100 * 80);
+        const long nf = oracle_stream_mel(samples.data(), 16000, 400, 160, 80, sr, want.data(), 100);
+        long got = 0;
+        float sd = 0.0f;
+        for (int p = 0; p < 16000; p += 1000) {
+            rb.add_frame(std::vector<float>(samples.begin() + p, samples.begin() + p + 1000));
+            while (auto col = rb.maybe_mel()) {
+                if (got < nf)
+                    for (size_t m = 0; m < 80; ++m) sd = std::fmax(sd, std::fabs((*col)[m] - want[got * 80 + m]));
+                ++got;
+            }
+        }
+        std::printf("streaming frames %ld (want %ld) max delta %.3g\n", got, nf, sd);
+        if (got != nf || !(sd <= 1e-4f)) { std::puts("FAIL: streaming"); return 1; }
+
+        melspec::TgaCodec codec;
+        std::vector<float> img(80 * 98);
+        for (size_t f = 0; f < 98; ++f)
+            for (size_t m = 0; m < 80; ++m) img[m * 98 + f] = cpu[f * 80 + m];
+        const auto blobs = codec.tga_8bit(img, 80);
+        std::vector<unsigned char> ref(26 + img.size());
+        oracle_tga_8bit_data(img.data(), static_cast<long>(img.size()), 80, ref.data());
+        if (blobs.size() != 1 || blobs[0] != ref) { std::puts("FAIL: tga bytes"); return 1; }
+        const auto back = codec.parse_tga_8bit(blobs[0]);
+        const auto qr = codec.quantize(img);
+        if (back.size() != img.size() || !std::equal(qr.first.begin(), qr.first.end(), ref.begin() + 26)) { std::puts("FAIL: quantize"); return 1; }
+    }
     std::puts("OK");
     return 0;
 }
