@@ -278,6 +278,33 @@ int melspec_quantize_host(melspec_tga *q, const float *frame, size_t n, uint8_t 
 int melspec_dequantize_host(melspec_tga *q, const uint8_t *data, size_t n, const float *range, float *out);
 int melspec_tga_synchronize(melspec_tga *q);
 
+/* ---- VAD column classification: vad_boundaries (src/vad.rs:256-340) -------------------- */
+/* The reference's consumer of the mel image ([n_mels][width], what interleave_frames(.., false, ..) or
+ * to_array2 (src/quant.rs:168-174) produce): a 3x3 Sobel stencil, per column the count of rows
+ * y in [min(min_mel, n_mels-2), n_mels-2) whose squared gradient reaches min_energy^2, raw[x] = count >= min_y
+ * (classify_columns_in_frame, :373-415), then a +-4 moving-window majority vote (smooth_mask, :343-360).
+ * EdgeInfo::intersected() are the set entries of `smoothed`, non_intersected() the clear ones.  Same f64
+ * arithmetic on the same f32 pixels as the reference: the masks are identical, not close. */
+typedef struct melspec_vad_settings {      /* DetectionSettings, src/vad.rs:5-22 */
+    double min_energy;                     /* 0.98 */
+    int min_y;                             /* 11 */
+    int min_x;                             /* 5: window of VoiceActivityDetector::add, not used by vad_boundaries */
+    int min_mel;                           /* 2 */
+} melspec_vad_settings;
+void melspec_vad_default_settings(melspec_vad_settings *s);
+/* width - 2, or 0 when n_mels < 3 or width < 3 (the reference then returns an empty EdgeInfo) */
+size_t melspec_vad_mask_len(int n_mels, size_t width);
+/* n_images images at d_images + i*image_stride floats -> byte masks at d_raw / d_smoothed + i*mask_stride
+ * (melspec_vad_mask_len entries each) and, if d_longest_run != NULL, the longest run of consecutive intersected
+ * columns per image (vad_on(edge_info, n), src/vad.rs:229-254, is `longest_run >= n` for n >= 2).
+ * Asynchronous on `stream` of the current device. */
+int melspec_vad_boundaries_device(const float *d_images, size_t image_stride, int n_mels, size_t width, uint32_t n_images,
+                                  const melspec_vad_settings *settings, uint8_t *d_raw, uint8_t *d_smoothed, size_t mask_stride,
+                                  uint32_t *d_longest_run, void *stream);
+/* one image in host memory (device < 0: the current one); raw_out may be NULL */
+int melspec_vad_boundaries_host(int device, const float *image, int n_mels, size_t width, const melspec_vad_settings *settings,
+                                uint8_t *raw_out, uint8_t *smoothed_out, uint32_t *longest_run);
+
 /* ---- device memory helpers for hosts with no HIP binding of their own --------------- */
 /* (what the cudaMalloc/cudaMemcpyAsync externs of src/cuda.rs:185-199 give the Rust side) */
 int melspec_malloc(void **dptr, size_t bytes);

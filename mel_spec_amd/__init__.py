@@ -6,7 +6,9 @@ from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, D
 from .parallel import shard_range
 from .quant import QuantizationRange, TgaCodec, to_array2
 from .stream import RingBuffer, StreamBank
+from .vad import DetectionSettings, EdgeInfo, VoiceActivity, VoiceActivityDetector, vad_boundaries, vad_on
 
 __all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError",
            "HipUnavailable", "device_count", "device_synchronize", "hann_window", "kaldi_mel_filterbank", "mel",
-           "synth_pcm_device", "synth_pcm_window", "shard_range", "QuantizationRange", "TgaCodec", "to_array2", "RingBuffer", "StreamBank"]
+           "synth_pcm_device", "synth_pcm_window", "shard_range", "QuantizationRange", "TgaCodec", "to_array2", "RingBuffer", "StreamBank", "DetectionSettings", "EdgeInfo", "VoiceActivity", "VoiceActivityDetector",
+           "vad_boundaries", "vad_on"]

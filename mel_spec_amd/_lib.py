@@ -15,6 +15,10 @@ ERR_UNSUPPORTED = -4
 ERR_INTERNAL = -5
 
 
+class VadSettingsC(C.Structure):
+    _fields_ = [("min_energy", C.c_double), ("min_y", C.c_int), ("min_x", C.c_int), ("min_mel", C.c_int)]
+
+
 class FbankConfigC(C.Structure):
     """melspec_fbank_config (include/melspec_hip.h) == FbankConfig (src/fbank.rs:25-64)."""
     _fields_ = [
@@ -95,6 +99,10 @@ SIGNATURES = {
     "melspec_stream_flush_host": (C.c_int, [_vp, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p]),
     "melspec_stream_input_ptr": (_vp, [_vp, C.c_uint32]),
     "melspec_stream_push_device": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, _vp, _u64p, _u32p, _vp]),
+    "melspec_vad_default_settings": (None, [_vp]),
+    "melspec_vad_mask_len": (C.c_size_t, [C.c_int, C.c_size_t]),
+    "melspec_vad_boundaries_device": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "melspec_vad_boundaries_host": (C.c_int, [C.c_int, _f32p, C.c_int, C.c_size_t, _vp, _vp, _vp, _u32p]),
     "melspec_tga_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "melspec_tga_destroy": (None, [_vp]),
     "melspec_tga_layout": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),

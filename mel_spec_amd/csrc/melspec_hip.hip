@@ -23,6 +23,7 @@
 #include "melspec_kernels.hpp"
 #include "stream_plan.hpp"
 #include "tga_quant.hpp"
+#include "vad_columns.hpp"
 #include "tables.hpp"
 
 using namespace melspec;
@@ -1300,6 +1301,80 @@ int melspec_tga_decode_host(melspec_tga *q, const uint8_t *blob, size_t n_bytes,
     HIP_TRY(hipStreamSynchronize(q->stream));
     if (n_values) *n_values = npx;
     return MELSPEC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------
+// VAD column classification (vad_boundaries, src/vad.rs:256-340)
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+void melspec_vad_default_settings(melspec_vad_settings *s) {          // DetectionSettings::default, src/vad.rs:13-22
+    if (!s) return;
+    s->min_energy = 0.98; s->min_y = 11; s->min_x = 5; s->min_mel = 2;
+}
+
+size_t melspec_vad_mask_len(int n_mels, size_t width) { return (n_mels < 3 || width < 3) ? 0 : width - 2; }
+
+int melspec_vad_boundaries_device(const float *d_images, size_t image_stride, int n_mels, size_t width, uint32_t n_images,
+                                  const melspec_vad_settings *settings, uint8_t *d_raw, uint8_t *d_smoothed, size_t mask_stride,
+                                  uint32_t *d_longest_run, void *stream) {
+    if (!settings) return fail(MELSPEC_ERR_INVALID_ARG, "settings is NULL");
+    if (n_mels < 0 || settings->min_y < 0 || settings->min_mel < 0) return fail(MELSPEC_ERR_INVALID_ARG, "negative size");
+    const size_t n = melspec_vad_mask_len(n_mels, width);
+    if (n_images == 0) return MELSPEC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (n == 0) {                                        // EdgeInfo::new(empty, empty), src/vad.rs:270-272
+        if (d_longest_run) HIP_TRY(hipMemsetAsync(d_longest_run, 0, sizeof(uint32_t) * n_images, s));
+        return MELSPEC_OK;
+    }
+    if (!d_images || !d_smoothed) return fail(MELSPEC_ERR_INVALID_ARG, "image/mask pointer is NULL");
+    if (!d_raw) return fail(MELSPEC_ERR_INVALID_ARG, "d_raw is NULL (the vote reads the raw mask)");
+    if (mask_stride < n) return fail(MELSPEC_ERR_INVALID_ARG, "mask_stride < width - 2");
+    if (image_stride < static_cast<size_t>(n_mels) * width) return fail(MELSPEC_ERR_INVALID_ARG, "image_stride < n_mels * width");
+    if (width > 0xffffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "image wider than 2^32-1 columns");
+    VadDesc d{};
+    d.img = d_images; d.raw = d_raw; d.smoothed = d_smoothed; d.longest = d_longest_run;
+    d.img_stride = image_stride; d.mask_stride = mask_stride;
+    d.height = static_cast<uint32_t>(n_mels); d.width = static_cast<uint32_t>(width); d.n_images = n_images;
+    d.min_mel = settings->min_mel; d.min_y = settings->min_y; d.thr = settings->min_energy * settings->min_energy;
+    const uint64_t bpi = (n + 255) / 256;
+    if (bpi * n_images > 0x7fffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "batch too large for one launch");
+    const unsigned grid = static_cast<unsigned>(bpi * n_images);
+    hipLaunchKernelGGL(vad_raw_kernel, dim3(grid), dim3(256), 0, s, d, static_cast<uint32_t>(bpi), d_raw);
+    hipLaunchKernelGGL(vad_smooth_kernel, dim3(grid), dim3(256), 0, s, d, static_cast<uint32_t>(bpi), d_raw);
+    if (d_longest_run) hipLaunchKernelGGL(vad_run_kernel, dim3(n_images), dim3(64), 0, s, d);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int melspec_vad_boundaries_host(int device, const float *image, int n_mels, size_t width, const melspec_vad_settings *settings,
+                                uint8_t *raw_out, uint8_t *smoothed_out, uint32_t *longest_run) {
+    if (!settings) return fail(MELSPEC_ERR_INVALID_ARG, "settings is NULL");
+    if (longest_run) *longest_run = 0;
+    const size_t n = melspec_vad_mask_len(n_mels, width);
+    if (n == 0) return MELSPEC_OK;
+    if (!image || !smoothed_out) return fail(MELSPEC_ERR_INVALID_ARG, "image/out is NULL");
+    DeviceInfo info;
+    int rc = pick_device(device, info);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(info.device));
+    DevBuf img, masks, run;
+    const size_t px = static_cast<size_t>(n_mels) * width, ms = (n + 15) & ~static_cast<size_t>(15);
+    auto done = [&](int code) { img.release(); masks.release(); run.release(); return code; };
+    if ((rc = img.ensure(px * sizeof(float))) || (rc = masks.ensure(2 * ms)) || (rc = run.ensure(16))) return done(rc);
+    if (hipMemcpy(img.p, image, px * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "hipMemcpy failed"));
+    uint8_t *m = static_cast<uint8_t *>(masks.p);
+    rc = melspec_vad_boundaries_device(static_cast<const float *>(img.p), px, n_mels, width, 1, settings, m, m + ms, ms,
+                                       static_cast<uint32_t *>(run.p), nullptr);
+    if (rc) return done(rc);
+    if (hipDeviceSynchronize() != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "vad kernels failed"));
+    if (raw_out && hipMemcpy(raw_out, m, n, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "hipMemcpy failed"));
+    if (hipMemcpy(smoothed_out, m + ms, n, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "hipMemcpy failed"));
+    if (longest_run && hipMemcpy(longest_run, run.p, sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(MELSPEC_ERR_INTERNAL, "hipMemcpy failed"));
+    return done(MELSPEC_OK);
 }
 
 }  // extern "C"

@@ -360,6 +360,47 @@ int64_t oracle_tga_8bit_data(const float *data, int64_t n, int n_mels, uint8_t *
     return 26 + n;
 }
 
+/* ---- src/vad.rs: column classification of a mel image ---------------------------------------------
+ * vad_boundaries (src/vad.rs:256-340) on one [height][width] image (the reference concatenates its
+ * Array2<f64> frames along the time axis; values are f32 widened to f64, to_array2 src/quant.rs:168-174):
+ * raw[x], x < width-2: at least min_y of the rows y in [min(min_mel, height-2), height-2) have a 3x3 Sobel
+ * gradient (sobel_gradient_sq, :470-486) with gx^2+gy^2 >= min_energy^2 (classify_columns_in_frame,
+ * :373-415); smoothed = moving-window majority vote over [x-4, x+4] clipped to the mask (smooth_mask,
+ * :343-360).  Returns the mask length (0 when height < 3 or width < 3). */
+int64_t oracle_vad_boundaries(const float *img, int height, int64_t width, int min_mel, int min_y, double min_energy,
+                              uint8_t *raw, uint8_t *smoothed) {
+    if (height < 3 || width < 3) return 0;
+    const int64_t n = width - 2;
+    const double thr = min_energy * min_energy;
+    const int start_y = min_mel < height - 2 ? min_mel : height - 2;
+    for (int64_t x = 0; x < n; ++x) {
+        int count = 0;
+        uint8_t active = min_y == 0;
+        for (int y = start_y; y < height - 2 && !active; ++y) {
+            const float *r0 = img + (int64_t)y * width + x, *r1 = r0 + width, *r2 = r1 + width;
+            const double tl = r0[0], tc = r0[1], tr = r0[2], ml = r1[0], mr = r1[2], bl = r2[0], bc = r2[1], br = r2[2];
+            const double gx = (tr + (2.0 * mr) + br) - (tl + (2.0 * ml) + bl);
+            const double gy = (bl + (2.0 * bc) + br) - (tl + (2.0 * tc) + tr);
+            if ((gx * gx) + (gy * gy) >= thr && ++count >= min_y) active = 1;
+        }
+        raw[x] = active;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t start = i >= 4 ? i - 4 : 0, end = i + 5 < n ? i + 5 : n;
+        int64_t c = 0;
+        for (int64_t k = start; k < end; ++k) c += raw[k];
+        smoothed[i] = (uint8_t)(c * 2 >= end - start);
+    }
+    return n;
+}
+
+/* longest run of consecutive set columns; vad_on(edge_info, n) (src/vad.rs:229-254) == (n <= 1 ? any set : run >= n) */
+int64_t oracle_vad_longest_run(const uint8_t *mask, int64_t n) {
+    int64_t best = 0, cur = 0;
+    for (int64_t i = 0; i < n; ++i) { cur = mask[i] ? cur + 1 : 0; if (cur > best) best = cur; }
+    return best;
+}
+
 /* Many clips, clips split across OpenMP threads (the all-cores CPU baseline of
  * bench.py).  Clip c is samples[c*clip_stride .. +clip_len); out is
  * [clip][frame][mel].  Same arithmetic as the function above. */

@@ -80,6 +80,10 @@ def lib():
         L.oracle_dequantize.argtypes = [u8p, C.c_int64, f32p, f32p]
         L.oracle_tga_8bit_data.restype = C.c_int64
         L.oracle_tga_8bit_data.argtypes = [f32p, C.c_int64, C.c_int, u8p]
+        L.oracle_vad_boundaries.restype = C.c_int64
+        L.oracle_vad_boundaries.argtypes = [f32p, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, u8p, u8p]
+        L.oracle_vad_longest_run.restype = C.c_int64
+        L.oracle_vad_longest_run.argtypes = [u8p, C.c_int64]
         L.oracle_max_threads.restype = C.c_int
         L.oracle_stream_mel.restype = C.c_int64
         L.oracle_stream_mel.argtypes = [f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double, f32p, C.c_int64]
@@ -240,6 +244,27 @@ def parse_tga_8bit(blob: bytes) -> np.ndarray:
         raise ValueError("failed to fill whole buffer")
     rng = np.frombuffer(blob[18:26], "<f4")
     return dequantize(np.frombuffer(blob[26:], np.uint8), rng)
+
+
+# ---- src/vad.rs ------------------------------------------------------------------------------------
+
+def vad_boundaries(image, min_energy=0.98, min_y=11, min_x=5, min_mel=2):
+    """vad_boundaries (src/vad.rs:256-340) on a [n_mels, width] image -> (raw mask, smoothed mask), bool arrays of width-2."""
+    x = _f32(image)
+    h, w = x.shape
+    raw = np.zeros(max(0, w - 2), np.uint8)
+    sm = np.zeros(max(0, w - 2), np.uint8)
+    n = lib().oracle_vad_boundaries(_p(x, C.c_float), h, w, min_mel, min_y, float(min_energy), _p(raw, C.c_uint8), _p(sm, C.c_uint8))
+    return raw[:n].astype(bool), sm[:n].astype(bool)
+
+
+def vad_on(smoothed, n: int) -> bool:
+    """vad_on (src/vad.rs:229-254): the run counter is only tested from the second intersected column on, so
+    n <= 1 means "at least two intersected columns" and n >= 2 "a run of n consecutive ones"."""
+    m = np.ascontiguousarray(smoothed, np.uint8)
+    if n <= 1:
+        return int(m.sum()) >= 2
+    return int(lib().oracle_vad_longest_run(_p(m, C.c_uint8), m.shape[0])) >= n
 
 
 def max_threads() -> int:

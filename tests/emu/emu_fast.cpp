@@ -13,6 +13,7 @@
 #include "../../mel_spec_amd/csrc/whisper_wave.hpp"
 #include "../../mel_spec_amd/csrc/fbank_tables.hpp"
 #include "../../mel_spec_amd/csrc/tga_quant.hpp"
+#include "../../mel_spec_amd/csrc/vad_columns.hpp"
 
 using namespace melspec;
 
@@ -543,4 +544,14 @@ extern "C" long long emu_stream_push(void *p, const uint32_t *ids, const float *
     stream_commit_push(s->g, s->bk, ids, lens, n, flush != 0);
     if (frames_out) for (uint32_t i = 0; i < n; ++i) frames_out[i] = pl.frames[i];
     return static_cast<long long>(pl.total_frames);
+}
+
+// ---- vad_columns.hpp: the per-thread functions of the two mask kernels ---------------------------------
+extern "C" long long emu_vad_boundaries(const float *img, uint32_t height, uint32_t width, int min_mel, int min_y, double min_energy,
+                                        uint8_t *raw, uint8_t *smoothed) {
+    if (height < 3 || width < 3) return 0;
+    const uint32_t n = width - 2;
+    for (uint32_t x = 0; x < n; ++x) raw[x] = vad_classify_column(img, height, width, x, min_mel, min_y, min_energy * min_energy);
+    for (uint32_t x = 0; x < n; ++x) smoothed[x] = vad_smooth_at(raw, n, x);
+    return n;
 }
