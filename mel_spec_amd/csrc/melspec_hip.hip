@@ -359,11 +359,11 @@ int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, boo
 
 constexpr int kPreciseWaves = 8;
 
-template <int NSLOTS, class Lens>
-int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+template <int NSLOTS, class Lens, bool LAYOUT>
+int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     static bool attr_done = false;
     if (!attr_done) {
-        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves>, "hipFuncSetAttribute(whisper400_precise_kernel)");
+        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>, "hipFuncSetAttribute(whisper400_precise_kernel)");
         if (rc) return rc;
         attr_done = true;
     }
@@ -377,18 +377,21 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     pp.slots = c->ft.slots;
     const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
     const unsigned grid = grid_for(blocks, c->dev.cus, 8);
-    hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves>), dim3(grid), dim3(kPreciseWaves * 64),
+    hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>), dim3(grid), dim3(kPreciseWaves * 64),
                        c->precise_lds, stream, pp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
+}
+template <int NSLOTS, class Lens>
+int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+    return layout ? launch_precise_l<NSLOTS, Lens, true>(c, desc, stream) : launch_precise_l<NSLOTS, Lens, false>(c, desc, stream);
 }
 
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     if (desc.n_units == 0) return MELSPEC_OK;
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precise) {
-        if (desc.mel_major || desc.out_width != desc.frames_per_clip)
-            return fail(MELSPEC_ERR_UNSUPPORTED, "the precise build has no padded / mel-major layout yet");
         if (c->ft.slots.n_slots <= 8)
             return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stream) : launch_precise_t<8, LensRuntime>(c, desc, stream);
         return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stream) : launch_precise_t<12, LensRuntime>(c, desc, stream);
@@ -496,7 +499,8 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     }
     if (const char *e = std::getenv("MELSPEC_GRID_PER_CU")) { const int g = std::atoi(e); if (g > 0 && g <= 64) c->grid_per_cu = g; }
     const char *ep = std::getenv("MELSPEC_PRECISE");
-    if (ep && ep[0] == '1' && c->fast && (rc = melspec_set_precise(c, 1))) return bail(rc);
+    // a preference, not a requirement: filterbanks outside the interval scheme keep the f32 kernel
+    if (ep && ep[0] == '1' && c->fast && (rc = melspec_set_precise(c, 1)) && rc != MELSPEC_ERR_UNSUPPORTED) return bail(rc);
     *out = c;
     return MELSPEC_OK;
 }

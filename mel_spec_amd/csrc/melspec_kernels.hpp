@@ -222,7 +222,7 @@ struct PreciseParams {
     MelSlots slots;       // woff[] as in the f32 blob (float offsets from FastBlob's base)
 };
 
-template <int NSLOTS, class Lens, int WAVES>
+template <int NSLOTS, class Lens, int WAVES, bool LAYOUT = false>
 __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const PreciseParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
@@ -249,8 +249,12 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
     for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = loc.frames - f0;
+        const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
+        const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
+        const uint64_t wleft = width - f0;
+        const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
         precise_phase1(fl, j, act && j < kFftJobs, p.hop, tb, src, rows);
@@ -263,7 +267,10 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
         wave_phase3i_finish<NSLOTS>(fl3, j3, act3, p.n_mels, rise, fnext, slice, vals);
         __builtin_amdgcn_wave_barrier();
-        wave_phase4<NSLOTS, false>(fl3, j3, act3, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
+        if (LAYOUT && p.b.mel_major)
+            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0, (long long)width);
+        else
+            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         __builtin_amdgcn_wave_barrier();
     }
 }
