@@ -64,6 +64,14 @@ int allow_big_lds(K kernel, const char *name) {
     return MELSPEC_OK;
 }
 
+inline uint64_t current_device_bit() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return 1ull << (dev & 63);
+}
+inline bool device_done(uint64_t mask) { return (mask & current_device_bit()) != 0; }
+inline void mark_device_done(uint64_t &mask) { mask |= current_device_bit(); }
+
 struct DeviceInfo {
     int device = -1;
     int cus = 0;
@@ -292,11 +300,11 @@ int launch_block_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
 
 template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW, bool INTERVAL, bool LAYOUT>
 int launch_wave_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>, "hipFuncSetAttribute(whisper400_wave_kernel)");
         if (rc) return rc;
-        attr_done = true;
+        mark_device_done(attr_done);
     }
     const FastParams fp = fast_params(c, desc);
     const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
@@ -361,11 +369,11 @@ constexpr int kPreciseWaves = 8;
 
 template <int NSLOTS, class Lens, bool LAYOUT>
 int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>, "hipFuncSetAttribute(whisper400_precise_kernel)");
         if (rc) return rc;
-        attr_done = true;
+        mark_device_done(attr_done);
     }
     PreciseParams pp{};
     pp.b = desc;
@@ -716,12 +724,12 @@ int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
 
 template <class T, int FLAVOR, int NSLOTS>
 int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    if (!device_done(attr_done)) {
         int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
         if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
         if (rc) return rc;
-        attr_done = true;
+        mark_device_done(attr_done);
     }
     const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
     const unsigned grid = grid_for(blocks, cus, 8);

@@ -72,7 +72,7 @@ def _tone_over_noise_floor(n=32000, level_db=-70.0, f=3333.3, seed=0):
 def test_precise_mode(gpu, oracle, jfk, n_mels):
     """melspec_set_precise: f64 window/FFT/power (the reference's arithmetic, src/stft.rs:98-111)."""
     m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
-    assert m.uses_fast_path and not m.precise
+    assert m.uses_fast_path and (m.precise == (os.environ.get("MELSPEC_PRECISE") == "1"))   # the suite is also run with MELSPEC_PRECISE=1
     m.set_precise(True)
     assert m.precise
     want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels, SR)
