@@ -123,20 +123,10 @@ def main() -> None:
     def step():
         mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
 
-    # Untimed spin-up: the GPU leaves its idle power state only after tens of milliseconds of work
-    # (measured: the first ~100 launches run ~15 % slower), so run launches for ~0.3 s before the
-    # W warmup steps.  Nothing here is timed.
-    spin_t0, spinup_steps = time.perf_counter(), 0
-    while time.perf_counter() - spin_t0 < 0.3:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-        spinup_steps += 20
-    for _ in range(args.warmup):
-        step()
+    # parity spot check first (3 clips vs the oracle), so that nothing CPU-bound sits between the spin-up and
+    # the timed region: the GPU drops back to its idle clocks within milliseconds of an empty queue
+    step()
     torch.cuda.synchronize()
-
-    # quick parity spot check outside the timed region (3 clips vs the oracle)
     parity = None
     if rank == 0:
         from oracle import oracle as O
@@ -148,6 +138,20 @@ def main() -> None:
         parity = worst
         if worst > 1e-4:
             raise SystemExit(f"parity check failed before timing: max|diff| = {worst}")
+    if distributed:
+        dist.barrier()
+
+    # Untimed spin-up: the GPU leaves its idle power state only after tens of milliseconds of work
+    # (measured: the first ~100 launches run ~15 % slower), so run launches for ~0.3 s, then the W warmup
+    # steps, then straight into the timed region.  Nothing here is timed.
+    spin_t0, spinup_steps = time.perf_counter(), 0
+    while time.perf_counter() - spin_t0 < 0.3:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        spinup_steps += 20
+    for _ in range(args.warmup):
+        step()
 
     # timed region: barrier + synchronize on both sides, MAX over ranks (mel_spec_amd.parallel.timed_steps);
     # HIP events on the launch stream bracket the same K launches for the kernel-side figure.
