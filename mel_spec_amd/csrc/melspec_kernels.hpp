@@ -276,7 +276,7 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
 }
 
 // ------------------------------------------------------------------------------------
-// Fused Kaldi-fbank kernel (phases in fbank_wave.hpp): 7 frames per wavefront, no workgroup barrier
+// Fused Kaldi-fbank kernel (phases in fbank_wave.hpp): 4 frames per wavefront (16 lanes each), no workgroup barrier
 // in the loop.  Writes un-normalised features; CMN is cmn_kernel.
 // ------------------------------------------------------------------------------------
 struct FbankFastParams {
