@@ -216,6 +216,14 @@ unsigned grid_for(uint64_t units, int cus, int per_cu) {
     const uint64_t g = units < cap ? units : cap;
     return static_cast<unsigned>(g ? g : 1);
 }
+// same, rounded up to a multiple of the 8 XCDs for the kernels that reorder their workgroups (xcd_logical_block);
+// MELSPEC_XCD=0 keeps the dispatcher's order (odd grid sizes switch the reordering off in the kernel)
+unsigned grid_for_xcd(uint64_t units, int cus, int per_cu) {
+    static const bool off = [] { const char *e = std::getenv("MELSPEC_XCD"); return e && e[0] == '0'; }();
+    const unsigned g = grid_for(units, cus, per_cu);
+    if (off) return (g % 8 == 0 && g > 1) ? g - 1 : g;
+    return (g + 7u) & ~7u;
+}
 
 int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, bool fbank, int use_log, int use_power,
                    double preemph, double floor_v, int cus, hipStream_t stream) {
@@ -308,7 +316,7 @@ int launch_wave_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     }
     const FastParams fp = fast_params(c, desc);
     const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
-    const unsigned grid = grid_for(blocks, c->dev.cus, c->grid_per_cu);
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, c->grid_per_cu);
     hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>), dim3(grid),
                        dim3(WAVES * 64), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
@@ -384,7 +392,7 @@ int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     pp.n_mels = c->n_mels;
     pp.slots = c->ft.slots;
     const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
-    const unsigned grid = grid_for(blocks, c->dev.cus, 8);
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, 8);
     hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>), dim3(grid), dim3(kPreciseWaves * 64),
                        c->precise_lds, stream, pp);
     HIP_TRY(hipGetLastError());
@@ -732,7 +740,7 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
         mark_device_done(attr_done);
     }
     const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
-    const unsigned grid = grid_for(blocks, cus, 8);
+    const unsigned grid = grid_for_xcd(blocks, cus, 8);
     if (waves == 8)
         hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(512), lds, s, fp);
     else

@@ -65,6 +65,18 @@ __device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit
     return r;
 }
 
+// XCD-aware workgroup order.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs,
+// each with its own L2.  Neighbouring workgroups share data -- the 240-sample frame-tail halo on the read side
+// and, for mel-major stores, the cache lines at the ends of their 20-byte row pieces -- so consecutive
+// *logical* workgroups are placed on the same XCD: logical = (id % 8) * (grid / 8) + id / 8 (grids are launched
+// as multiples of 8).  Measured on the mel-major store: HBM writes 690 MB -> see profiles/r01_variants.txt
+// (two L2s each holding half a dirty line write it back twice).
+constexpr unsigned kXcds = 8;
+__device__ __forceinline__ unsigned xcd_logical_block() {
+    const unsigned per = gridDim.x / kXcds;
+    return (gridDim.x % kXcds) ? blockIdx.x : (blockIdx.x % kXcds) * per + blockIdx.x / kXcds;
+}
+
 // ------------------------------------------------------------------------------------
 // Fused Whisper kernel, n_fft = 400.  One workgroup walks tiles of FPB consecutive frames.
 // LDS: [table blob][region A: PCM tile / power rows][region B: FFT exchange][frame maxima]
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
 
-    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
-    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
     const T preemph = static_cast<T>(p.preemph);
 
-    for (uint64_t unit = (uint64_t)blockIdx.x * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
+    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFbFPW;
         const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
