@@ -174,6 +174,11 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     b.frames_per_clip = frames_per_clip;
     b.out_width = out_width;
     b.mel_major = mel_major ? 1 : 0;
+    // mel-major stores keep the waves of a workgroup in step (one barrier per round): MELSPEC_MM_SYNC=0 switches that off,
+    // MELSPEC_FM_SYNC=1 switches it on for the padded frame-major layout too (both for A/B measurements)
+    static const bool mm_off = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); return e && e[0] == '0'; }();
+    static const bool fm_on = [] { const char *e = std::getenv("MELSPEC_FM_SYNC"); return e && e[0] == '1'; }();
+    b.sync_rounds = mel_major ? !mm_off : fm_on;
     b.units_per_clip = static_cast<uint32_t>((out_width + frames_per_unit - 1) / frames_per_unit);
     b.n_clips = n_clips;
     b.n_units = static_cast<uint64_t>(b.units_per_clip) * n_clips;

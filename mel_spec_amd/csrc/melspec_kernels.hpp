@@ -30,6 +30,7 @@ struct BatchDesc {
     uint64_t n_units;
     uint64_t out_width;        // uniform: output columns per clip (>= frames_per_clip; the excess is zero-filled)
     int mel_major;             // uniform: 0 = [frame][mel] rows, 1 = [mel][out_width] rows (interleave_frames, src/mel.rs:480-544)
+    int sync_rounds;           // LAYOUT kernels: re-align the waves of a workgroup once per round (set for mel-major stores)
     const uint64_t *d_off;       // ragged (device): first sample of clip c
     const uint64_t *d_frames;    // ragged: frames in clip c
     const uint64_t *d_out_off;   // ragged: first output float of clip c
@@ -161,14 +162,19 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
 
-    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
-        const UnitLoc loc = locate_unit(p.b, unit);
+    // LAYOUT builds walk the units workgroup-uniformly (a wave without a unit idles through the round) so that the
+    // mel-major store can re-align the waves once per round, see the end of the loop
+    const uint64_t w_off = LAYOUT ? 0 : wave;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t unit = LAYOUT ? first + wave : first;
+        const bool have = !LAYOUT || unit < p.b.n_units;
+        const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
+        const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
         const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
-        const uint64_t wleft = width - f0;
+        const uint64_t wleft = have ? width - f0 : 0;
         const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
 #if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 10
 #ifndef MELSPEC_ABL_MASK
@@ -217,6 +223,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         else
             wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         __builtin_amdgcn_wave_barrier();
+        // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
+        // reach L2 within microseconds of each other and leave it as one full line
+        if (LAYOUT && p.b.sync_rounds) __syncthreads();
     }
 }
 
@@ -258,14 +267,17 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
-    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
-        const UnitLoc loc = locate_unit(p.b, unit);
+    const uint64_t w_off = LAYOUT ? 0 : wave;      // LAYOUT: workgroup-uniform rounds, see whisper400_wave_kernel
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t unit = LAYOUT ? first + wave : first;
+        const bool have = !LAYOUT || unit < p.b.n_units;
+        const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = (!LAYOUT || f0 < loc.frames) ? loc.frames - f0 : 0;
+        const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
         const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
-        const uint64_t wleft = width - f0;
+        const uint64_t wleft = have ? width - f0 : 0;
         const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         else
             wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT && p.b.sync_rounds) __syncthreads();
     }
 }
 
