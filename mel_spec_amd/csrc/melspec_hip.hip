@@ -745,7 +745,8 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
         mark_device_done(attr_done);
     }
     const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
-    const unsigned grid = grid_for_xcd(blocks, cus, 8);
+    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_FB_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU; measured best
+    const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
     if (waves == 8)
         hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(512), lds, s, fp);
     else
