@@ -397,7 +397,8 @@ int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     pp.n_mels = c->n_mels;
     pp.slots = c->ft.slots;
     const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
-    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, 8);
+    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_PRECISE_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
     hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>), dim3(grid), dim3(kPreciseWaves * 64),
                        c->precise_lds, stream, pp);
     HIP_TRY(hipGetLastError());
