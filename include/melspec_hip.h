@@ -70,7 +70,7 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
 /* Arithmetic of the fused n_fft = 400 kernel.  Default (0): f32 FFT -- within ~3e-5 of the f64 reference
  * on speech/noise, up to ~9e-5 on a pure tone over a -70 dB noise floor (the bands at the per-frame clamp).
  * Precise (1): f64 window/FFT/power like the reference's own arithmetic (src/stft.rs:98-111), ~1e-6
- * everywhere, about a third of the throughput.  Geometries on the generic kernel are always f64. */
+ * everywhere, about 60 % of the throughput.  Geometries on the generic kernel are always f64. */
 int melspec_set_precise(melspec_ctx *ctx, int on);
 int melspec_is_precise(const melspec_ctx *ctx);
 
