@@ -153,6 +153,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
     const bool in = lane < kFPW * kMelJobs;
     // interval scheme: 12 lanes per frame in phases 3-4
+    int uoff, voff;
+    WaveLayout::row_offsets(j, uoff, voff);
     const int fl3 = INTERVAL ? lane / 12 : fl, j3 = INTERVAL ? lane - fl3 * 12 : j;
     const bool in3 = INTERVAL ? lane < kFPW * 12 : in;
     int st[NSLOTS];
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
 #endif
         __builtin_amdgcn_wave_barrier();
 #if !defined(MELSPEC_ABLATE) || (MELSPEC_ABLATE != 2 && MELSPEC_ABLATE != 12)
-        wave_phase2<!INTERVAL>(fl, j, act, blob, slice);
+        wave_phase2<!INTERVAL>(fl, j, act, blob, slice, uoff, voff);
 #endif
         __builtin_amdgcn_wave_barrier();
         float vals[NSLOTS];

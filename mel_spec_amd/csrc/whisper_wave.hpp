@@ -21,9 +21,23 @@ constexpr int kFPW = 5;   // frames per wavefront (5 * 11 = 55 of 64 lanes)
 struct WaveLayout {
     static constexpr int kXRow = 20;
     static constexpr int kXStride = 436;                 // == 20 (mod 32): conflict-free b64 row writes
-    static constexpr int kPStride = 201;
+    static constexpr int kPStride = 207;                 // power rows: 207 halves the write conflicts of 201 at equal read cost (tools/lds_sim2.py)
     static constexpr int kPmaxStride = 12;               // 11 maxima + 1 pad, 48 B rows (16-byte aligned)
-    static constexpr int kPmaxOff = 1008;                // after the 5 power rows (5*201 = 1005)
+    static constexpr int kPmaxOff = 1036;                // after the 5 power rows (5*207 = 1035)
+    // Where exchange row k1 lives inside a frame's block of 21 rows.  Phase 1 writes whole rows (any order is
+    // conflict-free); phase 2 reads rows j and 20-j (20 for j = 0) from 55 lanes at once, and with the rows in
+    // natural order the 16-byte reads of lanes from different frames collide 11 cycles per pair of reads; this
+    // order (hill-climbed on the bank model of tools/lds_sim.py, which reproduces SQ_LDS_BANK_CONFLICT) leaves 4.
+    MS_HD static constexpr int row_pos(int k1) {
+        constexpr int t[21] = {20, 1, 19, 9, 6, 8, 11, 3, 16, 5, 14, 7, 15, 17, 2, 12, 13, 0, 4, 18, 10};
+        return t[k1];
+    }
+    // per-lane constants of phase 2 (computed once per kernel: j is fixed per lane)
+    MS_HD static void row_offsets(int j, int &uoff, int &voff) {
+        uoff = 0; voff = 0;
+        for (int k = 0; k <= 10; ++k)            // a select chain, not an indexed load
+            if (k == j) { uoff = row_pos(k) * kXRow; voff = row_pos(k == 0 ? 20 : 20 - k) * kXRow; }
+    }
     static constexpr int slice_floats(int hop, bool staged) {
         const int x = kFPW * kXStride;                   // 2180
         const int pcm = staged ? (kFPW - 1) * hop + 400 : 0;
@@ -124,25 +138,25 @@ MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, 
     {
         const f2 m = *reinterpret_cast<const f2 *>(blob + FastBlob::kMod + 2 * t);
         const cf y = cmul(x[0], cf{m.x, m.y});
-        *reinterpret_cast<f2 *>(xo + 20 * WaveLayout::kXRow) = f2{y.re, y.im};
-        *reinterpret_cast<f2 *>(xo) = f2{x[0].re, x[0].im};
+        *reinterpret_cast<f2 *>(xo + WaveLayout::row_pos(20) * WaveLayout::kXRow) = f2{y.re, y.im};
+        *reinterpret_cast<f2 *>(xo + WaveLayout::row_pos(0) * WaveLayout::kXRow) = f2{x[0].re, x[0].im};
     }
 #pragma unroll
     for (int k1 = 1; k1 < 20; ++k1) {
         const f2 wv = *reinterpret_cast<const f2 *>(tw + 2 * k1);
         const cf y = cmul(x[k1], cf{wv.x, wv.y});
-        *reinterpret_cast<f2 *>(xo + k1 * WaveLayout::kXRow) = f2{y.re, y.im};
+        *reinterpret_cast<f2 *>(xo + WaveLayout::row_pos(k1) * WaveLayout::kXRow) = f2{y.re, y.im};
     }
 }
 
 // ---- phase 2: reads the exchange rows, writes the power row over the same slice ----------
 // SCALED: store |X|^2 (x 1/4 applied here); otherwise store 4*|X|^2 (the interval mel weights carry the 1/4).
 template <bool SCALED = true>
-MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *slice) {
+MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *slice, int uoff, int voff) {
     if (!active) return;
-    const int brow = (j == 0) ? 20 : 20 - j;
-    const float *ua = slice + fl * WaveLayout::kXStride + j * WaveLayout::kXRow;
-    const float *va = slice + fl * WaveLayout::kXStride + brow * WaveLayout::kXRow;
+    // uoff / voff: float offsets of rows j and 20-j (20 for j = 0) inside the frame's block, WaveLayout::row_offsets()
+    const float *ua = slice + fl * WaveLayout::kXStride + uoff;
+    const float *va = slice + fl * WaveLayout::kXStride + voff;
     cf u[10], v[10];
 #pragma unroll
     for (int i = 0; i < 5; ++i) {

@@ -88,7 +88,9 @@ static long long run_wave(const float *pcm, long long n, int hop, int n_mels, do
             const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
             const bool act = lane < kFPW * kMelJobs && fl < nv;
             std::vector<float> tmp(snap);
-            wave_phase2<!INTERVAL>(fl, j, act, T.blob.data(), tmp.data());
+            int uoff, voff;
+            WaveLayout::row_offsets(j, uoff, voff);
+            wave_phase2<!INTERVAL>(fl, j, act, T.blob.data(), tmp.data(), uoff, voff);
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
