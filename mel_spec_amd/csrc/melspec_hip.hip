@@ -429,8 +429,8 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
 }
 
 template <class Lens>
-bool lens_match(const MelSlots &ms) {
-    if (ms.n_slots != Lens::kSlots) return false;
+bool lens_match(const MelSlots &ms, int n_mels) {
+    if (ms.n_slots != Lens::kSlots || n_mels != Lens::kMels) return false;
     for (int i = 0; i < Lens::kSlots; ++i)
         if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
     return true;
@@ -489,9 +489,9 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     if (c->fast) {
         if (c->variant >= 7 && !c->ft.interval) c->variant = 5;   // filterbank is not two-filters-per-bin
         if (c->variant >= 7)
-            c->lens_kind = lens_match<LensI80>(c->ft.slots) ? 1 : (lens_match<LensI128>(c->ft.slots) ? 2 : 0);
+            c->lens_kind = lens_match<LensI80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensI128>(c->ft.slots, n_mels) ? 2 : 0);
         else
-            c->lens_kind = lens_match<LensW80>(c->ft.slots) ? 1 : (lens_match<LensW128>(c->ft.slots) ? 2 : 0);
+            c->lens_kind = lens_match<LensW80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensW128>(c->ft.slots, n_mels) ? 2 : 0);
         if (el && el[0] == '1') c->lens_kind = 0;
         if (c->variant == 0) {
             using L = FastLayout<kFPB>;

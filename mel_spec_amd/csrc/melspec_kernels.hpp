@@ -155,6 +155,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     // interval scheme: 12 lanes per frame in phases 3-4
     int uoff, voff;
     WaveLayout::row_offsets(j, uoff, voff);
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;     // compile-time for the two Whisper banks
     const int fl3 = INTERVAL ? lane / 12 : fl, j3 = INTERVAL ? lane - fl3 * 12 : j;
     const bool in3 = INTERVAL ? lane < kFPW * 12 : in;
     int st[NSLOTS];
@@ -214,16 +215,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
             wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
 #pragma unroll
             for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-            wave_phase3i_finish<NSLOTS>(fl3, j3, act3, p.n_mels, rise, fnext, slice, vals);
+            wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         } else {
-            wave_phase3<NSLOTS, Lens>(fl, j, act, p.n_mels, p.slots, blob, slice, vals);
+            wave_phase3<NSLOTS, Lens>(fl, j, act, n_mels, p.slots, blob, slice, vals);
         }
 #endif
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT && p.b.mel_major)
-            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0, (long long)width);
+            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
-            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
+            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
     float *slice = reinterpret_cast<float *>(rows);
     const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
     const bool in = lane < kFPW * kMelJobs;
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     int st[NSLOTS];
@@ -291,12 +293,12 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, fblob, slice, st, rise, fprev);
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-        wave_phase3i_finish<NSLOTS>(fl3, j3, act3, p.n_mels, rise, fnext, slice, vals);
+        wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT && p.b.mel_major)
-            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0, (long long)width);
+            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
-            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, p.n_mels, slice, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
+            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT && p.b.sync_rounds) __syncthreads();
     }

@@ -50,13 +50,15 @@ struct WaveLayout {
 struct LensRuntime {
     static constexpr bool kStatic = false;
     static constexpr int kSlots = kMaxSlots;
+    static constexpr int kMels = 0;
     MS_HD static int len(int) { return 0; }
     MS_HD static int woff(int) { return 0; }
 };
-template <int... L>
+template <int MELS, int... L>
 struct LensStatic {
     static constexpr bool kStatic = true;
     static constexpr int kSlots = sizeof...(L);
+    static constexpr int kMels = MELS;          // the mel count is part of the compile-time shape: store masks fold
     MS_HD static constexpr int len(int i) {
         constexpr int t[sizeof...(L)] = {L...};
         return t[i];
@@ -68,15 +70,16 @@ struct LensStatic {
         return FastBlob::kMelW + kMelJobs * s;
     }
 };
-using LensW80 = LensStatic<2, 2, 2, 4, 6, 8, 13, 14>;
-using LensW128 = LensStatic<2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 8, 9>;
+using LensW80 = LensStatic<80, 2, 2, 2, 4, 6, 8, 13, 14>;
+using LensW128 = LensStatic<128, 2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 8, 9>;
 
 // Interval scheme (build_interval_mel): padded interval lengths per slot, weights are float pairs
 // over 12 lanes, so a slot of length L occupies 24*L floats.
-template <int... L>
+template <int MELS, int... L>
 struct LensIntervalStatic {
     static constexpr bool kStatic = true;
     static constexpr int kSlots = sizeof...(L);
+    static constexpr int kMels = MELS;
     MS_HD static constexpr int len(int i) {
         constexpr int t[sizeof...(L)] = {L...};
         return t[i];
@@ -88,8 +91,8 @@ struct LensIntervalStatic {
         return FastBlob::kMelW + 24 * s;
     }
 };
-using LensI80 = LensIntervalStatic<1, 1, 1, 2, 3, 4, 7, 7>;
-using LensI128 = LensIntervalStatic<1, 1, 1, 1, 1, 1, 2, 2, 3, 3, 4, 5>;
+using LensI80 = LensIntervalStatic<80, 1, 1, 1, 2, 3, 4, 7, 7>;
+using LensI128 = LensIntervalStatic<128, 1, 1, 1, 1, 1, 1, 2, 2, 3, 3, 4, 5>;
 
 // 8-byte load from a pointer that is only 4-byte aligned (clip offsets are arbitrary).
 MS_DEV f2 load2_unaligned(const float *p) {
