@@ -20,9 +20,10 @@ struct FbankFastTables {
 // needs more than `max_slots` slots of 15 intervals.
 template <class T>
 inline bool build_fused512_tables(const std::vector<double> &window, const std::vector<double> &dense, int n_mels,
-                                  double scale, int max_slots, FbankFastTables &out) {
-    constexpr int N = 512, FL = 400;
-    if (n_mels < 1 || n_mels > kFbOwn * max_slots - 1 || static_cast<int>(window.size()) != FL) return false;
+                                  double scale, int max_slots, FbankFastTables &out, int bin_limit = 257) {
+    constexpr int N = 512;
+    const int FL = static_cast<int>(window.size());       // 400 taps (Kaldi, NeMo) or 512 (Whisper flavour)
+    if (n_mels < 1 || n_mels > kFbOwn * max_slots - 1 || (FL != 400 && FL != 512)) return false;
     std::vector<T> t(FbankBlob::kTCount, T(0));
     for (int i = 0; i < FL; ++i) t[FbankBlob::kWin + i] = static_cast<T>(window[i]);
     for (int n2 = 0; n2 < 16; ++n2)
@@ -39,7 +40,7 @@ inline bool build_fused512_tables(const std::vector<double> &window, const std::
         }
     const int bins = N / 2 + 1;
     std::vector<float> mel(FbankBlob::kMelW, 0.0f);
-    if (!build_interval_mel(dense, n_mels, bins, bins, mel, out.slots, kFbLanes, scale, FbankBlob::kMelStart, max_slots))
+    if (!build_interval_mel(dense, n_mels, bins, bin_limit, mel, out.slots, kFbLanes, scale, FbankBlob::kMelStart, max_slots))
         return false;
     while (mel.size() % 4) mel.push_back(0.0f);
     const size_t t_words = t.size() * sizeof(T) / 4;
@@ -76,6 +77,14 @@ inline bool build_blm_fast_tables(int sample_rate, int n_mels, double f_min, dou
     std::vector<double> dense = mel_filterbank(static_cast<double>(sample_rate), 512, n_mels, f_min > 0.0 ? f_min : -1.0, f_max, htk, norm);
     for (double &w : dense) w = static_cast<double>(static_cast<float>(w));
     return build_fused512_tables<T>(win, dense, n_mels, 0.25, kBlmSlots, out);
+}
+
+// Whisper flavour at n_fft = 512: periodic Hann(512) (src/stft.rs:141-145), Slaney mel() over 257 bins of which
+// project_stft_log10 uses those below n_fft/2 = 256 (src/mel.rs:155-163).
+template <class T>
+inline bool build_whisper512_tables(double sample_rate, int n_mels, FbankFastTables &out) {
+    const std::vector<double> dense = mel_filterbank(sample_rate, 512, n_mels, -1.0, -1.0, false, true);
+    return build_fused512_tables<T>(hann_window(512), dense, n_mels, 0.25, kBlmSlots, out, 256);
 }
 
 }  // namespace melspec

@@ -43,12 +43,12 @@ constexpr int kBlmSlots = 10;    // up to 149 mel bins (NeMo/Parakeet uses 80 or
 
 // Table blob: a T-typed part (offsets in units of T) followed by the f32/int mel section.
 struct FbankBlob {
-    static constexpr int kWin = 0;                         // [400] Povey window
+    static constexpr int kWin = 0;                         // [512] window taps (400 used by the Kaldi / NeMo flavours)
     static constexpr int kTw1Stride = 36;                  // 16 complex + 4 pad
-    static constexpr int kTw1 = 400;                       // [16 n2][36] W_256^{n2*k1}
+    static constexpr int kTw1 = 512;                       // [16 n2][36] W_256^{n2*k1}
     static constexpr int kTw2Stride = 20;                  // 9 complex + 2 pad: conflict-free 16-byte reads over a row's lanes
     static constexpr int kTw2 = kTw1 + 16 * kTw1Stride;    // [16 r][20] complex W_512^{r+16s}, s = 0..8
-    static constexpr int kTCount = kTw2 + 16 * kTw2Stride; // 1296 elements of T
+    static constexpr int kTCount = kTw2 + 16 * kTw2Stride; // 1408 elements of T
     // mel section, float offsets from its own base
     static constexpr int kMelStart = 0;                                // [kBlmSlots*16] ints
     static constexpr int kMelW = (kBlmSlots * kFbLanes + 3) & ~3;      // pairs [slot][r][16][2]
@@ -120,6 +120,24 @@ MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this fra
                       T mean, T preemph, const T *tblob, T *slice) {
     if (!active) return;
     fb_column<T>(frame, t, preemph, mean, clip_start && t == 0, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
+}
+
+// ---- Whisper flavour with n_fft = 512 (Spectrogram::compute_mel_spectrogram_cpu, src/stft.rs:119-138, at the
+// geometry the reference's RingBuffer golden test and its WGPU tests use: 512/160/80) --------------------------
+// Frame = 512 samples, periodic Hann(512), no pre-emphasis / DC removal: every one of the 16 inputs of a column is a
+// real sample pair.  Phase 2 is shared; the epilogue is Whisper's log10 / max-8 clamp / (x+4)/4.
+template <class T>
+MS_DEV void w512_phase1(int fl, int t, bool active, const float *frame, const T *tblob, T *slice) {
+    if (!active) return;
+    cpx<T> x[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        const int i = 32 * n1 + 2 * t;
+        const f2 s = load2_unaligned(frame + i);
+        const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
+        x[n1] = {static_cast<T>(s.x) * w.re, static_cast<T>(s.y) * w.im};
+    }
+    fb_column_finish<T>(x, t, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
 }
 
 // ---- NeMo/Parakeet flavour (BatchLogMelSpectrogram, src/mel.rs:299-385) --------------------------
@@ -292,6 +310,42 @@ MS_DEV void nemo_phase3_store(int fl, int j, bool store, bool valid, int n_mels,
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kFbOwn * i;
         if (m < n_mels) o[static_cast<long long>(kFbOwn * i) * row_w] = valid ? fast_ln((rise[i] + fnext[i]) + guard) : 0.0f;
+    }
+}
+
+// Whisper epilogue for the 512 flavour.  log10(max(E, 1e-10)) (src/mel.rs:148-168); the frame maximum goes through
+// 16 LDS words per frame (pmax, behind the power rows), then max(x, mx - 8), (x + 4) / 4 (src/mel.rs:645-654).
+constexpr int kW512PmaxOff = kFbFPW * 259 + 4;       // float offset of the maxima inside the slice (16-byte aligned)
+template <int NSLOTS>
+MS_DEV void w512_phase3_log(int fl, int j, bool active, int n_mels, const float (&rise)[NSLOTS], const float (&fnext)[NSLOTS],
+                            float *slice_f, float (&vals)[NSLOTS]) {
+    if (!active) return;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const float e = rise[i] + fnext[i];
+        const float v = e > 1e-10f ? fast_log2(e) * 0.30102999566398120f : -10.0f;
+        vals[i] = v;
+        if (j < kFbOwn && j + kFbOwn * i < n_mels) mx = __builtin_fmaxf(mx, v);
+    }
+    slice_f[kW512PmaxOff + fl * kFbLanes + j] = mx;
+}
+template <int NSLOTS>
+MS_DEV void w512_phase4(int fl, int j, bool active, int n_mels, const float *slice_f, const float (&vals)[NSLOTS], float *out_tile) {
+    if (!active || j >= kFbOwn) return;
+    const float *pm = slice_f + kW512PmaxOff + fl * kFbLanes;
+    float lo = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < kFbLanes; k += 4) {
+        const f4 a = *reinterpret_cast<const f4 *>(pm + k);
+        lo = __builtin_fmaxf(lo, __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w)));
+    }
+    lo -= 8.0f;
+    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const int m = j + kFbOwn * i;
+        if (m < n_mels) o[kFbOwn * i] = (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f;
     }
 }
 

@@ -179,6 +179,7 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     static const bool mm_off = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); return e && e[0] == '0'; }();
     static const bool fm_on = [] { const char *e = std::getenv("MELSPEC_FM_SYNC"); return e && e[0] == '1'; }();
     b.sync_rounds = mel_major ? !mm_off : fm_on;
+    b.frames_per_unit = frames_per_unit;
     b.units_per_clip = static_cast<uint32_t>((out_width + frames_per_unit - 1) / frames_per_unit);
     b.n_clips = n_clips;
     b.n_units = static_cast<uint64_t>(b.units_per_clip) * n_clips;
@@ -210,7 +211,7 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
     const uint64_t *d = static_cast<const uint64_t *>(rs.buf.p);
     BatchDesc &b = pl.desc;
     b = BatchDesc{};
-    b.pcm = d_pcm; b.out = d_out; b.n_clips = n_clips; b.n_units = units;
+    b.pcm = d_pcm; b.out = d_out; b.n_clips = n_clips; b.n_units = units; b.frames_per_unit = frames_per_unit;
     b.d_off = d; b.d_frames = d + n_clips; b.d_out_off = d + 2 * n_clips; b.d_unit_prefix = d + 3 * n_clips;
     pl.total_frames = total;
     return MELSPEC_OK;
@@ -251,6 +252,36 @@ int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, bool
 
 }  // namespace
 
+namespace {
+// Waves per workgroup of the fused 512-point kernels: 8 (two per SIMD, one workgroup per CU) when the tables
+// and eight 18.5 KB slices fit in LDS, else 4.  MELSPEC_FB_WAVES=4 forces the small shape.
+int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
+    const char *e = std::getenv("MELSPEC_FB_WAVES");
+    if (e && std::atoi(e) == 4) return 4;
+    return blob_bytes + 8 * slice_bytes <= kLdsLimit ? 8 : 4;
+}
+
+template <class T, int FLAVOR, int NSLOTS>
+int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
+    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
+        if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
+    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_FB_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU; measured best
+    const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
+    if (waves == 8)
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(512), lds, s, fp);
+    else
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(256), lds, s, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------
 // Whisper log-mel context
 // ------------------------------------------------------------------------------------
@@ -270,6 +301,12 @@ struct melspec_ctx {
     int slice_floats = 0;
     int frames_per_unit = 1;
     int grid_per_cu = 4;    // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops (2 are resident; 4 measured best)
+    // fused n_fft = 512 build (f64, Whisper flavour of the 512-point kernel): plain and ragged batches
+    bool fast512 = false;
+    FbankFastTables ft512;
+    DevBuf d_blob512;
+    size_t lds512 = 0;
+    int waves512 = 4;
     // precise (f64 FFT) build of the fused kernel, melspec_set_precise
     bool precise = false;
     PreciseTables pt;
@@ -283,6 +320,13 @@ struct melspec_ctx {
 };
 
 namespace {
+
+// frames per work unit of the kernel a batch will run on; `plain`: [frame][mel] output without padding (the
+// fused 512 build stores nothing else, its other layouts go through the generic kernel, one frame per unit)
+int ctx_frames_per_unit(const melspec_ctx *c, bool plain) {
+    if (c->fast) return c->frames_per_unit;
+    return c->fast512 && plain ? kFbFPW : 1;
+}
 
 int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
     frames = n < static_cast<uint64_t>(c->fft_size) ? 0 : (n - c->fft_size) / c->hop_size + 1;
@@ -412,6 +456,19 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
 
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     if (desc.n_units == 0) return MELSPEC_OK;
+    if (!c->fast && c->fast512 && desc.frames_per_unit == kFbFPW) {
+        FbankFastParams fp{};
+        fp.b = desc;
+        fp.d_blob = static_cast<const uint32_t *>(c->d_blob512.p);
+        fp.blob_words = static_cast<int>(c->ft512.blob.size());
+        fp.mel_off_words = c->ft512.mel_off_words;
+        fp.shift = c->hop_size;
+        fp.n_mels = c->n_mels;
+        fp.use_log = 1; fp.use_power = 1;
+        fp.slots = c->ft512.slots;
+        return c->ft512.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorWhisper, kFbSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream)
+                                                  : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
+    }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precise) {
         if (c->ft.slots.n_slots <= 8)
@@ -507,11 +564,20 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         }
         if (c->fast_lds > kLdsLimit) c->fast = false;
     }
+    if (!c->fast && fft_size == 512 && !(std::getenv("MELSPEC_W512") && std::getenv("MELSPEC_W512")[0] == '0') &&
+        build_whisper512_tables<double>(sampling_rate, n_mels, c->ft512)) {
+        const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double) + 512;      // + the frame maxima
+        c->waves512 = fused512_waves(c->ft512.blob.size() * 4, slice_bytes);
+        c->lds512 = c->ft512.blob.size() * 4 + static_cast<size_t>(c->waves512) * slice_bytes;
+        c->fast512 = c->lds512 <= kLdsLimit;
+        if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
+    }
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
         if ((rc = allow_big_lds(&whisper400_kernel<kFPB, kNT, 8>, "hipFuncSetAttribute(whisper400_kernel<8>)"))) return bail(rc);
         if ((rc = allow_big_lds(&whisper400_kernel<kFPB, kNT, 12>, "hipFuncSetAttribute(whisper400_kernel<12>)"))) return bail(rc);
-    } else {
+    }
+    if (!c->fast) {          // the generic kernel also serves the layouts the fused 512 build does not store
         const int bins = fft_size / 2 + 1;
         const std::vector<double> dense = mel_filterbank(sampling_rate, fft_size, n_mels, -1.0, -1.0, false, true);
         // bins >= n_fft/2 contribute nothing (src/mel.rs:155-163)
@@ -531,7 +597,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
     delete c;
 }
 
@@ -543,7 +609,7 @@ size_t melspec_num_frames(const melspec_ctx *c, size_t n_samples) {
 int melspec_fft_size(const melspec_ctx *c) { return c ? c->fft_size : 0; }
 int melspec_hop_size(const melspec_ctx *c) { return c ? c->hop_size : 0; }
 int melspec_n_mels(const melspec_ctx *c) { return c ? c->n_mels : 0; }
-int melspec_uses_fast_path(const melspec_ctx *c) { return c && c->fast ? 1 : 0; }
+int melspec_uses_fast_path(const melspec_ctx *c) { return c && (c->fast || c->fast512) ? 1 : 0; }
 
 int melspec_set_precise(melspec_ctx *c, int on) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
@@ -561,7 +627,7 @@ int melspec_set_precise(melspec_ctx *c, int on) {
     c->precise = true;
     return MELSPEC_OK;
 }
-int melspec_is_precise(const melspec_ctx *c) { return c && (c->precise || !c->fast) ? 1 : 0; }
+int melspec_is_precise(const melspec_ctx *c) { return c && (c->precise || !c->fast) ? 1 : 0; }   // generic and fused-512 paths are f64
 
 int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                    uint32_t n_clips, float *d_out, void *stream) {
@@ -574,7 +640,7 @@ int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t 
         return fail(MELSPEC_ERR_INVALID_ARG, "clip_stride smaller than clip_len");
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? c->frames_per_unit : 1);
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c, true));
     return launch_ctx(c, pl.desc, s);
 }
 
@@ -603,7 +669,7 @@ int melspec_compute_uniform_device_interleaved(melspec_ctx *c, const float *d_pc
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (c->fast && c->variant == 0) return fail(MELSPEC_ERR_UNSUPPORTED, "the block kernel (MELSPEC_VARIANT=0) has no layout option");
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, c->fast ? c->frames_per_unit : 1,
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c, false),
                                       interleaved_width(fpc, min_width), major_column_order == 0);
     return launch_ctx(c, pl.desc, s);
 }
@@ -623,7 +689,7 @@ int melspec_compute_ragged_device(melspec_ctx *c, const float *d_pcm, const uint
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     BatchPlan pl;
     int rc = plan_ragged(c->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, c->n_mels,
-                         c->fast ? c->frames_per_unit : 1, pl);
+                         ctx_frames_per_unit(c, true), pl);
     if (rc) return rc;
     return launch_ctx(c, pl.desc, s);
 }
@@ -727,35 +793,6 @@ struct melspec_fbank {
     DevBuf h2d, d2h;
 };
 
-namespace {
-// Waves per workgroup of the fused 512-point kernels: 8 (two per SIMD, one workgroup per CU) when the tables
-// and eight 18.5 KB slices fit in LDS, else 4.  MELSPEC_FB_WAVES=4 forces the small shape.
-int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
-    const char *e = std::getenv("MELSPEC_FB_WAVES");
-    if (e && std::atoi(e) == 4) return 4;
-    return blob_bytes + 8 * slice_bytes <= kLdsLimit ? 8 : 4;
-}
-
-template <class T, int FLAVOR, int NSLOTS>
-int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
-    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
-    if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
-        if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
-        if (rc) return rc;
-        mark_device_done(attr_done);
-    }
-    const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
-    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_FB_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU; measured best
-    const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
-    if (waves == 8)
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(512), lds, s, fp);
-    else
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(256), lds, s, fp);
-    HIP_TRY(hipGetLastError());
-    return MELSPEC_OK;
-}
-}  // namespace
 
 namespace {
 uint64_t fbank_frames(const melspec_fbank *fb, uint64_t n) {

@@ -30,6 +30,7 @@ struct BatchDesc {
     uint64_t n_units;
     uint64_t out_width;        // uniform: output columns per clip (>= frames_per_clip; the excess is zero-filled)
     int mel_major;             // uniform: 0 = [frame][mel] rows, 1 = [mel][out_width] rows (interleave_frames, src/mel.rs:480-544)
+    int frames_per_unit;       // frames a work unit covers (set by the planner; picks the kernel on contexts that have two)
     int sync_rounds;           // LAYOUT kernels: re-align the waves of a workgroup once per round (set for mel-major stores)
     const uint64_t *d_off;       // ragged (device): first sample of clip c
     const uint64_t *d_frames;    // ragged: frames in clip c
@@ -323,9 +324,11 @@ struct FbankFastParams {
     MelSlots slots;
 };
 
-constexpr int kFlavorKaldi = 0, kFlavorNemo = 1;
+constexpr int kFlavorKaldi = 0, kFlavorNemo = 1, kFlavorWhisper = 2;
 
 // FLAVOR = Kaldi: Fbank::compute (src/fbank.rs:141-236), frame-major output, CMN by cmn_kernel.
+// FLAVOR = Whisper: compute_mel_spectrogram_cpu at n_fft = 512 (src/stft.rs:119-138): 512-sample frames, Hann,
+//                 log10 / per-frame clamp / (x+4)/4, frame-major output (plain and ragged batches).
 // FLAVOR = NeMo:  BatchLogMelSpectrogram::compute (src/mel.rs:321-385), feature-major output of
 //                 b.out_width columns per mel row (columns past the valid frames are zero).
 template <class T, int WAVES, int MINW, int FLAVOR = kFlavorKaldi, int NSLOTS = kFbSlots>
@@ -372,6 +375,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             }
             __builtin_amdgcn_wave_barrier();
             fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+        } else if (FLAVOR == kFlavorWhisper) {
+            w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
         } else {
             const long long org = (long long)(f0 + (uint64_t)fl) * p.shift + p.org0;
             nemo_phase1<T>(fl, j, act, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
@@ -391,6 +396,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
         if (FLAVOR == kFlavorKaldi) {
             fb_phase3_store<NSLOTS>(fl, j, act, p.n_mels, p.floor_v, use_log, rise, fnext, loc.out + f0 * (uint64_t)p.n_mels);
+        } else if (FLAVOR == kFlavorWhisper) {
+            float vals[NSLOTS];
+            float *slice_f = reinterpret_cast<float *>(slice);
+            w512_phase3_log<NSLOTS>(fl, j, act, p.n_mels, rise, fnext, slice_f, vals);
+            __builtin_amdgcn_wave_barrier();
+            w512_phase4<NSLOTS>(fl, j, act, p.n_mels, slice_f, vals, loc.out + f0 * (uint64_t)p.n_mels);
         } else {
             const uint64_t wleft = p.b.out_width - f0;
             const int ns = wleft < (uint64_t)kFbFPW ? (int)wleft : kFbFPW;

@@ -557,3 +557,71 @@ extern "C" long long emu_vad_boundaries(const float *img, uint32_t height, uint3
     for (uint32_t x = 0; x < n; ++x) smoothed[x] = vad_smooth_at(raw, n, x);
     return n;
 }
+
+// ---- Whisper flavour of the fused 512-point kernel (w512_phase1 / fb_phase2_* / fb_phase3_sums / w512_phase3_log / w512_phase4) ----
+extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+    using T = double;
+    using L = FbankLayout<T>;
+    constexpr int NS = kBlmSlots;
+    FbankFastTables F;
+    if (!build_whisper512_tables<T>(sr, n_mels, F)) return -1;
+    const T *tblob = reinterpret_cast<const T *>(F.blob.data());
+    const float *mel = reinterpret_cast<const float *>(F.blob.data() + F.mel_off_words);
+    if (n < 512) return 0;
+    const long long frames = (n - 512) / hop + 1;
+    std::vector<T> slice(L::slice_elems());
+    const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+    for (long long f0 = 0; f0 < frames; f0 += kFbFPW) {
+        const int nv = static_cast<int>(std::min<long long>(kFbFPW, frames - f0));
+        std::fill(slice.begin(), slice.end(), T(1.0e30));
+        auto lane_info = [&](int lane, int &fl, int &j, bool &act) {
+            fl = lane / kFbLanes; j = lane - fl * kFbLanes; act = lane < kFbFPW * kFbLanes && fl < nv;
+        };
+        std::vector<T> snap(slice), next(slice);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            std::vector<T> tmp(snap);
+            w512_phase1<T>(fl, j, act, pcm + (f0 + (act ? fl : 0)) * hop, tblob, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        std::vector<cpx<T>> own(64 * 16);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            fb_phase2_dft<T>(fl, j, act, snap.data(), *reinterpret_cast<cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            std::vector<T> tmp(snap);
+            cpx<T> part[8];
+            const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);
+            for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
+            fb_phase2_split<T>(fl, j, act, true, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]), part, tmp.data());
+            const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
+            uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
+            for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];
+        }
+        slice = next;
+        float *slice_f = reinterpret_cast<float *>(slice.data());
+        std::vector<float> rise(64 * NS), fprev(65 * NS, 0.0f), vals(64 * NS);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            int st[NS];
+            for (int i = 0; i < NS; ++i) st[i] = starts[i * kFbLanes + j];
+            fb_phase3_sums<T, NS>(fl, j, act, F.slots, mel, slice.data(), st,
+                                  *reinterpret_cast<float(*)[NS]>(&rise[static_cast<size_t>(lane) * NS]),
+                                  *reinterpret_cast<float(*)[NS]>(&fprev[static_cast<size_t>(lane) * NS]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            w512_phase3_log<NS>(fl, j, act, n_mels, *reinterpret_cast<const float(*)[NS]>(&rise[static_cast<size_t>(lane) * NS]),
+                                *reinterpret_cast<const float(*)[NS]>(&fprev[static_cast<size_t>(lane + 1) * NS]), slice_f,
+                                *reinterpret_cast<float(*)[NS]>(&vals[static_cast<size_t>(lane) * NS]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            w512_phase4<NS>(fl, j, act, n_mels, slice_f, *reinterpret_cast<const float(*)[NS]>(&vals[static_cast<size_t>(lane) * NS]), out + f0 * n_mels);
+        }
+    }
+    return frames;
+}

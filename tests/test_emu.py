@@ -27,6 +27,8 @@ def emu():
     L.emu_whisper_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
     L.emu_whisper_precise.restype = C.c_longlong
     L.emu_whisper_precise.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
+    L.emu_w512_wave.restype = C.c_longlong
+    L.emu_w512_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
     L.emu_blm_wave.restype = C.c_longlong
     L.emu_blm_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                C.c_float, C.c_int, C.c_float, C.c_longlong, f32p]
@@ -236,3 +238,31 @@ def test_nemo_frontend_fused_f64_matches_oracle(emu, oracle, jfk, kw):
         assert got == valid and np.abs(out - want).max() <= 2e-5
         lit, _ = oracle.blm_compute(x, cfg, False)
         assert np.abs(out - lit).max() < 5e-3 and np.abs(out - lit).mean() < 1e-5
+
+
+# ---- Whisper flavour of the fused 512-point kernel (n_fft = 512, f64 FFT) -----------------------------------
+
+def _w512(emu, x, hop=160, n_mels=80, sr=16000.0):
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 512 else (len(x) - 512) // hop + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    f32p = C.POINTER(C.c_float)
+    assert emu.lib.emu_w512_wave(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, out.ctypes.data_as(f32p)) == nf
+    return out
+
+
+def test_whisper512_flavour_reproduces_the_reference_golden(emu, jfk):
+    """rust_jfk_golden.npy (src/rb.rs:134-179, 512/160/80, @1e-6 in the reference) = batch frames of samples[128:]."""
+    want = np.load(os.path.join(ROOT, "tests", "golden", "rust_jfk_golden.npy"))
+    got = _w512(emu, jfk[128:])
+    assert got[:1097].T.shape == want.shape and np.abs(got[:1097].T - want).max() <= 1e-6
+
+
+@pytest.mark.parametrize("hop,n_mels,sr,n", [(160, 80, 16000.0, 40000), (128, 128, 16000.0, 20000), (200, 40, 8000.0, 9000), (161, 80, 16000.0, 9000),
+                                             (160, 80, 16000.0, 512), (160, 80, 16000.0, 512 + 3 * 160), (160, 80, 16000.0, 512 + 4 * 160 + 7)])
+def test_whisper512_flavour_matches_oracle(emu, oracle, jfk, hop, n_mels, sr, n):
+    x = jfk[20000:20000 + n]
+    want = oracle.compute_mel_spectrogram_cpu(x, 512, hop, n_mels, sr)
+    got = _w512(emu, x, hop, n_mels, sr)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    assert _w512(emu, np.zeros(511, np.float32)).shape == (0, 80)

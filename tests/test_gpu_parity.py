@@ -430,3 +430,33 @@ def test_nemo_per_feature_normalisation_row_lengths(gpu, oracle, seconds, frames
     assert wvalid == frames and got.shape == want.shape
     assert np.abs(got - want).max() <= TOL
     fe.close()
+
+
+def test_fused_512_whisper_flavour(gpu, oracle, jfk):
+    """n_fft = 512 (the geometry of the reference's RingBuffer golden and WGPU tests) on the f64 512-point kernel:
+    plain, batched, ragged and streamed; padded / mel-major layouts fall back to the generic kernel and agree."""
+    for hop, n_mels, sr in ((160, 80, SR), (128, 128, SR), (200, 40, 8000.0), (161, 80, SR)):
+        m = gpu.HipMelSpectrogram(512, hop, sr, n_mels)
+        assert m.uses_fast_path and m.precise
+        x = jfk[20000:61000]
+        want = oracle.compute_mel_spectrogram_cpu(x, 512, hop, n_mels, sr)
+        got = m.compute_mel_spectrogram(x)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+        for n in (0, 511, 512, 512 + 3 * hop, 512 + 4 * hop + 7):
+            y = oracle.synth_pcm(5, n)
+            g = m.compute_mel_spectrogram(y)
+            w = oracle.compute_mel_spectrogram_cpu(y, 512, hop, n_mels, sr)
+            assert g.shape == w.shape and (g.size == 0 or np.abs(g - w).max() <= 2e-6)
+        clips = np.stack([oracle.synth_pcm(c, 8000) for c in range(21)])
+        b = m.compute_batch(clips)
+        for c in (0, 9, 20):
+            assert np.abs(b[c] - oracle.compute_mel_spectrogram_cpu(clips[c], 512, hop, n_mels, sr)).max() <= 2e-6
+        rag = m.compute_ragged([jfk[:3000], np.zeros(0, np.float32), jfk[100:700], jfk[5:9000]])
+        for r, src in zip(rag, (jfk[:3000], np.zeros(0, np.float32), jfk[100:700], jfk[5:9000])):
+            w = oracle.compute_mel_spectrogram_cpu(src, 512, hop, n_mels, sr)
+            assert r.shape == w.shape and (r.size == 0 or np.abs(r - w).max() <= 2e-6)
+        il = m.compute_batch_interleaved(clips[:3], False, 0)             # generic kernel, one frame per unit
+        for c in range(3):
+            w = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(clips[c], 512, hop, n_mels, sr), False, 0)
+            assert il[c].shape == w.shape and np.abs(il[c] - w).max() <= 2e-6
+        m.close()
