@@ -330,22 +330,29 @@ MS_DEV void w512_phase3_log(int fl, int j, bool active, int n_mels, const float 
     }
     slice_f[kW512PmaxOff + fl * kFbLanes + j] = mx;
 }
+// store: this lane's column exists in the output; valid: it is a real frame (otherwise a zero column of a padded
+// layout).  row_w == 0: [frame][mel] rows of n_mels; row_w > 0: [mel][row_w] rows (interleave_frames, src/mel.rs:480-544).
 template <int NSLOTS>
-MS_DEV void w512_phase4(int fl, int j, bool active, int n_mels, const float *slice_f, const float (&vals)[NSLOTS], float *out_tile) {
-    if (!active || j >= kFbOwn) return;
-    const float *pm = slice_f + kW512PmaxOff + fl * kFbLanes;
-    float lo = -3.0e38f;
+MS_DEV void w512_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice_f, const float (&vals)[NSLOTS],
+                        float *out_tile, long long row_w) {
+    if (!store || j >= kFbOwn) return;
+    float lo = 0.0f;
+    if (valid) {
+        const float *pm = slice_f + kW512PmaxOff + fl * kFbLanes;
+        lo = -3.0e38f;
 #pragma unroll
-    for (int k = 0; k < kFbLanes; k += 4) {
-        const f4 a = *reinterpret_cast<const f4 *>(pm + k);
-        lo = __builtin_fmaxf(lo, __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w)));
+        for (int k = 0; k < kFbLanes; k += 4) {
+            const f4 a = *reinterpret_cast<const f4 *>(pm + k);
+            lo = __builtin_fmaxf(lo, __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w)));
+        }
+        lo -= 8.0f;
     }
-    lo -= 8.0f;
-    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+    float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
+    const long long step = row_w ? kFbOwn * row_w : kFbOwn;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kFbOwn * i;
-        if (m < n_mels) o[kFbOwn * i] = (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f;
+        if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
     }
 }
 

@@ -321,11 +321,10 @@ struct melspec_ctx {
 
 namespace {
 
-// frames per work unit of the kernel a batch will run on; `plain`: [frame][mel] output without padding (the
-// fused 512 build stores nothing else, its other layouts go through the generic kernel, one frame per unit)
-int ctx_frames_per_unit(const melspec_ctx *c, bool plain) {
+// frames per work unit of the kernel a batch will run on
+int ctx_frames_per_unit(const melspec_ctx *c, bool) {
     if (c->fast) return c->frames_per_unit;
-    return c->fast512 && plain ? kFbFPW : 1;
+    return c->fast512 ? kFbFPW : 1;
 }
 
 int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {

@@ -401,7 +401,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             float *slice_f = reinterpret_cast<float *>(slice);
             w512_phase3_log<NSLOTS>(fl, j, act, p.n_mels, rise, fnext, slice_f, vals);
             __builtin_amdgcn_wave_barrier();
-            w512_phase4<NSLOTS>(fl, j, act, p.n_mels, slice_f, vals, loc.out + f0 * (uint64_t)p.n_mels);
+            // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
+            const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+            const uint64_t wleft = width - f0;
+            const int ns = wleft < (uint64_t)kFbFPW ? (int)wleft : kFbFPW;
+            if (p.b.mel_major)
+                w512_phase4<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, slice_f, vals, loc.out + f0, (long long)width);
+            else
+                w512_phase4<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, slice_f, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         } else {
             const uint64_t wleft = p.b.out_width - f0;
             const int ns = wleft < (uint64_t)kFbFPW ? (int)wleft : kFbFPW;

@@ -620,7 +620,7 @@ extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n
         }
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
-            w512_phase4<NS>(fl, j, act, n_mels, slice_f, *reinterpret_cast<const float(*)[NS]>(&vals[static_cast<size_t>(lane) * NS]), out + f0 * n_mels);
+            w512_phase4<NS>(fl, j, act, act, n_mels, slice_f, *reinterpret_cast<const float(*)[NS]>(&vals[static_cast<size_t>(lane) * NS]), out + f0 * n_mels, 0);
         }
     }
     return frames;

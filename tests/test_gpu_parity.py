@@ -434,7 +434,7 @@ def test_nemo_per_feature_normalisation_row_lengths(gpu, oracle, seconds, frames
 
 def test_fused_512_whisper_flavour(gpu, oracle, jfk):
     """n_fft = 512 (the geometry of the reference's RingBuffer golden and WGPU tests) on the f64 512-point kernel:
-    plain, batched, ragged and streamed; padded / mel-major layouts fall back to the generic kernel and agree."""
+    plain, batched, ragged, streamed, and the padded / mel-major layouts of interleave_frames."""
     for hop, n_mels, sr in ((160, 80, SR), (128, 128, SR), (200, 40, 8000.0), (161, 80, SR)):
         m = gpu.HipMelSpectrogram(512, hop, sr, n_mels)
         assert m.uses_fast_path and m.precise
@@ -455,8 +455,9 @@ def test_fused_512_whisper_flavour(gpu, oracle, jfk):
         for r, src in zip(rag, (jfk[:3000], np.zeros(0, np.float32), jfk[100:700], jfk[5:9000])):
             w = oracle.compute_mel_spectrogram_cpu(src, 512, hop, n_mels, sr)
             assert r.shape == w.shape and (r.size == 0 or np.abs(r - w).max() <= 2e-6)
-        il = m.compute_batch_interleaved(clips[:3], False, 0)             # generic kernel, one frame per unit
-        for c in range(3):
-            w = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(clips[c], 512, hop, n_mels, sr), False, 0)
-            assert il[c].shape == w.shape and np.abs(il[c] - w).max() <= 2e-6
+        for major, min_width in ((False, 0), (False, 100), (True, 2), (True, 64)):
+            il = m.compute_batch_interleaved(clips[:3], major, min_width)
+            for c in range(3):
+                w = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(clips[c], 512, hop, n_mels, sr), major, min_width)
+                assert il[c].shape == w.shape and np.abs(il[c] - w).max() <= 2e-6
         m.close()
