@@ -461,3 +461,39 @@ def test_fused_512_whisper_flavour(gpu, oracle, jfk):
                 w = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(clips[c], 512, hop, n_mels, sr), major, min_width)
                 assert il[c].shape == w.shape and np.abs(il[c] - w).max() <= 2e-6
         m.close()
+
+
+def test_seeded_sweep_of_geometries_and_lengths(gpu, oracle, jfk):
+    """60 seeded (n_fft, hop, n_mels, sr, length, precise) combinations across the fused-400 (f32 and precise), fused-512
+    and generic kernels, each against the oracle on a random slice of jfk_f32le.wav."""
+    rng = np.random.default_rng(20260928)
+    worst = {}
+    for _ in range(60):
+        fft = int(rng.choice([400, 400, 400, 512, 512, 256, 320, 1024]))
+        hop = int(rng.choice([80, 128, 160, 161, 200, 256, 320]))
+        n_mels = int(rng.choice([1, 20, 40, 64, 80, 80, 100, 128, 140]))
+        sr = float(rng.choice([8000.0, 16000.0, 22050.0]))
+        if n_mels > fft // 4:
+            n_mels = fft // 8
+        n = int(rng.integers(0, 6 * fft + 40 * hop))
+        x = jfk[int(rng.integers(0, 100000)):][:n]
+        try:
+            want = oracle.compute_mel_spectrogram_cpu(x, fft, hop, n_mels, sr)
+        except Exception:
+            continue
+        m = gpu.HipMelSpectrogram(fft, hop, sr, n_mels)
+        kind = "f32" if (m.uses_fast_path and not m.precise) else "f64"
+        if kind == "f32" and rng.random() < 0.4:
+            try:
+                m.set_precise(True)
+                kind = "f64"
+            except gpu.HipRuntimeError:
+                pass
+        got = m.compute_mel_spectrogram(x)
+        assert got.shape == want.shape, (fft, hop, n_mels, sr, n)
+        if got.size:
+            d = float(np.abs(got - want).max())
+            worst[kind] = max(worst.get(kind, 0.0), d)
+            assert d <= (TOL if kind == "f32" else 3e-6), (fft, hop, n_mels, sr, n, kind, d)
+        m.close()
+    assert set(worst) == {"f32", "f64"}
