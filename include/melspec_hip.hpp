@@ -200,6 +200,33 @@ private:
     std::vector<float> pending_, ready_;
 };
 
+// src/vad.rs: DetectionSettings, vad_boundaries -> EdgeInfo, vad_on
+struct DetectionSettings : melspec_vad_settings {
+    DetectionSettings() { melspec_vad_default_settings(this); }                       // 0.98, 11, 5, 2
+    DetectionSettings(double min_energy_, int min_y_, int min_x_, int min_mel_) {
+        min_energy = min_energy_; min_y = min_y_; min_x = min_x_; min_mel = min_mel_;
+    }
+};
+struct EdgeInfo {
+    std::vector<std::size_t> non_intersected_columns, intersected_columns;
+    std::uint32_t longest_run = 0;
+    const std::vector<std::size_t> &non_intersected() const { return non_intersected_columns; }
+    const std::vector<std::size_t> &intersected() const { return intersected_columns; }
+};
+// one (n_mels x width) image, row-major (the reference concatenates its Array2 frames along the time axis)
+inline EdgeInfo vad_boundaries(const std::vector<float> &image, std::size_t n_mels, const DetectionSettings &settings, int device = -1) {
+    EdgeInfo e;
+    const std::size_t width = n_mels ? image.size() / n_mels : 0;
+    std::vector<std::uint8_t> mask(melspec_vad_mask_len(static_cast<int>(n_mels), width));
+    detail::check(melspec_vad_boundaries_host(device, image.data(), static_cast<int>(n_mels), width, &settings, nullptr, mask.data(),
+                                              &e.longest_run), false);
+    for (std::size_t x = 0; x < mask.size(); ++x) (mask[x] ? e.intersected_columns : e.non_intersected_columns).push_back(x);
+    return e;
+}
+inline bool vad_on(const EdgeInfo &e, std::size_t n) {          // src/vad.rs:229-254
+    return n <= 1 ? e.intersected_columns.size() >= 2 : e.longest_run >= n;
+}
+
 // dense [n_mels][n_fft/2+1] row-major; std::nullopt == None
 inline std::vector<double> mel(double sr, std::size_t n_fft, std::size_t n_mels, std::optional<double> f_min = std::nullopt,
                                std::optional<double> f_max = std::nullopt, bool htk = false, bool norm = true) {

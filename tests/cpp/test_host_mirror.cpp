@@ -13,6 +13,7 @@ extern "C" long oracle_compute_mel_spectrogram_cpu(const float *, long, int, int
 extern "C" long oracle_stream_mel(const float *, long, int, int, int, double, float *, long);
 extern "C" void oracle_quantize(const float *, long, unsigned char *, float *);
 extern "C" long oracle_tga_8bit_data(const float *, long, int, unsigned char *);
+extern "C" long oracle_vad_boundaries(const float *, int, long, int, int, double, unsigned char *, unsigned char *);
 
 int main() {
     const double sr = 16000.0;
@@ -96,6 +97,15 @@ int main() {
         const auto back = codec.parse_tga_8bit(blobs[0]);
         const auto qr = codec.quantize(img);
         if (back.size() != img.size() || !std::equal(qr.first.begin(), qr.first.end(), ref.begin() + 26)) { std::puts("FAIL: quantize"); return 1; }
+        // VAD masks of the same image: identical to the oracle's
+        std::vector<unsigned char> raw(96), sm(96);
+        const melspec::DetectionSettings st(0.5, 3, 5, 0);
+        const long nmask = oracle_vad_boundaries(img.data(), 80, 98, st.min_mel, st.min_y, st.min_energy, raw.data(), sm.data());
+        const melspec::EdgeInfo e = melspec::vad_boundaries(img, 80, st);
+        size_t set = 0;
+        for (long x = 0; x < nmask; ++x) set += sm[x];
+        if (nmask != 96 || e.intersected().size() != set || e.intersected().size() + e.non_intersected().size() != 96) { std::puts("FAIL: vad mask"); return 1; }
+        for (size_t x : e.intersected()) if (!sm[x]) { std::puts("FAIL: vad column"); return 1; }
     }
     std::puts("OK");
     return 0;
