@@ -166,8 +166,41 @@ inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_
 }  // namespace melspec
 
 #include "whisper_wave_f64.hpp"
+#include "whisper_six.hpp"
 
 namespace melspec {
+
+// Tables of the six-frames-per-wave kernel (SixBlob in whisper_six.hpp).  false: filterbank outside its coverage
+// (more than 9 slots of 9 intervals, or not a two-filters-per-bin bank).
+inline bool build_six_tables(double sr, int n_mels, FastTables &out) {
+    constexpr int N = 400, M = 200;
+    if (n_mels < 1 || n_mels > kSixOwn * kSixMaxSlots - 1) return false;
+    std::vector<float> &b = out.blob;
+    b.assign(SixBlob::kMelW, 0.0f);
+    const std::vector<double> win = hann_window(N);
+    for (int i = 0; i < N; ++i) b[SixBlob::kWin + i] = static_cast<float>(win[i]);
+    for (int t = 0; t < 10; ++t)
+        for (int k1 = 0; k1 < 20; ++k1) {
+            const double a = -2.0 * kPi * ((t * k1) % M) / M;
+            b[SixBlob::kTw1 + t * SixBlob::kTw1Stride + 2 * k1] = static_cast<float>(std::cos(a));
+            b[SixBlob::kTw1 + t * SixBlob::kTw1Stride + 2 * k1 + 1] = static_cast<float>(std::sin(a));
+        }
+    for (int j = 0; j < kSixLanes; ++j)
+        for (int s = 0; s < 11; ++s) {
+            int k = j + 20 * s;                                   // lanes 1..9 (slot 10 unused)
+            if (j == 0) k = s < 6 ? 20 * s : 10 + 20 * (s - 6);   // lane 0: residue 0, then residue 10
+            const double a = -2.0 * kPi * k / N;
+            b[SixBlob::kTw2 + j * SixBlob::kTw2Stride + 2 * s] = static_cast<float>(std::cos(a));
+            b[SixBlob::kTw2 + j * SixBlob::kTw2Stride + 2 * s + 1] = static_cast<float>(std::sin(a));
+        }
+    const int bins = N / 2 + 1;
+    const std::vector<double> dense = mel_filterbank(sr, N, n_mels, -1.0, -1.0, false, true);
+    out.n_mels = n_mels;
+    out.nnz = 0;
+    out.interval = build_interval_mel(dense, n_mels, bins, M, b, out.slots, kSixLanes, 0.25, SixBlob::kMelStart, kSixMaxSlots);
+    while (b.size() % 4) b.push_back(0.0f);
+    return out.interval;
+}
 
 // Blob of the precise kernel: [PreciseBlob tables in f64][the mel section of an interval-scheme f32 blob].
 struct PreciseTables {

@@ -51,7 +51,8 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kFPB = 23;       // frames per workgroup tile (23*11 = 253 <= 256 threads)
 constexpr int kNT = 256;
 constexpr int kGenericNT = 256;
-constexpr int kDefaultVariant = 8;   // wave kernel, 8 waves/workgroup, direct PCM reads, interval mel scheme
+constexpr int kDefaultVariant = 11;  // six frames per wave where the filterbank allows it (<= 80 mels), else variant 8:
+                                     // wave kernel, 8 waves/workgroup, direct PCM reads, interval mel scheme
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
@@ -301,6 +302,12 @@ struct melspec_ctx {
     int slice_floats = 0;
     int frames_per_unit = 1;
     int grid_per_cu = 4;    // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops (2 are resident; 4 measured best)
+    // six-frames-per-wave build (variant 11): plain [frame][mel] batches, uniform or ragged
+    bool six = false;
+    int six_static = 0;     // 1: LensSix80 matches the tables
+    FastTables ft6;
+    DevBuf d_blob6;
+    size_t lds6 = 0;
     // fused n_fft = 512 build (f64, Whisper flavour of the 512-point kernel): plain and ragged batches
     bool fast512 = false;
     FbankFastTables ft512;
@@ -322,8 +329,8 @@ struct melspec_ctx {
 namespace {
 
 // frames per work unit of the kernel a batch will run on
-int ctx_frames_per_unit(const melspec_ctx *c, bool) {
-    if (c->fast) return c->frames_per_unit;
+int ctx_frames_per_unit(const melspec_ctx *c, bool plain) {
+    if (c->fast) return (c->six && plain && !c->precise) ? kSixFrames : c->frames_per_unit;
     return c->fast512 ? kFbFPW : 1;
 }
 
@@ -411,6 +418,7 @@ int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, boo
         switch (v) {
             case 7: return launch_wave_t<NSLOTS, true, 4, StaticLens, 1, true>(c, desc, stream);
             case 8: return launch_wave_t<NSLOTS, true, 8, StaticLens, 4, true>(c, desc, stream);
+            case 10: return launch_wave_t<NSLOTS, true, 16, StaticLens, 4, true>(c, desc, stream);     // one 16-wave workgroup per CU
             default: return launch_wave_t<NSLOTS, false, 8, StaticLens, 4, true>(c, desc, stream);
         }
     }
@@ -469,6 +477,31 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
                                                   : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
+    if (c->six && desc.frames_per_unit == kSixFrames) {
+        static uint64_t attr_done = 0;
+        if (!device_done(attr_done)) {
+            int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (rc) return rc;
+            mark_device_done(attr_done);
+        }
+        FastParams fp{};
+        fp.b = desc;
+        fp.d_blob = static_cast<const float *>(c->d_blob6.p);
+        fp.blob_len = static_cast<int>(c->ft6.blob.size());
+        fp.hop = c->hop_size;
+        fp.n_mels = c->n_mels;
+        fp.slots = c->ft6.slots;
+        const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
+        static const int per_cu = [] { const char *e = std::getenv("MELSPEC_SIX_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();
+        const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
+        if (c->six_static)
+            hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80>), dim3(grid), dim3(kSixWaves * 64), c->lds6, stream, fp);
+        else
+            hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime>), dim3(grid), dim3(kSixWaves * 64), c->lds6, stream, fp);
+        HIP_TRY(hipGetLastError());
+        return MELSPEC_OK;
+    }
     if (c->precise) {
         if (c->ft.slots.n_slots <= 8)
             return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stream) : launch_precise_t<8, LensRuntime>(c, desc, stream);
@@ -539,7 +572,7 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     const char *ev = std::getenv("MELSPEC_VARIANT");
     const char *el = std::getenv("MELSPEC_RUNTIME_LENS");
     c->variant = ev ? std::atoi(ev) : kDefaultVariant;
-    if (c->variant < 0 || c->variant > 9) c->variant = kDefaultVariant;
+    if (c->variant < 0 || c->variant > 11) c->variant = kDefaultVariant;
     c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) &&
               build_fast_tables(sampling_rate, n_mels, c->ft, c->variant >= 7);
     if (c->fast) {
@@ -556,7 +589,7 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
             c->fast_lds = sizeof(float) * (c->ft.blob.size() + c->region_a + L::region_b() + L::region_max());
         } else {
             const bool staged = c->variant <= 6 ? (c->variant % 2) == 0 : c->variant == 9;
-            const int waves = (c->variant <= 2 || c->variant == 7) ? 4 : 8;
+            const int waves = (c->variant <= 2 || c->variant == 7) ? 4 : (c->variant == 10 ? 16 : 8);
             c->frames_per_unit = kFPW;
             c->slice_floats = WaveLayout::slice_floats(hop_size, staged);
             c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(waves) * c->slice_floats);
@@ -570,6 +603,18 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         c->lds512 = c->ft512.blob.size() * 4 + static_cast<size_t>(c->waves512) * slice_bytes;
         c->fast512 = c->lds512 <= kLdsLimit;
         if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
+    }
+    if (c->fast && c->variant == 11) {                 // the six-frame build shares the context with variant 8 (layouts, precise)
+        c->variant = 8;
+        if (build_six_tables(sampling_rate, n_mels, c->ft6)) {
+            c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats());
+            c->six = c->lds6 <= kLdsLimit;
+            bool st = c->ft6.slots.n_slots == LensSix80::kSlots && n_mels == LensSix80::kMels;
+            for (int i = 0; st && i < LensSix80::kSlots; ++i)
+                st = c->ft6.slots.len[i] == LensSix80::len(i) && c->ft6.slots.woff[i] == LensSix80::woff(i);
+            c->six_static = st && !(el && el[0] == '1');
+            if (c->six && (rc = upload(c->d_blob6, c->ft6.blob))) return bail(rc);
+        }
     }
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
@@ -596,7 +641,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
     delete c;
 }
 
@@ -615,13 +660,16 @@ int melspec_set_precise(melspec_ctx *c, int on) {
     if (!on) { c->precise = false; return MELSPEC_OK; }
     if (!c->fast) return MELSPEC_OK;          // the generic kernel is f64 already
     if (c->variant < 7 || !c->ft.interval) return fail(MELSPEC_ERR_UNSUPPORTED, "the precise build needs the interval mel scheme");
-    if (c->pt.blob.empty()) {
-        if (!build_precise_tables(c->ft, c->pt)) return fail(MELSPEC_ERR_INTERNAL, "precise tables");
-        c->precise_lds = c->pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double);
-        if (c->precise_lds > kLdsLimit) return fail(MELSPEC_ERR_UNSUPPORTED, "precise tables do not fit in LDS");
+    if (c->d_blob64.p == nullptr) {              // first use: build, check and upload before anything is committed to the ctx
+        PreciseTables pt;
+        if (!build_precise_tables(c->ft, pt)) return fail(MELSPEC_ERR_INTERNAL, "precise tables");
+        const size_t lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double);
+        if (lds > kLdsLimit) return fail(MELSPEC_ERR_UNSUPPORTED, "precise tables do not fit in LDS");
         HIP_TRY(hipSetDevice(c->dev.device));
-        int rc = upload(c->d_blob64, c->pt.blob);
-        if (rc) return rc;
+        int rc = upload(c->d_blob64, pt.blob);
+        if (rc) { c->d_blob64.release(); return rc; }
+        c->pt = std::move(pt);
+        c->precise_lds = lds;
     }
     c->precise = true;
     return MELSPEC_OK;

@@ -13,6 +13,7 @@
 #include "whisper_wave.hpp"
 #include "fbank_wave.hpp"
 #include "whisper_wave_f64.hpp"
+#include "whisper_six.hpp"
 #include "stream_plan.hpp"
 
 namespace melspec {
@@ -230,6 +231,55 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
         if (LAYOUT && p.b.sync_rounds) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Six frames per wavefront (phases in whisper_six.hpp), one 16-wave workgroup per CU, plain [frame][mel] output.
+// ------------------------------------------------------------------------------------
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const FastParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *blob = lds;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    float *slice = blob + p.blob_len + wave * SixLayout::slice_floats();
+    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
+    const bool in = lane < kSixFrames * kSixLanes;
+    int uoff, voff;
+    SixLayout::row_offsets(j, uoff, voff);
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
+    const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
+    for (uint64_t unit = (uint64_t)xcd_logical_block() * kSixWaves + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * kSixWaves) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * kSixFrames;
+        const uint64_t left = loc.frames - f0;
+        const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv;
+        six_phase1(fl, j, act, p.hop, blob, src, slice);
+        __builtin_amdgcn_wave_barrier();
+        six_phase2(fl, j, act, blob, slice, uoff, voff);
+        __builtin_amdgcn_wave_barrier();
+        float vals[NSLOTS];
+        {
+            // per-lane start bins: re-read every unit (9 LDS words) rather than held in registers across the loop
+            int st[NSLOTS];
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, blob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
+        }
+        __builtin_amdgcn_wave_barrier();
+        six_phase4<NSLOTS>(fl, j, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

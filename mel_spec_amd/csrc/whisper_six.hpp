@@ -1,0 +1,235 @@
+// whisper_six.hpp -- the fused n_fft = 400 log-mel pipeline with SIX frames per wavefront, ten lanes per frame
+// in every phase (lane = 10*frame + j, 60 of 64 lanes busy throughout).
+//
+// whisper_wave.hpp gives a frame 10 lanes in phase 1 (one DFT-20 column each) but 11 in phase 2 (residue pairs
+// j / 20-j, j = 0..10) and 12 in phases 3-4, which caps a wave at 5 frames and leaves 14 lanes idle in phase 1.
+// Two of the eleven phase-2 jobs are half jobs: residue 0 pairs with itself (Z[20q] with Z[200-20q]) and so does
+// residue 10 (Z[10+20q] with Z[190-20q]); each needs ONE 10-point DFT and five or six Hermitian pairs.  Here lane 0
+// of a frame does both (rows 0 and 10: two DFT-10s and eleven pairs, one more than the ten of lanes 1..9), selecting
+// its operands with v_cndmask, and the "modulated copy of row 0" that made the pairing uniform is gone.  Phases 3-4
+// use the interval scheme over 10-lane groups (9 intervals + ghost per slot; 9 slots for Whisper's 80 mels).
+//
+// Same arithmetic as whisper_wave.hpp up to the order of a few f32 additions; same tables except tw2 and the mel
+// section.  One 16-wave workgroup per CU: 16 slices of 6*404 floats + one table blob = 162.5 KB of the 160 KiB LDS.
+//
+// Reference steps: frame_windows src/stft.rs:147-169; FFT src/stft.rs:105-111; sparse mel + log10
+// src/mel.rs:148-168; per-frame normalisation src/mel.rs:645-654.
+#pragma once
+#include "whisper_wave.hpp"
+
+namespace melspec {
+
+constexpr int kSixFrames = 6;     // frames per wavefront
+constexpr int kSixLanes = 10;     // lanes per frame in every phase
+constexpr int kSixOwn = 9;        // intervals a 10-lane group owns per slot (lane 9 is the ghost)
+constexpr int kSixWaves = 16;     // waves per workgroup (one workgroup per CU)
+constexpr int kSixMaxSlots = 9;   // ceil(81 / 9): up to 80 mel bins
+
+struct SixBlob {                  // float offsets inside the table blob
+    static constexpr int kWin = 0;                        // [400] Hann
+    static constexpr int kTw1Stride = 44;                 // 20 complex + 4 pad
+    static constexpr int kTw1 = 400;                      // [10][44] W_200^{t*k1}
+    static constexpr int kTw2Stride = 24;                 // 11 complex + 2 pad
+    static constexpr int kTw2 = kTw1 + 10 * kTw1Stride;   // [10][24]: lane j >= 1: W_400^{j+20s}, s < 10;
+                                                          //   lane 0: W_400^{20s} (s <= 5), W_400^{10+20(s-6)} (s = 6..10)
+    static constexpr int kMelStart = kTw2 + 10 * kTw2Stride;              // [kSixMaxSlots*10] ints
+    static constexpr int kMelW = (kMelStart + kSixMaxSlots * kSixLanes + 3) & ~3;   // (rise, fall) pairs [slot][r][10][2]
+};
+
+struct SixLayout {
+    static constexpr int kXRow = 20;
+    static constexpr int kXStride = 404;                  // == 20 (mod 32): conflict-free b64 row writes for 10-lane frames
+    static constexpr int kPStride = 213;                  // power rows (tools/lds_sim: least conflicts among 201..213)
+    static constexpr int kPmaxOff = 1280;                 // after the 6 power rows (6*213 = 1278)
+    static constexpr int kPmaxStride = 12;                // 10 maxima + 2 pad
+    static constexpr int slice_floats() { return kSixFrames * kXStride; }     // 2424
+    // position of exchange row k1 inside a frame's block of 20 rows (hill-climbed on the bank model: the two 16-byte
+    // row reads of phase 2 collide 6 cycles per pair instead of 15 in natural order; the row writes stay conflict-free)
+    MS_HD static constexpr int row_pos(int k1) {
+        constexpr int t[20] = {14, 1, 13, 4, 16, 3, 17, 11, 6, 8, 19, 9, 7, 15, 18, 5, 2, 12, 0, 10};
+        return t[k1];
+    }
+    // per-lane constants of phase 2: float offsets of the two rows lane j reads (rows j and 20-j; lane 0: rows 0 and 10)
+    MS_HD static void row_offsets(int j, int &uoff, int &voff) {
+        uoff = 0; voff = 0;
+        for (int k = 0; k < kSixLanes; ++k)
+            if (k == j) { uoff = row_pos(k) * kXRow; voff = row_pos(k == 0 ? 10 : 20 - k) * kXRow; }
+    }
+};
+
+// compile-time slot lengths of Whisper's 80-mel bank over 10-lane groups
+template <int MELS, int... L>
+struct LensSixStatic {
+    static constexpr bool kStatic = true;
+    static constexpr int kSlots = sizeof...(L);
+    static constexpr int kMels = MELS;
+    MS_HD static constexpr int len(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        return t[i];
+    }
+    MS_HD static constexpr int woff(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        int s = 0;
+        for (int k = 0; k < i; ++k) s += t[k];
+        return SixBlob::kMelW + 2 * kSixLanes * s;
+    }
+};
+using LensSix80 = LensSixStatic<80, 1, 1, 1, 2, 2, 3, 4, 6, 7>;
+
+// ---- phase 1: window, DFT-20 over n1 of column t, twiddle W_200^{t*k1}, 20 exchange rows ----------------------
+MS_DEV void six_phase1(int fl, int t, bool active, int hop, const float *blob, const float *gsrc /* unit's first sample */,
+                       float *slice) {
+    if (!active) return;
+    const float *w = blob + SixBlob::kWin + 2 * t;
+    const float *s = gsrc + fl * hop + 2 * t;
+    cf x[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) {
+        const f2 sv = load2_unaligned(s + 20 * n1);
+        const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
+        x[n1] = {sv.x * wv.x, sv.y * wv.y};
+    }
+    fft20(x);
+    const float *tw = blob + SixBlob::kTw1 + t * SixBlob::kTw1Stride;
+    float *xo = slice + fl * SixLayout::kXStride + 2 * t;
+    *reinterpret_cast<f2 *>(xo + SixLayout::row_pos(0) * SixLayout::kXRow) = f2{x[0].re, x[0].im};
+#pragma unroll
+    for (int k1 = 1; k1 < 20; ++k1) {
+        const f2 wv = *reinterpret_cast<const f2 *>(tw + 2 * k1);
+        const cf y = cmul(x[k1], cf{wv.x, wv.y});
+        *reinterpret_cast<f2 *>(xo + SixLayout::row_pos(k1) * SixLayout::kXRow) = f2{y.re, y.im};
+    }
+}
+
+// ---- phase 2: two DFT-10s, Hermitian pairs with W_400, 4*|X|^2 to the power row ------------------------------
+// Lanes 1..9: u = DFT(row j), v = DFT(row 20-j); pair s: Z[k] = u[s], Z[200-k] = v[9-s], k = j + 20s.
+// Lane 0:     u = DFT(row 0), v = DFT(row 10);   pairs 0..5: u[s] with u[(10-s)%10] (k = 20s);
+//             pairs 6..10: v[s-6] with v[15-s] (k = 10 + 20(s-6)).  koff = j (lanes 1..9) or -110 (lane 0).
+MS_DEV void six_phase2(int fl, int j, bool active, const float *blob, float *slice, int uoff, int voff) {
+    if (!active) return;
+    const float *ua = slice + fl * SixLayout::kXStride + uoff;
+    const float *va = slice + fl * SixLayout::kXStride + voff;
+    cf u[10], v[10];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const f4 a = *reinterpret_cast<const f4 *>(ua + 4 * i);
+        const f4 b = *reinterpret_cast<const f4 *>(va + 4 * i);
+        u[2 * i] = {a.x, a.y};
+        u[2 * i + 1] = {a.z, a.w};
+        v[2 * i] = {b.x, b.y};
+        v[2 * i + 1] = {b.z, b.w};
+    }
+    fft10(u);
+    fft10(v);
+    const bool lane0 = j == 0;
+    const int koff = lane0 ? -110 : j;
+    const float *tw = blob + SixBlob::kTw2 + j * SixBlob::kTw2Stride;
+    float *p = slice + fl * SixLayout::kPStride;
+    auto pair = [&](cf zk, cf zm, cf W, int k) {
+        const cf S = {zk.re + zm.re, zk.im - zm.im};
+        const cf D = {zk.re - zm.re, zk.im + zm.im};
+        const cf wd = cmul(W, D);
+        const float ar = S.re + wd.im, ai = S.im - wd.re;
+        const float br = S.re - wd.im, bi = S.im + wd.re;
+        p[k] = ar * ar + ai * ai;             // 4*|X[k]|^2 (the mel weights carry the 1/4)
+        p[200 - k] = br * br + bi * bi;
+    };
+#pragma unroll
+    for (int s = 0; s < 10; s += 2) {
+        const f4 w2 = *reinterpret_cast<const f4 *>(tw + 2 * s);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ss = s + h;
+            cf zk, zm;
+            if (ss < 6) {
+                const cf own = u[(10 - ss) % 10];
+                zk = u[ss];
+                zm = {lane0 ? own.re : v[9 - ss].re, lane0 ? own.im : v[9 - ss].im};
+            } else {
+                zk = {lane0 ? v[ss - 6].re : u[ss].re, lane0 ? v[ss - 6].im : u[ss].im};
+                zm = {lane0 ? v[15 - ss].re : v[9 - ss].re, lane0 ? v[15 - ss].im : v[9 - ss].im};
+            }
+            const cf W = h == 0 ? cf{w2.x, w2.y} : cf{w2.z, w2.w};
+            pair(zk, zm, W, ss < 6 ? j + 20 * ss : koff + 20 * ss);
+        }
+    }
+    if (lane0) {                              // eleventh pair: Z[90] with Z[110]
+        const f2 w2 = *reinterpret_cast<const f2 *>(tw + 20);
+        pair(v[4], v[5], cf{w2.x, w2.y}, 90);
+    }
+}
+
+// ---- phase 3: interval sums (each bin read once, feeding a rising and a falling filter), 10-lane groups ----------
+template <int NSLOTS, class Lens>
+MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *blob, const float *slice,
+                            const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
+    if (!active) return;
+    const float *p = slice + fl * SixLayout::kPStride;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        float ar = 0.0f, af = 0.0f;
+        if (Lens::kStatic) {
+            if (i < Lens::kSlots) {
+                const float *pp = p + st[i];
+                const float *w = blob + Lens::woff(i < Lens::kSlots ? i : 0) + 2 * j;
+#pragma unroll
+                for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
+                    const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kSixLanes * r);
+                    const float pv = pp[r];
+                    ar += wv.x * pv;
+                    af += wv.y * pv;
+                }
+            }
+        } else if (i < ms.n_slots) {
+            const float *pp = p + st[i];
+            const float *w = blob + ms.woff[i] + 2 * j;
+            const int len = ms.len[i];
+            for (int r = 0; r < len; ++r) {
+                const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kSixLanes * r);
+                const float pv = pp[r];
+                ar += wv.x * pv;
+                af += wv.y * pv;
+            }
+        }
+        rise[i] = ar;
+        fprev[i] = af;
+    }
+}
+
+// mel[m] = rise of interval m (this lane) + fall of interval m+1 (next lane); log10, lane maximum to LDS
+template <int NSLOTS>
+MS_DEV void six_phase3_finish(int fl, int j, bool active, int n_mels, const float (&rise)[NSLOTS],
+                              const float (&fnext)[NSLOTS] /* fprev of lane+1 */, float *slice, float (&vals)[NSLOTS]) {
+    if (!active) return;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const float e = rise[i] + fnext[i];
+        const float v = e > 1e-10f ? fast_log2(e) * 0.30102999566398120f : -10.0f;
+        vals[i] = v;
+        if (j < kSixOwn && j + kSixOwn * i < n_mels) mx = __builtin_fmaxf(mx, v);
+    }
+    slice[SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride + j] = mx;
+}
+
+// ---- phase 4: frame maximum, clamp at max - 8, (x + 4) / 4, [frame][mel] store ---------------------------------
+template <int NSLOTS>
+MS_DEV void six_phase4(int fl, int j, bool active, int n_mels, const float *slice, const float (&vals)[NSLOTS], float *out_tile) {
+    if (!active || j >= kSixOwn) return;
+    const float *pm = slice + SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride;
+    const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4);
+    const f2 c = *reinterpret_cast<const f2 *>(pm + 8);
+    const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
+    const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(c.x, c.y)) - 8.0f;
+    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) {
+        const int m = j + kSixOwn * i;
+        if (m < n_mels) o[kSixOwn * i] = (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f;
+    }
+}
+
+}  // namespace melspec

@@ -625,3 +625,80 @@ extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n
     }
     return frames;
 }
+
+// ---- whisper_six.hpp: six frames per wave, ten lanes per frame ------------------------------------------------
+template <int NSLOTS, class Lens>
+static long long run_six(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+    FastTables T;
+    if (!build_six_tables(sr, n_mels, T)) return -1;
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / hop + 1;
+    std::vector<float> slice(SixLayout::slice_floats());
+    std::vector<float> vals(static_cast<size_t>(64) * NSLOTS);
+    const int *starts = reinterpret_cast<const int *>(T.blob.data() + SixBlob::kMelStart);
+    for (long long f0 = 0; f0 < frames; f0 += kSixFrames) {
+        const int nv = static_cast<int>(std::min<long long>(kSixFrames, frames - f0));
+        std::fill(slice.begin(), slice.end(), 1.0e30f);
+        const float *src = pcm + f0 * hop;
+        auto info = [&](int lane, int &fl, int &j, bool &act) { fl = lane / kSixLanes; j = lane - fl * kSixLanes; act = lane < kSixFrames * kSixLanes && fl < nv; };
+        std::vector<float> snap(slice), next(slice);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; info(lane, fl, j, act);
+            std::vector<float> tmp(snap);
+            six_phase1(fl, j, act, hop, T.blob.data(), src, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; info(lane, fl, j, act);
+            std::vector<float> tmp(snap);
+            int uoff, voff;
+            SixLayout::row_offsets(j, uoff, voff);
+            six_phase2(fl, j, act, T.blob.data(), tmp.data(), uoff, voff);
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next; snap = slice;
+        std::vector<float> rise(64 * NSLOTS), fprev(65 * NSLOTS, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; info(lane, fl, j, act);
+            int st[NSLOTS];
+            for (int i = 0; i < NSLOTS; ++i) st[i] = lane < kSixFrames * kSixLanes ? starts[i * kSixLanes + j] : 0;
+            six_phase3_sums<NSLOTS, Lens>(fl, j, act, T.slots, T.blob.data(), snap.data(), st,
+                                          *reinterpret_cast<float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                          *reinterpret_cast<float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane) * NSLOTS]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {     // wave_shl:1 -> lane l sees lane l+1
+            int fl, j; bool act; info(lane, fl, j, act);
+            std::vector<float> tmp(snap);
+            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, *reinterpret_cast<const float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                      *reinterpret_cast<const float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane + 1) * NSLOTS]), tmp.data(),
+                                      *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+            for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
+        }
+        slice = next;
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; info(lane, fl, j, act);
+            six_phase4<NSLOTS>(fl, j, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+                               out + f0 * n_mels);
+        }
+    }
+    return frames;
+}
+
+template <class Lens>
+static bool six_lens_ok(const MelSlots &ms, int n_mels) {
+    if (ms.n_slots != Lens::kSlots || n_mels != Lens::kMels) return false;
+    for (int i = 0; i < Lens::kSlots; ++i)
+        if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
+    return true;
+}
+
+// mode 0: runtime slot lengths, 1: compile-time lengths (Whisper 80 mels only)
+extern "C" long long emu_whisper_six(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+    if (mode == 1) {
+        FastTables T;
+        if (!build_six_tables(sr, n_mels, T) || !six_lens_ok<LensSix80>(T.slots, n_mels)) return -2;
+        return run_six<kSixMaxSlots, LensSix80>(pcm, n, hop, n_mels, sr, out);
+    }
+    return run_six<kSixMaxSlots, LensRuntime>(pcm, n, hop, n_mels, sr, out);
+}

@@ -27,6 +27,8 @@ def emu():
     L.emu_whisper_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
     L.emu_whisper_precise.restype = C.c_longlong
     L.emu_whisper_precise.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
+    L.emu_whisper_six.restype = C.c_longlong
+    L.emu_whisper_six.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
     L.emu_w512_wave.restype = C.c_longlong
     L.emu_w512_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
     L.emu_blm_wave.restype = C.c_longlong
@@ -266,3 +268,43 @@ def test_whisper512_flavour_matches_oracle(emu, oracle, jfk, hop, n_mels, sr, n)
     got = _w512(emu, x, hop, n_mels, sr)
     assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
     assert _w512(emu, np.zeros(511, np.float32)).shape == (0, 80)
+
+
+# ---- six frames per wave (whisper_six.hpp), the default build for <= 80 mels ------------------------------------
+
+def _six(emu, x, mode, hop=160, n_mels=80, sr=16000.0):
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 400 else (len(x) - 400) // hop + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    f32p = C.POINTER(C.c_float)
+    got = emu.lib.emu_whisper_six(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, mode, out.ctypes.data_as(f32p))
+    return got, out
+
+
+@pytest.mark.parametrize("mode", [0, 1])      # runtime / compile-time slot lengths
+def test_six_frame_kernel_jfk(emu, oracle, jfk, mode):
+    got, out = _six(emu, jfk, mode)
+    want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, 80)
+    assert got == 1098 and np.abs(out - want).max() <= TOL
+
+
+@pytest.mark.parametrize("hop,n_mels,sr", [(160, 64, 16000.0), (128, 40, 8000.0), (320, 80, 22050.0), (160, 1, 16000.0), (200, 79, 16000.0)])
+def test_six_frame_kernel_other_filterbanks(emu, oracle, jfk, hop, n_mels, sr):
+    x = jfk[20000:27000]
+    got, out = _six(emu, x, 0, hop, n_mels, sr)
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr)
+    assert got == want.shape[0] and np.abs(out - want).max() <= TOL
+
+
+def test_six_frame_kernel_edges_and_coverage(emu, oracle, four_tone):
+    assert _six(emu, np.zeros(399, np.float32), 1)[0] == 0
+    for n in (400, 559, 560, 400 + 5 * 160, 400 + 6 * 160, 400 + 11 * 160 + 3):       # around the 6-frame unit size
+        x = oracle.synth_pcm(2, n)
+        got, out = _six(emu, x, 1)
+        want = oracle.compute_mel_spectrogram_cpu(x)
+        assert got == want.shape[0] and np.abs(out - want).max() <= TOL
+    z = np.zeros(8000, np.float32); z[4321] = 1.0
+    assert np.abs(_six(emu, z, 1)[1] - oracle.compute_mel_spectrogram_cpu(z)).max() <= TOL
+    assert np.abs(_six(emu, four_tone, 1)[1] - oracle.compute_mel_spectrogram_cpu(four_tone)).max() <= TOL
+    assert _six(emu, np.zeros(4000, np.float32), 0, n_mels=81)[0] == -1           # 82 intervals > 9 slots of 9: not covered
+    assert _six(emu, np.zeros(4000, np.float32), 1, n_mels=64)[0] == -2           # compile-time lengths are Whisper-80 only

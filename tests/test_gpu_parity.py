@@ -100,10 +100,18 @@ def test_precise_mode_batch_and_other_geometry(gpu, oracle):
     got = m.compute_batch(clips)
     for c in (0, 17, 36):
         assert np.abs(got[c] - oracle.compute_mel_spectrogram_cpu(clips[c], 400, 128, 40, 8000.0)).max() <= 2e-6
-    g = gpu.HipMelSpectrogram(512, 160, SR, 80)     # generic kernel: always f64
+    g = gpu.HipMelSpectrogram(512, 160, SR, 80)     # fused 512 kernel: always f64
     assert g.precise
     g.set_precise(True)
-    m.close(); g.close()
+    # a bank whose precise tables do not fit in LDS: every attempt is refused and the context keeps working in f32
+    w = gpu.HipMelSpectrogram(400, 160, SR, 1)
+    x = oracle.synth_pcm(1, 4000)
+    for _ in range(2):
+        with pytest.raises(gpu.HipRuntimeError):
+            w.set_precise(True)
+        assert not w.precise
+        assert np.abs(w.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_cpu(x, 400, 160, 1, SR)).max() <= TOL
+    m.close(); g.close(); w.close()
 
 
 def test_generic_kernel_agrees_with_fused_kernel(gpu, w80, oracle, jfk):
