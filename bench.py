@@ -214,7 +214,8 @@ def main() -> None:
             "realtime_x": value * (HOP / SR),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "melspec::whisper400_wave_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "melspec::whisper400_six_kernel" if (n_mels <= 80 and os.environ.get("MELSPEC_VARIANT", "11") == "11") else "melspec::whisper400_wave_kernel",
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch},
             "parity_max_abs_diff": parity, "spinup_steps_untimed": spinup_steps,
         }
