@@ -302,7 +302,7 @@ struct melspec_ctx {
     int slice_floats = 0;
     int frames_per_unit = 1;
     int grid_per_cu = 4;    // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops (2 are resident; 4 measured best)
-    // six-frames-per-wave build (variant 11): plain [frame][mel] batches, uniform or ragged
+    // six-frames-per-wave build (variant 11): every batch shape and layout while the context is in f32 mode
     bool six = false;
     int six_static = 0;     // 1: LensSix80 matches the tables
     FastTables ft6;
@@ -330,7 +330,8 @@ namespace {
 
 // frames per work unit of the kernel a batch will run on
 int ctx_frames_per_unit(const melspec_ctx *c, bool plain) {
-    if (c->fast) return (c->six && plain && !c->precise) ? kSixFrames : c->frames_per_unit;
+    (void)plain;
+    if (c->fast) return (c->six && !c->precise) ? kSixFrames : c->frames_per_unit;
     return c->fast512 ? kFbFPW : 1;
 }
 
@@ -480,8 +481,10 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     if (c->six && desc.frames_per_unit == kSixFrames) {
         static uint64_t attr_done = 0;
         if (!device_done(attr_done)) {
-            int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80>, "hipFuncSetAttribute(whisper400_six_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
             if (rc) return rc;
             mark_device_done(attr_done);
         }
@@ -494,11 +497,15 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
         fp.slots = c->ft6.slots;
         const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
         static const int per_cu = [] { const char *e = std::getenv("MELSPEC_SIX_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();
-        const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
-        if (c->six_static)
-            hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80>), dim3(grid), dim3(kSixWaves * 64), c->lds6, stream, fp);
-        else
-            hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime>), dim3(grid), dim3(kSixWaves * 64), c->lds6, stream, fp);
+        const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
+        const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+        if (layout) {
+            if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, true>), grid, block, c->lds6, stream, fp);
+            else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>), grid, block, c->lds6, stream, fp);
+        } else {
+            if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, false>), grid, block, c->lds6, stream, fp);
+            else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>), grid, block, c->lds6, stream, fp);
+        }
         HIP_TRY(hipGetLastError());
         return MELSPEC_OK;
     }

@@ -235,9 +235,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
 }
 
 // ------------------------------------------------------------------------------------
-// Six frames per wavefront (phases in whisper_six.hpp), one 16-wave workgroup per CU, plain [frame][mel] output.
+// Six frames per wavefront (phases in whisper_six.hpp), one 16-wave workgroup per CU.
 // ------------------------------------------------------------------------------------
-template <int NSLOTS, class Lens>
+// LAYOUT = true: padded and/or mel-major output (workgroup-uniform rounds; mel-major re-aligns the waves once per round,
+// see whisper400_wave_kernel).
+template <int NSLOTS, class Lens, bool LAYOUT = false>
 __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const FastParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
@@ -254,11 +256,18 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     SixLayout::row_offsets(j, uoff, voff);
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    for (uint64_t unit = (uint64_t)xcd_logical_block() * kSixWaves + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * kSixWaves) {
-        const UnitLoc loc = locate_unit(p.b, unit);
+    const uint64_t w_off = LAYOUT ? 0 : wave;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
+        const uint64_t unit = LAYOUT ? first + wave : first;
+        const bool have = !LAYOUT || unit < p.b.n_units;
+        const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kSixFrames;
-        const uint64_t left = loc.frames - f0;
+        const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
+        const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
+        const uint64_t wleft = have ? width - f0 : 0;
+        const int ns = LAYOUT ? (wleft < (uint64_t)kSixFrames ? (int)wleft : kSixFrames) : nv;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
         six_phase1(fl, j, act, p.hop, blob, src, slice);
@@ -278,8 +287,12 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        six_phase4<NSLOTS>(fl, j, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels);
+        if (LAYOUT && p.b.mel_major)
+            six_phase4<NSLOTS, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0, (long long)width);
+        else
+            six_phase4<NSLOTS, LAYOUT>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT && p.b.sync_rounds) __syncthreads();
     }
 }
 

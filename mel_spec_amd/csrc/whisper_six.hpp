@@ -214,21 +214,29 @@ MS_DEV void six_phase3_finish(int fl, int j, bool active, int n_mels, const floa
     slice[SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride + j] = mx;
 }
 
-// ---- phase 4: frame maximum, clamp at max - 8, (x + 4) / 4, [frame][mel] store ---------------------------------
-template <int NSLOTS>
-MS_DEV void six_phase4(int fl, int j, bool active, int n_mels, const float *slice, const float (&vals)[NSLOTS], float *out_tile) {
-    if (!active || j >= kSixOwn) return;
-    const float *pm = slice + SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride;
-    const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4);
-    const f2 c = *reinterpret_cast<const f2 *>(pm + 8);
-    const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
-    const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(c.x, c.y)) - 8.0f;
-    float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
+// ---- phase 4: frame maximum, clamp at max - 8, (x + 4) / 4, store ---------------------------------------------------
+// store: this lane's frame column exists in the output; valid: it is a real frame (otherwise a zero column of a padded
+// layout).  row_w == 0: [frame][mel] rows; row_w > 0: [mel][row_w] rows (interleave_frames, src/mel.rs:480-544).
+template <int NSLOTS, bool LAYOUT = false>
+MS_DEV void six_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
+                       float *out_tile, long long row_w) {
+    if (!LAYOUT) { valid = true; row_w = 0; }
+    if (!store || j >= kSixOwn) return;
+    float lo = 0.0f;
+    if (valid) {
+        const float *pm = slice + SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride;
+        const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4);
+        const f2 c = *reinterpret_cast<const f2 *>(pm + 8);
+        const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
+        const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
+        lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(c.x, c.y)) - 8.0f;
+    }
+    float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
+    const long long step = row_w ? kSixOwn * row_w : kSixOwn;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kSixOwn * i;
-        if (m < n_mels) o[kSixOwn * i] = (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f;
+        if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
     }
 }
 

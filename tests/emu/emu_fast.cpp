@@ -678,8 +678,8 @@ static long long run_six(const float *pcm, long long n, int hop, int n_mels, dou
         slice = next;
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; info(lane, fl, j, act);
-            six_phase4<NSLOTS>(fl, j, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
-                               out + f0 * n_mels);
+            six_phase4<NSLOTS>(fl, j, act, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+                               out + f0 * n_mels, 0);
         }
     }
     return frames;
