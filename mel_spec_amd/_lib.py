@@ -124,7 +124,7 @@ def lib() -> C.CDLL:
     """Load libmelspec_hip.so (built in-tree by mel_spec_amd.build / __graft_entry__.build)."""
     global _lib
     if _lib is None:
-        path = os.environ.get("MELSPEC_LIB", LIB_PATH)   # tuning builds of the same ABI
+        path = os.environ.get("MELSPEC_LIB") or LIB_PATH   # tuning builds of the same ABI
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} is missing: the HIP extension has not been built "

@@ -16,6 +16,16 @@
 #include "whisper_six.hpp"
 #include "stream_plan.hpp"
 
+// Issue priority of the wave (s_setprio 0..3).  The persistent kernels raise it as a unit progresses (loads + first FFT
+// stage 0, second stage 1, mel / log / store 2): the waves sharing a SIMD then stop advancing in lock-step through the
+// VMEM-, VALU- and LDS-heavy phases.  Measured (profiles/r01_variants.txt): six-frame Whisper kernel -2.3 .. -3.5 %, fused
+// 512-point kernels -8 % (Kaldi) / -11 % (Whisper-512) / 0 (NeMo), precise kernel -3.8 %; the 5-frame kernel with two
+// 8-wave workgroups per CU loses 1-4 % under every table tried and stays at the default priority.
+#ifndef MELSPEC_NO_PRIO
+#define MS_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define MS_PRIO(n)
+#endif
 namespace melspec {
 
 // How work units (tiles of frames) map onto clips.  Uniform batches are pure arithmetic;
@@ -270,10 +280,13 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         const int ns = LAYOUT ? (wleft < (uint64_t)kSixFrames ? (int)wleft : kSixFrames) : nv;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
+        MS_PRIO(0);
         six_phase1(fl, j, act, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(1);
         six_phase2(fl, j, act, blob, slice, uoff, voff);
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
         float vals[NSLOTS];
         {
             // per-lane start bins: re-read every unit (9 LDS words) rather than held in registers across the loop
@@ -349,10 +362,13 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
+        MS_PRIO(0);
         precise_phase1(fl, j, act && j < kFftJobs, p.hop, tb, src, rows);
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(1);
         precise_phase2(fl, j, act, tb, rows);
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
         float vals[NSLOTS], rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
         wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, fblob, slice, st, rise, fprev);
 #pragma unroll
@@ -424,6 +440,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
         const bool act = in && fl < nv;
+        MS_PRIO(0);
         if (FLAVOR == kFlavorKaldi) {
             const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
             // frame mean (src/fbank.rs:165-166): 16 partial sums of 24-26 samples through LDS, fixed tree
@@ -445,6 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             nemo_phase1<T>(fl, j, act, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
         }
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(1);
         {
             cpx<T> own[16], part[8];
             fb_phase2_dft<T>(fl, j, act, slice, own);
@@ -453,6 +471,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             fb_phase2_split<T>(fl, j, act, use_power, tblob, own, part, slice);
         }
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
         fb_phase3_sums<T, NSLOTS>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
 #pragma unroll

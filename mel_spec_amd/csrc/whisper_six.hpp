@@ -22,7 +22,10 @@ namespace melspec {
 constexpr int kSixFrames = 6;     // frames per wavefront
 constexpr int kSixLanes = 10;     // lanes per frame in every phase
 constexpr int kSixOwn = 9;        // intervals a 10-lane group owns per slot (lane 9 is the ghost)
-constexpr int kSixWaves = 16;     // waves per workgroup (one workgroup per CU)
+#ifndef MELSPEC_SIX_WAVES
+#define MELSPEC_SIX_WAVES 16
+#endif
+constexpr int kSixWaves = MELSPEC_SIX_WAVES;     // waves per workgroup (one workgroup per CU)
 constexpr int kSixMaxSlots = 9;   // ceil(81 / 9): up to 80 mel bins
 
 struct SixBlob {                  // float offsets inside the table blob
