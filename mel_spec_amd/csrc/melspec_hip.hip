@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
@@ -70,8 +71,9 @@ inline uint64_t current_device_bit() {
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     return 1ull << (dev & 63);
 }
-inline bool device_done(uint64_t mask) { return (mask & current_device_bit()) != 0; }
-inline void mark_device_done(uint64_t &mask) { mask |= current_device_bit(); }
+// the masks are shared by every context of the process (one context per thread and device is the threading model)
+inline bool device_done(const std::atomic<uint64_t> &mask) { return (mask.load(std::memory_order_acquire) & current_device_bit()) != 0; }
+inline void mark_device_done(std::atomic<uint64_t> &mask) { mask.fetch_or(current_device_bit(), std::memory_order_release); }
 
 struct DeviceInfo {
     int device = -1;
@@ -264,7 +266,7 @@ int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
 
 template <class T, int FLAVOR, int NSLOTS>
 int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
-    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
         if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
@@ -364,7 +366,7 @@ int launch_block_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
 
 template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW, bool INTERVAL, bool LAYOUT>
 int launch_wave_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>, "hipFuncSetAttribute(whisper400_wave_kernel)");
         if (rc) return rc;
@@ -434,7 +436,7 @@ constexpr int kPreciseWaves = 8;
 
 template <int NSLOTS, class Lens, bool LAYOUT>
 int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static uint64_t attr_done = 0;          // one bit per device: function attributes are per device
+    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>, "hipFuncSetAttribute(whisper400_precise_kernel)");
         if (rc) return rc;
@@ -479,7 +481,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->six && desc.frames_per_unit == kSixFrames) {
-        static uint64_t attr_done = 0;
+        static std::atomic<uint64_t> attr_done{0};
         if (!device_done(attr_done)) {
             int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>, "hipFuncSetAttribute(whisper400_six_kernel)");

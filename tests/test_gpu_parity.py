@@ -505,3 +505,30 @@ def test_seeded_sweep_of_geometries_and_lengths(gpu, oracle, jfk):
             assert d <= (TOL if kind == "f32" else 3e-6), (fft, hop, n_mels, sr, n, kind, d)
         m.close()
     assert set(worst) == {"f32", "f64"}
+
+
+def test_one_context_per_thread_runs_concurrently(gpu, oracle, jfk):
+    """Threading model of the boundary (src/cuda.rs:246-247: one stream per object): one context per thread; four threads
+    with their own contexts (Whisper 80 / 128, fbank, NeMo) compute at the same time and agree with the oracle."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def whisper(n_mels):
+        m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+        worst = 0.0
+        want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels, SR)
+        for _ in range(8):
+            worst = max(worst, float(np.abs(m.compute_mel_spectrogram(jfk) - want).max()))
+        m.close()
+        return worst
+
+    def fbank():
+        fb = gpu.Fbank()
+        want = oracle.fbank_compute(jfk)
+        worst = max(float(np.abs(fb.compute(jfk) - want).max()) for _ in range(8))
+        fb.close()
+        return worst
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        futs = [ex.submit(whisper, 80), ex.submit(whisper, 128), ex.submit(fbank), ex.submit(whisper, 80)]
+        worst = [f.result() for f in futs]
+    assert max(worst) <= TOL, worst
