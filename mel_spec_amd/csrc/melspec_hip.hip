@@ -177,11 +177,13 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     b.frames_per_clip = frames_per_clip;
     b.out_width = out_width;
     b.mel_major = mel_major ? 1 : 0;
-    // mel-major stores keep the waves of a workgroup in step (one barrier per round): MELSPEC_MM_SYNC=0 switches that off,
-    // MELSPEC_FM_SYNC=1 switches it on for the padded frame-major layout too (both for A/B measurements)
-    static const bool mm_off = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); return e && e[0] == '0'; }();
+    // mel-major stores keep waves that hold adjacent units in step, so that the 24-byte pieces of a 32-byte sector reach L2
+    // together.  MELSPEC_MM_SYNC: 0 none, 1 one workgroup barrier per round (the 5-frame and precise kernels always use this
+    // form), 2/4/8 sub-group barrier over consecutive waves, 16 + 2/4/8 over waves on different SIMDs (six-frame kernel;
+    // default 20 = four waves, one per SIMD).  MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
+    static const int mm_mode = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); const int v = e ? std::atoi(e) : 20; const int sz = v & 15; return (v == 0 || v == 1 || ((sz == 2 || sz == 4 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();
     static const bool fm_on = [] { const char *e = std::getenv("MELSPEC_FM_SYNC"); return e && e[0] == '1'; }();
-    b.sync_rounds = mel_major ? !mm_off : fm_on;
+    b.sync_rounds = mel_major ? mm_mode : (fm_on ? 1 : 0);
     b.frames_per_unit = frames_per_unit;
     b.units_per_clip = static_cast<uint32_t>((out_width + frames_per_unit - 1) / frames_per_unit);
     b.n_clips = n_clips;
@@ -616,7 +618,7 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     if (c->fast && c->variant == 11) {                 // the six-frame build shares the context with variant 8 (layouts, precise)
         c->variant = 8;
         if (build_six_tables(sampling_rate, n_mels, c->ft6)) {
-            c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats());
+            c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves);   // + arrival counters
             c->six = c->lds6 <= kLdsLimit;
             bool st = c->ft6.slots.n_slots == LensSix80::kSlots && n_mels == LensSix80::kMels;
             for (int i = 0; st && i < LensSix80::kSlots; ++i)

@@ -255,6 +255,9 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
+    // arrival counters of the sub-group barrier (mel-major stores), behind the last slice
+    unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());
+    if (LAYOUT && tid < kSixWaves) arrive[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -267,8 +270,15 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
     const uint64_t w_off = LAYOUT ? 0 : wave;
+    unsigned round = 0;
+    // sub-group barrier of the mel-major store: gsize waves that hold adjacent units of a round.  "across" builds the groups
+    // from waves kSixWaves / gsize apart (different SIMDs), the plain form from consecutive waves.
+    const int gsize = p.b.sync_rounds & 15, across = p.b.sync_rounds >> 4;
+    const int ngroups = gsize > 1 ? kSixWaves / gsize : 1;
+    const int g = gsize > 1 ? (across ? wave % ngroups : wave / gsize) : 0;
+    const int slot = (LAYOUT && gsize > 1 && across) ? g * gsize + wave / ngroups : wave;
     for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
-        const uint64_t unit = LAYOUT ? first + wave : first;
+        const uint64_t unit = LAYOUT ? first + slot : first;
         const bool have = !LAYOUT || unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kSixFrames;
@@ -300,12 +310,25 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT && gsize > 1) {
+            // sub-group barrier: the p.b.sync_rounds waves holding adjacent units (one per SIMD for 4) store together; the
+            // sub-groups of a workgroup drift freely, so the waves sharing a SIMD keep their phases apart
+            ++round;
+            MS_PRIO(0);                                  // the waiting wave must not take issue slots from the working ones
+            if (lane == 0) {
+                __hip_atomic_fetch_add(arrive + g, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned target = round * (unsigned)gsize;
+                while (__hip_atomic_load(arrive + g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_wave_barrier();
+            MS_PRIO(3);
+        }
         if (LAYOUT && p.b.mel_major)
             six_phase4<NSLOTS, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
             six_phase4<NSLOTS, LAYOUT>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && p.b.sync_rounds) __syncthreads();
+        if (LAYOUT && p.b.sync_rounds == 1) __syncthreads();
     }
 }
 
