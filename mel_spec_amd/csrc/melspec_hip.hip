@@ -178,10 +178,10 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     b.out_width = out_width;
     b.mel_major = mel_major ? 1 : 0;
     // mel-major stores keep waves that hold adjacent units in step, so that the 24-byte pieces of a 32-byte sector reach L2
-    // together.  MELSPEC_MM_SYNC: 0 none, 1 one workgroup barrier per round (the 5-frame and precise kernels always use this
-    // form), 2/4/8 sub-group barrier over consecutive waves, 16 + 2/4/8 over waves on different SIMDs (six-frame kernel;
-    // default 20 = four waves, one per SIMD).  MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
-    static const int mm_mode = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); const int v = e ? std::atoi(e) : 20; const int sz = v & 15; return (v == 0 || v == 1 || ((sz == 2 || sz == 4 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();
+    // together (RoundSync in melspec_kernels.hpp).  MELSPEC_MM_SYNC: 0 none, 1 one workgroup barrier per round, 2/4/8 sub-group
+    // barrier over consecutive waves, 16 + 2/4/8 over waves WAVES / size apart; unset (-1): the measured best of the kernel
+    // that runs, resolved in launch_ctx.  MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
+    static const int mm_mode = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); if (!e) return -1; const int v = std::atoi(e); const int sz = v & 15; return (v == 0 || v == 1 || ((sz == 2 || sz == 4 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();
     static const bool fm_on = [] { const char *e = std::getenv("MELSPEC_FM_SYNC"); return e && e[0] == '1'; }();
     b.sync_rounds = mel_major ? mm_mode : (fm_on ? 1 : 0);
     b.frames_per_unit = frames_per_unit;
@@ -466,8 +466,17 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     return layout ? launch_precise_l<NSLOTS, Lens, true>(c, desc, stream) : launch_precise_l<NSLOTS, Lens, false>(c, desc, stream);
 }
 
-int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    if (desc.n_units == 0) return MELSPEC_OK;
+int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
+    if (desc_in.n_units == 0) return MELSPEC_OK;
+    BatchDesc desc = desc_in;
+    if (desc.sync_rounds < 0) {
+        // measured (profiles/r01_variants.txt): six-frame kernel, 16 waves: four waves 4 apart; precise kernel, 8 waves:
+        // consecutive pairs; 5-frame kernel, two 8-wave workgroups per CU: pairs 4 apart
+        if (c->fast && c->six && desc.frames_per_unit == kSixFrames) desc.sync_rounds = 20;
+        else if (c->fast && c->precise) desc.sync_rounds = 2;
+        else if (c->fast && (c->variant == 8 || c->variant == 9 || c->variant == 11)) desc.sync_rounds = 18;
+        else desc.sync_rounds = 1;
+    }
     if (!c->fast && c->fast512 && desc.frames_per_unit == kFbFPW) {
         FbankFastParams fp{};
         fp.b = desc;
@@ -603,7 +612,7 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
             const int waves = (c->variant <= 2 || c->variant == 7) ? 4 : (c->variant == 10 ? 16 : 8);
             c->frames_per_unit = kFPW;
             c->slice_floats = WaveLayout::slice_floats(hop_size, staged);
-            c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(waves) * c->slice_floats);
+            c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(waves) * c->slice_floats + waves);   // + RoundSync counters
         }
         if (c->fast_lds > kLdsLimit) c->fast = false;
     }
@@ -674,7 +683,8 @@ int melspec_set_precise(melspec_ctx *c, int on) {
     if (c->d_blob64.p == nullptr) {              // first use: build, check and upload before anything is committed to the ctx
         PreciseTables pt;
         if (!build_precise_tables(c->ft, pt)) return fail(MELSPEC_ERR_INTERNAL, "precise tables");
-        const size_t lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double);
+        const size_t lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double) +
+                           kPreciseWaves * sizeof(uint32_t);   // + RoundSync counters
         if (lds > kLdsLimit) return fail(MELSPEC_ERR_UNSUPPORTED, "precise tables do not fit in LDS");
         HIP_TRY(hipSetDevice(c->dev.device));
         int rc = upload(c->d_blob64, pt.blob);

@@ -149,6 +149,43 @@ __device__ __forceinline__ float wave_shift_down1(float v) {
                                                                  0xf, 0xf, false));
 }
 
+// Sub-group barrier of the mel-major stores (BatchDesc::sync_rounds = gsize + 16 * across, gsize in {2, 4, 8}): only the
+// gsize waves that hold adjacent units of a round wait for each other (LDS arrival counters, the waiting wave at priority 0
+// polling with s_sleep), so the pieces of a 32-byte sector reach L2 together while the other waves of the workgroup keep
+// their phases apart.  "across": the group is made of waves WAVES / gsize apart and the units of a round are dealt so that
+// it still holds adjacent ones.  sync_rounds == 1 is the plain workgroup barrier, 0 none.
+template <int WAVES>
+struct RoundSync {
+    int gsize, g, slot;
+    unsigned round = 0;
+    unsigned *arrive;
+    __device__ __forceinline__ RoundSync(int mode, int wave, unsigned *counters) : arrive(counters) {
+        gsize = mode & 15;
+        const int across = mode >> 4;
+        const int ngroups = gsize > 1 ? WAVES / gsize : 1;
+        g = gsize > 1 ? (across ? wave % ngroups : wave / gsize) : 0;
+        slot = (gsize > 1 && across) ? g * gsize + wave / ngroups : wave;
+    }
+    // before the stores of a round
+    template <int RESTORE_PRIO>
+    __device__ __forceinline__ void before_stores(int lane) {
+        if (gsize <= 1) return;
+        ++round;
+        __builtin_amdgcn_s_setprio(0);
+        if (lane == 0) {
+            __hip_atomic_fetch_add(arrive + g, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned target = round * (unsigned)gsize;
+            while (__hip_atomic_load(arrive + g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_setprio(RESTORE_PRIO);
+    }
+    // at the end of a round
+    __device__ __forceinline__ void after_round() const {
+        if (gsize == 1) __syncthreads();
+    }
+};
+
 // LAYOUT = false: plain [clip][frame][mel] output (the hot configuration, no padding logic compiled in);
 // LAYOUT = true: padded and/or mel-major output (interleave_frames, BatchDesc::out_width / mel_major).
 template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false, bool LAYOUT = false>
@@ -157,6 +194,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
+    unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // RoundSync counters
+    if (LAYOUT && tid < WAVES) arrive[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,8 +219,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     // LAYOUT builds walk the units workgroup-uniformly (a wave without a unit idles through the round) so that the
     // mel-major store can re-align the waves once per round, see the end of the loop
     const uint64_t w_off = LAYOUT ? 0 : wave;
+    RoundSync<WAVES> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
-        const uint64_t unit = LAYOUT ? first + wave : first;
+        const uint64_t unit = LAYOUT ? first + rs.slot : first;
         const bool have = !LAYOUT || unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
@@ -233,6 +273,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         }
 #endif
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT) rs.template before_stores<0>(lane);
         if (LAYOUT && p.b.mel_major)
             wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
@@ -240,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         __builtin_amdgcn_wave_barrier();
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
-        if (LAYOUT && p.b.sync_rounds) __syncthreads();
+        if (LAYOUT) rs.after_round();
     }
 }
 
@@ -270,15 +311,9 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
     const uint64_t w_off = LAYOUT ? 0 : wave;
-    unsigned round = 0;
-    // sub-group barrier of the mel-major store: gsize waves that hold adjacent units of a round.  "across" builds the groups
-    // from waves kSixWaves / gsize apart (different SIMDs), the plain form from consecutive waves.
-    const int gsize = p.b.sync_rounds & 15, across = p.b.sync_rounds >> 4;
-    const int ngroups = gsize > 1 ? kSixWaves / gsize : 1;
-    const int g = gsize > 1 ? (across ? wave % ngroups : wave / gsize) : 0;
-    const int slot = (LAYOUT && gsize > 1 && across) ? g * gsize + wave / ngroups : wave;
+    RoundSync<kSixWaves> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
     for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
-        const uint64_t unit = LAYOUT ? first + slot : first;
+        const uint64_t unit = LAYOUT ? first + rs.slot : first;
         const bool have = !LAYOUT || unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kSixFrames;
@@ -310,25 +345,13 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && gsize > 1) {
-            // sub-group barrier: the p.b.sync_rounds waves holding adjacent units (one per SIMD for 4) store together; the
-            // sub-groups of a workgroup drift freely, so the waves sharing a SIMD keep their phases apart
-            ++round;
-            MS_PRIO(0);                                  // the waiting wave must not take issue slots from the working ones
-            if (lane == 0) {
-                __hip_atomic_fetch_add(arrive + g, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned target = round * (unsigned)gsize;
-                while (__hip_atomic_load(arrive + g, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
-            }
-            __builtin_amdgcn_wave_barrier();
-            MS_PRIO(3);
-        }
+        if (LAYOUT) rs.template before_stores<3>(lane);
         if (LAYOUT && p.b.mel_major)
             six_phase4<NSLOTS, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
             six_phase4<NSLOTS, LAYOUT>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && p.b.sync_rounds == 1) __syncthreads();
+        if (LAYOUT) rs.after_round();
     }
 }
 
@@ -351,6 +374,8 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    unsigned *arrive = ldsw + p.blob_words + WAVES * PreciseLayout::slice_doubles() * 2;   // RoundSync counters
+    if (LAYOUT && tid < WAVES) arrive[tid] = 0;
     __syncthreads();
     const double *tb = reinterpret_cast<const double *>(ldsw);
     // the shared phase-3 code addresses the mel tables as offsets from the base of the f32 blob
@@ -372,8 +397,9 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
     const uint64_t w_off = LAYOUT ? 0 : wave;      // LAYOUT: workgroup-uniform rounds, see whisper400_wave_kernel
+    RoundSync<WAVES> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
-        const uint64_t unit = LAYOUT ? first + wave : first;
+        const uint64_t unit = LAYOUT ? first + rs.slot : first;
         const bool have = !LAYOUT || unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
@@ -398,12 +424,13 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
         wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT) rs.template before_stores<2>(lane);
         if (LAYOUT && p.b.mel_major)
             wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
             wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && p.b.sync_rounds) __syncthreads();
+        if (LAYOUT) rs.after_round();
     }
 }
 
