@@ -209,12 +209,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;     // compile-time for the two Whisper banks
     const int fl3 = INTERVAL ? lane / 12 : fl, j3 = INTERVAL ? lane - fl3 * 12 : j;
     const bool in3 = INTERVAL ? lane < kFPW * 12 : in;
-    int st[NSLOTS];
-    if (INTERVAL) {
-        const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart);
-#pragma unroll
-        for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
-    }
+    const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
 
     // LAYOUT builds walk the units workgroup-uniformly (a wave without a unit idles through the round) so that the
     // mel-major store can re-align the waves once per round, see the end of the loop
@@ -263,6 +258,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
         if (act3) slice[WaveLayout::kPmaxOff + fl3 * WaveLayout::kPmaxStride + j3] = vals[0];
 #else
         if (INTERVAL) {
+            // per-lane start bins: re-read every unit (NSLOTS LDS words) rather than held in registers across the loop
+            int st[NSLOTS];
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
             float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
             wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
 #pragma unroll
