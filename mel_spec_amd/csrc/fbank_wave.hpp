@@ -66,16 +66,18 @@ struct FbankLayout {
 };
 
 // frame-sum partial: lane (f,t) adds the samples of its own column, pairs 32*n1 + 2t + {0,1} below 400
+// All 13 loads are unconditional (lanes t >= 8 re-read pair 0 for the 13th and drop it), so the compiler issues them
+// back to back; a guarded 13th load costs a separate memory round trip per unit.
 template <class T>
 MS_DEV T fb_partial_sum(const float *frame, int t) {
+    f2 a[13];
+#pragma unroll
+    for (int n1 = 0; n1 < 12; ++n1) a[n1] = load2_unaligned(frame + 32 * n1 + 2 * t);
+    a[12] = load2_unaligned(frame + (t < 8 ? 384 + 2 * t : 0));
     T s = 0;
 #pragma unroll
-    for (int n1 = 0; n1 < 13; ++n1) {
-        if (n1 < 12 || t < 8) {
-            const f2 a = load2_unaligned(frame + 32 * n1 + 2 * t);
-            s += static_cast<T>(a.x) + static_cast<T>(a.y);
-        }
-    }
+    for (int n1 = 0; n1 < 12; ++n1) s += static_cast<T>(a[n1].x) + static_cast<T>(a[n1].y);
+    if (t < 8) s += static_cast<T>(a[12].x) + static_cast<T>(a[12].y);
     return s;
 }
 
@@ -95,6 +97,16 @@ MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *tblob, T *xo /* &
 template <class T>
 MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_first, const T *tblob, T *xo /* &row[0][n2] */) {
     cpx<T> x[16];
+    // every load first and unconditional: 13 pairs (lanes n2 >= 8 have no 13th pair: they re-read pair 0 and drop it) and
+    // the sample in front of each pair (the first sample of a clip has none: it re-reads itself and the value is unused)
+    f2 c[13];
+    float prev[13];
+#pragma unroll
+    for (int n1 = 0; n1 < 13; ++n1) {
+        const int i = (n1 < 12 || n2 < 8) ? 32 * n1 + 2 * n2 : 0;
+        c[n1] = load2_unaligned(frame + i);
+        prev[n1] = frame[(n1 == 0 && patch_first) ? 0 : i - 1];
+    }
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         x[n1] = {T(0), T(0)};
@@ -102,10 +114,9 @@ MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_
             const int i = 32 * n1 + 2 * n2;
             // frame_buf[i] = x[i] - mean; frame_buf[i] -= preemph * frame_buf[i-1]  (src/fbank.rs:165-181);
             // the first sample of a clip gets no pre-emphasis
-            const f2 s = load2_unaligned(frame + i);
-            const T b0 = static_cast<T>(s.x) - mean, b1 = static_cast<T>(s.y) - mean;
-            T y0 = b0;
-            if (!(n1 == 0 && patch_first)) y0 = b0 - preemph * (static_cast<T>(frame[i - 1]) - mean);
+            const T b0 = static_cast<T>(c[n1].x) - mean, b1 = static_cast<T>(c[n1].y) - mean;
+            const T pe = b0 - preemph * (static_cast<T>(prev[n1]) - mean);
+            const T y0 = (n1 == 0 && patch_first) ? b0 : pe;
             const T y1 = b1 - preemph * b0;
             const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
             x[n1] = {y0 * w.re, y1 * w.im};
@@ -155,21 +166,36 @@ MS_DEV float nemo_sample(const float *clip, long long s, long long len, float co
 // `inside`: every sample this frame touches, and the one before its first, lies inside the clip (all frames
 // but the first two and last two of a centred clip), so the guards and the clip-start special case drop out
 // and the pair comes from one 8-byte load.
-template <class T>
-MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2, float coeff, bool inside, const T *tblob, T *xo) {
+// INSIDE / PRE are wave-uniform and resolved outside the unrolled loop: a data-dependent `coeff == 0 ? a : b` around the
+// opaque rounding barrier of f32_mul_rn becomes a branch per sample with an s_waitcnt vmcnt(0) in front of it, i.e. 26
+// serialised memory round trips per unit (measured: 1.51 ms per launch against 0.95 ms for this form).
+template <class T, bool INSIDE, bool PRE>
+MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2, float coeff, const T *tblob, T *xo) {
     cpx<T> x[16];
+    f2 c[13];
+    float prev[13];
+    if (INSIDE) {
+        // interior frame: every load first (13 pairs and the 13 samples in front of them), arithmetic afterwards
+#pragma unroll
+        for (int n1 = 0; n1 < 13; ++n1) {
+            c[n1] = {0.0f, 0.0f};
+            prev[n1] = 0.0f;
+            if (n1 < 12 || n2 < 8) {
+                const float *s = clip + org + 32 * n1 + 2 * n2;
+                c[n1] = load2_unaligned(s);
+                if (PRE) prev[n1] = s[-1];
+            }
+        }
+    }
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
         x[n1] = {T(0), T(0)};
         if (n1 < 12 || (n1 == 12 && n2 < 8)) {
             const int i = 32 * n1 + 2 * n2;
             float y0, y1;
-            if (inside) {
-                const float *s = clip + org + i;
-                const f2 c = load2_unaligned(s);
-                const float prev = s[-1];
-                y0 = coeff == 0.0f ? c.x : c.x - f32_mul_rn(coeff, prev);
-                y1 = coeff == 0.0f ? c.y : c.y - f32_mul_rn(coeff, c.x);
+            if (INSIDE) {
+                y0 = PRE ? c[n1].x - f32_mul_rn(coeff, prev[n1]) : c[n1].x;
+                y1 = PRE ? c[n1].y - f32_mul_rn(coeff, c[n1].x) : c[n1].y;
             } else {
                 y0 = nemo_sample(clip, org + i, len, coeff);
                 y1 = nemo_sample(clip, org + i + 1, len, coeff);
@@ -181,12 +207,21 @@ MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2,
     fb_column_finish<T>(x, n2, tblob, xo);
 }
 
+// all_inside: wave-uniform -- every active frame of the wave is an interior frame (the guarded form runs only for the
+// units at the two ends of a clip)
 template <class T>
-MS_DEV void nemo_phase1(int fl, int t, bool active, const float *clip, long long org, long long len, float coeff,
+MS_DEV void nemo_phase1(int fl, int t, bool active, bool all_inside, const float *clip, long long org, long long len, float coeff,
                         const T *tblob, T *slice) {
-    if (!active) return;
-    const bool inside = org >= 1 && org + 400 <= len;
-    nemo_column<T>(clip, org, len, t, coeff, inside, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
+    T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
+    if (all_inside) {
+        if (coeff != 0.0f) {
+            if (active) nemo_column<T, true, true>(clip, org, len, t, coeff, tblob, xo);
+        } else {
+            if (active) nemo_column<T, true, false>(clip, org, len, t, coeff, tblob, xo);
+        }
+    } else {
+        if (active) nemo_column<T, false, true>(clip, org, len, t, coeff, tblob, xo);
+    }
 }
 
 // Value held by lane (16 - r) & 15 of the caller's 16-lane row (r = lane & 15): row_mirror (lane i <- 15-i)

@@ -508,7 +508,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
         } else {
             const long long org = (long long)(f0 + (uint64_t)fl) * p.shift + p.org0;
-            nemo_phase1<T>(fl, j, act, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
+            const bool inside = org >= 1 && org + 400 <= (long long)p.clip_len;
+            const bool all_inside = __builtin_amdgcn_ballot_w64(act && !inside) == 0;
+            nemo_phase1<T>(fl, j, act, all_inside, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
         }
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(1);

@@ -283,10 +283,16 @@ extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_
             fl = lane / kFbLanes; j = lane - fl * kFbLanes; act = lane < kFbFPW * kFbLanes && fl < nv;
         };
         std::vector<T> snap(slice), next(slice);
+        bool all_inside = true;     // the kernel's wave-uniform ballot
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; lane_info(lane, fl, j, act);
+            const long long org = (f0 + fl) * hop + org0;
+            if (act && !(org >= 1 && org + 400 <= n)) all_inside = false;
+        }
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; lane_info(lane, fl, j, act);
             std::vector<T> tmp(snap);
-            nemo_phase1<T>(fl, j, act, pcm, (f0 + fl) * hop + org0, n, preemph, tblob, tmp.data());
+            nemo_phase1<T>(fl, j, act, all_inside, pcm, (f0 + fl) * hop + org0, n, preemph, tblob, tmp.data());
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
