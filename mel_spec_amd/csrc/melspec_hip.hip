@@ -155,9 +155,34 @@ struct GenericTables {
 };
 
 // Device-side copies of a ragged batch description.
+// A ragged plan travels host -> pinned slot -> device slot -> kernel.  Four slots per context, each with an event recorded
+// behind the launch that reads it: a call neither waits for the stream (the copy is truly asynchronous from pinned
+// memory) nor overwrites a plan an earlier launch -- possibly on another stream -- may still be reading.
+struct RaggedSlot {
+    DevBuf dev;
+    void *host = nullptr;
+    size_t host_cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+    int ensure_host(size_t bytes) {
+        if (bytes <= host_cap) return MELSPEC_OK;
+        if (host) { (void)hipHostFree(host); host = nullptr; host_cap = 0; }
+        HIP_TRY(hipHostMalloc(&host, bytes, hipHostMallocDefault));
+        host_cap = bytes;
+        return MELSPEC_OK;
+    }
+    void release() {
+        if (ev) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); ev = nullptr; }
+        if (host) { (void)hipHostFree(host); host = nullptr; host_cap = 0; }
+        dev.release();
+        pending = false;
+    }
+};
 struct RaggedScratch {
-    DevBuf buf;
-    const uint64_t *d_off = nullptr, *d_frames = nullptr, *d_out_off = nullptr, *d_prefix = nullptr;
+    static constexpr unsigned kSlots = 4;
+    RaggedSlot slot[kSlots];
+    unsigned next = 0;
+    void release() { for (auto &s : slot) s.release(); }
 };
 
 struct BatchPlan {
@@ -192,34 +217,56 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     return pl;
 }
 
+// Fills the next slot and queues its upload on `stream`.  The caller launches on `stream` and then calls plan_ragged_done.
 int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float *d_out, const uint64_t *h_off,
                 const std::vector<uint64_t> &frames, const uint64_t *h_out_off, uint32_t n_clips, int n_mels,
-                int frames_per_unit, BatchPlan &pl) {
-    std::vector<uint64_t> host(static_cast<size_t>(n_clips) * 4 + 1);
-    uint64_t *off = host.data(), *fr = off + n_clips, *oo = fr + n_clips, *pre = oo + n_clips;
-    uint64_t units = 0, out_cursor = 0, total = 0;
+                int frames_per_unit, BatchPlan &pl, RaggedSlot *&used) {
+    RaggedSlot &sl = rs.slot[rs.next++ % RaggedScratch::kSlots];
+    used = &sl;
+    if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.pending) { HIP_TRY(hipEventSynchronize(sl.ev)); sl.pending = false; }
+    uint64_t units = 0;
+    for (uint32_t c = 0; c < n_clips; ++c) units += (frames[c] + frames_per_unit - 1) / frames_per_unit;
+    const uint64_t n_blocks = (units + kUnitBlock - 1) / kUnitBlock;
+    const size_t words64 = static_cast<size_t>(n_clips) * 4 + 1;
+    const size_t bytes = words64 * sizeof(uint64_t) + static_cast<size_t>(n_blocks ? n_blocks : 1) * sizeof(uint32_t);
+    int rc = sl.ensure_host(bytes);
+    if (rc) return rc;
+    if ((rc = sl.dev.ensure(bytes))) return rc;
+    uint64_t *off = static_cast<uint64_t *>(sl.host), *fr = off + n_clips, *oo = fr + n_clips, *pre = oo + n_clips;
+    uint32_t *blk = reinterpret_cast<uint32_t *>(off + words64);
+    uint64_t cursor = 0, out_cursor = 0, total = 0;
     for (uint32_t c = 0; c < n_clips; ++c) {
         off[c] = h_off[c];
         fr[c] = frames[c];
         oo[c] = h_out_off ? h_out_off[c] : out_cursor;
         out_cursor += frames[c] * static_cast<uint64_t>(n_mels);
-        pre[c] = units;
-        units += (frames[c] + frames_per_unit - 1) / frames_per_unit;
+        pre[c] = cursor;
+        cursor += (frames[c] + frames_per_unit - 1) / frames_per_unit;
         total += frames[c];
     }
     pre[n_clips] = units;
-    int rc = rs.buf.ensure(host.size() * sizeof(uint64_t));
-    if (rc) return rc;
-    // pageable source: the runtime stages it before returning, so `host` may die here
-    HIP_TRY(hipMemcpyAsync(rs.buf.p, host.data(), host.size() * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const uint64_t *d = static_cast<const uint64_t *>(rs.buf.p);
+    {
+        uint32_t c = 0;
+        for (uint64_t k = 0; k < n_blocks; ++k) {
+            const uint64_t u = k * kUnitBlock;
+            while (pre[c + 1] <= u) ++c;      // u < units = pre[n_clips]
+            blk[k] = c;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host, bytes, hipMemcpyHostToDevice, stream));
+    const uint64_t *d = static_cast<const uint64_t *>(sl.dev.p);
     BatchDesc &b = pl.desc;
     b = BatchDesc{};
     b.pcm = d_pcm; b.out = d_out; b.n_clips = n_clips; b.n_units = units; b.frames_per_unit = frames_per_unit;
     b.d_off = d; b.d_frames = d + n_clips; b.d_out_off = d + 2 * n_clips; b.d_unit_prefix = d + 3 * n_clips;
+    b.d_unit_block = reinterpret_cast<const uint32_t *>(d + words64);
     pl.total_frames = total;
     return MELSPEC_OK;
+}
+// behind the launch (or the failed attempt) that used the slot
+void plan_ragged_done(RaggedSlot *sl, hipStream_t stream) {
+    if (sl && sl->ev && hipEventRecord(sl->ev, stream) == hipSuccess) sl->pending = true;
 }
 
 unsigned grid_for(uint64_t units, int cus, int per_cu) {
@@ -661,7 +708,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.buf.release(); c->h2d.release(); c->d2h.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release(); c->h2d.release(); c->d2h.release();
     delete c;
 }
 
@@ -756,10 +803,12 @@ int melspec_compute_ragged_device(melspec_ctx *c, const float *d_pcm, const uint
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
     BatchPlan pl;
+    RaggedSlot *slot = nullptr;
     int rc = plan_ragged(c->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, c->n_mels,
-                         ctx_frames_per_unit(c, true), pl);
-    if (rc) return rc;
-    return launch_ctx(c, pl.desc, s);
+                         ctx_frames_per_unit(c, true), pl, slot);
+    if (!rc) rc = launch_ctx(c, pl.desc, s);
+    plan_ragged_done(slot, s);
+    return rc;
 }
 
 int melspec_time_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,

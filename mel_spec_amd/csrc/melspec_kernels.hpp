@@ -29,7 +29,7 @@
 namespace melspec {
 
 // How work units (tiles of frames) map onto clips.  Uniform batches are pure arithmetic;
-// ragged batches binary-search a prefix table of units per clip.
+// ragged batches look the clip up in a per-16-units table and a prefix table of units per clip.
 struct BatchDesc {
     const float *pcm;
     float *out;
@@ -47,7 +47,10 @@ struct BatchDesc {
     const uint64_t *d_frames;    // ragged: frames in clip c
     const uint64_t *d_out_off;   // ragged: first output float of clip c
     const uint64_t *d_unit_prefix;  // ragged: first unit of clip c, [n_clips+1]
+    const uint32_t *d_unit_block;   // ragged: clip that holds unit k * kUnitBlock
 };
+
+constexpr uint32_t kUnitBlock = 16;   // granularity of BatchDesc::d_unit_block
 
 struct UnitLoc {
     const float *pcm;   // first sample of the clip
@@ -65,11 +68,10 @@ __device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit
         r.out = b.out + clip * b.out_stride;
         r.frames = b.frames_per_clip;
     } else {
-        uint32_t lo = 0, hi = b.n_clips;   // prefix[lo] <= unit < prefix[hi]
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (b.d_unit_prefix[mid] <= unit) lo = mid; else hi = mid;
-        }
+        // d_unit_block[k] = clip that holds unit k * kUnitBlock; from there a short walk (clips without frames, clip ends
+        // inside the block) instead of a binary search of ~log2(n_clips) dependent loads per unit
+        uint32_t lo = b.d_unit_block[unit / kUnitBlock];
+        while (b.d_unit_prefix[lo + 1] <= unit) ++lo;       // prefix[n_clips] = n_units > unit
         r.unit = unit - b.d_unit_prefix[lo];
         r.pcm = b.pcm + b.d_off[lo];
         r.out = b.out + b.d_out_off[lo];
