@@ -212,9 +212,28 @@ __global__ __launch_bounds__(kQuantThreads) void quant_encode_kernel(const Quant
     const float mn = key_to_float(d.keys[2 * item]), mx = key_to_float(d.keys[2 * item + 1]);
     const float scale = f32_div_rn(255.0f, mx - mn);                       // src/quant.rs:145
     if (d.ranges && blk == 0 && threadIdx.x == 0) { d.ranges[2 * item] = mn; d.ranges[2 * item + 1] = mx; }
+    const uint64_t dw0 = static_cast<uint64_t>(blk) * kQuantDwPerBlock + threadIdx.x;
+    const uint64_t dw3 = dw0 + 3 * kQuantThreads;
+    if (d.vec && 4 * dw0 >= d.header && 4 * dw3 - d.header + 4 <= npx) {
+        // all four dwords of this thread are whole pixel quads: the eight loads first, then the arithmetic (a load inside
+        // each `if` is a memory round trip of its own)
+        f2 a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float *src = img + (4 * (dw0 + static_cast<uint64_t>(k) * kQuantThreads) - d.header);
+            a[k] = *reinterpret_cast<const f2 *>(src);
+            b[k] = *reinterpret_cast<const f2 *>(src + 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            out[dw0 + static_cast<uint64_t>(k) * kQuantThreads] =
+                quantize_px(a[k].x, mn, scale) | (quantize_px(a[k].y, mn, scale) << 8) | (quantize_px(b[k].x, mn, scale) << 16) |
+                (quantize_px(b[k].y, mn, scale) << 24);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint64_t dw = static_cast<uint64_t>(blk) * kQuantDwPerBlock + static_cast<uint64_t>(k) * kQuantThreads + threadIdx.x;
+        const uint64_t dw = dw0 + static_cast<uint64_t>(k) * kQuantThreads;
         if (dw < ndw) out[dw] = encode_dword(d, img, c, cw, npx, dw, mn, mx, scale);
     }
 }
@@ -237,10 +256,17 @@ __global__ __launch_bounds__(kQuantThreads) void quant_decode_kernel(const Quant
     }
     const float scale = f32_div_rn(mx - mn, 255.0f);                       // src/quant.rs:158
     const uint32_t *words = reinterpret_cast<const uint32_t *>(blob);
+    const uint64_t dw0 = static_cast<uint64_t>(blk) * kQuantDwPerBlock + threadIdx.x;
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {           // the four loads first
+        const uint64_t dw = dw0 + static_cast<uint64_t>(k) * kQuantThreads;
+        w[k] = words[dw < ndw ? dw : 0];
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint64_t dw = static_cast<uint64_t>(blk) * kQuantDwPerBlock + static_cast<uint64_t>(k) * kQuantThreads + threadIdx.x;
-        if (dw < ndw) decode_dword(d, img, c, cw, npx, dw, words[dw], mn, scale);
+        const uint64_t dw = dw0 + static_cast<uint64_t>(k) * kQuantThreads;
+        if (dw < ndw) decode_dword(d, img, c, cw, npx, dw, w[k], mn, scale);
     }
 }
 
