@@ -287,8 +287,31 @@ MS_DEV void fb_phase2_split(int fl, int r, bool active, bool use_power, const T 
     if (lane0) pair(8, own[8], part[0]);
 }
 
+// Compile-time slot lengths of the default filterbanks over 16-lane groups (any other bank: LensRuntime).  With them the
+// bin loop unrolls and its LDS reads are issued together; the run-time loop pays one LDS round trip per bin (26-30 per
+// unit), which two waves per SIMD cannot hide.
+template <int... L>
+struct LensFbStatic {
+    static constexpr bool kStatic = true;
+    static constexpr int kSlots = sizeof...(L);
+    MS_HD static constexpr int len(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        return t[i];
+    }
+    MS_HD static constexpr int woff(int i) {          // float offset from the mel section base
+        constexpr int t[sizeof...(L)] = {L...};
+        int s = 0;
+        for (int k = 0; k < i; ++k) s += t[k];
+        return FbankBlob::kMelW + 2 * kFbLanes * s;
+    }
+};
+using LensKaldi80 = LensFbStatic<2, 2, 3, 5, 7, 9>;              // Kaldi mel scale, 80 bins, 20 Hz .. 8 kHz at 16 kHz (FbankConfig::default)
+using LensSlaney80 = LensFbStatic<2, 2, 3, 5, 8, 10>;            // NeMo: Slaney, 80 mels, 0 .. 8 kHz, bins 0..256
+using LensSlaney80W = LensFbStatic<2, 2, 3, 5, 8, 9>;            // Whisper at n_fft 512: the same bank over bins < 256
+using LensSlaney128 = LensFbStatic<1, 1, 1, 2, 2, 3, 4, 5, 7>;   // 128 mels, both
+
 // phase 3: interval sums over 16-lane groups (lane j<15 owns interval j + 15*slot, j=15 is the ghost)
-template <class T, int NSLOTS = kFbSlots>
+template <class T, int NSLOTS = kFbSlots, class Lens = LensRuntime>
 MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *mel /* mel section base */,
                            const T *slice, const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
 #pragma unroll
@@ -298,7 +321,19 @@ MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         float ar = 0.0f, af = 0.0f;
-        if (i < ms.n_slots) {
+        if (Lens::kStatic) {
+            if (i < Lens::kSlots) {
+                const float *pp = p + st[i];
+                const float *w = mel + Lens::woff(i < Lens::kSlots ? i : 0) + 2 * j;
+#pragma unroll
+                for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
+                    const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kFbLanes * r);
+                    const float pv = pp[r];
+                    ar += wv.x * pv;
+                    af += wv.y * pv;
+                }
+            }
+        } else if (i < ms.n_slots) {
             const float *pp = p + st[i];
             const float *w = mel + ms.woff[i] + 2 * j;
             const int len = ms.len[i];

@@ -313,12 +313,14 @@ int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
     return blob_bytes + 8 * slice_bytes <= kLdsLimit ? 8 : 4;
 }
 
-template <class T, int FLAVOR, int NSLOTS>
+// Lens: compile-time slot lengths when the context's filterbank is one of the default banks (8-wave shape only; the
+// 4-wave fallback for oversized tables keeps the run-time loop)
+template <class T, int FLAVOR, int NSLOTS, class Lens = LensRuntime>
 int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
-        if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
+        int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
+        if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
@@ -326,11 +328,21 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
     static const int per_cu = [] { const char *e = std::getenv("MELSPEC_FB_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU; measured best
     const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
     if (waves == 8)
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(512), lds, s, fp);
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>), dim3(grid), dim3(512), lds, s, fp);
     else
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS>), dim3(grid), dim3(256), lds, s, fp);
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>), dim3(grid), dim3(256), lds, s, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
+}
+
+// does the context's bank have exactly the compile-time slot lengths of Lens?  MELSPEC_RUNTIME_LENS=1 forces the run-time loop.
+template <class Lens>
+bool fb_lens_match(const MelSlots &ms) {
+    static const bool off = [] { const char *e = std::getenv("MELSPEC_RUNTIME_LENS"); return e && e[0] == '1'; }();
+    if (off || ms.n_slots != Lens::kSlots) return false;
+    for (int i = 0; i < Lens::kSlots; ++i)
+        if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
+    return true;
 }
 }  // namespace
 
@@ -534,6 +546,8 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         fp.n_mels = c->n_mels;
         fp.use_log = 1; fp.use_power = 1;
         fp.slots = c->ft512.slots;
+        if (fb_lens_match<LensSlaney80W>(c->ft512.slots)) return launch_fused512<double, kFlavorWhisper, kFbSlots, LensSlaney80W>(c->waves512, fp, c->lds512, c->dev.cus, stream);
+        if (fb_lens_match<LensSlaney128>(c->ft512.slots)) return launch_fused512<double, kFlavorWhisper, kBlmSlots, LensSlaney128>(c->waves512, fp, c->lds512, c->dev.cus, stream);
         return c->ft512.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorWhisper, kFbSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream)
                                                   : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
     }
@@ -1017,8 +1031,11 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         fp.use_log = fb->cfg.use_log_fbank;
         fp.use_power = fb->cfg.use_power;
         fp.slots = fb->ft.slots;
-        rc = fb->ft.f64 ? launch_fused512<double, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s)
-                        : launch_fused512<float, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
+        if (fb->ft.f64 && fb_lens_match<LensKaldi80>(fb->ft.slots))
+            rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi80>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
+        else
+            rc = fb->ft.f64 ? launch_fused512<double, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s)
+                            : launch_fused512<float, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         if (rc) return rc;
         // the CMN pass below walks clips, not units
     } else {
@@ -1668,8 +1685,11 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
     fp.clip_len = static_cast<long long>(clip_len);
     fp.org0 = b->cfg.center ? -200 : 56;      // tap 0 of the window sits at position (512-400)/2 of the frame
     fp.slots = b->ft.slots;
-    int rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
-                                             : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+    int rc;
+    if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+    else if (fb_lens_match<LensSlaney80>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kFbSlots, LensSlaney80>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+    else rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
+                                              : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
     if (rc) return rc;
     if (b->cfg.normalize_per_feature && valid > 0) {
         BlmNormParams np{};

@@ -461,7 +461,7 @@ constexpr int kFlavorKaldi = 0, kFlavorNemo = 1, kFlavorWhisper = 2;
 //                 log10 / per-frame clamp / (x+4)/4, frame-major output (plain and ragged batches).
 // FLAVOR = NeMo:  BatchLogMelSpectrogram::compute (src/mel.rs:321-385), feature-major output of
 //                 b.out_width columns per mel row (columns past the valid frames are zero).
-template <class T, int WAVES, int MINW, int FLAVOR = kFlavorKaldi, int NSLOTS = kFbSlots>
+template <class T, int WAVES, int MINW, int FLAVOR = kFlavorKaldi, int NSLOTS = kFbSlots, class Lens = LensRuntime>
 __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const FbankFastParams p) {
     using L = FbankLayout<T>;
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(2);
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
-        fb_phase3_sums<T, NSLOTS>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
+        fb_phase3_sums<T, NSLOTS, Lens>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
         if (FLAVOR == kFlavorKaldi) {
