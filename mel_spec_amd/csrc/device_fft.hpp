@@ -19,6 +19,10 @@
 #define MS_DEV inline
 #define MS_HD inline
 #endif
+// The table blob is read-only while the kernels run and never overlaps a wave's slice; without the qualifier every table
+// read stays behind the preceding slice write (one LDS round trip per twiddle: ds_write / ds_read / s_waitcnt lgkmcnt(0)
+// triples in the ISA, tools/isa_schedule.py).  Used where two waves per SIMD cannot hide that latency.
+#define MS_RESTRICT __restrict__
 
 namespace melspec {
 

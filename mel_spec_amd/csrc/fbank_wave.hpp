@@ -83,7 +83,7 @@ MS_DEV T fb_partial_sum(const float *frame, int t) {
 
 // DFT over n1 of one column, twiddle by W_256^{n2*k1}, write the 16 exchange rows.
 template <class T>
-MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *tblob, T *xo /* &row[0][n2] */) {
+MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *MS_RESTRICT tblob, T *MS_RESTRICT xo /* &row[0][n2] */) {
     using L = FbankLayout<T>;
     fft16(x);
     const T *tw = tblob + FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride;
@@ -255,7 +255,7 @@ MS_DEV void fb_phase2_dft(int fl, int r, bool active, const T *slice, cpx<T> (&o
 //   pair s: Z[k], k = r + 16s, with Z[256-k] = partner[15 - s]; for r == 0 the partner index is 16 - s
 //   (mod 16: Z[256 - 16s]), i.e. own[0] for s = 0 and part[8 - s] for s = 1..8.
 template <class T>
-MS_DEV void fb_phase2_split(int fl, int r, bool active, bool use_power, const T *tblob, const cpx<T> (&own)[16],
+MS_DEV void fb_phase2_split(int fl, int r, bool active, bool use_power, const T *MS_RESTRICT tblob, const cpx<T> (&own)[16],
                             const cpx<T> (&part)[8], T *slice) {
     if (!active) return;
     const T *tw = tblob + FbankBlob::kTw2 + r * FbankBlob::kTw2Stride;
