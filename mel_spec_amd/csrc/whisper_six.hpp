@@ -188,13 +188,7 @@ MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, cons
         } else if (i < ms.n_slots) {
             const float *pp = p + st[i];
             const float *w = blob + ms.woff[i] + 2 * j;
-            const int len = ms.len[i];
-            for (int r = 0; r < len; ++r) {
-                const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kSixLanes * r);
-                const float pv = pp[r];
-                ar += wv.x * pv;
-                af += wv.y * pv;
-            }
+            interval_bins_runtime<2 * kSixLanes>(pp, w, ms.len[i], ar, af);
         }
         rise[i] = ar;
         fprev[i] = af;

@@ -45,6 +45,34 @@ struct WaveLayout {
     }
 };
 
+// Run-time slot lengths (any bank that is not one of the compile-time ones): the bins of a slot four at a time, so that the
+// eight LDS reads of a group are in flight together; one read pair per iteration is one LDS round trip per bin.  The
+// summation order is that of the plain loop.
+template <int WSTRIDE>
+MS_DEV void interval_bins_runtime(const float *pp, const float *w, int len, float &ar, float &af) {
+    int r = 0;
+    for (; r + 4 <= len; r += 4) {
+        f2 wv[4];
+        float pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wv[q] = *reinterpret_cast<const f2 *>(w + WSTRIDE * (r + q));
+            pv[q] = pp[r + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ar += wv[q].x * pv[q];
+            af += wv[q].y * pv[q];
+        }
+    }
+    for (; r < len; ++r) {
+        const f2 wv = *reinterpret_cast<const f2 *>(w + WSTRIDE * r);
+        const float pv = pp[r];
+        ar += wv.x * pv;
+        af += wv.y * pv;
+    }
+}
+
 // Compile-time slot lengths for the two Whisper filterbanks (16 kHz, 80 / 128 mels); any
 // other (sr, n_mels) uses the runtime lengths in MelSlots.
 struct LensRuntime {
@@ -223,13 +251,7 @@ MS_DEV void wave_phase3i_sums(int fl, int j12, bool active, const MelSlots &ms, 
         } else if (i < ms.n_slots) {
             const float *pp = p + st[i];
             const float *w = blob + ms.woff[i] + 2 * j12;
-            const int len = ms.len[i];
-            for (int r = 0; r < len; ++r) {
-                const f2 wv = *reinterpret_cast<const f2 *>(w + 24 * r);
-                const float pv = pp[r];
-                ar += wv.x * pv;
-                af += wv.y * pv;
-            }
+            interval_bins_runtime<24>(pp, w, ms.len[i], ar, af);
         }
         rise[i] = ar;
         fprev[i] = af;
