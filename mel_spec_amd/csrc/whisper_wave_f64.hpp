@@ -29,7 +29,7 @@ struct PreciseLayout {
     static constexpr int slice_doubles() { return kFPW * kXStride; }   // 2320 doubles; power rows / maxima alias its head
 };
 
-MS_DEV void precise_phase1(int fl, int t, bool active, int hop, const double *tb, const float *gsrc, double *rows) {
+MS_DEV void precise_phase1(int fl, int t, bool active, int hop, const double *MS_RESTRICT tb, const float *MS_RESTRICT gsrc, double *MS_RESTRICT rows) {
     if (!active) return;
     const float *s = gsrc + fl * hop + 2 * t;
     cd x[20];
@@ -49,7 +49,7 @@ MS_DEV void precise_phase1(int fl, int t, bool active, int hop, const double *tb
 }
 
 // writes 4*|X|^2 as f32 power rows (stride WaveLayout::kPStride) over the head of the same slice
-MS_DEV void precise_phase2(int fl, int j, bool active, const double *tb, double *rows) {
+MS_DEV void precise_phase2(int fl, int j, bool active, const double *MS_RESTRICT tb, double *MS_RESTRICT rows) {
     if (!active) return;
     const int brow = (j == 0) ? 20 : 20 - j;
     const double *ua = rows + fl * PreciseLayout::kXStride + j * PreciseLayout::kXRow;
