@@ -163,6 +163,7 @@ struct RoundSync {
     unsigned *arrive;
     __device__ __forceinline__ RoundSync(int mode, int wave, unsigned *counters) : arrive(counters) {
         gsize = mode & 15;
+        if (gsize > WAVES) gsize = 1;                 // a group cannot be larger than the workgroup: plain barrier
         const int across = mode >> 4;
         const int ngroups = gsize > 1 ? WAVES / gsize : 1;
         g = gsize > 1 ? (across ? wave % ngroups : wave / gsize) : 0;
