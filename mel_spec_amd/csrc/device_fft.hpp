@@ -67,6 +67,14 @@ MS_HD float f32_mul_rn(float a, float b) {
     return p;
 #endif
 }
+// a / b correctly rounded in f32 (the reference's plain `/`)
+MS_HD float f32_div_rn(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    return a / b;
+#endif
+}
 template <class T> MS_DEV cpx<T> operator+(cpx<T> a, cpx<T> b) { return {a.re + b.re, a.im + b.im}; }
 template <class T> MS_DEV cpx<T> operator-(cpx<T> a, cpx<T> b) { return {a.re - b.re, a.im - b.im}; }
 template <class T> MS_DEV cpx<T> cmul(cpx<T> a, cpx<T> b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }

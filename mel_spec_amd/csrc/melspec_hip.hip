@@ -1696,10 +1696,32 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         np.out = d_out; np.clip_stride = cols * static_cast<uint64_t>(nm); np.row_w = cols; np.valid = valid;
         np.n_clips = n_clips; np.n_mels = nm;
         const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
-        const unsigned g2 = grid_for((rows + 3) / 4, b->dev.cus, 16);
-        if (valid <= 64 * 16) hipLaunchKernelGGL((blm_normalize_kernel<4, 16>), dim3(g2), dim3(256), 0, s, np);
-        else if (valid <= 64 * 48) hipLaunchKernelGGL((blm_normalize_kernel<4, 48>), dim3(g2), dim3(256), 0, s, np);
-        else hipLaunchKernelGGL((blm_normalize_kernel<4, 0>), dim3(g2), dim3(256), 0, s, np);
+        // four workgroups of <= 38 KB per CU measured best (1024 x 10 s x 128 mels, ms per call incl. the 0.72 ms mel kernel: 150 KB x 1: 1.72,
+        // 76 x 2: 1.45, 50 x 3: 1.34, 38 x 4: 1.28, 25 x 6: 1.68); MELSPEC_NORM_KB / MELSPEC_NORM_PER_CU override
+        size_t stride = (static_cast<size_t>(valid) + 31) & ~static_cast<size_t>(31);      // whole groups of 32 floats ...
+        if ((stride / 4) % 2 == 0) stride += 4;                                              // ... and 4 * odd
+        np.vec = (cols % 4 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0) ? 1 : 0;
+        static const int norm_kb = [] { const char *e = std::getenv("MELSPEC_NORM_KB"); const int v = e ? std::atoi(e) : 0; return v >= 8 && v <= 158 ? v : 38; }();
+        static const int norm_per_cu = [] { const char *e = std::getenv("MELSPEC_NORM_PER_CU"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 16 ? v : 4; }();
+        const size_t budget = static_cast<size_t>(norm_kb) * 1024 - 64 * 2 * sizeof(float);
+        size_t per = budget / (stride * sizeof(float));
+        if (per > 64) per = 64;
+        np.rows_per_group = static_cast<int>(per);
+        np.lds_stride = static_cast<int>(stride);
+        static std::atomic<uint64_t> attr_done{0};
+        if (!device_done(attr_done)) {
+            int rc2 = allow_big_lds(&blm_normalize_kernel, "hipFuncSetAttribute(blm_normalize_kernel)");
+            if (rc2) return rc2;
+            mark_device_done(attr_done);
+        }
+        if (per == 0) {
+            const unsigned g2 = grid_for((rows + kBlmNormThreads - 1) / kBlmNormThreads, b->dev.cus, 4);
+            hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), 0, s, np);
+        } else {
+            const size_t lds = (per * stride + 2 * per) * sizeof(float);
+            const unsigned g2 = grid_for((rows + per - 1) / per, b->dev.cus, norm_per_cu);
+            hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), lds, s, np);
+        }
         HIP_TRY(hipGetLastError());
     }
     return MELSPEC_OK;

@@ -555,9 +555,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     }
 }
 
-// Per-feature normalisation of the NeMo frontend (normalize_per_feature, src/mel.rs:721-749): for every
-// (clip, mel) row: mean over the valid frames, unbiased variance, (v - mean) / (sqrt(var) + 1e-5).
-// One wavefront per row, fixed summation order (lane-strided partials, then a fixed tree).
+// Per-feature normalisation of the NeMo frontend (normalize_per_feature, src/mel.rs:721-749): for every (clip, mel) row the
+// mean over the valid frames, the unbiased variance, (v - mean) / (sqrt(var) + 1e-5) -- in the reference's f32 and in the
+// reference's order: `iter().sum::<f32>()` is a left fold, and its rounding error in the mean (~1e-4 for 1000 values near
+// -10) divided by a small standard deviation is visible in the output (2e-3; a silent clip comes out as a constant
+// 0.16 instead of 0).  A tree sum is more accurate and therefore different, so the sums run sequentially: a workgroup
+// stages `rows_per_group` whole rows in LDS with coalesced loads, one lane per row folds its row left to right (twice),
+// then all threads normalise and store.  rows_per_group == 0 (a row does not fit in LDS): one thread per row from HBM.
 struct BlmNormParams {
     float *out;
     uint64_t clip_stride;   // floats between clips = n_mels * row_w
@@ -565,57 +569,189 @@ struct BlmNormParams {
     uint64_t valid;         // valid frames
     uint32_t n_clips;
     int n_mels;
+    int rows_per_group;     // rows staged per workgroup round (<= 64), 0: rows too long for LDS
+    int lds_stride;         // floats between staged rows: 4 * odd (16-byte aligned rows whose per-lane walks spread over the banks)
+    int vec;                // rows are 16-byte aligned: float4 loads and stores
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+constexpr int kBlmNormThreads = 256;
+
+__device__ __forceinline__ float *blm_row(const BlmNormParams &p, uint64_t row) {
+    const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
+    return p.out + clip * p.clip_stride + m * p.row_w;
 }
 
-// ITEMS > 0: the row (<= 64*ITEMS valid frames) is read once into registers, and mean, variance and the
-// normalised values all come from there (one read + one write of the row instead of three reads + one write;
-// same values, same summation order).  ITEMS == 0: any length, three passes over the row.
-template <int WAVES, int ITEMS>
-__global__ __launch_bounds__(WAVES * 64) void blm_normalize_kernel(const BlmNormParams p) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
-    for (uint64_t row = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6); row < rows; row += (uint64_t)gridDim.x * WAVES) {
-        const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
-        float *r = p.out + clip * p.clip_stride + m * p.row_w;
-        float denom = (float)p.valid - 1.0f;
-        denom = denom < 1.0f ? 1.0f : denom;
-        if (ITEMS > 0) {
-            float v[ITEMS > 0 ? ITEMS : 1];
-            float s = 0.0f;
+// mean and standard deviation (+1e-5) of one row, left folds in f32 exactly like the reference (no FMA contraction of
+// c * c + s).  The fold is a chain of `valid` dependent adds per pass and nothing else should be on its critical path:
+// the row is read 32 floats at a time (eight 16-byte reads) and the next 32 are in flight while the current ones are added.
+// row: 16-byte aligned, readable up to the next multiple of 32 floats past `valid` (the excess is never added).
+__device__ __forceinline__ void blm_row_stats_lds(const float *row, uint32_t valid, float &mean, float &sd) {
+    constexpr int kQ = 8;                      // float4s per group
+    const uint32_t groups = (valid + 4 * kQ - 1) / (4 * kQ);
+    auto fetch = [&](uint32_t g, f4 (&v)[kQ]) {
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const uint64_t f = (uint64_t)k * 64 + lane;
-                v[k] = f < p.valid ? r[f] : 0.0f;
-                if (f < p.valid) s += v[k];
-            }
-            const float mean = wave_sum(s) / (float)p.valid;
-            float q = 0.0f;
+        for (int i = 0; i < kQ; ++i) v[i] = *reinterpret_cast<const f4 *>(row + (g * kQ + i) * 4);
+    };
+    float s = 0.0f;
+    {
+        f4 cur[kQ], nxt[kQ];
+        fetch(0, cur);
+        for (uint32_t g = 0; g < groups; ++g) {
+            fetch(g + 1 < groups ? g + 1 : g, nxt);
+            const uint32_t k0 = g * 4 * kQ;
+            if (k0 + 4 * kQ <= valid) {
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const uint64_t f = (uint64_t)k * 64 + lane;
-                if (f < p.valid) { const float d = v[k] - mean; q += d * d; }
-            }
-            const float sd = sqrtf(wave_sum(q) / denom) + 1e-5f;
+                for (int i = 0; i < kQ; ++i) { s += cur[i].x; s += cur[i].y; s += cur[i].z; s += cur[i].w; }
+            } else {
 #pragma unroll
-            for (int k = 0; k < ITEMS; ++k) {
-                const uint64_t f = (uint64_t)k * 64 + lane;
-                if (f < p.valid) r[f] = (v[k] - mean) / sd;
+                for (int i = 0; i < kQ; ++i) {
+                    if (k0 + 4 * i + 0 < valid) s += cur[i].x;
+                    if (k0 + 4 * i + 1 < valid) s += cur[i].y;
+                    if (k0 + 4 * i + 2 < valid) s += cur[i].z;
+                    if (k0 + 4 * i + 3 < valid) s += cur[i].w;
+                }
             }
-        } else {
-            float s = 0.0f;
-            for (uint64_t f = lane; f < p.valid; f += 64) s += r[f];
-            const float mean = wave_sum(s) / (float)p.valid;
-            float q = 0.0f;
-            for (uint64_t f = lane; f < p.valid; f += 64) { const float d = r[f] - mean; q += d * d; }
-            const float sd = sqrtf(wave_sum(q) / denom) + 1e-5f;
-            for (uint64_t f = lane; f < p.valid; f += 64) r[f] = (r[f] - mean) / sd;
+#pragma unroll
+            for (int i = 0; i < kQ; ++i) cur[i] = nxt[i];
         }
+    }
+    mean = f32_div_rn(s, static_cast<float>(valid));
+    float q = 0.0f;
+    {
+        f4 cur[kQ], nxt[kQ];
+        fetch(0, cur);
+        for (uint32_t g = 0; g < groups; ++g) {
+            fetch(g + 1 < groups ? g + 1 : g, nxt);
+            const uint32_t k0 = g * 4 * kQ;
+            float sq[4 * kQ];
+#pragma unroll
+            for (int i = 0; i < kQ; ++i) {
+                const float c0 = cur[i].x - mean, c1 = cur[i].y - mean, c2 = cur[i].z - mean, c3 = cur[i].w - mean;
+                sq[4 * i] = f32_mul_rn(c0, c0); sq[4 * i + 1] = f32_mul_rn(c1, c1); sq[4 * i + 2] = f32_mul_rn(c2, c2); sq[4 * i + 3] = f32_mul_rn(c3, c3);
+            }
+            if (k0 + 4 * kQ <= valid) {
+#pragma unroll
+                for (int i = 0; i < 4 * kQ; ++i) q += sq[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4 * kQ; ++i)
+                    if (k0 + i < valid) q += sq[i];
+            }
+#pragma unroll
+            for (int i = 0; i < kQ; ++i) cur[i] = nxt[i];
+        }
+    }
+    float denom = static_cast<float>(valid) - 1.0f;
+    denom = denom < 1.0f ? 1.0f : denom;
+    sd = __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
+}
+
+// the same from HBM, one value at a time (rows too long for LDS)
+__device__ __forceinline__ void blm_row_stats_slow(const float *r, uint64_t valid, float &mean, float &sd) {
+    float s = 0.0f;
+    for (uint64_t k = 0; k < valid; ++k) s += r[k];
+    mean = f32_div_rn(s, static_cast<float>(valid));
+    float q = 0.0f;
+    for (uint64_t k = 0; k < valid; ++k) {
+        const float c = r[k] - mean;
+        q += f32_mul_rn(c, c);
+    }
+    float denom = static_cast<float>(valid) - 1.0f;
+    denom = denom < 1.0f ? 1.0f : denom;
+    sd = __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
+}
+
+__global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const BlmNormParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
+    const int tid = threadIdx.x;
+    if (p.rows_per_group == 0) {
+        for (uint64_t row = (uint64_t)blockIdx.x * kBlmNormThreads + tid; row < rows; row += (uint64_t)gridDim.x * kBlmNormThreads) {
+            float *r = blm_row(p, row);
+            float mean, sd;
+            blm_row_stats_slow(r, p.valid, mean, sd);
+            for (uint64_t k = 0; k < p.valid; ++k) r[k] = f32_div_rn(r[k] - mean, sd);
+        }
+        return;
+    }
+    const int R = p.rows_per_group, S = p.lds_stride;
+    float *stat = tile + (size_t)R * S;      // [R][2]
+    // rows of one clip are contiguous and so are the clips (clip_stride == n_mels * row_w): row r starts at out + r * row_w.
+    // vec: 16-byte aligned rows -> one float4 per thread and row, kRowsAtOnce rows in flight (a load inside a per-row `if`
+    // would be one memory round trip per row; rows past the group re-read its last row instead)
+    const bool vec = p.vec != 0;
+    constexpr int kRowsAtOnce = 9;
+    const uint64_t nq = (p.valid + 3) / 4;
+    for (uint64_t row0 = (uint64_t)blockIdx.x * R; row0 < rows; row0 += (uint64_t)gridDim.x * R) {
+        const int nr = rows - row0 < (uint64_t)R ? (int)(rows - row0) : R;
+        float *base = p.out + row0 * p.row_w;
+        if (vec) {
+            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce)
+                for (uint64_t q = tid; q < nq; q += kBlmNormThreads) {
+                    f4 v[kRowsAtOnce];
+#pragma unroll
+                    for (int i = 0; i < kRowsAtOnce; ++i) {
+                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
+                        v[i] = *reinterpret_cast<const f4 *>(base + (uint64_t)rr * p.row_w + 4 * q);
+                    }
+#pragma unroll
+                    for (int i = 0; i < kRowsAtOnce; ++i) {
+                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
+                        float *d = tile + (size_t)rr * S + 4 * q;
+                        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+                    }
+                }
+        } else {
+            for (int rr = 0; rr < nr; ++rr) {
+                const float *src = base + (uint64_t)rr * p.row_w;
+                float *dst = tile + (size_t)rr * S;
+                for (uint64_t k = tid; k < p.valid; k += kBlmNormThreads) dst[k] = src[k];
+            }
+        }
+        __syncthreads();
+        if (tid < nr) {
+            const float *row = tile + (size_t)tid * S;
+            float mean, sd;
+            blm_row_stats_lds(row, static_cast<uint32_t>(p.valid), mean, sd);
+            stat[2 * tid] = mean;
+            stat[2 * tid + 1] = sd;
+        }
+        __syncthreads();
+        if (vec) {
+            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce)
+                for (uint64_t q = tid; q < nq; q += kBlmNormThreads) {
+                    float v[kRowsAtOnce][4], mean[kRowsAtOnce], sd[kRowsAtOnce];
+#pragma unroll
+                    for (int i = 0; i < kRowsAtOnce; ++i) {           // every LDS read first (rows past the group: its last row again)
+                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
+                        const float *src = tile + (size_t)rr * S + 4 * q;
+                        v[i][0] = src[0]; v[i][1] = src[1]; v[i][2] = src[2]; v[i][3] = src[3];
+                        mean[i] = stat[2 * rr]; sd[i] = stat[2 * rr + 1];
+                    }
+#pragma unroll
+                    for (int i = 0; i < kRowsAtOnce; ++i) {
+                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
+                        f4 o;                                         // columns past the valid frames keep their zeros
+                        o.x = f32_div_rn(v[i][0] - mean[i], sd[i]);
+                        o.y = f32_div_rn(v[i][1] - mean[i], sd[i]);
+                        o.z = f32_div_rn(v[i][2] - mean[i], sd[i]);
+                        o.w = f32_div_rn(v[i][3] - mean[i], sd[i]);
+                        if (4 * q + 0 >= p.valid) o.x = 0.0f;
+                        if (4 * q + 1 >= p.valid) o.y = 0.0f;
+                        if (4 * q + 2 >= p.valid) o.z = 0.0f;
+                        if (4 * q + 3 >= p.valid) o.w = 0.0f;
+                        *reinterpret_cast<f4 *>(base + (uint64_t)rr * p.row_w + 4 * q) = o;
+                    }
+                }
+        } else {
+            for (int rr = 0; rr < nr; ++rr) {
+                float *dstg = base + (uint64_t)rr * p.row_w;
+                const float *src = tile + (size_t)rr * S;
+                const float mean = stat[2 * rr], sd = stat[2 * rr + 1];
+                for (uint64_t k = tid; k < p.valid; k += kBlmNormThreads) dstg[k] = f32_div_rn(src[k] - mean, sd);
+            }
+        }
+        __syncthreads();
     }
 }
 

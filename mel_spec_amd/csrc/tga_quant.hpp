@@ -71,14 +71,6 @@ MS_HD uint64_t image_index(const QuantDesc &d, uint32_t c, uint32_t cw, uint64_t
     return r * d.width + static_cast<uint64_t>(c) * d.chunk_w + (idx - r * cw);
 }
 
-MS_HD float f32_div_rn(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __fdiv_rn(a, b);
-#else
-    return a / b;
-#endif
-}
-
 // src/quant.rs:147-150
 MS_HD uint32_t quantize_px(float v, float mn, float scale) {
     const float dlt = v - mn;

@@ -1,0 +1,11 @@
+import sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, mel_spec_amd as M
+n_clips, clip_len = 1024, 160000
+pcm = M.DeviceBuffer(n_clips * clip_len * 4)
+M.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips); M.device_synchronize()
+fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24, normalize_per_feature=True))
+out = M.DeviceBuffer(n_clips * fe.padded_frames(clip_len) * 128 * 4)
+for _ in range(30):
+    fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+fe.synchronize()

@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU (not part of the test suite): ragged batches, uniform batches with every store layout,
+the streaming bank, the Kaldi and NeMo frontends, f32 and precise modes -- each case against the CPU oracle.
+Usage: tools/fuzz_gpu.py [seconds] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import mel_spec_amd as M
+from oracle import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+stats = {}
+def note(kind, d):
+    n, w = stats.get(kind, (0, 0.0))
+    stats[kind] = (n + 1, max(w, d))
+
+def signal(n):
+    k = rng.integers(0, 4)
+    if k == 0: return rng.standard_normal(n).astype(np.float32) * np.float32(10.0 ** rng.uniform(-4, 0))
+    if k == 1: return (np.sin(np.arange(n) * rng.uniform(0.01, 3.0)) * rng.uniform(0.01, 1.0)).astype(np.float32)
+    if k == 2: return np.zeros(n, np.float32)
+    x = rng.standard_normal(n).astype(np.float32) * 1e-3
+    x[:: int(rng.integers(50, 500))] += 0.7
+    return x
+
+def case_whisper():
+    fft = int(rng.choice([400, 400, 400, 512]))
+    hop = int(rng.choice([160, 160, 160, 80, 200, 320, int(rng.integers(40, 400))]))
+    n_mels = int(rng.choice([80, 80, 128, 20, 40, 64, 96, 100]))
+    sr = float(rng.choice([16000.0, 16000.0, 8000.0, 22050.0]))
+    m = M.HipMelSpectrogram(fft, hop, sr, n_mels)
+    precise = False
+    if m.uses_fast_path and rng.random() < 0.3:
+        try:
+            m.set_precise(True); precise = True
+        except M.HipRuntimeError:
+            pass
+    tol = 3e-6 if (precise or not m.uses_fast_path or fft == 512) else 1e-4
+    mode = int(rng.integers(0, 4))
+    tag = f"whisper fft={fft} hop={hop} mels={n_mels} sr={sr:.0f} precise={precise} mode={mode}"
+    if mode == 0:                                   # ragged batch, host API
+        n_clips = int(rng.integers(1, 40))
+        clips = [signal(int(rng.choice([0, fft - 1, fft, fft + hop - 1, fft + hop, int(rng.integers(0, 30 * hop + fft))]))) for _ in range(n_clips)]
+        got = m.compute_ragged(clips)
+        for c, g in zip(clips, got):
+            want = O.compute_mel_spectrogram_cpu(c, fft, hop, n_mels, sr)
+            assert g.shape == want.shape, (tag, len(c), g.shape, want.shape)
+            if g.size: d = float(np.abs(g - want).max()); assert d <= tol, (tag, len(c), d); note("ragged", d)
+    elif mode == 1:                                 # uniform batch
+        n_clips, n = int(rng.integers(1, 30)), int(rng.integers(fft, fft + 60 * hop))
+        x = np.stack([signal(n) for _ in range(n_clips)])
+        got = m.compute_batch(x)
+        for c in range(n_clips):
+            want = O.compute_mel_spectrogram_cpu(x[c], fft, hop, n_mels, sr)
+            d = float(np.abs(got[c] - want).max()); assert d <= tol, (tag, n, d); note("uniform", d)
+    elif mode == 2:                                 # store layouts on the device API
+        n_clips, n = int(rng.integers(1, 20)), int(rng.integers(fft, fft + 40 * hop))
+        frame_major = bool(rng.integers(0, 2)); min_w = int(rng.choice([0, 0, 2, 50, 3000]))
+        x = np.stack([signal(n) for _ in range(n_clips)])
+        f = m.num_frames(n); W = m.interleaved_width(n, min_w)
+        din, dout = M.DeviceBuffer(x.nbytes), M.DeviceBuffer(n_clips * W * n_mels * 4)
+        din.upload(x)
+        try:
+            m.compute_uniform_device_interleaved(din.ptr, n, n, n_clips, dout.ptr, frame_major, min_w); m.synchronize()
+        except M.HipRuntimeError:
+            din.free(); dout.free(); m.close(); return
+        got = dout.download((n_clips, W, n_mels) if frame_major else (n_clips, n_mels, W))
+        for c in range(n_clips):
+            want = O.compute_mel_spectrogram_cpu(x[c], fft, hop, n_mels, sr)
+            g = got[c] if frame_major else got[c].T
+            d = float(np.abs(g[:f] - want).max()); assert d <= tol, (tag, n, frame_major, min_w, d)
+            assert not g[f:].any(), (tag, "padding not zero")
+            note("layout", d)
+        din.free(); dout.free()
+    else:                                           # streaming bank against the batch result on samples[off:]
+        n_streams = int(rng.integers(1, 12)); max_chunk = int(rng.integers(1, 6 * hop + fft))
+        bank = M.StreamBank(m, n_streams, max_chunk)
+        sig = [signal(int(rng.integers(0, 12 * max_chunk))) for _ in range(n_streams)]
+        pos = [0] * n_streams; outs = [[] for _ in range(n_streams)]
+        while any(pos[s] < len(sig[s]) for s in range(n_streams)):
+            ids = [s for s in range(n_streams) if pos[s] < len(sig[s]) and rng.random() < 0.8]
+            if not ids: continue
+            chunks = []
+            for s in ids:
+                k = int(rng.integers(0, max_chunk + 1)); chunks.append(sig[s][pos[s]:pos[s] + k]); pos[s] += len(chunks[-1])
+            for s, fr in zip(ids, bank.push(ids, chunks)): outs[s].append(fr)
+        for s in range(n_streams):
+            got = np.concatenate(outs[s]) if outs[s] else np.zeros((0, n_mels), np.float32)
+            want = O.stream_mel(sig[s], fft, hop, n_mels, sr, flush_tail=False) if hasattr(O, "stream_mel") else None
+            if want is not None:
+                assert got.shape == want.shape, (tag, s, got.shape, want.shape)
+                if got.size: d = float(np.abs(got - want).max()); assert d <= tol, (tag, s, d); note("stream", d)
+        bank.close()
+    m.close()
+
+def case_fbank():
+    kw = dict(num_mel_bins=int(rng.choice([80, 80, 40, 23, 64])), preemphasis=float(rng.choice([0.97, 0.0, 0.9])),
+              apply_cmn=bool(rng.integers(0, 2)), use_log_fbank=bool(rng.random() < 0.8), use_power=bool(rng.random() < 0.8))
+    fb = M.Fbank(M.FbankConfig(**kw))
+    oc = O.fbank_default_config()
+    oc.num_mel_bins = kw["num_mel_bins"]; oc.preemphasis = kw["preemphasis"]; oc.apply_cmn = int(kw["apply_cmn"])
+    oc.use_log_fbank = int(kw["use_log_fbank"]); oc.use_power = int(kw["use_power"])
+    x = signal(int(rng.choice([399, 400, 559, 560, int(rng.integers(400, 40000))])))
+    got = fb.compute(x)
+    want = O.fbank_compute(x, oc)
+    assert got.shape == want.shape, ("fbank", kw, got.shape, want.shape)
+    if got.size:
+        scale = 1.0
+        if not kw["use_log_fbank"]:       # linear energies: f32 resolution of the values before the mean is subtracted
+            oc.apply_cmn = 0
+            scale = max(1.0, float(np.abs(O.fbank_compute(x, oc)).max()))
+        d = float(np.abs(got - want).max()) / scale
+        assert d <= 1e-4, ("fbank", kw, len(x), d)
+        note("fbank", d)
+    fb.close()
+
+def case_nemo():
+    kw = dict(n_mels=int(rng.choice([80, 128, 64])), preemphasis=float(rng.choice([0.97, 0.0])), center=bool(rng.random() < 0.8),
+              log_zero_guard=2.0 ** -24, normalize_per_feature=bool(rng.integers(0, 2)))
+    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(**kw))
+    x = signal(int(rng.integers(600, 50000)))
+    got = fe.compute(x)
+    want = O.blm_compute(x, O.blm_default_config(**kw), True)[0]
+    assert got.shape == want.shape, ("nemo", kw, got.shape, want.shape)
+    tol = 2e-3 if kw["normalize_per_feature"] else 1e-4
+    d = float(np.abs(got - want).max())
+    if d > tol:
+        # ill-conditioned rows (tiny std over the valid frames) amplify rounding: judge against the reference's own f32 path
+        lit = O.blm_compute(x, O.blm_default_config(**kw), False)[0]
+        dl = float(np.abs(lit - want).max())
+        i = np.unravel_index(np.argmax(np.abs(got - want)), got.shape)
+        print("nemo ill-conditioned?", kw, len(x), "gpu-f64", d, "f32ref-f64", dl, "at", i, "got", got[i], "want", want[i], "lit", lit[i],
+              "row std", float(want[i[0]].std()), "sig absmax", float(np.abs(x).max()), flush=True)
+        if float(want[i[0]].std()) > 1e-3: assert d <= max(tol, 3.0 * dl), ("nemo", kw, len(x), d, dl)   # constant rows: rounding noise / 1e-5
+    note("nemo", d)
+    fe.close()
+
+n = 0
+while time.time() < t_end:
+    r = rng.random()
+    (case_whisper if r < 0.7 else case_fbank if r < 0.85 else case_nemo)()
+    n += 1
+print("cases", n, {k: (v[0], float(f"{v[1]:.3g}")) for k, v in stats.items()})
