@@ -882,12 +882,11 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
     }
 }
 
-// CMN (src/fbank.rs:224-233): per clip and mel column subtract the f32 mean over the clip's frames.
-// One workgroup per clip; thread (g, m) accumulates frames g, g+G, g+2G, ... of column m in f32
-// (4 independent partial sums so the loads pipeline), the G partials are combined in a fixed order,
-// so the result is deterministic.  The reference folds left-to-right in f32 (ndarray's mean() on a
-// strided column); the two orders differ by ~1e-5 of a feature value, far inside the 1e-4 budget, and
-// both are dominated by the f32 rounding of the same sum.
+// CMN (src/fbank.rs:224-233): per clip and mel column subtract the f32 mean over the clip's frames.  The reference's
+// `column(m).mean()` (ndarray on a strided view) is a left fold in f32 followed by one division, and its rounding error
+// (~1e-5 of a feature value at 1000 frames, more on longer clips) is part of its output, so the sum runs in that order:
+// one workgroup per clip, thread m folds column m over the frames (16 rows in flight: the row reads are coalesced over
+// the columns), then every thread subtracts.
 struct CmnParams {
     BatchDesc b;   // only the clip geometry is used
     int n_mels;
@@ -895,7 +894,6 @@ struct CmnParams {
 
 template <int NT>
 __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
-    __shared__ float part[NT];
     __shared__ float mean_s[NT];
     const int nm = p.n_mels;
     const int tid = threadIdx.x;
@@ -914,23 +912,20 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
             const int cols = nm - m0 < NT ? nm - m0 : NT;
             const int G = NT / cols;                           // frame groups per column
             const int g = tid / cols, m = m0 + tid - g * cols;
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            if (g < G) {
-                uint64_t f = g;
-                for (; f + 3 * (uint64_t)G < frames; f += 4 * (uint64_t)G) {
-                    s0 += o[f * nm + m];
-                    s1 += o[(f + G) * nm + m];
-                    s2 += o[(f + 2 * (uint64_t)G) * nm + m];
-                    s3 += o[(f + 3 * (uint64_t)G) * nm + m];
-                }
-                for (; f < frames; f += G) s0 += o[f * nm + m];
-            }
-            part[tid] = (s0 + s1) + (s2 + s3);
-            __syncthreads();
             if (tid < cols) {
-                float s = part[tid];
-                for (int k = 1; k < G; ++k) s += part[tid + k * cols];
-                mean_s[tid] = s / (float)frames;
+                constexpr int kB = 16;
+                const float *col = o + m0 + tid;
+                float s = 0.0f;
+                uint64_t f = 0;
+                for (; f + kB <= frames; f += kB) {
+                    float v[kB];
+#pragma unroll
+                    for (int i = 0; i < kB; ++i) v[i] = col[(f + i) * nm];
+#pragma unroll
+                    for (int i = 0; i < kB; ++i) s += v[i];
+                }
+                for (; f < frames; ++f) s += col[f * nm];
+                mean_s[tid] = f32_div_rn(s, (float)frames);
             }
             __syncthreads();
             if (g < G) {
