@@ -39,7 +39,8 @@ def case_whisper():
             m.set_precise(True); precise = True
         except M.HipRuntimeError:
             pass
-    tol = 3e-6 if (precise or not m.uses_fast_path or fft == 512) else 1e-4
+    # f32 FFT: 1e-4 on speech and noise; a line over a >80 dB quieter floor inside one frame reaches 3.8e-4, the soak draws such signals
+    tol = 3e-6 if (precise or not m.uses_fast_path or fft == 512) else 4e-4
     mode = int(rng.integers(0, 4))
     tag = f"whisper fft={fft} hop={hop} mels={n_mels} sr={sr:.0f} precise={precise} mode={mode}"
     if mode == 0:                                   # ragged batch, host API
@@ -135,7 +136,19 @@ def case_nemo():
         i = np.unravel_index(np.argmax(np.abs(got - want)), got.shape)
         print("nemo ill-conditioned?", kw, len(x), "gpu-f64", d, "f32ref-f64", dl, "at", i, "got", got[i], "want", want[i], "lit", lit[i],
               "row std", float(want[i[0]].std()), "sig absmax", float(np.abs(x).max()), flush=True)
-        if float(want[i[0]].std()) > 1e-3: assert d <= max(tol, 3.0 * dl), ("nemo", kw, len(x), d, dl)   # constant rows: rounding noise / 1e-5
+        allowed = tol
+        if kw["normalize_per_feature"]:
+            # (v - mean) / (std + 1e-5) amplifies the ~1 ulp (2e-6) differences of ln() between GPU and CPU by 1 / (std + 1e-5):
+            # 0.17 on a band that sits at the log guard, 1e-3 on a 13-frame clip with std 1e-3.  Judge by the row's own std.
+            kw2 = dict(kw, normalize_per_feature=False)
+            fe2 = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(**kw2)); g2 = fe2.compute(x); fe2.close()
+            w2 = O.blm_compute(x, O.blm_default_config(**kw2), True)[0]
+            r = i[0]
+            nv = fe.num_frames(len(x))
+            un = float(np.abs(g2[r] - w2[r]).max())
+            allowed = max(tol, 4.0 * (un + 2e-6) / (float(w2[r][:nv].std()) + 1e-5), 2.0 * dl)    # dl: what the reference's own f32 path does to this row
+            print("   un-normalised row", r, "gpu-f64", un, "row std", float(w2[r][:nv].std()), "allowed", allowed, flush=True)
+        assert d <= allowed, ("nemo", kw, len(x), d, dl, allowed)
     note("nemo", d)
     fe.close()
 
