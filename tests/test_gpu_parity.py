@@ -532,3 +532,19 @@ def test_one_context_per_thread_runs_concurrently(gpu, oracle, jfk):
         futs = [ex.submit(whisper, 80), ex.submit(whisper, 128), ex.submit(fbank), ex.submit(whisper, 80)]
         worst = [f.result() for f in futs]
     assert max(worst) <= TOL, worst
+
+
+@pytest.mark.parametrize("n", [1276, 12623, 43882])
+def test_nemo_normalisation_of_a_silent_clip_matches_the_reference_fold(gpu, oracle, n):
+    """normalize_per_feature (src/mel.rs:721-749) folds its sums left to right in f32; on a silent clip every row is the
+    constant ln(guard), the fold's rounding error in the mean divided by (0 + 1e-5) is the whole output (0.16, -0.53, ...
+    depending on the frame count), and the GPU has to land on the same constant -- a more accurate sum gives 0."""
+    kw = dict(n_mels=128, preemphasis=0.0, center=True, log_zero_guard=2.0 ** -24, normalize_per_feature=True)
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+    x = np.zeros(n, np.float32)
+    got = fe.compute(x)
+    want, valid = oracle.blm_compute(x, oracle.blm_default_config(**{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}), True)
+    assert got.shape == want.shape
+    assert np.abs(want[:, :valid]).max() > 0.1            # the artefact is there in the reference
+    assert np.abs(got - want).max() <= 1e-6
+    fe.close()
