@@ -623,11 +623,19 @@ __device__ __forceinline__ void blm_row_stats_lds(const float *row, uint32_t val
         for (uint32_t g = 0; g < groups; ++g) {
             fetch(g + 1 < groups ? g + 1 : g, nxt);
             const uint32_t k0 = g * 4 * kQ;
+            // a lone wave issues one VALU instruction per ~5.6 cycles and a dependent add takes 10.5 (tools/dep_add.hip): the
+            // centring and squaring go through the packed f32 ops (two elements per instruction, same IEEE results) so that
+            // the pass is bound by its chain of adds, not by instruction issue
             float sq[4 * kQ];
 #pragma unroll
             for (int i = 0; i < kQ; ++i) {
-                const float c0 = cur[i].x - mean, c1 = cur[i].y - mean, c2 = cur[i].z - mean, c3 = cur[i].w - mean;
-                sq[4 * i] = f32_mul_rn(c0, c0); sq[4 * i + 1] = f32_mul_rn(c1, c1); sq[4 * i + 2] = f32_mul_rn(c2, c2); sq[4 * i + 3] = f32_mul_rn(c3, c3);
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                const v2f m2 = {mean, mean};
+                v2f a = {cur[i].x, cur[i].y}, b = {cur[i].z, cur[i].w};
+                a = a - m2; b = b - m2;
+                v2f sa = a * a, sb = b * b;
+                asm("" : "+v"(sa), "+v"(sb));            // products rounded on their own (no contraction into the adds below)
+                sq[4 * i] = sa.x; sq[4 * i + 1] = sa.y; sq[4 * i + 2] = sb.x; sq[4 * i + 3] = sb.y;
             }
             if (k0 + 4 * kQ <= valid) {
 #pragma unroll
