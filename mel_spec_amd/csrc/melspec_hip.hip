@@ -1705,6 +1705,11 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         static const int norm_per_cu = [] { const char *e = std::getenv("MELSPEC_NORM_PER_CU"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 16 ? v : 4; }();
         const size_t budget = static_cast<size_t>(norm_kb) * 1024 - 64 * 2 * sizeof(float);
         size_t per = budget / (stride * sizeof(float));
+        int per_cu = norm_per_cu;
+        if (per < 4) {                            // long rows (> ~25 s): one workgroup per CU with the whole LDS, up to ~6 min per row
+            per = (static_cast<size_t>(150) * 1024) / (stride * sizeof(float));
+            per_cu = 1;
+        }
         if (per > 64) per = 64;
         np.rows_per_group = static_cast<int>(per);
         np.lds_stride = static_cast<int>(stride);
@@ -1719,7 +1724,7 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
             hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), 0, s, np);
         } else {
             const size_t lds = (per * stride + 2 * per) * sizeof(float);
-            const unsigned g2 = grid_for((rows + per - 1) / per, b->dev.cus, norm_per_cu);
+            const unsigned g2 = grid_for((rows + per - 1) / per, b->dev.cus, per_cu);
             hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), lds, s, np);
         }
         HIP_TRY(hipGetLastError());
