@@ -217,6 +217,10 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     return pl;
 }
 
+__global__ void plan_upload_kernel(const uint4 *src, uint4 *dst, size_t n16) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n16; i += static_cast<size_t>(gridDim.x) * blockDim.x) dst[i] = src[i];
+}
+
 // Fills the next slot and queues its upload on `stream`.  The caller launches on `stream` and then calls plan_ragged_done.
 int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float *d_out, const uint64_t *h_off,
                 const std::vector<uint64_t> &frames, const uint64_t *h_out_off, uint32_t n_clips, int n_mels,
@@ -230,9 +234,9 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
     const uint64_t n_blocks = (units + kUnitBlock - 1) / kUnitBlock;
     const size_t words64 = static_cast<size_t>(n_clips) * 4 + 1;
     const size_t bytes = words64 * sizeof(uint64_t) + static_cast<size_t>(n_blocks ? n_blocks : 1) * sizeof(uint32_t);
-    int rc = sl.ensure_host(bytes);
+    int rc = sl.ensure_host((bytes + 15) & ~static_cast<size_t>(15));
     if (rc) return rc;
-    if ((rc = sl.dev.ensure(bytes))) return rc;
+    if ((rc = sl.dev.ensure((bytes + 15) & ~static_cast<size_t>(15)))) return rc;
     uint64_t *off = static_cast<uint64_t *>(sl.host), *fr = off + n_clips, *oo = fr + n_clips, *pre = oo + n_clips;
     uint32_t *blk = reinterpret_cast<uint32_t *>(off + words64);
     uint64_t cursor = 0, out_cursor = 0, total = 0;
@@ -254,7 +258,15 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
             blk[k] = c;
         }
     }
-    HIP_TRY(hipMemcpyAsync(sl.dev.p, sl.host, bytes, hipMemcpyHostToDevice, stream));
+    // the upload is a kernel on the launch stream that reads the pinned slot over the bus: an SDMA copy sits in another
+    // hardware queue and the hand-over between the queues costs more than the copy
+    {
+        const size_t n16 = (bytes + 15) / 16;
+        const unsigned blocks = static_cast<unsigned>((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
+        hipLaunchKernelGGL(plan_upload_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const uint4 *>(sl.host),
+                           static_cast<uint4 *>(sl.dev.p), n16);
+        HIP_TRY(hipGetLastError());
+    }
     const uint64_t *d = static_cast<const uint64_t *>(sl.dev.p);
     BatchDesc &b = pl.desc;
     b = BatchDesc{};

@@ -68,14 +68,25 @@ __device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit
         r.out = b.out + clip * b.out_stride;
         r.frames = b.frames_per_clip;
     } else {
-        // d_unit_block[k] = clip that holds unit k * kUnitBlock; from there a short walk (clips without frames, clip ends
-        // inside the block) instead of a binary search of ~log2(n_clips) dependent loads per unit
+        // d_unit_block[k] = clip that holds unit k * kUnitBlock.  The records of that clip and of the next one are fetched
+        // together (second round trip); only clips shorter than a block of units need the walk (third and later trips).
         uint32_t lo = b.d_unit_block[unit / kUnitBlock];
-        while (b.d_unit_prefix[lo + 1] <= unit) ++lo;       // prefix[n_clips] = n_units > unit
-        r.unit = unit - b.d_unit_prefix[lo];
-        r.pcm = b.pcm + b.d_off[lo];
-        r.out = b.out + b.d_out_off[lo];
-        r.frames = b.d_frames[lo];
+        uint64_t p0 = b.d_unit_prefix[lo], p1 = b.d_unit_prefix[lo + 1];
+        uint64_t off0 = b.d_off[lo], off1 = b.d_off[lo + 1];                 // [lo + 1] of the last clip: the next array of the
+        uint64_t oo0 = b.d_out_off[lo], oo1 = b.d_out_off[lo + 1];           // same plan buffer, fetched and not used
+        uint64_t fr0 = b.d_frames[lo], fr1 = b.d_frames[lo + 1];
+        if (p1 <= unit) {                                                    // prefix[n_clips] = n_units > unit
+            ++lo;
+            p0 = p1; off0 = off1; oo0 = oo1; fr0 = fr1;
+            if (b.d_unit_prefix[lo + 1] <= unit) {
+                do { ++lo; } while (b.d_unit_prefix[lo + 1] <= unit);
+                p0 = b.d_unit_prefix[lo]; off0 = b.d_off[lo]; oo0 = b.d_out_off[lo]; fr0 = b.d_frames[lo];
+            }
+        }
+        r.unit = unit - p0;
+        r.pcm = b.pcm + off0;
+        r.out = b.out + oo0;
+        r.frames = fr0;
     }
     return r;
 }
