@@ -1106,7 +1106,8 @@ struct melspec_stream {
     melspec_ctx *ctx = nullptr;          // geometry, tables, kernels; not owned
     StreamGeom geom{};
     StreamBook book;                     // pending / idx per stream (host side of the state)
-    DevBuf state, entries, staging, out;
+    DevBuf state, staging, out;
+    RaggedScratch ring;                  // per-push entry tables
 };
 
 namespace {
@@ -1126,10 +1127,22 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
                hipStream_t s) {
     melspec_ctx *c = st->ctx;
     HIP_TRY(hipSetDevice(c->dev.device));
-    int rc = st->entries.ensure(static_cast<size_t>(n) * sizeof(StreamEntry));
+    // the entries travel like a ragged plan: pinned slot, copy kernel on the launch stream (no SDMA queue hand-over)
+    RaggedSlot &sl = st->ring.slot[st->ring.next++ % RaggedScratch::kSlots];
+    if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    if (sl.pending) { HIP_TRY(hipEventSynchronize(sl.ev)); sl.pending = false; }
+    const size_t ebytes = (static_cast<size_t>(n) * sizeof(StreamEntry) + 15) & ~static_cast<size_t>(15);
+    int rc = sl.ensure_host(ebytes);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(st->entries.p, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry), hipMemcpyHostToDevice, s));
-    const StreamEntry *d_e = static_cast<const StreamEntry *>(st->entries.p);
+    if ((rc = sl.dev.ensure(ebytes))) return rc;
+    std::memcpy(sl.host, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry));
+    {
+        const size_t n16 = ebytes / 16;
+        const unsigned blocks = static_cast<unsigned>((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
+        hipLaunchKernelGGL(plan_upload_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, static_cast<const uint4 *>(sl.host),
+                           static_cast<uint4 *>(sl.dev.p), n16);
+    }
+    const StreamEntry *d_e = static_cast<const StreamEntry *>(sl.dev.p);
     float *state = static_cast<float *>(st->state.p);
     bool any_fill = d_src != nullptr;
     for (uint32_t i = 0; i < n && !any_fill; ++i) any_fill = pl.entries[i].zero_fill != 0;
@@ -1141,7 +1154,8 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
     }
     hipLaunchKernelGGL(stream_carry_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e);
     HIP_TRY(hipGetLastError());
-    // pl.entries is pageable host memory that dies with the caller's frame
+    plan_ragged_done(&sl, s);
+    // the contract of the push calls: the launches have completed on return (a device producer may refill its slot at once)
     HIP_TRY(hipStreamSynchronize(s));
     return MELSPEC_OK;
 }
@@ -1173,7 +1187,7 @@ int melspec_stream_create(melspec_stream **out, melspec_ctx *ctx, uint32_t n_str
 void melspec_stream_destroy(melspec_stream *st) {
     if (!st) return;
     if (st->ctx) { (void)hipSetDevice(st->ctx->dev.device); (void)hipStreamSynchronize(st->ctx->stream); }
-    st->state.release(); st->entries.release(); st->staging.release(); st->out.release();
+    st->state.release(); st->ring.release(); st->staging.release(); st->out.release();
     delete st;
 }
 
