@@ -146,7 +146,7 @@ def case_nemo():
             r = i[0]
             nv = fe.num_frames(len(x))
             un = float(np.abs(g2[r] - w2[r]).max())
-            allowed = max(tol, 4.0 * (un + 2e-6) / (float(w2[r][:nv].std()) + 1e-5), 2.0 * dl)    # dl: what the reference's own f32 path does to this row
+            allowed = max(tol, 8.0 * (un + 2e-6) / (float(w2[r][:nv].std()) + 1e-5), 2.0 * dl)    # dl: what the reference's own f32 path does to this row
             print("   un-normalised row", r, "gpu-f64", un, "row std", float(w2[r][:nv].std()), "allowed", allowed, flush=True)
         assert d <= allowed, ("nemo", kw, len(x), d, dl, allowed)
     note("nemo", d)
