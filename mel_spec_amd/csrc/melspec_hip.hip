@@ -571,6 +571,8 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_ragged_kernel<kSixMaxSlots, LensSix80>, "hipFuncSetAttribute(whisper400_six_ragged_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_ragged_kernel<kSixMaxSlots, LensRuntime>, "hipFuncSetAttribute(whisper400_six_ragged_kernel)");
             if (rc) return rc;
             mark_device_done(attr_done);
         }
@@ -585,9 +587,14 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         static const int per_cu = [] { const char *e = std::getenv("MELSPEC_SIX_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();
         const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
         const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+        static const bool ragged_round_robin = [] { const char *e = std::getenv("MELSPEC_RAGGED_RUNS"); return e && e[0] == '0'; }();
         if (layout) {
             if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, true>), grid, block, c->lds6, stream, fp);
             else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>), grid, block, c->lds6, stream, fp);
+        } else if (desc.d_unit_prefix != nullptr && !ragged_round_robin) {
+            // ragged: contiguous runs of units per wave (MELSPEC_RAGGED_RUNS=0: the round-robin deal of the uniform kernel)
+            if (c->six_static) hipLaunchKernelGGL((whisper400_six_ragged_kernel<kSixMaxSlots, LensSix80>), grid, block, c->lds6, stream, fp);
+            else hipLaunchKernelGGL((whisper400_six_ragged_kernel<kSixMaxSlots, LensRuntime>), grid, block, c->lds6, stream, fp);
         } else {
             if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, false>), grid, block, c->lds6, stream, fp);
             else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>), grid, block, c->lds6, stream, fp);

@@ -368,6 +368,84 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     }
 }
 
+// Ragged batches (plain [frame][mel] output) on the six-frame build.  A round-robin deal of the units costs two dependent
+// look-ups (block table, clip record) in front of every unit's PCM loads -- ~6 % at every batch size.  Here a wave takes a
+// contiguous run of units instead: it looks its first unit up once and from then on only steps to the next clip when the
+// run crosses a clip end (one load per clip boundary; the clip record lives in scalar registers).  The unit body is the
+// one of whisper400_six_kernel.
+__device__ __forceinline__ uint64_t scalar64(uint64_t v) {
+    // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
+
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_ragged_kernel(const FastParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *blob = lds;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    float *slice = blob + p.blob_len + wave * SixLayout::slice_floats();
+    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
+    const bool in = lane < kSixFrames * kSixLanes;
+    int uoff, voff;
+    SixLayout::row_offsets(j, uoff, voff);
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
+    const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
+
+    const uint64_t waves = (uint64_t)gridDim.x * kSixWaves;
+    const uint64_t run = (p.b.n_units + waves - 1) / waves;
+    uint64_t unit = ((uint64_t)xcd_logical_block() * kSixWaves + wave) * run;
+    const uint64_t end = unit + run < p.b.n_units ? unit + run : p.b.n_units;
+    if (unit >= end) return;
+    // the clip of the run's first unit
+    uint32_t clip = __builtin_amdgcn_readfirstlane(p.b.d_unit_block[unit / kUnitBlock]);
+    uint64_t c_end = scalar64(p.b.d_unit_prefix[clip + 1]);
+    while (c_end <= unit) { ++clip; c_end = scalar64(p.b.d_unit_prefix[clip + 1]); }          // prefix[n_clips] = n_units > unit
+    uint64_t c_start = scalar64(p.b.d_unit_prefix[clip]);
+    uint64_t c_frames = scalar64(p.b.d_frames[clip]);
+    const float *c_pcm = p.b.pcm + scalar64(p.b.d_off[clip]);
+    float *c_out = p.b.out + scalar64(p.b.d_out_off[clip]);
+    for (; unit < end; ++unit) {
+        if (unit >= c_end) {                               // wave-uniform: the run enters the next clip that has frames
+            do { ++clip; c_end = scalar64(p.b.d_unit_prefix[clip + 1]); } while (c_end <= unit);
+            c_start = scalar64(p.b.d_unit_prefix[clip]);
+            c_frames = scalar64(p.b.d_frames[clip]);
+            c_pcm = p.b.pcm + scalar64(p.b.d_off[clip]);
+            c_out = p.b.out + scalar64(p.b.d_out_off[clip]);
+        }
+        const uint64_t f0 = (unit - c_start) * kSixFrames;
+        const uint64_t left = c_frames - f0;
+        const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        const float *src = c_pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv;
+        MS_PRIO(0);
+        six_phase1(fl, j, act, p.hop, blob, src, slice);
+        __builtin_amdgcn_wave_barrier();
+        MS_PRIO(1);
+        six_phase2(fl, j, act, blob, slice, uoff, voff);
+        __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
+        float vals[NSLOTS];
+        {
+            int st[NSLOTS];
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, blob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
+        }
+        __builtin_amdgcn_wave_barrier();
+        six_phase4<NSLOTS, false>(fl, j, act, act, n_mels, slice, vals, c_out + f0 * (uint64_t)n_mels, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // "Precise" fused Whisper kernel: f64 FFT (whisper_wave_f64.hpp), f32 interval mel + normalisation.
 // LDS words: [f64 tables][f32 mel section][WAVES x slice of 2320 doubles].  Plain [frame][mel] output.

@@ -286,6 +286,21 @@ def test_sample_offsets_beyond_32_bits(gpu, w80, oracle):
         got = out.download((fpc, 80), offset_bytes=c * fpc * 80 * 4)
         want = oracle.compute_mel_spectrogram_cpu(oracle.synth_pcm(c, clip_len), 400, 160, 80, SR)
         assert np.abs(got - want).max() <= TOL
+    # the same buffer as a ragged batch (its own kernel: contiguous runs of units per wave, the clip record in scalar
+    # registers): sample offsets with bit 31 set and beyond 2^32, clips of 30 s / 12.3 s / 400 samples / nothing
+    lens = np.full(n_clips, clip_len, np.uint64)
+    lens[1::4] = 197000; lens[2::4] = 400; lens[3::4] = 0
+    offs = (np.arange(n_clips, dtype=np.uint64) * np.uint64(clip_len))
+    frames = np.array([w80.num_frames(int(n)) for n in lens], dtype=np.uint64)
+    ooff = np.concatenate([[0], np.cumsum(frames * 80)[:-1]]).astype(np.uint64)
+    w80.compute_ragged_device(pcm.ptr, offs, lens, out.ptr, ooff)
+    w80.synchronize()
+    for c in (0, 1, 2, 4472, 4473, 4474, 4475, 8948, 8997, 8998):       # 4474 * 480000 > 2^31, 8948 * 480000 > 2^32
+        if frames[c] == 0:
+            continue
+        got = out.download((int(frames[c]), 80), offset_bytes=int(ooff[c]) * 4)
+        want = oracle.compute_mel_spectrogram_cpu(oracle.synth_pcm(c, clip_len)[:int(lens[c])], 400, 160, 80, SR)
+        assert np.abs(got - want).max() <= TOL, c
     pcm.free(); out.free()
 
 

@@ -18,7 +18,7 @@ frames = np.array([m.num_frames(int(l)) for l in lens], dtype=np.uint64)
 ooff = np.concatenate([[0], np.cumsum(frames * n_mels)[:-1]]).astype(np.uint64)
 pcm = M.DeviceBuffer(n_clips * base_len * 4)
 M.synth_pcm_device(pcm.ptr, base_len, base_len, 0, n_clips); M.device_synchronize()
-out = M.DeviceBuffer(int(frames.sum()) * n_mels * 4 + 4096)
+out = M.DeviceBuffer(max(int(frames.sum()), n_clips * m.num_frames(base_len)) * n_mels * 4 + 4096)     # the uniform run of the same buffer can be the larger one
 REPS = int(os.environ.get("L_REPS", "200"))
 def bench(fn, reps=None):
     reps = reps or REPS
