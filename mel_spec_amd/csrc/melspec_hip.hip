@@ -486,10 +486,30 @@ int launch_wave_v(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, boo
     }
 }
 
+// ragged batches on the default 5-frame build (variant 8): contiguous runs of units per wave (whisper400_wave_ragged_kernel)
+template <int NSLOTS, class Lens>
+int launch_wave_ragged(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_wave_ragged_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_ragged_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const FastParams fp = fast_params(c, desc);
+    const uint64_t blocks = (desc.n_units + 7) / 8;
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, 2);          // the two resident workgroups per CU
+    hipLaunchKernelGGL((whisper400_wave_ragged_kernel<NSLOTS, Lens>), dim3(grid), dim3(8 * 64), c->fast_lds, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
 // interval-scheme variants: 7: 4 waves direct, 8: 8 waves direct (<=128 VGPRs), 9: 8 waves staged (<=128 VGPRs)
 template <int NSLOTS, class StaticLens>
 int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool static_ok) {
     const int v = c->variant;
+    static const bool ragged_round_robin = [] { const char *e = std::getenv("MELSPEC_RAGGED_RUNS"); return e && e[0] == '0'; }();
+    if (v == 8 && desc.d_unit_prefix != nullptr && !ragged_round_robin)
+        return static_ok ? launch_wave_ragged<NSLOTS, StaticLens>(c, desc, stream) : launch_wave_ragged<NSLOTS, LensRuntime>(c, desc, stream);
     if (static_ok) {
         switch (v) {
             case 7: return launch_wave_t<NSLOTS, true, 4, StaticLens, 1, true>(c, desc, stream);

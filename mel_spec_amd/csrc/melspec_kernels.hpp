@@ -378,6 +378,39 @@ __device__ __forceinline__ uint64_t scalar64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
+// A wave's contiguous run of units of a ragged batch and the clip it is in (everything wave-uniform, in scalar registers).
+struct ClipRun {
+    uint64_t unit, end, c_start, c_end, c_frames;
+    const float *c_pcm;
+    float *c_out;
+    uint32_t clip;
+    __device__ __forceinline__ void load_clip(const BatchDesc &b) {
+        c_start = scalar64(b.d_unit_prefix[clip]);
+        c_frames = scalar64(b.d_frames[clip]);
+        c_pcm = b.pcm + scalar64(b.d_off[clip]);
+        c_out = b.out + scalar64(b.d_out_off[clip]);
+    }
+    // false: this wave has no units
+    __device__ __forceinline__ bool init(const BatchDesc &b, uint64_t wave_id, uint64_t waves) {
+        const uint64_t run = (b.n_units + waves - 1) / waves;
+        unit = wave_id * run;
+        end = unit + run < b.n_units ? unit + run : b.n_units;
+        if (unit >= end) return false;
+        clip = __builtin_amdgcn_readfirstlane(b.d_unit_block[unit / kUnitBlock]);
+        c_end = scalar64(b.d_unit_prefix[clip + 1]);
+        while (c_end <= unit) { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); }     // prefix[n_clips] = n_units > unit
+        load_clip(b);
+        return true;
+    }
+    // before each unit: the run may have entered the next clip that has frames
+    __device__ __forceinline__ void enter(const BatchDesc &b) {
+        if (unit >= c_end) {
+            do { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); } while (c_end <= unit);
+            load_clip(b);
+        }
+    }
+};
+
 template <int NSLOTS, class Lens>
 __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_ragged_kernel(const FastParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -396,31 +429,14 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_ragged_kerne
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
 
-    const uint64_t waves = (uint64_t)gridDim.x * kSixWaves;
-    const uint64_t run = (p.b.n_units + waves - 1) / waves;
-    uint64_t unit = ((uint64_t)xcd_logical_block() * kSixWaves + wave) * run;
-    const uint64_t end = unit + run < p.b.n_units ? unit + run : p.b.n_units;
-    if (unit >= end) return;
-    // the clip of the run's first unit
-    uint32_t clip = __builtin_amdgcn_readfirstlane(p.b.d_unit_block[unit / kUnitBlock]);
-    uint64_t c_end = scalar64(p.b.d_unit_prefix[clip + 1]);
-    while (c_end <= unit) { ++clip; c_end = scalar64(p.b.d_unit_prefix[clip + 1]); }          // prefix[n_clips] = n_units > unit
-    uint64_t c_start = scalar64(p.b.d_unit_prefix[clip]);
-    uint64_t c_frames = scalar64(p.b.d_frames[clip]);
-    const float *c_pcm = p.b.pcm + scalar64(p.b.d_off[clip]);
-    float *c_out = p.b.out + scalar64(p.b.d_out_off[clip]);
-    for (; unit < end; ++unit) {
-        if (unit >= c_end) {                               // wave-uniform: the run enters the next clip that has frames
-            do { ++clip; c_end = scalar64(p.b.d_unit_prefix[clip + 1]); } while (c_end <= unit);
-            c_start = scalar64(p.b.d_unit_prefix[clip]);
-            c_frames = scalar64(p.b.d_frames[clip]);
-            c_pcm = p.b.pcm + scalar64(p.b.d_off[clip]);
-            c_out = p.b.out + scalar64(p.b.d_out_off[clip]);
-        }
-        const uint64_t f0 = (unit - c_start) * kSixFrames;
-        const uint64_t left = c_frames - f0;
+    ClipRun cr;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) return;
+    for (; cr.unit < cr.end; ++cr.unit) {
+        cr.enter(p.b);
+        const uint64_t f0 = (cr.unit - cr.c_start) * kSixFrames;
+        const uint64_t left = cr.c_frames - f0;
         const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
-        const float *src = c_pcm + f0 * (uint64_t)p.hop;
+        const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
         MS_PRIO(0);
         six_phase1(fl, j, act, p.hop, blob, src, slice);
@@ -441,7 +457,58 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_ragged_kerne
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        six_phase4<NSLOTS, false>(fl, j, act, act, n_mels, slice, vals, c_out + f0 * (uint64_t)n_mels, 0);
+        six_phase4<NSLOTS, false>(fl, j, act, act, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same for the 5-frame kernel (81..131 mels): interval mel scheme, direct PCM reads, 8-wave workgroups.
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_ragged_kernel(const FastParams p) {
+    constexpr int WAVES = 8;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *blob = lds;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    float *slice = blob + p.blob_len + wave * p.slice_floats;
+    const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+    const bool in = lane < kFPW * kMelJobs;
+    int uoff, voff;
+    WaveLayout::row_offsets(j, uoff, voff);
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
+    const int fl3 = lane / 12, j3 = lane - fl3 * 12;
+    const bool in3 = lane < kFPW * 12;
+    const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
+    ClipRun cr;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    for (; cr.unit < cr.end; ++cr.unit) {
+        cr.enter(p.b);
+        const uint64_t f0 = (cr.unit - cr.c_start) * kFPW;
+        const uint64_t left = cr.c_frames - f0;
+        const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
+        wave_phase1<true>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
+        __builtin_amdgcn_wave_barrier();
+        wave_phase2<false>(fl, j, act, blob, slice, uoff, voff);
+        __builtin_amdgcn_wave_barrier();
+        float vals[NSLOTS];
+        {
+            int st[NSLOTS];
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
+        }
+        __builtin_amdgcn_wave_barrier();
+        wave_phase4<NSLOTS, false>(fl3, j3, act3, act3, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
     }
 }
