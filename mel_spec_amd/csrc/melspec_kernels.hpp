@@ -850,21 +850,26 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
         const int nr = rows - row0 < (uint64_t)R ? (int)(rows - row0) : R;
         float *base = p.out + row0 * p.row_w;
         if (vec) {
-            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce)
+            // row pointers advance by increments (rows past the group repeat its last row): no 64-bit multiply per row
+            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
+                const float *g0 = base + (uint64_t)rr0 * p.row_w;
+                float *t0 = tile + (size_t)rr0 * S;
                 for (uint64_t q = tid; q < nq; q += kBlmNormThreads) {
                     f4 v[kRowsAtOnce];
+                    const float *g = g0 + 4 * q;
 #pragma unroll
                     for (int i = 0; i < kRowsAtOnce; ++i) {
-                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
-                        v[i] = *reinterpret_cast<const f4 *>(base + (uint64_t)rr * p.row_w + 4 * q);
+                        v[i] = *reinterpret_cast<const f4 *>(g);
+                        if (rr0 + i + 1 < nr) g += p.row_w;
                     }
+                    float *t = t0 + 4 * q;
 #pragma unroll
                     for (int i = 0; i < kRowsAtOnce; ++i) {
-                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
-                        float *d = tile + (size_t)rr * S + 4 * q;
-                        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+                        *reinterpret_cast<f4 *>(t) = v[i];          // S is a multiple of 4: one 16-byte write
+                        if (rr0 + i + 1 < nr) t += S;
                     }
                 }
+            }
         } else {
             for (int rr = 0; rr < nr; ++rr) {
                 const float *src = base + (uint64_t)rr * p.row_w;
@@ -882,31 +887,37 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
         }
         __syncthreads();
         if (vec) {
-            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce)
+            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
+                float *g0 = base + (uint64_t)rr0 * p.row_w;
+                const float *t0 = tile + (size_t)rr0 * S;
                 for (uint64_t q = tid; q < nq; q += kBlmNormThreads) {
-                    float v[kRowsAtOnce][4], mean[kRowsAtOnce], sd[kRowsAtOnce];
+                    f4 v[kRowsAtOnce];
+                    float mean[kRowsAtOnce], sd[kRowsAtOnce];
+                    const float *t = t0 + 4 * q;
+                    const float *st = stat + 2 * rr0;
 #pragma unroll
                     for (int i = 0; i < kRowsAtOnce; ++i) {           // every LDS read first (rows past the group: its last row again)
-                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
-                        const float *src = tile + (size_t)rr * S + 4 * q;
-                        v[i][0] = src[0]; v[i][1] = src[1]; v[i][2] = src[2]; v[i][3] = src[3];
-                        mean[i] = stat[2 * rr]; sd[i] = stat[2 * rr + 1];
+                        v[i] = *reinterpret_cast<const f4 *>(t);
+                        mean[i] = st[0]; sd[i] = st[1];
+                        if (rr0 + i + 1 < nr) { t += S; st += 2; }
                     }
+                    float *g = g0 + 4 * q;
 #pragma unroll
                     for (int i = 0; i < kRowsAtOnce; ++i) {
-                        const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
                         f4 o;                                         // columns past the valid frames keep their zeros
-                        o.x = f32_div_rn(v[i][0] - mean[i], sd[i]);
-                        o.y = f32_div_rn(v[i][1] - mean[i], sd[i]);
-                        o.z = f32_div_rn(v[i][2] - mean[i], sd[i]);
-                        o.w = f32_div_rn(v[i][3] - mean[i], sd[i]);
+                        o.x = f32_div_rn(v[i].x - mean[i], sd[i]);
+                        o.y = f32_div_rn(v[i].y - mean[i], sd[i]);
+                        o.z = f32_div_rn(v[i].z - mean[i], sd[i]);
+                        o.w = f32_div_rn(v[i].w - mean[i], sd[i]);
                         if (4 * q + 0 >= p.valid) o.x = 0.0f;
                         if (4 * q + 1 >= p.valid) o.y = 0.0f;
                         if (4 * q + 2 >= p.valid) o.z = 0.0f;
                         if (4 * q + 3 >= p.valid) o.w = 0.0f;
-                        *reinterpret_cast<f4 *>(base + (uint64_t)rr * p.row_w + 4 * q) = o;
+                        *reinterpret_cast<f4 *>(g) = o;
+                        if (rr0 + i + 1 < nr) g += p.row_w;
                     }
                 }
+            }
         } else {
             for (int rr = 0; rr < nr; ++rr) {
                 float *dstg = base + (uint64_t)rr * p.row_w;
