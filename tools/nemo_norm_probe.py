@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""30 launches of the NeMo frontend with per-feature normalisation (1024 x 10 s, 128 mels): the workload for rocprofv3 runs of blm_normalize_kernel."""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, mel_spec_amd as M
 n_clips, clip_len = 1024, 160000
 pcm = M.DeviceBuffer(n_clips * clip_len * 4)
