@@ -180,6 +180,29 @@ def test_ragged_batch_with_empty_and_short_clips(w80, oracle, jfk):
             assert np.abs(g - want).max() <= TOL
 
 
+@pytest.mark.parametrize("n_mels,precise", [(128, False), (100, False), (64, False), (80, True), (128, True)])
+def test_ragged_batches_on_every_kernel_shape(gpu, oracle, jfk, n_mels, precise):
+    """Ragged batches have kernels of their own (contiguous runs of units per wave): the six-frame build (<= 80 mels,
+    compile-time and run-time slot lengths), the 5-frame build (128 / 100 mels) and, through the round-robin deal, the precise
+    build.  300 clips so that a wave's run crosses clip ends, with empty and sub-frame clips among them."""
+    m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+    if precise:
+        m.set_precise(True)
+    rng = np.random.default_rng(n_mels)
+    lens = [int(v) for v in rng.integers(0, 9000, 300)]
+    lens[7] = 0; lens[8] = 399; lens[9] = 400; lens[299] = 0
+    clips = [jfk[(37 * i) % 100000:][:n].copy() for i, n in enumerate(lens)]
+    got = m.compute_ragged(clips)
+    worst = 0.0
+    for g, c in zip(got, clips):
+        want = oracle.compute_mel_spectrogram_cpu(c, 400, 160, n_mels, SR)
+        assert g.shape == want.shape
+        if want.size:
+            worst = max(worst, float(np.abs(g - want).max()))
+    assert worst <= (3e-6 if precise else TOL)
+    m.close()
+
+
 @pytest.mark.parametrize("n,min_width", [(16000, 0), (16000, 3000), (16160, 0), (16160, 2), (16160, 100), (16160, 200), (560, 3000)])
 def test_interleaved_layouts(gpu, w80, oracle, n, min_width):
     """interleave_frames (src/mel.rs:480-544) fused into the store: mel-major for whisper.cpp, even width, zero padding."""
