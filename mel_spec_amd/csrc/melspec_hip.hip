@@ -497,7 +497,8 @@ int launch_wave_ragged(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream
     }
     const FastParams fp = fast_params(c, desc);
     const uint64_t blocks = (desc.n_units + 7) / 8;
-    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, 2);          // the two resident workgroups per CU
+    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_RAGGED_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 64 ? g : 4; }();
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);     // two workgroups are resident per CU; 4 per CU measured best (8192 x 15..45 s x 128 mels: 9.17 vs 9.50 ms)
     hipLaunchKernelGGL((whisper400_wave_ragged_kernel<NSLOTS, Lens>), dim3(grid), dim3(8 * 64), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
