@@ -214,7 +214,7 @@ def main() -> None:
             "realtime_x": value * (HOP / SR),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "melspec::whisper400_six_kernel" if (n_mels <= 80 and os.environ.get("MELSPEC_VARIANT", "11") == "11") else "melspec::whisper400_wave_kernel",
+                         "kernel": ("melspec::whisper400_six_runs_kernel" if (n_mels <= 80 and os.environ.get("MELSPEC_VARIANT", "11") == "11") else "melspec::whisper400_wave_runs_kernel") if os.environ.get("MELSPEC_UNIFORM_RUNS", "1") != "0" else "melspec::whisper400_six_kernel / whisper400_wave_kernel (round-robin deal)",
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch},
             "parity_max_abs_diff": parity, "spinup_steps_untimed": spinup_steps,

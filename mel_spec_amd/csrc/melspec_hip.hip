@@ -486,12 +486,12 @@ int launch_wave_v(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, boo
     }
 }
 
-// ragged batches on the default 5-frame build (variant 8): contiguous runs of units per wave (whisper400_wave_ragged_kernel)
+// ragged batches on the default 5-frame build (variant 8): contiguous runs of units per wave (whisper400_wave_runs_kernel)
 template <int NSLOTS, class Lens>
-int launch_wave_ragged(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+int launch_wave_runs(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_wave_ragged_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_ragged_kernel)");
+        int rc = allow_big_lds(&whisper400_wave_runs_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_runs_kernel)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
@@ -499,7 +499,7 @@ int launch_wave_ragged(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream
     const uint64_t blocks = (desc.n_units + 7) / 8;
     static const int per_cu = [] { const char *e = std::getenv("MELSPEC_RAGGED_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 64 ? g : 4; }();
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);     // two workgroups are resident per CU; 4 per CU measured best (8192 x 15..45 s x 128 mels: 9.17 vs 9.50 ms)
-    hipLaunchKernelGGL((whisper400_wave_ragged_kernel<NSLOTS, Lens>), dim3(grid), dim3(8 * 64), c->fast_lds, stream, fp);
+    hipLaunchKernelGGL((whisper400_wave_runs_kernel<NSLOTS, Lens>), dim3(grid), dim3(8 * 64), c->fast_lds, stream, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
@@ -509,8 +509,10 @@ template <int NSLOTS, class StaticLens>
 int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool static_ok) {
     const int v = c->variant;
     static const bool ragged_round_robin = [] { const char *e = std::getenv("MELSPEC_RAGGED_RUNS"); return e && e[0] == '0'; }();
-    if (v == 8 && desc.d_unit_prefix != nullptr && !ragged_round_robin)
-        return static_ok ? launch_wave_ragged<NSLOTS, StaticLens>(c, desc, stream) : launch_wave_ragged<NSLOTS, LensRuntime>(c, desc, stream);
+    static const bool uniform_runs = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();   // cfg4 9.15 -> 9.05 ms
+    const bool plain = !desc.mel_major && desc.out_width == desc.frames_per_clip;
+    if (v == 8 && ((desc.d_unit_prefix != nullptr && !ragged_round_robin) || (uniform_runs && plain && desc.d_unit_prefix == nullptr)))
+        return static_ok ? launch_wave_runs<NSLOTS, StaticLens>(c, desc, stream) : launch_wave_runs<NSLOTS, LensRuntime>(c, desc, stream);
     if (static_ok) {
         switch (v) {
             case 7: return launch_wave_t<NSLOTS, true, 4, StaticLens, 1, true>(c, desc, stream);
@@ -592,8 +594,8 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
             if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_ragged_kernel<kSixMaxSlots, LensSix80>, "hipFuncSetAttribute(whisper400_six_ragged_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_ragged_kernel<kSixMaxSlots, LensRuntime>, "hipFuncSetAttribute(whisper400_six_ragged_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, LensRuntime>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
             if (rc) return rc;
             mark_device_done(attr_done);
         }
@@ -609,13 +611,16 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
         const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
         static const bool ragged_round_robin = [] { const char *e = std::getenv("MELSPEC_RAGGED_RUNS"); return e && e[0] == '0'; }();
+        // plain uniform batches take the run-per-wave kernel too (no division per unit, the clip record in scalar registers, a wave re-reads
+        // its own frame-tail halo): cfg2 0.3105 -> 0.3055 ms, 8192 x 30 s 7.55 -> 7.42 ms.  MELSPEC_UNIFORM_RUNS=0: round-robin deal.
+        static const bool uniform_runs = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();
         if (layout) {
             if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, true>), grid, block, c->lds6, stream, fp);
             else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>), grid, block, c->lds6, stream, fp);
-        } else if (desc.d_unit_prefix != nullptr && !ragged_round_robin) {
+        } else if ((desc.d_unit_prefix != nullptr && !ragged_round_robin) || uniform_runs) {
             // ragged: contiguous runs of units per wave (MELSPEC_RAGGED_RUNS=0: the round-robin deal of the uniform kernel)
-            if (c->six_static) hipLaunchKernelGGL((whisper400_six_ragged_kernel<kSixMaxSlots, LensSix80>), grid, block, c->lds6, stream, fp);
-            else hipLaunchKernelGGL((whisper400_six_ragged_kernel<kSixMaxSlots, LensRuntime>), grid, block, c->lds6, stream, fp);
+            if (c->six_static) hipLaunchKernelGGL((whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>), grid, block, c->lds6, stream, fp);
+            else hipLaunchKernelGGL((whisper400_six_runs_kernel<kSixMaxSlots, LensRuntime>), grid, block, c->lds6, stream, fp);
         } else {
             if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, false>), grid, block, c->lds6, stream, fp);
             else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>), grid, block, c->lds6, stream, fp);

@@ -368,11 +368,12 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     }
 }
 
-// Ragged batches (plain [frame][mel] output) on the six-frame build.  A round-robin deal of the units costs two dependent
-// look-ups (block table, clip record) in front of every unit's PCM loads -- ~6 % at every batch size.  Here a wave takes a
-// contiguous run of units instead: it looks its first unit up once and from then on only steps to the next clip when the
-// run crosses a clip end (one load per clip boundary; the clip record lives in scalar registers).  The unit body is the
-// one of whisper400_six_kernel.
+// Plain [frame][mel] output, uniform and ragged batches, on the six-frame build -- the default kernel of the bench workload.
+// A wave takes a contiguous run of units: it locates its first unit once and from then on only steps to the next clip when
+// the run crosses a clip end; the clip record lives in scalar registers.  Against the round-robin deal of
+// whisper400_six_kernel (which the padded / mel-major layouts keep, their stores want adjacent units in adjacent waves):
+// ragged batches lose the two dependent look-ups in front of every unit's PCM loads (-6 %), uniform ones the 64-bit division
+// per unit and a wave re-reads its own frame-tail halo (cfg2 -1.6 %, 8192 x 30 s -1.7 %).  The unit body is the same.
 __device__ __forceinline__ uint64_t scalar64(uint64_t v) {
     // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -385,6 +386,14 @@ struct ClipRun {
     float *c_out;
     uint32_t clip;
     __device__ __forceinline__ void load_clip(const BatchDesc &b) {
+        if (b.d_unit_prefix == nullptr) {                 // uniform batch: arithmetic
+            c_start = (uint64_t)clip * b.units_per_clip;
+            c_end = c_start + b.units_per_clip;
+            c_frames = b.frames_per_clip;
+            c_pcm = b.pcm + (uint64_t)clip * b.clip_stride;
+            c_out = b.out + (uint64_t)clip * b.out_stride;
+            return;
+        }
         c_start = scalar64(b.d_unit_prefix[clip]);
         c_frames = scalar64(b.d_frames[clip]);
         c_pcm = b.pcm + scalar64(b.d_off[clip]);
@@ -396,6 +405,11 @@ struct ClipRun {
         unit = wave_id * run;
         end = unit + run < b.n_units ? unit + run : b.n_units;
         if (unit >= end) return false;
+        if (b.d_unit_prefix == nullptr) {
+            clip = static_cast<uint32_t>(unit / b.units_per_clip);
+            load_clip(b);
+            return true;
+        }
         clip = __builtin_amdgcn_readfirstlane(b.d_unit_block[unit / kUnitBlock]);
         c_end = scalar64(b.d_unit_prefix[clip + 1]);
         while (c_end <= unit) { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); }     // prefix[n_clips] = n_units > unit
@@ -405,14 +419,15 @@ struct ClipRun {
     // before each unit: the run may have entered the next clip that has frames
     __device__ __forceinline__ void enter(const BatchDesc &b) {
         if (unit >= c_end) {
-            do { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); } while (c_end <= unit);
+            if (b.d_unit_prefix == nullptr) ++clip;
+            else do { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); } while (c_end <= unit);
             load_clip(b);
         }
     }
 };
 
 template <int NSLOTS, class Lens>
-__global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_ragged_kernel(const FastParams p) {
+__global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(const FastParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
     const int tid = threadIdx.x;
@@ -464,7 +479,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_ragged_kerne
 
 // The same for the 5-frame kernel (81..131 mels): interval mel scheme, direct PCM reads, 8-wave workgroups.
 template <int NSLOTS, class Lens>
-__global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_ragged_kernel(const FastParams p) {
+__global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_runs_kernel(const FastParams p) {
     constexpr int WAVES = 8;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
