@@ -535,9 +535,11 @@ int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>, "hipFuncSetAttribute(whisper400_precise_kernel)");
+        if (!rc && !LAYOUT) rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, false, true>, "hipFuncSetAttribute(whisper400_precise_kernel)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
+    static const bool runs = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();
     PreciseParams pp{};
     pp.b = desc;
     pp.d_blob = static_cast<const uint32_t *>(c->d_blob64.p);
@@ -549,8 +551,12 @@ int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
     static const int per_cu = [] { const char *e = std::getenv("MELSPEC_PRECISE_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
-    hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>), dim3(grid), dim3(kPreciseWaves * 64),
-                       c->precise_lds, stream, pp);
+    if (!LAYOUT && runs)
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, false, true>), dim3(grid), dim3(kPreciseWaves * 64),
+                           c->precise_lds, stream, pp);
+    else
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>), dim3(grid), dim3(kPreciseWaves * 64),
+                           c->precise_lds, stream, pp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }

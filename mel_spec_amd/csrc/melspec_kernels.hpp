@@ -416,6 +416,11 @@ struct ClipRun {
         load_clip(b);
         return true;
     }
+    __device__ __forceinline__ UnitLoc loc() const {
+        UnitLoc r;
+        r.unit = unit - c_start; r.pcm = c_pcm; r.out = c_out; r.frames = c_frames;
+        return r;
+    }
     // before each unit: the run may have entered the next clip that has frames
     __device__ __forceinline__ void enter(const BatchDesc &b) {
         if (unit >= c_end) {
@@ -542,7 +547,8 @@ struct PreciseParams {
     MelSlots slots;       // woff[] as in the f32 blob (float offsets from FastBlob's base)
 };
 
-template <int NSLOTS, class Lens, int WAVES, bool LAYOUT = false>
+// RUNS (plain layout only): a contiguous run of units per wave (ClipRun) instead of the round-robin deal.
+template <int NSLOTS, class Lens, int WAVES, bool LAYOUT = false, bool RUNS = false>
 __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const PreciseParams p) {
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
@@ -571,10 +577,19 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
     }
     const uint64_t w_off = LAYOUT ? 0 : wave;      // LAYOUT: workgroup-uniform rounds, see whisper400_wave_kernel
     RoundSync<WAVES> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
-    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
+    static_assert(!(LAYOUT && RUNS), "runs are for the plain layout");
+    ClipRun cr;
+    if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off;; first += (uint64_t)gridDim.x * WAVES) {
+        if (RUNS) {
+            if (cr.unit >= cr.end) break;
+            cr.enter(p.b);
+        } else if (first >= p.b.n_units) {
+            break;
+        }
         const uint64_t unit = LAYOUT ? first + rs.slot : first;
         const bool have = !LAYOUT || unit < p.b.n_units;
-        const UnitLoc loc = locate_unit(p.b, have ? unit : first);
+        const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
@@ -604,6 +619,7 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
             wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT) rs.after_round();
+        if (RUNS) ++cr.unit;
     }
 }
 
