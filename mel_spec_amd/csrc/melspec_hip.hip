@@ -329,17 +329,25 @@ int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
 // 4-wave fallback for oversized tables keeps the run-time loop)
 template <class T, int FLAVOR, int NSLOTS, class Lens = LensRuntime>
 int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
+    // frame-major plain output (Kaldi always, Whisper-512 without a layout): a contiguous run of units per wave, 8-wave shape only
+    constexpr bool kCanRun = FLAVOR != kFlavorNemo;
+    static const bool runs_on = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();
+    const bool plain = !fp.b.mel_major && (fp.b.d_unit_prefix != nullptr || fp.b.out_width == fp.b.frames_per_clip);
+    const bool runs = kCanRun && runs_on && plain && waves == 8;
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
         if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
+        if (!rc && kCanRun) rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>, "hipFuncSetAttribute(fbank512_wave_kernel, runs)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
     const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
     static const int per_cu = [] { const char *e = std::getenv("MELSPEC_FB_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU; measured best
     const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
-    if (waves == 8)
+    if (runs)
+        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>), dim3(grid), dim3(512), lds, s, fp);
+    else if (waves == 8)
         hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>), dim3(grid), dim3(512), lds, s, fp);
     else
         hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>), dim3(grid), dim3(256), lds, s, fp);

@@ -649,7 +649,8 @@ constexpr int kFlavorKaldi = 0, kFlavorNemo = 1, kFlavorWhisper = 2;
 //                 log10 / per-frame clamp / (x+4)/4, frame-major output (plain and ragged batches).
 // FLAVOR = NeMo:  BatchLogMelSpectrogram::compute (src/mel.rs:321-385), feature-major output of
 //                 b.out_width columns per mel row (columns past the valid frames are zero).
-template <class T, int WAVES, int MINW, int FLAVOR = kFlavorKaldi, int NSLOTS = kFbSlots, class Lens = LensRuntime>
+// RUNS (frame-major plain output: Kaldi always, Whisper-512 without a layout): a contiguous run of units per wave (ClipRun).
+template <class T, int WAVES, int MINW, int FLAVOR = kFlavorKaldi, int NSLOTS = kFbSlots, class Lens = LensRuntime, bool RUNS = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const FbankFastParams p) {
     using L = FbankLayout<T>;
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
@@ -673,8 +674,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
     const T preemph = static_cast<T>(p.preemph);
 
-    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave; unit < p.b.n_units; unit += (uint64_t)gridDim.x * WAVES) {
-        const UnitLoc loc = locate_unit(p.b, unit);
+    static_assert(!(RUNS && FLAVOR == kFlavorNemo), "the feature-major store wants adjacent units in adjacent waves");
+    ClipRun cr;
+    if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave;; unit += (uint64_t)gridDim.x * WAVES) {
+        if (RUNS) {
+            if (cr.unit >= cr.end) break;
+            cr.enter(p.b);
+        } else if (unit >= p.b.n_units) {
+            break;
+        }
+        const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, unit);
         const uint64_t f0 = loc.unit * kFbFPW;
         const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
@@ -739,6 +749,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
                                       (long long)p.b.out_width);
         }
         __builtin_amdgcn_wave_barrier();
+        if (RUNS) ++cr.unit;
     }
 }
 
