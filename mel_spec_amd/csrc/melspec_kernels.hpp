@@ -20,7 +20,8 @@
 // stage 0, second stage 1, mel / log / store 2): the waves sharing a SIMD then stop advancing in lock-step through the
 // VMEM-, VALU- and LDS-heavy phases.  Measured (profiles/r01_variants.txt): six-frame Whisper kernel -2.3 .. -3.5 %, fused
 // 512-point kernels -8 % (Kaldi) / -11 % (Whisper-512) / 0 (NeMo), precise kernel -3.8 %; the 5-frame kernel with two
-// 8-wave workgroups per CU loses 1-4 % under every table tried and stays at the default priority.
+// 8-wave workgroups per CU loses 1-4 % under every table tried in its round-robin form and stays at the default priority
+// there; its run-per-wave form (whisper400_wave_runs_kernel) gains 5 % (cfg4 9.02 -> 8.53 ms).
 #ifndef MELSPEC_NO_PRIO
 #define MS_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #else
@@ -512,10 +513,13 @@ __global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_runs_kernel(const F
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
+        MS_PRIO(0);
         wave_phase1<true>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(1);
         wave_phase2<false>(fl, j, act, blob, slice, uoff, voff);
         __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
         float vals[NSLOTS];
         {
             int st[NSLOTS];
