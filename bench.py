@@ -1,11 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- mel frames/s of the fused MI355X log-mel kernel (Whisper 400/160/80 @16 kHz).
 
-A "step" is one pass of the hot path over one batch of synthetic PCM that is already
-resident in HBM: BASELINE.json configs[1], 1024 x 10 s f32 clips per GPU -> 1 021 952 frames
-of 80 mels per step.  N>1: one process per GPU (torch.distributed / RCCL), every rank owns its
-own 1024 clips (weak scaling, per-clip split, no data-path collective); the timed region is
-bracketed by barrier + synchronize and the MAX over ranks is reported.
+A "step" is one pass of the hot path over one batch of synthetic PCM that is already resident in HBM.
+
+  --config 2 (default)  BASELINE.json configs[1]: 1024 x 10 s f32 clips PER GPU -> 1 021 952 frames of 80 mels per
+                        step and GPU (weak scaling: rank r owns clips [1024 r, 1024 (r+1)))
+  --config 4            configs[3]: Whisper large-v3, 128 mels, 8192 x 30 s clips per GPU
+  --config 5            configs[4]: 65 536 x 30 s clips, 80 mels, split over the ranks with
+                        mel_spec_amd.parallel.shard_range (strong scaling: 8192 clips per rank at N = 8).  A rank whose
+                        share does not fit its HBM walks it in sub-shards inside the step (the JSON says how many).
+
+N > 1: one process per GPU over torch.distributed / RCCL.  `python bench.py --gpus N` re-executes itself under
+torch.distributed.run when it was not launched by it; every rank owns its own clips (per-clip split, no data-path
+collective); the timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.  --gather also
+times the optional consolidation of the per-rank outputs on rank 0 (RCCL send/recv over xGMI), reported separately.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     algorithmic bytes (640 B PCM in + 4*n_mels B out per frame) / kernel time vs 8 TB/s
@@ -16,6 +24,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -24,27 +33,43 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 SR = 16000.0
-N_FFT, HOP, N_MELS = 400, 160, 80
-CLIP_SECONDS = 10
-CLIPS_PER_GPU = 1024
+N_FFT, HOP = 400, 160
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CONFIGS = {             # name -> (clips, clip seconds, n_mels, scaling)
+    2: (1024, 10, 80, "weak"),
+    4: (8192, 30, 128, "weak"),
+    5: (65536, 30, 80, "strong"),
+}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU")
-    ap.add_argument("--clip-seconds", type=int, default=CLIP_SECONDS)
-    ap.add_argument("--n-mels", type=int, default=N_MELS)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--clips", type=int, default=None, help="override the clip count (per GPU for weak, total for strong)")
+    ap.add_argument("--clip-seconds", type=int, default=None)
+    ap.add_argument("--n-mels", type=int, default=None)
+    ap.add_argument("--precision", default="auto", choices=["auto", "f64", "f32"], help="melspec_set_precision (default: the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
-    ap.add_argument("--host-io", action="store_true", help="also time the PCIe-inclusive host API (not `value`)")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive host API figure (never `value`)")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time the consolidation of the outputs on rank 0")
     return ap.parse_args()
 
 
-def cpu_baseline(clip_len: int, n_mels: int, target_s: float) -> dict:
+def respawn_under_torchrun(args) -> None:
+    """`python bench.py --gpus N` with N > 1 and no launcher: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+def cpu_baseline(clip_len: int, n_mels: int, target_s: float, pool: int) -> dict:
     """Time the oracle (port of compute_mel_spectrogram_cpu) on a bounded sample of the same
     synthetic workload, all host cores (clips split across OpenMP threads)."""
     import numpy as np
@@ -54,7 +79,7 @@ def cpu_baseline(clip_len: int, n_mels: int, target_s: float) -> dict:
     t0 = time.perf_counter()
     O.compute_mel_batch(probe, N_FFT, HOP, n_mels, SR, n_threads=cores)
     dt = max(time.perf_counter() - t0, 1e-4)
-    n = int(min(CLIPS_PER_GPU, max(cores, round(cores * target_s / dt))))
+    n = int(min(pool, max(cores, round(cores * target_s / dt))))
     n -= n % cores or 0
     n = max(n, cores)
     clips = np.stack([O.synth_pcm(c, clip_len) for c in range(n)])
@@ -81,7 +106,7 @@ def cpu_baseline(clip_len: int, n_mels: int, target_s: float) -> dict:
         pass
     return {
         "value": frames / dt, "unit": "mel frames/s", "cores": cores, "kind": "port", "cpu": cpu_model,
-        "sample": f"{n} of the {CLIPS_PER_GPU} synthetic {clip_len / SR:.0f} s clips x {reps} passes ({frames} frames) in {dt:.2f} s, "
+        "sample": f"{n} of the synthetic {clip_len / SR:.0f} s clips x {reps} passes ({frames} frames) in {dt:.2f} s, "
                   f"oracle/melspec_oracle.c (f64 restatement of Spectrogram::compute_mel_spectrogram_cpu), OpenMP over clips",
         "single_thread_frames_per_s": o1.shape[0] * o1.shape[1] / dt1,
     }
@@ -89,55 +114,92 @@ def cpu_baseline(clip_len: int, n_mels: int, target_s: float) -> dict:
 
 def main() -> None:
     args = parse_args()
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        respawn_under_torchrun(args)          # does not return
     import numpy as np
     import torch
     import mel_spec_amd as M
+    from mel_spec_amd.parallel import shard_range, timed_steps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    n_mels = args.n_mels
-    clip_len = int(args.clip_seconds * SR)
-    n_clips = args.clips
-    first_clip = rank * n_clips            # weak scaling: rank r owns clips [r*n, (r+1)*n)
+    cfg_clips, cfg_seconds, cfg_mels, scaling = CONFIGS[args.config]
+    n_mels = args.n_mels or cfg_mels
+    clip_seconds = args.clip_seconds or cfg_seconds
+    clip_len = int(clip_seconds * SR)
+    total_or_per = args.clips or cfg_clips
+    if scaling == "weak":
+        n_clips, first_clip = total_or_per, rank * total_or_per          # rank r owns clips [r*n, (r+1)*n)
+    else:
+        lo, hi = shard_range(total_or_per, rank, world)                  # contiguous per-clip split of the fixed set
+        n_clips, first_clip = hi - lo, lo
+    steps = args.steps if args.steps is not None else (1000 if args.config == 2 else 20)
+    warmup = args.warmup if args.warmup is not None else (100 if args.config == 2 else 3)
+
     mel = M.HipMelSpectrogram(N_FFT, HOP, SR, n_mels, device=local_rank)
+    mel.set_precision(args.precision)
     fpc = mel.num_frames(clip_len)
+
+    # resident share, or sub-shards walked inside the step when the share does not fit (config 5 on few GPUs)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    bytes_per_clip = clip_len * 4 + fpc * n_mels * 4 + fpc * 4 / 6 * 1.05      # PCM + mel + the precision guard's queue
+    sub = 1
+    while n_clips / sub * bytes_per_clip > 0.9 * free_b:
+        sub *= 2
+    sub_clips = (n_clips + sub - 1) // sub
+    pcm = torch.empty(sub_clips * clip_len, dtype=torch.float32, device=dev)
+    out = torch.empty(sub_clips * fpc * n_mels, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
     frames_per_step = fpc * n_clips
 
-    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
-    out = torch.empty(frames_per_step * n_mels, dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, first_clip, n_clips, stream=stream)
+    def fill(shard: int) -> int:
+        c0 = shard * sub_clips
+        k = min(sub_clips, n_clips - c0)
+        M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, first_clip + c0, k, stream=stream)
+        return k
+
+    k0 = fill(0)
     torch.cuda.synchronize()
 
     def step():
-        mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+        if sub == 1:
+            mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+        else:                       # the share in `sub` passes over one resident buffer (the refill is part of the step)
+            for s in range(sub):
+                k = fill(s)
+                mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, k, out.data_ptr(), stream=stream)
 
     # parity spot check first (3 clips vs the oracle), so that nothing CPU-bound sits between the spin-up and
     # the timed region: the GPU drops back to its idle clocks within milliseconds of an empty queue
-    step()
+    mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, k0, out.data_ptr(), stream=stream)
     torch.cuda.synchronize()
-    parity = None
+    parity, queued = None, None
     if rank == 0:
         from oracle import oracle as O
         worst = 0.0
-        o3 = out.view(n_clips, fpc, n_mels)
-        for c in sorted({0, n_clips // 2, n_clips - 1}):
+        o3 = out[: k0 * fpc * n_mels].view(k0, fpc, n_mels)
+        for c in sorted({0, k0 // 2, k0 - 1}):
             want = O.compute_mel_spectrogram_cpu(O.synth_pcm(first_clip + c, clip_len), N_FFT, HOP, n_mels, SR)
             worst = max(worst, float((o3[c].cpu().numpy() - want).__abs__().max()))
         parity = worst
         if worst > 1e-4:
             raise SystemExit(f"parity check failed before timing: max|diff| = {worst}")
+        queued = mel.guard_last_count() if args.precision == "auto" else None
     if distributed:
         dist.barrier()
 
@@ -146,16 +208,15 @@ def main() -> None:
     # steps, then straight into the timed region.  Nothing here is timed.
     spin_t0, spinup_steps = time.perf_counter(), 0
     while time.perf_counter() - spin_t0 < 0.3:
-        for _ in range(20):
+        for _ in range(20 if args.config == 2 else 1):
             step()
         torch.cuda.synchronize()
-        spinup_steps += 20
-    for _ in range(args.warmup):
+        spinup_steps += 20 if args.config == 2 else 1
+    for _ in range(warmup):
         step()
 
     # timed region: barrier + synchronize on both sides, MAX over ranks (mel_spec_amd.parallel.timed_steps);
     # HIP events on the launch stream bracket the same K launches for the kernel-side figure.
-    from mel_spec_amd.parallel import timed_steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     state = {"n": 0}
 
@@ -164,65 +225,104 @@ def main() -> None:
             ev0.record()
         step()
         state["n"] += 1
-        if state["n"] == args.steps:
+        if state["n"] == steps:
             ev1.record()
 
-    elapsed = timed_steps(timed_step, torch.cuda.synchronize, args.steps, 0, dist if distributed else None, dev)
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+    elapsed = timed_steps(timed_step, torch.cuda.synchronize, steps, 0, dist if distributed else None, dev)
+    my_kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
+    kernel_ms = my_kernel_ms
+    per_rank = [[float(frames_per_step), my_kernel_ms]]
     if distributed:
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_ms = float(k.item())
+        mine = torch.tensor([float(frames_per_step), my_kernel_ms], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)                   # per-rank {frames, ms}: tiny, the only collective of the run
+        per_rank = [[float(t[0].item()), float(t[1].item())] for t in allr]
+        kernel_ms = max(p[1] for p in per_rank)
+
+    gather = None
+    if distributed and args.gather and sub == 1:
+        # optional consolidation on rank 0: every peer sends its share over its own xGMI link
+        n_out = fpc * n_clips * n_mels
+        sizes = [int(p[0]) * n_mels for p in per_rank]
+        bufs = [torch.empty(sz, dtype=torch.float32, device=dev) for sz in sizes[1:]] if rank == 0 else []
+        dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if rank == 0:
+            reqs = [dist.irecv(b, src=r + 1) for r, b in enumerate(bufs)]
+        else:
+            reqs = [dist.isend(out[:n_out], dst=0)]
+        for r in reqs:
+            r.wait()
+        torch.cuda.synchronize(); dist.barrier()
+        gdt = time.perf_counter() - t0
+        if rank == 0:
+            gb = sum(sizes[1:]) * 4 / 1e9
+            gather = {"seconds": gdt, "gigabytes_into_rank0": gb, "GB_per_s": gb / gdt, "note": "RCCL send/recv, not part of `value`"}
 
     host_io = None
-    if args.host_io and rank == 0:
+    if not args.no_host_io and rank == 0:
         from oracle import oracle as O
-        x = np.concatenate([O.synth_pcm(c, clip_len) for c in range(8)])
-        mel.compute_mel_spectrogram(x)
+        x = np.stack([O.synth_pcm(c, clip_len) for c in range(64)])
+        mel.compute_batch(x)
+        reps = 5
         t1 = time.perf_counter()
-        for _ in range(5):
-            y = mel.compute_mel_spectrogram(x)
-        host_io = 5 * y.shape[0] / (time.perf_counter() - t1)
+        for _ in range(reps):
+            y = mel.compute_batch(x)
+        host_io = reps * y.shape[0] * y.shape[1] / (time.perf_counter() - t1)
 
     if rank == 0:
-        total_frames = frames_per_step * world * args.steps
+        total_frames = sum(p[0] for p in per_rank) * steps
         value = total_frames / elapsed
         bytes_per_frame = HOP * 4 + n_mels * 4
         algo_bytes_per_launch = frames_per_step * bytes_per_frame
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == 2:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("clips") == n_clips and tj.get("clip_seconds") == args.clip_seconds and tj.get("n_mels") == n_mels:
+                if tj.get("clips") == n_clips and tj.get("clip_seconds") == clip_seconds and tj.get("n_mels") == n_mels:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = (f"committed rocprofv3 PMC passes of this command (profiles/traffic.json, source {tj.get('source')}): "
+                                      "2 x FETCH_SIZE + WRITE_SIZE per launch; not re-measured in this run")
             except Exception:
                 traffic = None
         res = {
             "metric": "mel frames/sec/GPU (Whisper 400/160/80 @16 kHz); realtime x vs CPU ref",
             "value": value, "unit": "mel frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: batched {n_clips} synthetic {args.clip_seconds} s f32 clips @16 kHz per GPU, "
-                                   f"Whisper n_fft={N_FFT} hop={HOP} n_mels={n_mels}, PCM and mel resident in HBM",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32" if args.precision != "f64" else "f64", "data": "synthetic",
+            "config": {"workload": (f"configs[{args.config - 1}]: " + (
+                           f"batched {n_clips} synthetic {clip_seconds} s f32 clips @16 kHz per GPU" if scaling == "weak" else
+                           f"{total_or_per} synthetic {clip_seconds} s f32 clips @16 kHz split per clip over {world} GPU(s), {n_clips} on rank 0")
+                           + f", Whisper n_fft={N_FFT} hop={HOP} n_mels={n_mels}, PCM and mel resident in HBM"),
                        "clips_per_gpu": n_clips, "frames_per_step_per_gpu": frames_per_step,
+                       "sub_shards_per_step": sub,
+                       "precision": f"melspec_set_precision({args.precision}): " + (
+                           "f32 FFT, frames failing the error bound recomputed in f64 by a second launch inside the step" if args.precision == "auto" else
+                           ("f64 FFT on every frame" if args.precision == "f64" else "f32 FFT, no guard")),
+                       "frames_recomputed_in_f64_per_step": queued,
                        "parallelism": f"per-clip split x{world}, no data-path collective"},
             "per_gpu_frames_per_s": value / world,
+            "per_rank": [{"frames_per_step": p[0], "kernel_ms": p[1]} for p in per_rank],
             "realtime_x": value * (HOP / SR),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("melspec::whisper400_six_runs_kernel" if (n_mels <= 80 and os.environ.get("MELSPEC_VARIANT", "11") == "11") else "melspec::whisper400_wave_runs_kernel") if os.environ.get("MELSPEC_UNIFORM_RUNS", "1") != "0" else "melspec::whisper400_six_kernel / whisper400_wave_kernel (round-robin deal)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": mel.plain_kernel_name(),
                          "kernel_ms": kernel_ms,
+                         "kernel_ms_note": "HIP events on the launch stream around the K timed steps / K: the f32 kernel plus the (empty-queue) f64 fix-up launch",
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch},
             "parity_max_abs_diff": parity, "spinup_steps_untimed": spinup_steps,
         }
         if host_io is not None:
             res["host_api_frames_per_s_pcie_inclusive"] = host_io
+            res["host_api_note"] = "64 host clips of the same length through compute_batch (pinned staging, H2D + kernels + D2H per call); never `value`"
+        if gather is not None:
+            res["gather_to_rank0"] = gather
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(clip_len, n_mels, args.cpu_seconds)
+            cb = cpu_baseline(clip_len, n_mels, args.cpu_seconds, 1024)
             res["cpu_baseline"] = cb
             res["realtime_x_vs_cpu"] = value / cb["value"]
         print(json.dumps(res), flush=True)

@@ -67,12 +67,29 @@ int melspec_n_mels(const melspec_ctx *ctx);
 /* 1 if this geometry runs on the fused FFT kernel, 0 if on the generic DFT kernel. */
 int melspec_uses_fast_path(const melspec_ctx *ctx);
 
-/* Arithmetic of the fused n_fft = 400 kernel.  Default (0): f32 FFT -- within ~3e-5 of the f64 reference
- * on speech/noise, up to ~9e-5 on a pure tone over a -70 dB noise floor (the bands at the per-frame clamp).
- * Precise (1): f64 window/FFT/power like the reference's own arithmetic (src/stft.rs:98-111), ~1e-6
- * everywhere, about 60 % of the throughput.  Geometries on the generic kernel are always f64. */
+/* Arithmetic of the fused n_fft = 400 kernels (the reference computes in f64, src/stft.rs:98-111, and its CUDA plugin runs
+ * an f64 FFT too, cufftExecZ2Z src/cuda.rs:204-219).  Every mode but F32 is within 1e-4 of the f64 reference on every input.
+ *   AUTO (default)  f32 FFT; in the same pass every frame is checked against an error bound -- a mel band within two
+ *                   decades of the per-frame clamp (max - 8, src/mel.rs:645-654) is where the f32 FFT's rounding noise can
+ *                   exceed 1e-4 -- and the frames that fail it are recomputed with the f64 kernel by a second launch on the
+ *                   same stream.  Noise-like input queues nothing (the bench workload runs at the f32 rate); a line over a
+ *                   quiet floor or speech with > 60 dB of in-frame dynamic range queues most frames, and F64 is then the
+ *                   faster choice because it skips the f32 pass.
+ *   F64             window, FFT and |X|^2 in f64 for every frame: ~4e-7 from the reference, about 60 % of the f32 rate.
+ *   F32             the f32 kernel alone: ~3e-5 on speech and noise, up to ~5e-4 on a line over a floor 70..90 dB down.
+ * Geometries on the generic kernel and the fused n_fft = 512 kernel always compute in f64. */
+#define MELSPEC_PRECISION_AUTO 0
+#define MELSPEC_PRECISION_F64  1
+#define MELSPEC_PRECISION_F32  2
+int melspec_set_precision(melspec_ctx *ctx, int mode);
+int melspec_precision(const melspec_ctx *ctx);
+/* melspec_set_precision(ctx, on ? F64 : AUTO); is_precise: 1 when every frame is computed in f64. */
 int melspec_set_precise(melspec_ctx *ctx, int on);
 int melspec_is_precise(const melspec_ctx *ctx);
+/* Name of the kernel(s) a plain [clip][frame][mel] batch of this context runs on (for profiles and bench lines). */
+const char *melspec_plain_kernel_name(const melspec_ctx *ctx);
+/* Frames the last AUTO call on this context recomputed in f64 (waits for that call). */
+int melspec_guard_last_count(melspec_ctx *ctx, uint64_t *frames);
 
 /* compute_mel_spectrogram(&mut self, samples: &[f32]) -> Vec<Vec<f32>> (src/cuda.rs:88-101)
  * == Spectrogram::compute_mel_spectrogram_cpu (src/stft.rs:119-138) on the GPU.
@@ -153,6 +170,9 @@ size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples); /* s
 int melspec_fbank_num_mel_bins(const melspec_fbank *fb);
 /* 1 if this configuration runs on the fused 512-point kernel, 0 if on the generic f64 kernel. */
 int melspec_fbank_uses_fast_path(const melspec_fbank *fb);
+/* on != 0: run this object on the generic f64 direct-DFT kernel (an independent device path, kept as the on-device
+ * cross-check of the fused kernel; ~60x slower). */
+int melspec_fbank_use_generic(melspec_fbank *fb, int on);
 /* Fbank::compute(&self, samples) -> Array2<f32> (frames, num_mel_bins) (src/fbank.rs:141-236). */
 int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n_samples,
                                float *out, size_t out_capacity_floats, size_t *n_frames);

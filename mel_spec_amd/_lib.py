@@ -54,6 +54,10 @@ SIGNATURES = {
     "melspec_hop_size": (C.c_int, [_vp]),
     "melspec_n_mels": (C.c_int, [_vp]),
     "melspec_uses_fast_path": (C.c_int, [_vp]),
+    "melspec_set_precision": (C.c_int, [_vp, C.c_int]),
+    "melspec_precision": (C.c_int, [_vp]),
+    "melspec_guard_last_count": (C.c_int, [_vp, _u64p]),
+    "melspec_plain_kernel_name": (C.c_char_p, [_vp]),
     "melspec_set_precise": (C.c_int, [_vp, C.c_int]),
     "melspec_is_precise": (C.c_int, [_vp]),
     "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -73,6 +77,7 @@ SIGNATURES = {
     "melspec_fbank_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
     "melspec_fbank_num_mel_bins": (C.c_int, [_vp]),
     "melspec_fbank_uses_fast_path": (C.c_int, [_vp]),
+    "melspec_fbank_use_generic": (C.c_int, [_vp, C.c_int]),
     "melspec_fbank_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_fbank_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "melspec_fbank_synchronize": (C.c_int, [_vp, _vp]),

@@ -49,14 +49,23 @@ int fail_hip(hipError_t e, const char *where) {
         if (e_ != hipSuccess) return fail_hip(e_, #expr);     \
     } while (0)
 
-constexpr int kFPB = 23;       // frames per workgroup tile (23*11 = 253 <= 256 threads)
-constexpr int kNT = 256;
 constexpr int kGenericNT = 256;
-constexpr int kDefaultVariant = 11;  // six frames per wave where the filterbank allows it (<= 80 mels), else variant 8:
-                                     // wave kernel, 8 waves/workgroup, direct PCM reads, interval mel scheme
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
+
+// Tuning switches exist only in -DMELSPEC_LAB builds (mel_spec_amd.build.build(lab=True), used by tools/): the product
+// library runs the measured defaults below and reads no environment variable except MELSPEC_PRECISE (melspec_create).
+#ifdef MELSPEC_LAB
+int lab_int(const char *name, int dflt, int lo, int hi) {
+    const char *e = std::getenv(name);
+    if (!e) return dflt;
+    const int v = std::atoi(e);
+    return v >= lo && v <= hi ? v : dflt;
+}
+#else
+constexpr int lab_int(const char *, int dflt, int, int) { return dflt; }
+#endif
 
 template <typename K>
 int allow_big_lds(K kernel, const char *name) {
@@ -203,11 +212,11 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     b.out_width = out_width;
     b.mel_major = mel_major ? 1 : 0;
     // mel-major stores keep waves that hold adjacent units in step, so that the 24-byte pieces of a 32-byte sector reach L2
-    // together (RoundSync in melspec_kernels.hpp).  MELSPEC_MM_SYNC: 0 none, 1 one workgroup barrier per round, 2/4/8 sub-group
-    // barrier over consecutive waves, 16 + 2/4/8 over waves WAVES / size apart; unset (-1): the measured best of the kernel
-    // that runs, resolved in launch_ctx.  MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
-    static const int mm_mode = [] { const char *e = std::getenv("MELSPEC_MM_SYNC"); if (!e) return -1; const int v = std::atoi(e); const int sz = v & 15; return (v == 0 || v == 1 || ((sz == 2 || sz == 4 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();
-    static const bool fm_on = [] { const char *e = std::getenv("MELSPEC_FM_SYNC"); return e && e[0] == '1'; }();
+    // together (RoundSync in melspec_kernels.hpp): -1 = the measured best of the kernel that runs, resolved in launch_ctx.
+    // Lab builds: MELSPEC_MM_SYNC 0 none, 1 one workgroup barrier per round, 2/4/8 sub-group barrier over consecutive waves,
+    // 16 + 2/4/8 over waves WAVES / size apart; MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
+    static const int mm_mode = [] { const int v = lab_int("MELSPEC_MM_SYNC", -1, -1, 31); const int sz = v & 15; return (v <= 1 || ((sz == 2 || sz == 4 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();
+    static const bool fm_on = lab_int("MELSPEC_FM_SYNC", 0, 0, 1) != 0;
     b.sync_rounds = mel_major ? mm_mode : (fm_on ? 1 : 0);
     b.frames_per_unit = frames_per_unit;
     b.units_per_clip = static_cast<uint32_t>((out_width + frames_per_unit - 1) / frames_per_unit);
@@ -287,9 +296,9 @@ unsigned grid_for(uint64_t units, int cus, int per_cu) {
     return static_cast<unsigned>(g ? g : 1);
 }
 // same, rounded up to a multiple of the 8 XCDs for the kernels that reorder their workgroups (xcd_logical_block);
-// MELSPEC_XCD=0 keeps the dispatcher's order (odd grid sizes switch the reordering off in the kernel)
+// lab builds: MELSPEC_XCD=0 keeps the dispatcher's order (odd grid sizes switch the reordering off in the kernel)
 unsigned grid_for_xcd(uint64_t units, int cus, int per_cu) {
-    static const bool off = [] { const char *e = std::getenv("MELSPEC_XCD"); return e && e[0] == '0'; }();
+    static const bool off = lab_int("MELSPEC_XCD", 1, 0, 1) == 0;
     const unsigned g = grid_for(units, cus, per_cu);
     if (off) return (g % 8 == 0 && g > 1) ? g - 1 : g;
     return (g + 7u) & ~7u;
@@ -318,10 +327,9 @@ int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, bool
 
 namespace {
 // Waves per workgroup of the fused 512-point kernels: 8 (two per SIMD, one workgroup per CU) when the tables
-// and eight 18.5 KB slices fit in LDS, else 4.  MELSPEC_FB_WAVES=4 forces the small shape.
+// and eight 18.5 KB slices fit in LDS, else 4.
 int fused512_waves(size_t blob_bytes, size_t slice_bytes) {
-    const char *e = std::getenv("MELSPEC_FB_WAVES");
-    if (e && std::atoi(e) == 4) return 4;
+    if (lab_int("MELSPEC_FB_WAVES", 8, 4, 8) == 4) return 4;
     return blob_bytes + 8 * slice_bytes <= kLdsLimit ? 8 : 4;
 }
 
@@ -331,9 +339,8 @@ template <class T, int FLAVOR, int NSLOTS, class Lens = LensRuntime>
 int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, hipStream_t s) {
     // frame-major plain output (Kaldi always, Whisper-512 without a layout): a contiguous run of units per wave, 8-wave shape only
     constexpr bool kCanRun = FLAVOR != kFlavorNemo;
-    static const bool runs_on = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();
     const bool plain = !fp.b.mel_major && (fp.b.d_unit_prefix != nullptr || fp.b.out_width == fp.b.frames_per_clip);
-    const bool runs = kCanRun && runs_on && plain && waves == 8;
+    const bool runs = kCanRun && plain && waves == 8;
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
@@ -343,7 +350,7 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
         mark_device_done(attr_done);
     }
     const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
-    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_FB_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU; measured best
+    static const int per_cu = lab_int("MELSPEC_FB_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU; measured best
     const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
     if (runs)
         hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>), dim3(grid), dim3(512), lds, s, fp);
@@ -355,10 +362,10 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
     return MELSPEC_OK;
 }
 
-// does the context's bank have exactly the compile-time slot lengths of Lens?  MELSPEC_RUNTIME_LENS=1 forces the run-time loop.
+// does the context's bank have exactly the compile-time slot lengths of Lens?  (lab builds: MELSPEC_RUNTIME_LENS=1 forces the run-time loop)
 template <class Lens>
 bool fb_lens_match(const MelSlots &ms) {
-    static const bool off = [] { const char *e = std::getenv("MELSPEC_RUNTIME_LENS"); return e && e[0] == '1'; }();
+    static const bool off = lab_int("MELSPEC_RUNTIME_LENS", 0, 0, 1) != 0;
     if (off || ms.n_slots != Lens::kSlots) return false;
     for (int i = 0; i < Lens::kSlots; ++i)
         if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
@@ -369,23 +376,27 @@ bool fb_lens_match(const MelSlots &ms) {
 // ------------------------------------------------------------------------------------
 // Whisper log-mel context
 // ------------------------------------------------------------------------------------
+// Queue of the precision guard (GuardSink in melspec_kernels.hpp): u32 frame ids + three control words.
+struct GuardQueue {
+    DevBuf list, ctl;
+    hipStream_t last_stream = nullptr;   // the queue is stream-ordered: a call on another stream first waits for this one
+    bool used = false;
+    void release() { list.release(); ctl.release(); used = false; last_stream = nullptr; }
+};
+
 struct melspec_ctx {
     DeviceInfo dev;
     int fft_size = 0, hop_size = 0, n_mels = 0;
     double sr = 0.0;
-    bool fast = false;
     hipStream_t stream = nullptr;
-    // fast path
+    // fused n_fft = 400 build, five frames per wave (whisper400_wave_*): every bank of <= 131 mels; serves 81..131 mels and
+    // carries the tables the f64 kernels share
+    bool fast = false;
     FastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
-    int region_a = 0;
-    int variant = 0;        // 0: block kernel (23 frames / 256 threads); 1..4: wave kernels (see launch_ctx)
     int lens_kind = 0;      // 0 runtime slot lengths, 1 static Whisper-80, 2 static Whisper-128
-    int slice_floats = 0;
-    int frames_per_unit = 1;
-    int grid_per_cu = 4;    // MELSPEC_GRID_PER_CU: cap of workgroups per CU for the persistent loops (2 are resident; 4 measured best)
-    // six-frames-per-wave build (variant 11): every batch shape and layout while the context is in f32 mode
+    // six-frames-per-wave build (whisper400_six_*): <= 80 mels, every batch shape and layout while the context computes in f32
     bool six = false;
     int six_static = 0;     // 1: LensSix80 matches the tables
     FastTables ft6;
@@ -397,11 +408,12 @@ struct melspec_ctx {
     DevBuf d_blob512;
     size_t lds512 = 0;
     int waves512 = 4;
-    // precise (f64 FFT) build of the fused kernel, melspec_set_precise
-    bool precise = false;
+    // f64 FFT build of the n_fft = 400 kernel: the whole batch (MELSPEC_PRECISION_F64) or the queued frames (AUTO)
+    int precision = MELSPEC_PRECISION_AUTO;
     PreciseTables pt;
     DevBuf d_blob64;
     size_t precise_lds = 0;
+    GuardQueue guard;
     // generic path
     GenericTables gt;
     // scratch
@@ -412,9 +424,8 @@ struct melspec_ctx {
 namespace {
 
 // frames per work unit of the kernel a batch will run on
-int ctx_frames_per_unit(const melspec_ctx *c, bool plain) {
-    (void)plain;
-    if (c->fast) return (c->six && !c->precise) ? kSixFrames : c->frames_per_unit;
+int ctx_frames_per_unit(const melspec_ctx *c) {
+    if (c->fast) return (c->six && c->precision != MELSPEC_PRECISION_F64) ? kSixFrames : kFPW;
     return c->fast512 ? kFbFPW : 1;
 }
 
@@ -423,131 +434,7 @@ int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
     return MELSPEC_OK;
 }
 
-FastParams fast_params(melspec_ctx *c, const BatchDesc &desc) {
-    FastParams fp{};
-    fp.b = desc;
-    fp.d_blob = static_cast<const float *>(c->d_blob.p);
-    fp.blob_len = static_cast<int>(c->ft.blob.size());
-    fp.hop = c->hop_size;
-    fp.n_mels = c->n_mels;
-    fp.region_a = c->region_a;
-    fp.slice_floats = c->slice_floats;
-    fp.slots = c->ft.slots;
-    return fp;
-}
-
-template <int NSLOTS>
-int launch_block_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    const FastParams fp = fast_params(c, desc);
-    const unsigned grid = grid_for(desc.n_units, c->dev.cus, 8);
-    hipLaunchKernelGGL((whisper400_kernel<kFPB, kNT, NSLOTS>), dim3(grid), dim3(kNT), c->fast_lds, stream, fp);
-    HIP_TRY(hipGetLastError());
-    return MELSPEC_OK;
-}
-
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW, bool INTERVAL, bool LAYOUT>
-int launch_wave_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
-    if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>, "hipFuncSetAttribute(whisper400_wave_kernel)");
-        if (rc) return rc;
-        mark_device_done(attr_done);
-    }
-    const FastParams fp = fast_params(c, desc);
-    const uint64_t blocks = (desc.n_units + WAVES - 1) / WAVES;
-    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, c->grid_per_cu);
-    hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, LAYOUT>), dim3(grid),
-                       dim3(WAVES * 64), c->fast_lds, stream, fp);
-    HIP_TRY(hipGetLastError());
-    return MELSPEC_OK;
-}
-
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false>
-int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-    if (layout) return launch_wave_l<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, true>(c, desc, stream);
-    return launch_wave_l<NSLOTS, DIRECT, WAVES, Lens, MINW, INTERVAL, false>(c, desc, stream);
-}
-
-template <int NSLOTS, class StaticLens>
-int launch_wave_v(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool static_ok) {
-    // 1: 4 waves direct, 2: 4 waves staged, 3: 8 waves direct, 4: 8 waves staged,
-    // 5/6: as 3/4 with the register budget capped for 4 waves per SIMD (<=128 VGPRs)
-    const int v = c->variant;
-    if (static_ok) {
-        switch (v) {
-            case 1: return launch_wave_t<NSLOTS, true, 4, StaticLens>(c, desc, stream);
-            case 2: return launch_wave_t<NSLOTS, false, 4, StaticLens>(c, desc, stream);
-            case 3: return launch_wave_t<NSLOTS, true, 8, StaticLens>(c, desc, stream);
-            case 4: return launch_wave_t<NSLOTS, false, 8, StaticLens>(c, desc, stream);
-            case 5: return launch_wave_t<NSLOTS, true, 8, StaticLens, 4>(c, desc, stream);
-            default: return launch_wave_t<NSLOTS, false, 8, StaticLens, 4>(c, desc, stream);
-        }
-    }
-    switch (v) {
-        case 1: return launch_wave_t<NSLOTS, true, 4, LensRuntime>(c, desc, stream);
-        case 2: return launch_wave_t<NSLOTS, false, 4, LensRuntime>(c, desc, stream);
-        case 3: return launch_wave_t<NSLOTS, true, 8, LensRuntime>(c, desc, stream);
-        case 4: return launch_wave_t<NSLOTS, false, 8, LensRuntime>(c, desc, stream);
-        case 5: return launch_wave_t<NSLOTS, true, 8, LensRuntime, 4>(c, desc, stream);
-        default: return launch_wave_t<NSLOTS, false, 8, LensRuntime, 4>(c, desc, stream);
-    }
-}
-
-// ragged batches on the default 5-frame build (variant 8): contiguous runs of units per wave (whisper400_wave_runs_kernel)
-template <int NSLOTS, class Lens>
-int launch_wave_runs(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static std::atomic<uint64_t> attr_done{0};
-    if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_wave_runs_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_runs_kernel)");
-        if (rc) return rc;
-        mark_device_done(attr_done);
-    }
-    const FastParams fp = fast_params(c, desc);
-    const uint64_t blocks = (desc.n_units + 7) / 8;
-    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_RAGGED_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 64 ? g : 4; }();
-    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);     // two workgroups are resident per CU; 4 per CU measured best (8192 x 15..45 s x 128 mels: 9.17 vs 9.50 ms)
-    hipLaunchKernelGGL((whisper400_wave_runs_kernel<NSLOTS, Lens>), dim3(grid), dim3(8 * 64), c->fast_lds, stream, fp);
-    HIP_TRY(hipGetLastError());
-    return MELSPEC_OK;
-}
-
-// interval-scheme variants: 7: 4 waves direct, 8: 8 waves direct (<=128 VGPRs), 9: 8 waves staged (<=128 VGPRs)
-template <int NSLOTS, class StaticLens>
-int launch_wave_i(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool static_ok) {
-    const int v = c->variant;
-    static const bool ragged_round_robin = [] { const char *e = std::getenv("MELSPEC_RAGGED_RUNS"); return e && e[0] == '0'; }();
-    static const bool uniform_runs = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();   // cfg4 9.15 -> 9.05 ms
-    const bool plain = !desc.mel_major && desc.out_width == desc.frames_per_clip;
-    if (v == 8 && ((desc.d_unit_prefix != nullptr && !ragged_round_robin) || (uniform_runs && plain && desc.d_unit_prefix == nullptr)))
-        return static_ok ? launch_wave_runs<NSLOTS, StaticLens>(c, desc, stream) : launch_wave_runs<NSLOTS, LensRuntime>(c, desc, stream);
-    if (static_ok) {
-        switch (v) {
-            case 7: return launch_wave_t<NSLOTS, true, 4, StaticLens, 1, true>(c, desc, stream);
-            case 8: return launch_wave_t<NSLOTS, true, 8, StaticLens, 4, true>(c, desc, stream);
-            case 10: return launch_wave_t<NSLOTS, true, 16, StaticLens, 4, true>(c, desc, stream);     // one 16-wave workgroup per CU
-            default: return launch_wave_t<NSLOTS, false, 8, StaticLens, 4, true>(c, desc, stream);
-        }
-    }
-    switch (v) {
-        case 7: return launch_wave_t<NSLOTS, true, 4, LensRuntime, 1, true>(c, desc, stream);
-        case 8: return launch_wave_t<NSLOTS, true, 8, LensRuntime, 4, true>(c, desc, stream);
-        default: return launch_wave_t<NSLOTS, false, 8, LensRuntime, 4, true>(c, desc, stream);
-    }
-}
-
-constexpr int kPreciseWaves = 8;
-
-template <int NSLOTS, class Lens, bool LAYOUT>
-int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
-    if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>, "hipFuncSetAttribute(whisper400_precise_kernel)");
-        if (!rc && !LAYOUT) rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, false, true>, "hipFuncSetAttribute(whisper400_precise_kernel)");
-        if (rc) return rc;
-        mark_device_done(attr_done);
-    }
-    static const bool runs = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();
+PreciseParams precise_params(melspec_ctx *c, const BatchDesc &desc) {
     PreciseParams pp{};
     pp.b = desc;
     pp.d_blob = static_cast<const uint32_t *>(c->d_blob64.p);
@@ -556,22 +443,155 @@ int launch_precise_l(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     pp.hop = c->hop_size;
     pp.n_mels = c->n_mels;
     pp.slots = c->ft.slots;
+    return pp;
+}
+
+// the f64 kernel on the whole batch (MELSPEC_PRECISION_F64)
+template <int NSLOTS, class Lens>
+int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, false>, "hipFuncSetAttribute(whisper400_precise_kernel)");
+        if (!rc) rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, true>, "hipFuncSetAttribute(whisper400_precise_kernel, runs)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const PreciseParams pp = precise_params(c, desc);
     const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
-    static const int per_cu = [] { const char *e = std::getenv("MELSPEC_PRECISE_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();   // one workgroup is resident per CU
+    static const int per_cu = lab_int("MELSPEC_PRECISE_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
-    if (!LAYOUT && runs)
-        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, false, true>), dim3(grid), dim3(kPreciseWaves * 64),
-                           c->precise_lds, stream, pp);
+    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+    if (layout)
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, false>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
     else
-        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, kPreciseWaves, LAYOUT>), dim3(grid), dim3(kPreciseWaves * 64),
-                           c->precise_lds, stream, pp);
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, true>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
+
+int launch_precise(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    if (c->ft.slots.n_slots <= 8)
+        return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stream) : launch_precise_t<8, LensRuntime>(c, desc, stream);
+    return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stream) : launch_precise_t<12, LensRuntime>(c, desc, stream);
+}
+
+// the f64 recompute of the frames an f32 launch queued (MELSPEC_PRECISION_AUTO), behind that launch on the same stream
 template <int NSLOTS, class Lens>
-int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+int launch_fixup_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_fixup_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_fixup_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    FixupParams q{};
+    q.pp = precise_params(c, desc);
+    q.list = static_cast<const uint32_t *>(c->guard.list.p);
+    q.ctl = static_cast<uint32_t *>(c->guard.ctl.p);
+    q.fpu = static_cast<uint32_t>(desc.frames_per_unit);
+    // one workgroup per CU is resident; small batches cannot queue more than their own frames
+    const uint64_t slots = desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);
+    const uint64_t blocks = (slots + kPreciseWaves * kFPW - 1) / (kPreciseWaves * kFPW);
+    const unsigned grid = grid_for(blocks, c->dev.cus, 1);
+    hipLaunchKernelGGL((whisper400_fixup_kernel<NSLOTS, Lens>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, q);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int launch_fixup(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+    if (c->ft.slots.n_slots <= 8)
+        return c->lens_kind == 1 ? launch_fixup_t<8, LensI80>(c, desc, stream) : launch_fixup_t<8, LensRuntime>(c, desc, stream);
+    return c->lens_kind == 2 ? launch_fixup_t<12, LensI128>(c, desc, stream) : launch_fixup_t<12, LensRuntime>(c, desc, stream);
+}
+
+// Sizes the queue for this batch and orders it behind the previous user.  guard.list stays null when the queue cannot be
+// used (ids would not fit 32 bits): the caller then runs the f64 kernel on the whole batch.
+int guard_prepare(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, GuardSink &sink) {
+    sink = GuardSink{};
+    const uint64_t slots = desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);
+    if (slots >= 0xffffffffull) return MELSPEC_OK;
+    GuardQueue &g = c->guard;
+    if (g.used && g.last_stream != stream) HIP_TRY(hipStreamSynchronize(g.last_stream));
+    if (slots * sizeof(uint32_t) > g.list.cap) {
+        if (g.used) HIP_TRY(hipStreamSynchronize(g.last_stream));       // a launch in flight may still write the old list
+        int rc = g.list.ensure(static_cast<size_t>(slots) * sizeof(uint32_t));
+        if (rc) return rc;
+    }
+    if (!g.ctl.p) {
+        int rc = g.ctl.ensure(64);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(g.ctl.p, 0, 64, stream));
+    }
+    g.used = true;
+    g.last_stream = stream;
+    sink.list = static_cast<uint32_t *>(g.list.p);
+    sink.ctl = static_cast<uint32_t *>(g.ctl.p);
+    return MELSPEC_OK;
+}
+
+FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf &blob, melspec_ctx *c, const GuardSink &sink) {
+    FastParams fp{};
+    fp.b = desc;
+    fp.d_blob = static_cast<const float *>(blob.p);
+    fp.blob_len = static_cast<int>(ft.blob.size());
+    fp.hop = c->hop_size;
+    fp.n_mels = c->n_mels;
+    fp.slice_floats = WaveLayout::slice_floats();
+    fp.slots = ft.slots;
+    fp.guard = sink;
+    return fp;
+}
+
+// 5-frame f32 kernels: plain batches (uniform, ragged) on contiguous runs of units per wave, layouts round-robin
+template <int NSLOTS, class Lens>
+int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_kernel)");
+        if (!rc) rc = allow_big_lds(&whisper400_wave_runs_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_runs_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const FastParams fp = fast_params(desc, c->ft, c->d_blob, c, sink);
+    const uint64_t blocks = (desc.n_units + kWaveWaves - 1) / kWaveWaves;
+    // two workgroups are resident per CU; 4 per CU measured best (8192 x 15..45 s x 128 mels: 9.17 vs 9.50 ms)
+    static const int per_cu = lab_int("MELSPEC_GRID_PER_CU", 4, 1, 64);
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-    return layout ? launch_precise_l<NSLOTS, Lens, true>(c, desc, stream) : launch_precise_l<NSLOTS, Lens, false>(c, desc, stream);
+    if (layout)
+        hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, Lens>), dim3(grid), dim3(kWaveWaves * 64), c->fast_lds, stream, fp);
+    else
+        hipLaunchKernelGGL((whisper400_wave_runs_kernel<NSLOTS, Lens>), dim3(grid), dim3(kWaveWaves * 64), c->fast_lds, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int launch_wave(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, hipStream_t stream) {
+    if (c->ft.slots.n_slots <= 8)
+        return c->lens_kind == 1 ? launch_wave_t<8, LensI80>(c, desc, sink, stream) : launch_wave_t<8, LensRuntime>(c, desc, sink, stream);
+    return c->lens_kind == 2 ? launch_wave_t<12, LensI128>(c, desc, sink, stream) : launch_wave_t<12, LensRuntime>(c, desc, sink, stream);
+}
+
+template <class Lens>
+int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_kernel)");
+        if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const FastParams fp = fast_params(desc, c->ft6, c->d_blob6, c, sink);
+    const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
+    static const int per_cu = lab_int("MELSPEC_SIX_GRID_PER_CU", 1, 1, 4096);     // one 16-wave workgroup per CU
+    const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
+    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+    // plain batches, uniform and ragged, take the run-per-wave kernel (no division per unit, the clip record in scalar registers, a
+    // wave re-reads its own frame-tail halo): cfg2 0.3105 -> 0.3055 ms, 8192 x 30 s 7.55 -> 7.42 ms against the round-robin deal
+    if (layout) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
+    else hipLaunchKernelGGL((whisper400_six_runs_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
 }
 
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
@@ -580,9 +600,9 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (desc.sync_rounds < 0) {
         // measured (profiles/r01_variants.txt): six-frame kernel, 16 waves: four waves 4 apart; precise kernel, 8 waves:
         // consecutive pairs; 5-frame kernel, two 8-wave workgroups per CU: pairs 4 apart
-        if (c->fast && c->six && desc.frames_per_unit == kSixFrames) desc.sync_rounds = 20;
-        else if (c->fast && c->precise) desc.sync_rounds = 2;
-        else if (c->fast && (c->variant == 8 || c->variant == 9 || c->variant == 11)) desc.sync_rounds = 18;
+        if (c->fast && desc.frames_per_unit == kSixFrames) desc.sync_rounds = 20;
+        else if (c->fast && c->precision == MELSPEC_PRECISION_F64) desc.sync_rounds = 2;
+        else if (c->fast) desc.sync_rounds = 18;
         else desc.sync_rounds = 1;
     }
     if (!c->fast && c->fast512 && desc.frames_per_unit == kFbFPW) {
@@ -601,60 +621,23 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
                                                   : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
-    if (c->six && desc.frames_per_unit == kSixFrames) {
-        static std::atomic<uint64_t> attr_done{0};
-        if (!device_done(attr_done)) {
-            int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>, "hipFuncSetAttribute(whisper400_six_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensSix80, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>, "hipFuncSetAttribute(whisper400_six_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, LensRuntime>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
-            if (rc) return rc;
-            mark_device_done(attr_done);
+    if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, stream);
+    GuardSink sink{};
+    if (c->precision == MELSPEC_PRECISION_AUTO) {
+        int rc = guard_prepare(c, desc, stream, sink);
+        if (rc) return rc;
+        if (!sink.list) {                         // ids do not fit the queue: f64 on everything (units of 5 frames)
+            if (desc.frames_per_unit != kFPW) return fail(MELSPEC_ERR_UNSUPPORTED, "batch too large for one launch in MELSPEC_PRECISION_AUTO");
+            return launch_precise(c, desc, stream);
         }
-        FastParams fp{};
-        fp.b = desc;
-        fp.d_blob = static_cast<const float *>(c->d_blob6.p);
-        fp.blob_len = static_cast<int>(c->ft6.blob.size());
-        fp.hop = c->hop_size;
-        fp.n_mels = c->n_mels;
-        fp.slots = c->ft6.slots;
-        const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
-        static const int per_cu = [] { const char *e = std::getenv("MELSPEC_SIX_GRID_PER_CU"); const int g = e ? std::atoi(e) : 0; return g > 0 && g <= 4096 ? g : 1; }();
-        const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
-        const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-        static const bool ragged_round_robin = [] { const char *e = std::getenv("MELSPEC_RAGGED_RUNS"); return e && e[0] == '0'; }();
-        // plain uniform batches take the run-per-wave kernel too (no division per unit, the clip record in scalar registers, a wave re-reads
-        // its own frame-tail halo): cfg2 0.3105 -> 0.3055 ms, 8192 x 30 s 7.55 -> 7.42 ms.  MELSPEC_UNIFORM_RUNS=0: round-robin deal.
-        static const bool uniform_runs = [] { const char *e = std::getenv("MELSPEC_UNIFORM_RUNS"); return !(e && e[0] == '0'); }();
-        if (layout) {
-            if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, true>), grid, block, c->lds6, stream, fp);
-            else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, true>), grid, block, c->lds6, stream, fp);
-        } else if ((desc.d_unit_prefix != nullptr && !ragged_round_robin) || uniform_runs) {
-            // ragged: contiguous runs of units per wave (MELSPEC_RAGGED_RUNS=0: the round-robin deal of the uniform kernel)
-            if (c->six_static) hipLaunchKernelGGL((whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>), grid, block, c->lds6, stream, fp);
-            else hipLaunchKernelGGL((whisper400_six_runs_kernel<kSixMaxSlots, LensRuntime>), grid, block, c->lds6, stream, fp);
-        } else {
-            if (c->six_static) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensSix80, false>), grid, block, c->lds6, stream, fp);
-            else hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, LensRuntime, false>), grid, block, c->lds6, stream, fp);
-        }
-        HIP_TRY(hipGetLastError());
-        return MELSPEC_OK;
     }
-    if (c->precise) {
-        if (c->ft.slots.n_slots <= 8)
-            return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stream) : launch_precise_t<8, LensRuntime>(c, desc, stream);
-        return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stream) : launch_precise_t<12, LensRuntime>(c, desc, stream);
-    }
-    const bool small = c->ft.slots.n_slots <= 8;
-    if (c->variant >= 7) {
-        if (small) return launch_wave_i<8, LensI80>(c, desc, stream, c->lens_kind == 1);
-        return launch_wave_i<12, LensI128>(c, desc, stream, c->lens_kind == 2);
-    }
-    if (c->variant == 0) return small ? launch_block_t<8>(c, desc, stream) : launch_block_t<12>(c, desc, stream);
-    if (small) return launch_wave_v<8, LensW80>(c, desc, stream, c->lens_kind == 1);
-    return launch_wave_v<12, LensW128>(c, desc, stream, c->lens_kind == 2);
+    int rc;
+    if (c->six && desc.frames_per_unit == kSixFrames)
+        rc = c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
+    else
+        rc = launch_wave(c, desc, sink, stream);
+    if (rc || !sink.list) return rc;
+    return launch_fixup(c, desc, stream);
 }
 
 template <class Lens>
@@ -708,58 +691,40 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
 
-    // fused kernel: n_fft == 400, even hop (8-byte aligned LDS reads), n_mels <= 132
-    const char *ev = std::getenv("MELSPEC_VARIANT");
-    const char *el = std::getenv("MELSPEC_RUNTIME_LENS");
-    c->variant = ev ? std::atoi(ev) : kDefaultVariant;
-    if (c->variant < 0 || c->variant > 11) c->variant = kDefaultVariant;
-    c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) &&
-              build_fast_tables(sampling_rate, n_mels, c->ft, c->variant >= 7);
+    // fused kernels: n_fft == 400, even hop (8-byte PCM loads), a two-filters-per-bin bank of <= 131 mels
+    const bool runtime_lens = lab_int("MELSPEC_RUNTIME_LENS", 0, 0, 1) != 0;
+    c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft, true) &&
+              c->ft.interval;
     if (c->fast) {
-        if (c->variant >= 7 && !c->ft.interval) c->variant = 5;   // filterbank is not two-filters-per-bin
-        if (c->variant >= 7)
-            c->lens_kind = lens_match<LensI80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensI128>(c->ft.slots, n_mels) ? 2 : 0);
-        else
-            c->lens_kind = lens_match<LensW80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensW128>(c->ft.slots, n_mels) ? 2 : 0);
-        if (el && el[0] == '1') c->lens_kind = 0;
-        if (c->variant == 0) {
-            using L = FastLayout<kFPB>;
-            c->frames_per_unit = kFPB;
-            c->region_a = L::region_a(hop_size);
-            c->fast_lds = sizeof(float) * (c->ft.blob.size() + c->region_a + L::region_b() + L::region_max());
-        } else {
-            const bool staged = c->variant <= 6 ? (c->variant % 2) == 0 : c->variant == 9;
-            const int waves = (c->variant <= 2 || c->variant == 7) ? 4 : (c->variant == 10 ? 16 : 8);
-            c->frames_per_unit = kFPW;
-            c->slice_floats = WaveLayout::slice_floats(hop_size, staged);
-            c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(waves) * c->slice_floats + waves);   // + RoundSync counters
-        }
-        if (c->fast_lds > kLdsLimit) c->fast = false;
+        c->lens_kind = lens_match<LensI80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensI128>(c->ft.slots, n_mels) ? 2 : 0);
+        if (runtime_lens) c->lens_kind = 0;
+        c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(kWaveWaves) * WaveLayout::slice_floats() + kWaveWaves);   // + RoundSync counters
+        PreciseTables pt;
+        const bool pt_ok = build_precise_tables(c->ft, pt);
+        c->precise_lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double) +
+                         kPreciseWaves * sizeof(uint32_t);   // + RoundSync counters
+        if (c->fast_lds > kLdsLimit || !pt_ok || c->precise_lds > kLdsLimit) c->fast = false;
+        else c->pt = std::move(pt);
     }
-    if (!c->fast && fft_size == 512 && !(std::getenv("MELSPEC_W512") && std::getenv("MELSPEC_W512")[0] == '0') &&
-        build_whisper512_tables<double>(sampling_rate, n_mels, c->ft512)) {
+    if (!c->fast && fft_size == 512 && lab_int("MELSPEC_W512", 1, 0, 1) != 0 && build_whisper512_tables<double>(sampling_rate, n_mels, c->ft512)) {
         const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double) + 512;      // + the frame maxima
         c->waves512 = fused512_waves(c->ft512.blob.size() * 4, slice_bytes);
         c->lds512 = c->ft512.blob.size() * 4 + static_cast<size_t>(c->waves512) * slice_bytes;
         c->fast512 = c->lds512 <= kLdsLimit;
         if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
     }
-    if (c->fast && c->variant == 11) {                 // the six-frame build shares the context with variant 8 (layouts, precise)
-        c->variant = 8;
-        if (build_six_tables(sampling_rate, n_mels, c->ft6)) {
-            c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves);   // + arrival counters
-            c->six = c->lds6 <= kLdsLimit;
-            bool st = c->ft6.slots.n_slots == LensSix80::kSlots && n_mels == LensSix80::kMels;
-            for (int i = 0; st && i < LensSix80::kSlots; ++i)
-                st = c->ft6.slots.len[i] == LensSix80::len(i) && c->ft6.slots.woff[i] == LensSix80::woff(i);
-            c->six_static = st && !(el && el[0] == '1');
-            if (c->six && (rc = upload(c->d_blob6, c->ft6.blob))) return bail(rc);
-        }
+    if (c->fast && build_six_tables(sampling_rate, n_mels, c->ft6)) {
+        c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves);   // + arrival counters
+        c->six = c->lds6 <= kLdsLimit;
+        bool st = c->ft6.slots.n_slots == LensSix80::kSlots && n_mels == LensSix80::kMels;
+        for (int i = 0; st && i < LensSix80::kSlots; ++i)
+            st = c->ft6.slots.len[i] == LensSix80::len(i) && c->ft6.slots.woff[i] == LensSix80::woff(i);
+        c->six_static = st && !runtime_lens;
+        if (c->six && (rc = upload(c->d_blob6, c->ft6.blob))) return bail(rc);
     }
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
-        if ((rc = allow_big_lds(&whisper400_kernel<kFPB, kNT, 8>, "hipFuncSetAttribute(whisper400_kernel<8>)"))) return bail(rc);
-        if ((rc = allow_big_lds(&whisper400_kernel<kFPB, kNT, 12>, "hipFuncSetAttribute(whisper400_kernel<12>)"))) return bail(rc);
+        if ((rc = upload(c->d_blob64, c->pt.blob))) return bail(rc);
     }
     if (!c->fast) {          // the generic kernel also serves the layouts the fused 512 build does not store
         const int bins = fft_size / 2 + 1;
@@ -769,10 +734,11 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
         if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
     }
-    if (const char *e = std::getenv("MELSPEC_GRID_PER_CU")) { const int g = std::atoi(e); if (g > 0 && g <= 64) c->grid_per_cu = g; }
-    const char *ep = std::getenv("MELSPEC_PRECISE");
-    // a preference, not a requirement: filterbanks outside the interval scheme keep the f32 kernel
-    if (ep && ep[0] == '1' && c->fast && (rc = melspec_set_precise(c, 1)) && rc != MELSPEC_ERR_UNSUPPORTED) return bail(rc);
+    // MELSPEC_PRECISE=1 / =f32: the initial melspec_set_precision of every context (how the GPU suite is run a second time in f64 mode)
+    if (const char *ep = std::getenv("MELSPEC_PRECISE")) {
+        if (ep[0] == '1') c->precision = MELSPEC_PRECISION_F64;
+        else if (ep[0] == 'f') c->precision = MELSPEC_PRECISION_F32;
+    }
     *out = c;
     return MELSPEC_OK;
 }
@@ -782,6 +748,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release(); c->h2d.release(); c->d2h.release();
+    c->guard.release();
     delete c;
 }
 
@@ -795,27 +762,45 @@ int melspec_hop_size(const melspec_ctx *c) { return c ? c->hop_size : 0; }
 int melspec_n_mels(const melspec_ctx *c) { return c ? c->n_mels : 0; }
 int melspec_uses_fast_path(const melspec_ctx *c) { return c && (c->fast || c->fast512) ? 1 : 0; }
 
-int melspec_set_precise(melspec_ctx *c, int on) {
+int melspec_set_precision(melspec_ctx *c, int mode) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
-    if (!on) { c->precise = false; return MELSPEC_OK; }
-    if (!c->fast) return MELSPEC_OK;          // the generic kernel is f64 already
-    if (c->variant < 7 || !c->ft.interval) return fail(MELSPEC_ERR_UNSUPPORTED, "the precise build needs the interval mel scheme");
-    if (c->d_blob64.p == nullptr) {              // first use: build, check and upload before anything is committed to the ctx
-        PreciseTables pt;
-        if (!build_precise_tables(c->ft, pt)) return fail(MELSPEC_ERR_INTERNAL, "precise tables");
-        const size_t lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double) +
-                           kPreciseWaves * sizeof(uint32_t);   // + RoundSync counters
-        if (lds > kLdsLimit) return fail(MELSPEC_ERR_UNSUPPORTED, "precise tables do not fit in LDS");
-        HIP_TRY(hipSetDevice(c->dev.device));
-        int rc = upload(c->d_blob64, pt.blob);
-        if (rc) { c->d_blob64.release(); return rc; }
-        c->pt = std::move(pt);
-        c->precise_lds = lds;
-    }
-    c->precise = true;
+    if (mode != MELSPEC_PRECISION_AUTO && mode != MELSPEC_PRECISION_F64 && mode != MELSPEC_PRECISION_F32)
+        return fail(MELSPEC_ERR_INVALID_ARG, "precision must be MELSPEC_PRECISION_AUTO, _F64 or _F32");
+    c->precision = mode;        // geometries on the generic / fused-512 kernels are f64 whatever the mode
     return MELSPEC_OK;
 }
-int melspec_is_precise(const melspec_ctx *c) { return c && (c->precise || !c->fast) ? 1 : 0; }   // generic and fused-512 paths are f64
+int melspec_precision(const melspec_ctx *c) { return !c ? MELSPEC_PRECISION_AUTO : (c->fast ? c->precision : MELSPEC_PRECISION_F64); }
+int melspec_set_precise(melspec_ctx *c, int on) { return melspec_set_precision(c, on ? MELSPEC_PRECISION_F64 : MELSPEC_PRECISION_AUTO); }
+int melspec_is_precise(const melspec_ctx *c) { return c && (c->precision == MELSPEC_PRECISION_F64 || !c->fast) ? 1 : 0; }   // generic and fused-512 paths are f64
+
+const char *melspec_plain_kernel_name(const melspec_ctx *c) {
+    // the same decisions launch_ctx takes for a plain (uniform or ragged, [frame][mel]) batch
+    if (!c) return "";
+    if (!c->fast) {
+        if (c->fast512) return "melspec::fbank512_wave_kernel<double, 8, 1, kFlavorWhisper, RUNS> (n_fft = 512, f64)";
+        return "melspec::generic_frame_kernel<256> (f64 direct DFT)";
+    }
+    if (c->precision == MELSPEC_PRECISION_F64)
+        return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";
+    const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
+    if (c->six)
+        return c->six_static ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix80> + whisper400_fixup_kernel" : "melspec::whisper400_six_runs_kernel<9, LensSix80>")
+                             : (fix ? "melspec::whisper400_six_runs_kernel<9, LensRuntime> + whisper400_fixup_kernel" : "melspec::whisper400_six_runs_kernel<9, LensRuntime>");
+    if (c->ft.slots.n_slots <= 8) return fix ? "melspec::whisper400_wave_runs_kernel<8, .> + whisper400_fixup_kernel" : "melspec::whisper400_wave_runs_kernel<8, .>";
+    return fix ? "melspec::whisper400_wave_runs_kernel<12, .> + whisper400_fixup_kernel" : "melspec::whisper400_wave_runs_kernel<12, .>";
+}
+
+int melspec_guard_last_count(melspec_ctx *c, uint64_t *frames) {
+    if (!c || !frames) return fail(MELSPEC_ERR_INVALID_ARG, "ctx/frames is NULL");
+    *frames = 0;
+    if (!c->guard.used) return MELSPEC_OK;
+    HIP_TRY(hipSetDevice(c->dev.device));
+    HIP_TRY(hipStreamSynchronize(c->guard.last_stream));
+    uint32_t ctl[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpy(ctl, c->guard.ctl.p, sizeof(ctl), hipMemcpyDeviceToHost));
+    *frames = ctl[2];
+    return MELSPEC_OK;
+}
 
 int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                    uint32_t n_clips, float *d_out, void *stream) {
@@ -828,7 +813,7 @@ int melspec_compute_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t 
         return fail(MELSPEC_ERR_INVALID_ARG, "clip_stride smaller than clip_len");
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c, true));
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c));
     return launch_ctx(c, pl.desc, s);
 }
 
@@ -856,8 +841,7 @@ int melspec_compute_uniform_device_interleaved(melspec_ctx *c, const float *d_pc
     if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    if (c->fast && c->variant == 0) return fail(MELSPEC_ERR_UNSUPPORTED, "the block kernel (MELSPEC_VARIANT=0) has no layout option");
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c, false),
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c),
                                       interleaved_width(fpc, min_width), major_column_order == 0);
     return launch_ctx(c, pl.desc, s);
 }
@@ -878,7 +862,7 @@ int melspec_compute_ragged_device(melspec_ctx *c, const float *d_pcm, const uint
     BatchPlan pl;
     RaggedSlot *slot = nullptr;
     int rc = plan_ragged(c->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, c->n_mels,
-                         ctx_frames_per_unit(c, true), pl, slot);
+                         ctx_frames_per_unit(c), pl, slot);
     if (!rc) rc = launch_ctx(c, pl.desc, s);
     plan_ragged_done(slot, s);
     return rc;
@@ -975,6 +959,7 @@ struct melspec_fbank {
     int frame_len = 0, frame_shift = 0, fft_size = 0;
     hipStream_t stream = nullptr;
     bool fast = false;          // fused 512-point kernel (default Kaldi geometry) vs generic f64 kernel
+    bool use_generic = false;   // melspec_fbank_use_generic: the direct-DFT kernel as the on-device cross-check
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -1024,19 +1009,11 @@ int melspec_fbank_create(melspec_fbank **out, int device, const melspec_fbank_co
     if (hipStreamCreate(&fb->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
     const double high = cfg->high_freq == 0.0 ? cfg->sample_rate / 2.0 : cfg->high_freq;
     const int bins = fft_size / 2 + 1;
-    // MELSPEC_FBANK=generic forces the f64 direct-DFT kernel; =f32 selects the f32 build of the fused
-    // kernel (throughput experiments only: it cannot hold 1e-4 on quiet mel bands, see fbank_wave.hpp)
-    const char *eg = std::getenv("MELSPEC_FBANK");
-    const bool want_generic = eg && std::strcmp(eg, "generic") == 0;
-    const bool want_f32 = eg && std::strcmp(eg, "f32") == 0;
-    fb->fast = !want_generic && frame_len == 400 && fft_size == 512 &&
-               (want_f32 ? build_fbank_fast_tables<float>(cfg->sample_rate, cfg->num_mel_bins, cfg->low_freq, high,
-                                                          cfg->use_power != 0, fb->ft)
-                         : build_fbank_fast_tables<double>(cfg->sample_rate, cfg->num_mel_bins, cfg->low_freq, high,
-                                                           cfg->use_power != 0, fb->ft));
+    // the fused kernel computes in f64 up to |X|^2 (an f32 build cannot hold 1e-4 on quiet mel bands, see fbank_wave.hpp)
+    fb->fast = frame_len == 400 && fft_size == 512 &&
+               build_fbank_fast_tables<double>(cfg->sample_rate, cfg->num_mel_bins, cfg->low_freq, high, cfg->use_power != 0, fb->ft);
     if (fb->fast) {
-        const size_t slice_bytes = fb->ft.f64 ? FbankLayout<double>::slice_elems() * sizeof(double)
-                                              : FbankLayout<float>::slice_elems() * sizeof(float);
+        const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double);
         fb->waves = fused512_waves(fb->ft.blob.size() * 4, slice_bytes);
         fb->fast_lds = fb->ft.blob.size() * 4 + static_cast<size_t>(fb->waves) * slice_bytes;
         if (fb->fast_lds > kLdsLimit) fb->fast = false;
@@ -1062,7 +1039,12 @@ size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples) {
     return fb ? static_cast<size_t>(fbank_frames(fb, n_samples)) : 0;
 }
 int melspec_fbank_num_mel_bins(const melspec_fbank *fb) { return fb ? fb->cfg.num_mel_bins : 0; }
-int melspec_fbank_uses_fast_path(const melspec_fbank *fb) { return fb && fb->fast ? 1 : 0; }
+int melspec_fbank_uses_fast_path(const melspec_fbank *fb) { return fb && fb->fast && !fb->use_generic ? 1 : 0; }
+int melspec_fbank_use_generic(melspec_fbank *fb, int on) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    fb->use_generic = on != 0;
+    return MELSPEC_OK;
+}
 
 int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                          uint32_t n_clips, float *d_out, void *stream) {
@@ -1074,10 +1056,11 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
     HIP_TRY(hipSetDevice(fb->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fb->stream;
     const int nm = fb->cfg.num_mel_bins;
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, nm, fb->fast ? kFbFPW : 1);
+    const bool fused = fb->fast && !fb->use_generic;
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, nm, fused ? kFbFPW : 1);
     const double floor_v = fb->cfg.energy_floor > 0.0 ? fb->cfg.energy_floor : static_cast<double>(FLT_EPSILON);
     int rc = MELSPEC_OK;
-    if (fb->fast) {
+    if (fused) {
         FbankFastParams fp{};
         fp.b = pl.desc;
         fp.d_blob = static_cast<const uint32_t *>(fb->d_blob.p);
@@ -1090,11 +1073,10 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         fp.use_log = fb->cfg.use_log_fbank;
         fp.use_power = fb->cfg.use_power;
         fp.slots = fb->ft.slots;
-        if (fb->ft.f64 && fb_lens_match<LensKaldi80>(fb->ft.slots))
+        if (fb_lens_match<LensKaldi80>(fb->ft.slots))
             rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi80>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         else
-            rc = fb->ft.f64 ? launch_fused512<double, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s)
-                            : launch_fused512<float, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
+            rc = launch_fused512<double, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         if (rc) return rc;
         // the CMN pass below walks clips, not units
     } else {
@@ -1174,6 +1156,7 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
                hipStream_t s) {
     melspec_ctx *c = st->ctx;
     HIP_TRY(hipSetDevice(c->dev.device));
+    if (pl.total_frames && !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");      // before anything is queued
     // the entries travel like a ragged plan: pinned slot, copy kernel on the launch stream (no SDMA queue hand-over)
     RaggedSlot &sl = st->ring.slot[st->ring.next++ % RaggedScratch::kSlots];
     if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -1183,25 +1166,29 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
     if (rc) return rc;
     if ((rc = sl.dev.ensure(ebytes))) return rc;
     std::memcpy(sl.host, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry));
+    // from here on the slot is in use by queued work: every exit records its event (the next user of the slot waits for it)
+    struct SlotGuard { RaggedSlot *sl; hipStream_t s; ~SlotGuard() { plan_ragged_done(sl, s); } } slot_guard{&sl, s};
     {
         const size_t n16 = ebytes / 16;
         const unsigned blocks = static_cast<unsigned>((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
         hipLaunchKernelGGL(plan_upload_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, static_cast<const uint4 *>(sl.host),
                            static_cast<uint4 *>(sl.dev.p), n16);
+        HIP_TRY(hipGetLastError());
     }
     const StreamEntry *d_e = static_cast<const StreamEntry *>(sl.dev.p);
     float *state = static_cast<float *>(st->state.p);
     bool any_fill = d_src != nullptr;
     for (uint32_t i = 0; i < n && !any_fill; ++i) any_fill = pl.entries[i].zero_fill != 0;
-    if (any_fill) hipLaunchKernelGGL(stream_scatter_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e, d_src);
+    if (any_fill) {
+        hipLaunchKernelGGL(stream_scatter_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e, d_src);
+        HIP_TRY(hipGetLastError());
+    }
     if (pl.total_frames) {
-        if (!d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");
         rc = melspec_compute_ragged_device(c, state, pl.off.data(), pl.len.data(), n, d_out, h_out_off ? h_out_off : pl.out_off.data(), s);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(stream_carry_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e);
     HIP_TRY(hipGetLastError());
-    plan_ragged_done(&sl, s);
     // the contract of the push calls: the launches have completed on return (a device producer may refill its slot at once)
     HIP_TRY(hipStreamSynchronize(s));
     return MELSPEC_OK;
@@ -1329,6 +1316,10 @@ struct melspec_tga {
     DeviceInfo dev;
     hipStream_t stream = nullptr;
     DevBuf keys, ranges, h2d, d2h;
+    // the min/max keys are one scratch buffer per handle, used in stream order: a call on another stream first waits for
+    // the stream that used it last
+    hipStream_t keys_stream = nullptr;
+    bool keys_used = false;
 };
 
 namespace {
@@ -1387,6 +1378,8 @@ int quant_encode(melspec_tga *q, const float *d_img, size_t image_stride, uint32
     int rc = quant_plan(q, d, d_img, image_stride, rows, width, n_images, d_blob, blob_stride, header, items, bpx, bdw);
     if (rc) return rc;
     d.img = d_img; d.blob = d_blob; d.ranges = d_ranges;
+    if (q->keys_used && q->keys_stream != stream) HIP_TRY(hipStreamSynchronize(q->keys_stream));
+    q->keys_used = true; q->keys_stream = stream;
     hipLaunchKernelGGL(quant_init_keys_kernel, dim3((items + 255) / 256), dim3(256), 0, stream, d.keys, items);
     hipLaunchKernelGGL(quant_minmax_kernel, dim3(items * bpx), dim3(kQuantThreads), 0, stream, d, bpx);
     hipLaunchKernelGGL(quant_encode_kernel, dim3(items * bdw), dim3(kQuantThreads), 0, stream, d, bdw);
@@ -1774,8 +1767,8 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         size_t stride = (static_cast<size_t>(valid) + 31) & ~static_cast<size_t>(31);      // whole groups of 32 floats ...
         if ((stride / 4) % 2 == 0) stride += 4;                                              // ... and 4 * odd
         np.vec = (cols % 4 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0) ? 1 : 0;
-        static const int norm_kb = [] { const char *e = std::getenv("MELSPEC_NORM_KB"); const int v = e ? std::atoi(e) : 0; return v >= 8 && v <= 158 ? v : 38; }();
-        static const int norm_per_cu = [] { const char *e = std::getenv("MELSPEC_NORM_PER_CU"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 16 ? v : 4; }();
+        static const int norm_kb = lab_int("MELSPEC_NORM_KB", 38, 8, 158);
+        static const int norm_per_cu = lab_int("MELSPEC_NORM_PER_CU", 4, 1, 16);
         const size_t budget = static_cast<size_t>(norm_kb) * 1024 - 64 * 2 * sizeof(float);
         size_t per = budget / (stride * sizeof(float));
         int per_cu = norm_per_cu;

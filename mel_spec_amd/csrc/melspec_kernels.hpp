@@ -105,62 +105,50 @@ __device__ __forceinline__ unsigned xcd_logical_block() {
 }
 
 // ------------------------------------------------------------------------------------
-// Fused Whisper kernel, n_fft = 400.  One workgroup walks tiles of FPB consecutive frames.
-// LDS: [table blob][region A: PCM tile / power rows][region B: FFT exchange][frame maxima]
+// Fused Whisper kernels, n_fft = 400 (phases in whisper_wave.hpp / whisper_six.hpp).  A work unit is a run of
+// consecutive frames of one clip (5 or 6) and belongs to one wavefront; the waves of a workgroup share only the
+// table blob.  LDS: [table blob][WAVES x private slice].  No workgroup barrier in the unit loop.
 // ------------------------------------------------------------------------------------
+// Where the f32 kernels queue the frames whose result the precision guard does not trust (wave_phase4): u32 ids
+// `unit * frames_per_unit + frame_in_unit`, appended with one atomic per wave that has any.  list == nullptr: guard off
+// (MELSPEC_PRECISION_F32).  whisper400_fixup_kernel consumes the list behind the launch and resets the counter.
+struct GuardSink {
+    uint32_t *list;
+    uint32_t *ctl;      // [0] entries queued, [1] workgroups of the fix-up kernel that are done, [2] entries of the last call
+};
+
 struct FastParams {
     BatchDesc b;
     const float *d_blob;
     int blob_len;      // floats, multiple of 4
     int hop;
     int n_mels;
-    int region_a;      // floats (block kernel)
-    int slice_floats;  // floats per wave (wave kernel)
+    int slice_floats;  // floats per wave (5-frame kernels)
     MelSlots slots;
+    GuardSink guard;
 };
 
-template <int FPB, int NT, int NSLOTS>
-__global__ __launch_bounds__(NT) void whisper400_kernel(const FastParams p) {
-    using L = FastLayout<FPB>;
-    static_assert(L::kP2Threads <= NT, "workgroup too small for FPB frames");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *blob = lds;
-    float *reg_a = blob + p.blob_len;
-    float *reg_b = reg_a + p.region_a;
-    float *pmax = reg_b + L::region_b();
-    const int tid = threadIdx.x;
-
-    for (int i = tid; i < p.blob_len; i += NT) blob[i] = p.d_blob[i];
-
-    for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
-        const UnitLoc loc = locate_unit(p.b, unit);
-        const uint64_t f0 = loc.unit * FPB;
-        const uint64_t left = loc.frames - f0;
-        const int nv = left < (uint64_t)FPB ? (int)left : FPB;
-        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
-        const int need = (nv - 1) * p.hop + 400;
-        for (int i = tid; i < need; i += NT) reg_a[i] = src[i];
-        __syncthreads();
-        fast_phase1<FPB>(tid, nv, p.hop, blob, reg_a, reg_b);
-        __syncthreads();
-        fast_phase2<FPB>(tid, nv, blob, reg_b, reg_a);
-        __syncthreads();
-        float vals[NSLOTS];
-        fast_phase3<FPB, NSLOTS>(tid, nv, p.n_mels, p.slots, blob, reg_a, pmax, vals);
-        __syncthreads();
-        fast_phase4<FPB, NSLOTS>(tid, nv, p.n_mels, pmax, vals, loc.out + f0 * (uint64_t)p.n_mels);
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// Wave-autonomous fused Whisper kernel (phases in whisper_wave.hpp).  A work unit is kFPW = 5
-// consecutive frames of one clip and belongs to one wavefront; the WAVES waves of a workgroup
-// share only the table blob.  LDS: [table blob][WAVES x private slice].  No barrier in the loop.
-// ------------------------------------------------------------------------------------
 // One-lane-down shift across the whole wave (lane l receives lane l+1's value).
 __device__ __forceinline__ float wave_shift_down1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */,
                                                                  0xf, 0xf, false));
+}
+
+// Queue the frames of this wave's unit that have a guarded lane.  LANES lanes per frame (lane = LANES * fl + j); slot0 = the
+// id of the unit's frame 0.  The common case -- no lane set -- is one v_cmp, one s_cbranch.
+template <int LANES>
+__device__ __forceinline__ void guard_append(bool lane_flag, int lane, int fl, int j, uint64_t slot0, const GuardSink &g) {
+    const uint64_t any = __builtin_amdgcn_ballot_w64(lane_flag);
+    if (any == 0) return;
+    const uint64_t mine = (any >> (LANES * fl)) & ((1ull << LANES) - 1);
+    const bool lead = j == 0 && fl * LANES < 64 && mine != 0;
+    const uint64_t lb = __builtin_amdgcn_ballot_w64(lead);
+    const int first = __builtin_ctzll(lb);
+    unsigned base = 0;
+    if (lane == first) base = atomicAdd(g.ctl, static_cast<unsigned>(__builtin_popcountll(lb)));
+    base = __builtin_amdgcn_readlane(base, first);
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(lb >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(lb), 0u));
+    if (lead) g.list[base + rank] = static_cast<uint32_t>(slot0 + fl);
 }
 
 // Sub-group barrier of the mel-major stores (BatchDesc::sync_rounds = gsize + 16 * across, gsize in {2, 4, 8}): only the
@@ -201,16 +189,21 @@ struct RoundSync {
     }
 };
 
-// LAYOUT = false: plain [clip][frame][mel] output (the hot configuration, no padding logic compiled in);
-// LAYOUT = true: padded and/or mel-major output (interleave_frames, BatchDesc::out_width / mel_major).
-template <int NSLOTS, bool DIRECT, int WAVES, class Lens, int MINW = 1, bool INTERVAL = false, bool LAYOUT = false>
-__global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const FastParams p) {
+constexpr int kWaveWaves = 8;     // waves per workgroup of the 5-frame kernels (two workgroups per CU)
+
+// ---- 5 frames per wave (81..131 mels, and every bank the six-frame tables do not cover) ----------------------------
+// Padded and/or mel-major output (interleave_frames, BatchDesc::out_width / mel_major): the units are dealt round-robin
+// and walked in workgroup-uniform rounds (a wave without a unit idles through the round) so that the mel-major store can
+// re-align the waves that hold adjacent units once per round.
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(const FastParams p) {
+    constexpr int WAVES = kWaveWaves;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
     unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // RoundSync counters
-    if (LAYOUT && tid < WAVES) arrive[tid] = 0;
+    if (tid < WAVES) arrive[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,61 +211,35 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
     float *slice = blob + p.blob_len + wave * p.slice_floats;
     const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
     const bool in = lane < kFPW * kMelJobs;
-    // interval scheme: 12 lanes per frame in phases 3-4
     int uoff, voff;
     WaveLayout::row_offsets(j, uoff, voff);
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;     // compile-time for the two Whisper banks
-    const int fl3 = INTERVAL ? lane / 12 : fl, j3 = INTERVAL ? lane - fl3 * 12 : j;
-    const bool in3 = INTERVAL ? lane < kFPW * 12 : in;
+    const int fl3 = lane / 12, j3 = lane - fl3 * 12;               // 12 lanes per frame in phases 3-4
+    const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
+    const bool guard = p.guard.list != nullptr;
 
-    // LAYOUT builds walk the units workgroup-uniformly (a wave without a unit idles through the round) so that the
-    // mel-major store can re-align the waves once per round, see the end of the loop
-    const uint64_t w_off = LAYOUT ? 0 : wave;
-    RoundSync<WAVES> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
-    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
-        const uint64_t unit = LAYOUT ? first + rs.slot : first;
-        const bool have = !LAYOUT || unit < p.b.n_units;
+    RoundSync<WAVES> rs(p.b.sync_rounds, wave, arrive);
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t unit = first + rs.slot;
+        const bool have = unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
+        const uint64_t left = (have && f0 < loc.frames) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
-        const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
+        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         const uint64_t wleft = have ? width - f0 : 0;
-        const int ns = LAYOUT ? (wleft < (uint64_t)kFPW ? (int)wleft : kFPW) : nv;
-#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 10
-#ifndef MELSPEC_ABL_MASK
-#define MELSPEC_ABL_MASK 255
-#endif
-        const float *src = p.b.pcm + (unit & MELSPEC_ABL_MASK) * 800;     // ablation: same loads over a smaller footprint (L2 / MALL resident)
-#else
+        const int ns = wleft < (uint64_t)kFPW ? (int)wleft : kFPW;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
-#endif
         const bool act = in && fl < nv;
         const bool act3 = in3 && fl3 < nv;
-        if (!DIRECT) {
-            const int need = (nv - 1) * p.hop + 400;
-            for (int i = lane; i < need; i += 64) slice[i] = src[i];
-            __builtin_amdgcn_wave_barrier();
-        }
-        // MELSPEC_ABLATE=n builds (tools/ablate.py) drop one phase to measure its marginal cost; results are
-        // then wrong by design and such builds are never shipped.
-#if !defined(MELSPEC_ABLATE) || (MELSPEC_ABLATE != 1 && MELSPEC_ABLATE != 12)
-        wave_phase1<DIRECT>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
-#endif
+        wave_phase1(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
-#if !defined(MELSPEC_ABLATE) || (MELSPEC_ABLATE != 2 && MELSPEC_ABLATE != 12)
-        wave_phase2<!INTERVAL>(fl, j, act, blob, slice, uoff, voff);
-#endif
+        wave_phase2(fl, j, act, blob, slice, uoff, voff);
         __builtin_amdgcn_wave_barrier();
         float vals[NSLOTS];
-#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 3
-#pragma unroll
-        for (int i = 0; i < NSLOTS; ++i) vals[i] = slice[fl * WaveLayout::kPStride + j3 + 12 * i];
-        if (act3) slice[WaveLayout::kPmaxOff + fl3 * WaveLayout::kPmaxStride + j3] = vals[0];
-#else
-        if (INTERVAL) {
+        {
             // per-lane start bins: re-read every unit (NSLOTS LDS words) rather than held in registers across the loop
             int st[NSLOTS];
 #pragma unroll
@@ -282,29 +249,27 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void whisper400_wave_kernel(const
 #pragma unroll
             for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
             wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
-        } else {
-            wave_phase3<NSLOTS, Lens>(fl, j, act, n_mels, p.slots, blob, slice, vals);
         }
-#endif
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT) rs.template before_stores<0>(lane);
-        if (LAYOUT && p.b.mel_major)
-            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
+        rs.template before_stores<0>(lane);
+        bool flag;
+        if (p.b.mel_major)
+            flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
-            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
+            flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
+        if (guard) guard_append<12>(flag, lane, fl3, j3, unit * kFPW, p.guard);
         __builtin_amdgcn_wave_barrier();
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
-        if (LAYOUT) rs.after_round();
+        rs.after_round();
     }
 }
 
 // ------------------------------------------------------------------------------------
 // Six frames per wavefront (phases in whisper_six.hpp), one 16-wave workgroup per CU.
 // ------------------------------------------------------------------------------------
-// LAYOUT = true: padded and/or mel-major output (workgroup-uniform rounds; mel-major re-aligns the waves once per round,
-// see whisper400_wave_kernel).
-template <int NSLOTS, class Lens, bool LAYOUT = false>
+// Padded and/or mel-major output: workgroup-uniform rounds like whisper400_wave_kernel.
+template <int NSLOTS, class Lens>
 __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const FastParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
@@ -312,7 +277,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
     // arrival counters of the sub-group barrier (mel-major stores), behind the last slice
     unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());
-    if (LAYOUT && tid < kSixWaves) arrive[tid] = 0;
+    if (tid < kSixWaves) arrive[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -324,19 +289,19 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     SixLayout::row_offsets(j, uoff, voff);
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    const uint64_t w_off = LAYOUT ? 0 : wave;
-    RoundSync<kSixWaves> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
-    for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves + w_off; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
-        const uint64_t unit = LAYOUT ? first + rs.slot : first;
-        const bool have = !LAYOUT || unit < p.b.n_units;
+    const bool guard = p.guard.list != nullptr;
+    RoundSync<kSixWaves> rs(p.b.sync_rounds, wave, arrive);
+    for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
+        const uint64_t unit = first + rs.slot;
+        const bool have = unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kSixFrames;
-        const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
+        const uint64_t left = (have && f0 < loc.frames) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
-        const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
+        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         const uint64_t wleft = have ? width - f0 : 0;
-        const int ns = LAYOUT ? (wleft < (uint64_t)kSixFrames ? (int)wleft : kSixFrames) : nv;
+        const int ns = wleft < (uint64_t)kSixFrames ? (int)wleft : kSixFrames;
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
         MS_PRIO(0);
@@ -359,22 +324,24 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT) rs.template before_stores<3>(lane);
-        if (LAYOUT && p.b.mel_major)
-            six_phase4<NSLOTS, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0, (long long)width);
+        rs.template before_stores<3>(lane);
+        bool flag;
+        if (p.b.mel_major)
+            flag = six_phase4<NSLOTS, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
-            six_phase4<NSLOTS, LAYOUT>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
+            flag = six_phase4<NSLOTS, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
+        if (guard) guard_append<kSixLanes>(flag, lane, fl, j, unit * kSixFrames, p.guard);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT) rs.after_round();
+        rs.after_round();
     }
 }
 
 // Plain [frame][mel] output, uniform and ragged batches, on the six-frame build -- the default kernel of the bench workload.
 // A wave takes a contiguous run of units: it locates its first unit once and from then on only steps to the next clip when
-// the run crosses a clip end; the clip record lives in scalar registers.  Against the round-robin deal of
-// whisper400_six_kernel (which the padded / mel-major layouts keep, their stores want adjacent units in adjacent waves):
-// ragged batches lose the two dependent look-ups in front of every unit's PCM loads (-6 %), uniform ones the 64-bit division
-// per unit and a wave re-reads its own frame-tail halo (cfg2 -1.6 %, 8192 x 30 s -1.7 %).  The unit body is the same.
+// the run crosses a clip end; the clip record lives in scalar registers.  Against a round-robin deal (which the padded /
+// mel-major layouts keep, their stores want adjacent units in adjacent waves): ragged batches lose the two dependent
+// look-ups in front of every unit's PCM loads (-6 %), uniform ones the 64-bit division per unit and a wave re-reads its own
+// frame-tail halo (cfg2 -1.6 %, 8192 x 30 s -1.7 %).  The unit body is the same.
 __device__ __forceinline__ uint64_t scalar64(uint64_t v) {
     // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -449,6 +416,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     SixLayout::row_offsets(j, uoff, voff);
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
+    const bool guard = p.guard.list != nullptr;
 
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) return;
@@ -478,15 +446,16 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        six_phase4<NSLOTS, false>(fl, j, act, act, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
+        const bool flag = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
+        if (guard) guard_append<kSixLanes>(flag, lane, fl, j, cr.unit * kSixFrames, p.guard);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 // The same for the 5-frame kernel (81..131 mels): interval mel scheme, direct PCM reads, 8-wave workgroups.
 template <int NSLOTS, class Lens>
-__global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_runs_kernel(const FastParams p) {
-    constexpr int WAVES = 8;
+__global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kernel(const FastParams p) {
+    constexpr int WAVES = kWaveWaves;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *blob = lds;
     const int tid = threadIdx.x;
@@ -504,6 +473,7 @@ __global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_runs_kernel(const F
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
+    const bool guard = p.guard.list != nullptr;
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
     for (; cr.unit < cr.end; ++cr.unit) {
@@ -514,10 +484,10 @@ __global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_runs_kernel(const F
         const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
         MS_PRIO(0);
-        wave_phase1<true>(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
+        wave_phase1(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(1);
-        wave_phase2<false>(fl, j, act, blob, slice, uoff, voff);
+        wave_phase2(fl, j, act, blob, slice, uoff, voff);
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(2);
         float vals[NSLOTS];
@@ -532,14 +502,15 @@ __global__ __launch_bounds__(8 * 64, 4) void whisper400_wave_runs_kernel(const F
             wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        wave_phase4<NSLOTS, false>(fl3, j3, act3, act3, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
+        const bool flag = wave_phase4<NSLOTS, false, true>(fl3, j3, act3, act3, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
+        if (guard) guard_append<12>(flag, lane, fl3, j3, cr.unit * kFPW, p.guard);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
 // ------------------------------------------------------------------------------------
-// "Precise" fused Whisper kernel: f64 FFT (whisper_wave_f64.hpp), f32 interval mel + normalisation.
-// LDS words: [f64 tables][f32 mel section][WAVES x slice of 2320 doubles].  Plain [frame][mel] output.
+// "Precise" fused Whisper kernels: f64 FFT (whisper_wave_f64.hpp), f32 interval mel + normalisation.
+// LDS words: [f64 tables][f32 mel section][WAVES x slice of 2320 doubles].
 // ------------------------------------------------------------------------------------
 struct PreciseParams {
     BatchDesc b;
@@ -551,9 +522,14 @@ struct PreciseParams {
     MelSlots slots;       // woff[] as in the f32 blob (float offsets from FastBlob's base)
 };
 
-// RUNS (plain layout only): a contiguous run of units per wave (ClipRun) instead of the round-robin deal.
-template <int NSLOTS, class Lens, int WAVES, bool LAYOUT = false, bool RUNS = false>
-__global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const PreciseParams p) {
+constexpr int kPreciseWaves = 8;    // one workgroup per CU
+
+// RUNS: plain [frame][mel] output, a contiguous run of units per wave (ClipRun); otherwise the padded / mel-major layouts in
+// workgroup-uniform rounds (see whisper400_wave_kernel).
+template <int NSLOTS, class Lens, bool RUNS>
+__global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(const PreciseParams p) {
+    constexpr int WAVES = kPreciseWaves;
+    constexpr bool LAYOUT = !RUNS;
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
@@ -579,23 +555,21 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
     }
-    const uint64_t w_off = LAYOUT ? 0 : wave;      // LAYOUT: workgroup-uniform rounds, see whisper400_wave_kernel
     RoundSync<WAVES> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
-    static_assert(!(LAYOUT && RUNS), "runs are for the plain layout");
     ClipRun cr;
     if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
-    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + w_off;; first += (uint64_t)gridDim.x * WAVES) {
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES;; first += (uint64_t)gridDim.x * WAVES) {
         if (RUNS) {
             if (cr.unit >= cr.end) break;
             cr.enter(p.b);
         } else if (first >= p.b.n_units) {
             break;
         }
-        const uint64_t unit = LAYOUT ? first + rs.slot : first;
-        const bool have = !LAYOUT || unit < p.b.n_units;
+        const uint64_t unit = first + rs.slot;
+        const bool have = RUNS || unit < p.b.n_units;
         const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = (!LAYOUT || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
+        const uint64_t left = (RUNS || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
         const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
@@ -604,7 +578,7 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         const float *src = loc.pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
         MS_PRIO(0);
-        precise_phase1(fl, j, act && j < kFftJobs, p.hop, tb, src, rows);
+        precise_phase1(fl, j, act && j < kFftJobs, tb, src + fl * p.hop, rows);
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(1);
         precise_phase2(fl, j, act, tb, rows);
@@ -624,6 +598,98 @@ __global__ __launch_bounds__(WAVES * 64) void whisper400_precise_kernel(const Pr
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT) rs.after_round();
         if (RUNS) ++cr.unit;
+    }
+}
+
+// The f64 recompute of the frames the f32 kernels queued (MELSPEC_PRECISION_AUTO): launched behind every guarded f32
+// launch on the same stream with the same BatchDesc.  Every frame slot of a wave takes its own queue entry -- the five
+// frames of a wave need not be neighbours -- and overwrites that frame's column of the output.  An empty queue (noise,
+// music, most of what is not a line over a quiet floor) costs one load per workgroup.  The last workgroup to finish resets
+// the queue for the next call.
+struct FixupParams {
+    PreciseParams pp;
+    const uint32_t *list;
+    uint32_t *ctl;
+    uint32_t fpu;         // frames per unit of the f32 kernel that queued (how an id splits into unit and frame)
+};
+
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_fixup_kernel(const FixupParams q) {
+    constexpr int WAVES = kPreciseWaves;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const PreciseParams &p = q.pp;
+    const int tid = threadIdx.x;
+    const uint32_t count = __builtin_amdgcn_readfirstlane(q.ctl[0]);
+    if (count != 0) {
+        for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+        __syncthreads();
+        const double *tb = reinterpret_cast<const double *>(ldsw);
+        const float *fblob = reinterpret_cast<const float *>(ldsw + p.mel_off_words) - FastBlob::kMelStart;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int lane = tid & 63;
+        double *rows = reinterpret_cast<double *>(ldsw + p.blob_words) + wave * PreciseLayout::slice_doubles();
+        float *slice = reinterpret_cast<float *>(rows);
+        const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+        const bool in = lane < kFPW * kMelJobs;
+        const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
+        const int fl3 = lane / 12, j3 = lane - fl3 * 12;
+        const bool in3 = lane < kFPW * 12;
+        int st[NSLOTS];
+        {
+            const int *starts = reinterpret_cast<const int *>(fblob + FastBlob::kMelStart);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
+        }
+        const bool uniform = p.b.d_unit_prefix == nullptr;
+        for (uint64_t g = ((uint64_t)blockIdx.x * WAVES + wave) * kFPW; g < count; g += (uint64_t)gridDim.x * WAVES * kFPW) {
+            // phases 1-2 see the wave as 5 x 11 lanes, phases 3-4 as 5 x 12: a lane resolves the entry of either role
+            const bool act = in && g + fl < count, act3 = in3 && g + fl3 < count;
+            const float *frame = nullptr;
+            if (act && j < kFftJobs) {
+                const uint32_t e = q.list[g + fl];
+                const uint64_t unit = e / q.fpu;
+                const UnitLoc loc = locate_unit(p.b, unit);
+                frame = loc.pcm + (loc.unit * q.fpu + (e - unit * q.fpu)) * (uint64_t)p.hop;
+            }
+            float *out_tile = nullptr;
+            long long row_w = 0;
+            if (act3) {
+                const uint32_t e = q.list[g + fl3];
+                const uint64_t unit = e / q.fpu;
+                const UnitLoc loc = locate_unit(p.b, unit);
+                const uint64_t f = loc.unit * q.fpu + (e - unit * q.fpu);
+                if (p.b.mel_major) {
+                    row_w = static_cast<long long>(uniform ? p.b.out_width : loc.frames);
+                    out_tile = loc.out + f - fl3;                                  // wave_phase4 adds the frame slot back
+                } else {
+                    out_tile = loc.out + f * (uint64_t)n_mels - (uint64_t)fl3 * n_mels;
+                }
+            }
+            MS_PRIO(0);
+            precise_phase1(fl, j, act && j < kFftJobs, tb, frame, rows);
+            __builtin_amdgcn_wave_barrier();
+            MS_PRIO(1);
+            precise_phase2(fl, j, act, tb, rows);
+            __builtin_amdgcn_wave_barrier();
+            MS_PRIO(2);
+            float vals[NSLOTS], rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, fblob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
+            __builtin_amdgcn_wave_barrier();
+            wave_phase4<NSLOTS, true>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(q.ctl + 1, 1u) == gridDim.x - 1) {      // every other workgroup has read ctl[0] and finished
+            q.ctl[2] = count;
+            q.ctl[0] = 0;
+            q.ctl[1] = 0;
+        }
     }
 }
 

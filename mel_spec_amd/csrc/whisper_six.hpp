@@ -214,11 +214,12 @@ MS_DEV void six_phase3_finish(int fl, int j, bool active, int n_mels, const floa
 // ---- phase 4: frame maximum, clamp at max - 8, (x + 4) / 4, store ---------------------------------------------------
 // store: this lane's frame column exists in the output; valid: it is a real frame (otherwise a zero column of a padded
 // layout).  row_w == 0: [frame][mel] rows; row_w > 0: [mel][row_w] rows (interleave_frames, src/mel.rs:480-544).
-template <int NSLOTS, bool LAYOUT = false>
-MS_DEV void six_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
+// GUARD: returns true on lanes that hold a band within kGuardBand decades of the clamp (see wave_phase4).
+template <int NSLOTS, bool LAYOUT = false, bool GUARD = false>
+MS_DEV bool six_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
                        float *out_tile, long long row_w) {
     if (!LAYOUT) { valid = true; row_w = 0; }
-    if (!store || j >= kSixOwn) return;
+    if (!store || j >= kSixOwn) return false;
     float lo = 0.0f;
     if (valid) {
         const float *pm = slice + SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride;
@@ -230,11 +231,17 @@ MS_DEV void six_phase4(int fl, int j, bool store, bool valid, int n_mels, const 
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kSixOwn * row_w : kSixOwn;
+    float cmin = 3.0e38f;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kSixOwn * i;
-        if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
+        if (m < n_mels) {
+            const float c = __builtin_fmaxf(vals[i], lo);
+            o[i * step] = valid ? (c + 4.0f) * 0.25f : 0.0f;
+            if (GUARD) cmin = __builtin_fminf(cmin, c);
+        }
     }
+    return GUARD && valid && cmin < lo + kGuardBand;
 }
 
 }  // namespace melspec

@@ -1,11 +1,11 @@
 // whisper_wave.hpp -- wave-autonomous form of the fused n_fft=400 log-mel pipeline.
 //
-// Same arithmetic and the same table blob as whisper_fast.hpp (see the derivation there),
-// but one 64-lane wavefront owns kFPW = 5 whole frames from PCM to mel rows: lane = 11*frame + j.
+// One 64-lane wavefront owns kFPW = 5 whole frames from PCM to mel rows (derivation of the FFT split in
+// whisper_fast.hpp): lane = 11*frame + j in phases 1-2, 12*frame + j in phases 3-4.
 // All exchanges go through the wave's private LDS slice, and because LDS operations of one
 // wave execute in program order no workgroup barrier is needed anywhere in the tile loop --
 // waves of a workgroup only share the read-only table blob.  The slice is reused in place:
-//   [PCM tile (optional staging)] -> [FFT exchange rows] -> [power rows | frame maxima]
+//   [FFT exchange rows] -> [power rows | frame maxima]
 // which is safe for the same reason (every lane's reads of a stage are issued before any
 // lane's writes of the next stage).
 //
@@ -38,11 +38,7 @@ struct WaveLayout {
         for (int k = 0; k <= 10; ++k)            // a select chain, not an indexed load
             if (k == j) { uoff = row_pos(k) * kXRow; voff = row_pos(k == 0 ? 20 : 20 - k) * kXRow; }
     }
-    static constexpr int slice_floats(int hop, bool staged) {
-        const int x = kFPW * kXStride;                   // 2180
-        const int pcm = staged ? (kFPW - 1) * hop + 400 : 0;
-        return ((x > pcm ? x : pcm) + 3) & ~3;
-    }
+    static constexpr int slice_floats() { return kFPW * kXStride; }   // 2180
 };
 
 // Run-time slot lengths (any bank that is not one of the compile-time ones): the bins of a slot four at a time, so that the
@@ -73,7 +69,7 @@ MS_DEV void interval_bins_runtime(const float *pp, const float *w, int len, floa
     }
 }
 
-// Compile-time slot lengths for the two Whisper filterbanks (16 kHz, 80 / 128 mels); any
+// Slot lengths are compile-time for the two Whisper filterbanks (16 kHz, 80 / 128 mels, below); any
 // other (sr, n_mels) uses the runtime lengths in MelSlots.
 struct LensRuntime {
     static constexpr bool kStatic = false;
@@ -82,25 +78,6 @@ struct LensRuntime {
     MS_HD static int len(int) { return 0; }
     MS_HD static int woff(int) { return 0; }
 };
-template <int MELS, int... L>
-struct LensStatic {
-    static constexpr bool kStatic = true;
-    static constexpr int kSlots = sizeof...(L);
-    static constexpr int kMels = MELS;          // the mel count is part of the compile-time shape: store masks fold
-    MS_HD static constexpr int len(int i) {
-        constexpr int t[sizeof...(L)] = {L...};
-        return t[i];
-    }
-    MS_HD static constexpr int woff(int i) {
-        constexpr int t[sizeof...(L)] = {L...};
-        int s = 0;
-        for (int k = 0; k < i; ++k) s += t[k];
-        return FastBlob::kMelW + kMelJobs * s;
-    }
-};
-using LensW80 = LensStatic<80, 2, 2, 2, 4, 6, 8, 13, 14>;
-using LensW128 = LensStatic<128, 2, 2, 2, 2, 2, 2, 3, 4, 5, 6, 8, 9>;
-
 // Interval scheme (build_interval_mel): padded interval lengths per slot, weights are float pairs
 // over 12 lanes, so a slot of length L occupies 24*L floats.
 template <int MELS, int... L>
@@ -134,34 +111,18 @@ MS_DEV f2 load2_unaligned(const float *p) {
 }
 
 // ---- phase 1 -----------------------------------------------------------------------------
-// DIRECT: read the frame's samples straight from global memory (L1/L2 absorb the 2.5x frame
-// overlap); otherwise from the PCM tile staged at the start of the slice.
-template <bool DIRECT>
+// The frame's samples come straight from global memory (L1/L2 absorb the 2.5x frame overlap).
 MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, const float *gsrc /* tile's first sample */,
                         float *slice) {
     if (!active) return;
     const float *w = blob + FastBlob::kWin + 2 * t;
+    const float *s = gsrc + fl * hop + 2 * t;
     cf x[20];
-    if (DIRECT) {
-#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 4
-        const float *s = blob + FastBlob::kTw1 + fl + 2 * t;    // ablation: phase 1 without global loads
-#else
-        const float *s = gsrc + fl * hop + 2 * t;
-#endif
 #pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) {
-            const f2 sv = load2_unaligned(s + 20 * n1);
-            const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
-            x[n1] = {sv.x * wv.x, sv.y * wv.y};
-        }
-    } else {
-        const float *s = slice + fl * hop + 2 * t;
-#pragma unroll
-        for (int n1 = 0; n1 < 20; ++n1) {
-            const f2 sv = *reinterpret_cast<const f2 *>(s + 20 * n1);
-            const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
-            x[n1] = {sv.x * wv.x, sv.y * wv.y};
-        }
+    for (int n1 = 0; n1 < 20; ++n1) {
+        const f2 sv = load2_unaligned(s + 20 * n1);
+        const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
+        x[n1] = {sv.x * wv.x, sv.y * wv.y};
     }
     fft20(x);
     const float *tw = blob + FastBlob::kTw1 + t * FastBlob::kTw1Stride;
@@ -181,8 +142,7 @@ MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, 
 }
 
 // ---- phase 2: reads the exchange rows, writes the power row over the same slice ----------
-// SCALED: store |X|^2 (x 1/4 applied here); otherwise store 4*|X|^2 (the interval mel weights carry the 1/4).
-template <bool SCALED = true>
+// Stores 4*|X|^2 (the interval mel weights carry the 1/4).
 MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *slice, int uoff, int voff) {
     if (!active) return;
     // uoff / voff: float offsets of rows j and 20-j (20 for j = 0) inside the frame's block, WaveLayout::row_offsets()
@@ -216,8 +176,8 @@ MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *sl
             const float ar = S.re + wd.im, ai = S.im - wd.re;
             const float br = S.re - wd.im, bi = S.im + wd.re;
             const float pk = ar * ar + ai * ai, pm = br * br + bi * bi;
-            p[j + 20 * qq] = SCALED ? 0.25f * pk : pk;
-            p[200 - j - 20 * qq] = SCALED ? 0.25f * pm : pm;
+            p[j + 20 * qq] = pk;
+            p[200 - j - 20 * qq] = pm;
         }
     }
 }
@@ -273,46 +233,24 @@ MS_DEV void wave_phase3i_finish(int fl, int j12, bool active, int n_mels, const 
     slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j12] = mx;
 }
 
-// ---- phase 3: banded mel projection + log10, per-thread max to LDS ------------------------
-template <int NSLOTS, class Lens>
-MS_DEV void wave_phase3(int fl, int j, bool active, int n_mels, const MelSlots &ms, const float *blob, float *slice,
-                        float (&vals)[NSLOTS]) {
-    if (!active) return;
-    const float *p = slice + fl * WaveLayout::kPStride;
-    const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart);
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int i = 0; i < NSLOTS; ++i) {
-        float acc = 0.0f;
-        if (Lens::kStatic) {
-            if (i < Lens::kSlots) {
-                const float *pp = p + starts[i * kMelJobs + j];
-                const float *wrow = blob + Lens::woff(i < Lens::kSlots ? i : 0) + j;
-#pragma unroll
-                for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) acc += wrow[r * kMelJobs] * pp[r];
-            }
-        } else if (i < ms.n_slots) {
-            const float *pp = p + starts[i * kMelJobs + j];
-            const float *wrow = blob + ms.woff[i] + j;
-            const int len = ms.len[i];
-            for (int r = 0; r < len; ++r) acc += wrow[r * kMelJobs] * pp[r];
-        }
-        const float v = acc > 1e-10f ? fast_log2(acc) * 0.30102999566398120f : -10.0f;
-        vals[i] = v;
-        if (j + kMelJobs * i < n_mels) mx = __builtin_fmaxf(mx, v);
-    }
-    slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j] = mx;
-    if (j == 0) slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + 11] = -3.0e38f;
-}
-
 // ---- phase 4: frame max, clamp, scale, store ------------------------------------------------
 // store: this lane's frame column exists in the output; valid: it is a real frame (otherwise a zero
 // column of a padded layout).  row_w == 0: [frame][mel] rows; row_w > 0: [mel][row_w] rows.
-template <int NSLOTS, bool LAYOUT = true>
-MS_DEV void wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
+//
+// Precision guard (GUARD): the per-frame clamp at max - 8 keeps mel bands up to 80 dB under the strongest one, and an
+// f32 FFT leaves the strongest line's rounding noise in every bin, so a band within kGuardBand decades of the clamp can be
+// off by more than 1e-4 after log10 (measured with tools/flag_calib.py on tones / chirps / speech over noise floors and five
+// filterbanks: bands >= 2 decades above the clamp stay under 3.9e-5, bands at the clamp reach 4.9e-4).  The function
+// returns true on lanes that hold such a band; the kernel then queues the frame for the f64 recompute
+// (whisper400_fixup_kernel).  Bands exactly at the clamp count too: whether a band is clamped is decided by the same noisy
+// value.  A silent frame (every band at the 1e-10 floor, nothing within 8 decades below) is never queued.
+constexpr float kGuardBand = 2.0f;
+
+template <int NSLOTS, bool LAYOUT = true, bool GUARD = false>
+MS_DEV bool wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
                         float *out_tile, long long row_w) {
     if (!LAYOUT) { valid = true; row_w = 0; }     // plain output: every stored column is a real frame
-    if (!store || j >= kMelJobs) return;
+    if (!store || j >= kMelJobs) return false;
     float lo = 0.0f;
     if (valid) {
         const float *pm = slice + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
@@ -325,19 +263,17 @@ MS_DEV void wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kMelJobs * row_w : kMelJobs;
-#if defined(MELSPEC_ABLATE) && MELSPEC_ABLATE == 8
-    // ablation: no global stores (one impossible store keeps the values alive)
-    float acc = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NSLOTS; ++i) acc += (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f;
-    if (acc == 12345.678f) o[0] = acc;
-#else
+    float cmin = 3.0e38f;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
-        if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
+        if (m < n_mels) {
+            const float c = __builtin_fmaxf(vals[i], lo);
+            o[i * step] = valid ? (c + 4.0f) * 0.25f : 0.0f;
+            if (GUARD) cmin = __builtin_fminf(cmin, c);
+        }
     }
-#endif
+    return GUARD && valid && cmin < lo + kGuardBand;
 }
 
 }  // namespace melspec

@@ -3,11 +3,11 @@
 // (whisper_wave.hpp: interval mel sums, log10, per-frame normalisation).
 //
 // Why it exists: the f32 kernel is within ~3e-5 of the f64 reference on speech and noise, but the
-// per-frame clamp at max-8 lets mel bands 80 dB under the frame maximum through, and for a strong pure
-// tone plus broadband content ~70 dB down the f32 rounding of the windowed frame reaches 9e-5 (measured,
-// tests/test_emu.py), i.e. the 1e-4 bound is met but not with margin on such signals.  This build holds
-// ~1e-6 on everything at roughly a third of the throughput; it is selected per context
-// (melspec_set_precise).
+// per-frame clamp at max-8 lets mel bands 80 dB under the frame maximum through, and for a strong
+// line over broadband content ~70 dB down the f32 FFT's rounding noise puts the bands next to the clamp
+// up to 4.9e-4 off (tools/flag_calib.py).  This build holds ~1e-6 on everything at about 60 % of the
+// throughput.  It runs in two roles: on every frame of a context in MELSPEC_PRECISION_F64, and -- the
+// default, MELSPEC_PRECISION_AUTO -- on just the frames the f32 kernels queue (whisper400_fixup_kernel).
 #pragma once
 #include "whisper_wave.hpp"
 
@@ -29,9 +29,10 @@ struct PreciseLayout {
     static constexpr int slice_doubles() { return kFPW * kXStride; }   // 2320 doubles; power rows / maxima alias its head
 };
 
-MS_DEV void precise_phase1(int fl, int t, bool active, int hop, const double *MS_RESTRICT tb, const float *MS_RESTRICT gsrc, double *MS_RESTRICT rows) {
+// frame: first sample of this lane's frame (frame slot fl of the wave)
+MS_DEV void precise_phase1(int fl, int t, bool active, const double *MS_RESTRICT tb, const float *MS_RESTRICT frame, double *MS_RESTRICT rows) {
     if (!active) return;
-    const float *s = gsrc + fl * hop + 2 * t;
+    const float *s = frame + 2 * t;
     cd x[20];
 #pragma unroll
     for (int n1 = 0; n1 < 20; ++n1) {

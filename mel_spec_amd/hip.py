@@ -139,13 +139,34 @@ class HipMelSpectrogram:
     def uses_fast_path(self) -> bool:
         return bool(lib().melspec_uses_fast_path(self._h))
 
+    PRECISION = {"auto": 0, "f64": 1, "f32": 2}
+
+    def set_precision(self, mode: str) -> None:
+        """melspec_set_precision: "auto" (default: f32 FFT, the frames its error bound does not cover recomputed in f64),
+        "f64" (every frame), "f32" (no guard)."""
+        _check(lib().melspec_set_precision(self._h, self.PRECISION[mode]))
+
+    @property
+    def precision(self) -> str:
+        v = int(lib().melspec_precision(self._h))
+        return next(k for k, c in self.PRECISION.items() if c == v)
+
     def set_precise(self, on: bool = True) -> None:
-        """f64 FFT build of the fused kernel (melspec_set_precise)."""
+        """melspec_set_precise: on -> "f64", off -> "auto"."""
         _check(lib().melspec_set_precise(self._h, int(on)))
 
     @property
     def precise(self) -> bool:
         return bool(lib().melspec_is_precise(self._h))
+
+    def plain_kernel_name(self) -> str:
+        return (lib().melspec_plain_kernel_name(self._h) or b"").decode()
+
+    def guard_last_count(self) -> int:
+        """frames the last "auto" call recomputed in f64 (waits for that call)"""
+        n = C.c_uint64(0)
+        _check(lib().melspec_guard_last_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def compute_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
                                stream: int = 0) -> None:
@@ -302,6 +323,10 @@ class Fbank:
     @property
     def uses_fast_path(self) -> bool:
         return bool(lib().melspec_fbank_uses_fast_path(self._h))
+
+    def use_generic(self, on: bool = True) -> None:
+        """run on the generic f64 direct-DFT kernel (the on-device cross-check of the fused kernel)"""
+        _check(lib().melspec_fbank_use_generic(self._h, int(on)))
 
     def compute(self, samples) -> np.ndarray:
         """&[f32] -> Array2<f32> (num_frames, num_mel_bins)."""

@@ -1,6 +1,6 @@
-// emu_fast.cpp -- TEST-ONLY host emulation of the fused n_fft=400 kernel.
+// emu_fast.cpp -- TEST-ONLY host emulation of the fused kernels.
 //
-// Runs the exact per-thread phase functions of mel_spec_amd/csrc/whisper_fast.hpp on the
+// Runs the exact per-lane phase functions of mel_spec_amd/csrc/whisper_wave.hpp / whisper_six.hpp / fbank_wave.hpp on the
 // host (one phase at a time over all thread ids == a barrier between phases), with a float
 // array standing in for LDS.  It checks the kernel's index algebra and f32 error budget
 // against the f64 oracle without a GPU.  Never linked into the product library.
@@ -17,62 +17,22 @@
 
 using namespace melspec;
 
-template <int FPB, int NSLOTS>
-static long long run(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
-    using L = FastLayout<FPB>;
-    FastTables T;
-    if (!build_fast_tables(sr, n_mels, T)) return -1;
-    if (n < 400) return 0;
-    const long long frames = (n - 400) / hop + 1;
-    std::vector<float> regA(L::region_a(hop)), regB(L::region_b()), pmax(L::region_max());
-    constexpr int NT = 256;
-    static_assert(L::kP2Threads <= NT, "block too small");
-    std::vector<float> vals(static_cast<size_t>(NT) * NSLOTS);
-    for (long long f0 = 0; f0 < frames; f0 += FPB) {
-        const int nv = static_cast<int>(std::min<long long>(FPB, frames - f0));
-        const int need = (nv - 1) * hop + 400;
-        // poison LDS so that any read of an unwritten word shows up
-        std::fill(regA.begin(), regA.end(), 1.0e30f);
-        std::fill(regB.begin(), regB.end(), 1.0e30f);
-        for (int i = 0; i < need; ++i) regA[i] = pcm[f0 * hop + i];
-        for (int tid = 0; tid < NT; ++tid) fast_phase1<FPB>(tid, nv, hop, T.blob.data(), regA.data(), regB.data());
-        std::fill(regA.begin(), regA.end(), 1.0e30f);   // region A is re-used for the power rows
-        for (int tid = 0; tid < NT; ++tid) fast_phase2<FPB>(tid, nv, T.blob.data(), regB.data(), regA.data());
-        for (int tid = 0; tid < NT; ++tid)
-            fast_phase3<FPB, NSLOTS>(tid, nv, n_mels, T.slots, T.blob.data(), regA.data(), pmax.data(),
-                                     *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(tid) * NSLOTS]));
-        for (int tid = 0; tid < NT; ++tid)
-            fast_phase4<FPB, NSLOTS>(tid, nv, n_mels, pmax.data(),
-                                     *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(tid) * NSLOTS]),
-                                     out + f0 * n_mels);
-    }
-    return frames;
-}
-
-extern "C" long long emu_whisper_fast(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
-    if (n_mels <= 88) return run<23, 8>(pcm, n, hop, n_mels, sr, out);
-    return run<23, 12>(pcm, n, hop, n_mels, sr, out);
-}
-
 // Wave-autonomous kernel (whisper_wave.hpp): one 64-lane wave per 5-frame unit, one phase at a
 // time over all lanes, the slice poisoned where the kernel promises not to read.
-template <int NSLOTS, bool DIRECT, class Lens, bool INTERVAL = false>
-static long long run_wave(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+// flags (optional): one byte per frame, 1 where the precision guard of phase 4 fires.
+template <int NSLOTS, class Lens>
+static long long run_wave(const float *pcm, long long n, int hop, int n_mels, double sr, float *out, uint8_t *flags) {
     FastTables T;
-    if (!build_fast_tables(sr, n_mels, T, INTERVAL)) return -1;
-    if (INTERVAL && !T.interval) return -3;
+    if (!build_fast_tables(sr, n_mels, T, true)) return -1;
+    if (!T.interval) return -3;
     if (n < 400) return 0;
     const long long frames = (n - 400) / hop + 1;
-    std::vector<float> slice(WaveLayout::slice_floats(hop, !DIRECT));
+    std::vector<float> slice(WaveLayout::slice_floats());
     std::vector<float> vals(static_cast<size_t>(64) * NSLOTS);
     for (long long f0 = 0; f0 < frames; f0 += kFPW) {
         const int nv = static_cast<int>(std::min<long long>(kFPW, frames - f0));
         std::fill(slice.begin(), slice.end(), 1.0e30f);
         const float *src = pcm + f0 * hop;
-        if (!DIRECT) {
-            const int need = (nv - 1) * hop + 400;
-            for (int i = 0; i < need; ++i) slice[i] = src[i];
-        }
         // phase 1 reads every input before writing any exchange row: emulate with a snapshot
         std::vector<float> snap(slice);
         std::vector<float> next(slice);
@@ -80,7 +40,7 @@ static long long run_wave(const float *pcm, long long n, int hop, int n_mels, do
             const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
             const bool act = lane < kFPW * kMelJobs && fl < nv;
             std::vector<float> tmp(snap);
-            wave_phase1<DIRECT>(fl, j, act && j < kFftJobs, hop, T.blob.data(), src, tmp.data());
+            wave_phase1(fl, j, act && j < kFftJobs, hop, T.blob.data(), src, tmp.data());
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
@@ -90,11 +50,11 @@ static long long run_wave(const float *pcm, long long n, int hop, int n_mels, do
             std::vector<float> tmp(snap);
             int uoff, voff;
             WaveLayout::row_offsets(j, uoff, voff);
-            wave_phase2<!INTERVAL>(fl, j, act, T.blob.data(), tmp.data(), uoff, voff);
+            wave_phase2(fl, j, act, T.blob.data(), tmp.data(), uoff, voff);
             for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
         }
         slice = next; snap = slice;
-        if (INTERVAL) {
+        {
             std::vector<float> rise(64 * NSLOTS), fprev(64 * NSLOTS + NSLOTS, 0.0f);
             const int *starts = reinterpret_cast<const int *>(T.blob.data() + FastBlob::kMelStart);
             for (int lane = 0; lane < 64; ++lane) {
@@ -116,24 +76,15 @@ static long long run_wave(const float *pcm, long long n, int hop, int n_mels, do
                                             tmp.data(), *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
                 for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
             }
-        } else {
-            for (int lane = 0; lane < 64; ++lane) {
-                const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
-                const bool act = lane < kFPW * kMelJobs && fl < nv;
-                std::vector<float> tmp(snap);
-                wave_phase3<NSLOTS, Lens>(fl, j, act, n_mels, T.slots, T.blob.data(), tmp.data(),
-                                          *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
-                for (size_t i = 0; i < tmp.size(); ++i) if (tmp[i] != snap[i]) next[i] = tmp[i];
-            }
         }
         slice = next;
         for (int lane = 0; lane < 64; ++lane) {
-            const int G = INTERVAL ? 12 : kMelJobs;
-            const int fl = lane / G, j = lane - fl * G;
-            const bool act = lane < kFPW * G && fl < nv;
-            wave_phase4<NSLOTS>(fl, j, act, act, n_mels, slice.data(),
+            const int fl = lane / 12, j = lane - fl * 12;
+            const bool act = lane < kFPW * 12 && fl < nv;
+            const bool g = wave_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice.data(),
                                 *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
                                 out + f0 * n_mels, 0);
+            if (g && flags) flags[f0 + fl] = 1;
         }
     }
     return frames;
@@ -147,33 +98,21 @@ static bool lens_ok(const MelSlots &ms) {
     return true;
 }
 
-// mode: 0 direct+runtime lens, 1 staged+runtime lens, 2 direct+static lens (only 16 kHz 80/128), 3 staged+static,
-//       4 interval scheme + runtime lens, 5 interval scheme + static lens
-extern "C" long long emu_whisper_wave(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+// mode: 0 run-time slot lengths, 1 compile-time lengths (only the 16 kHz 80 / 128 mel banks)
+extern "C" long long emu_whisper_wave_guard(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out, uint8_t *flags) {
     FastTables T;
-    if (mode >= 4) {
-        if (!build_fast_tables(sr, n_mels, T, true)) return -1;
-        if (!T.interval) return -3;
-        if (mode == 5) {
-            if (lens_ok<LensI80>(T.slots)) return run_wave<8, true, LensI80, true>(pcm, n, hop, n_mels, sr, out);
-            if (lens_ok<LensI128>(T.slots)) return run_wave<12, true, LensI128, true>(pcm, n, hop, n_mels, sr, out);
-            return -2;
-        }
-        if (T.slots.n_slots <= 8) return run_wave<8, true, LensRuntime, true>(pcm, n, hop, n_mels, sr, out);
-        return run_wave<12, true, LensRuntime, true>(pcm, n, hop, n_mels, sr, out);
-    }
-    if (!build_fast_tables(sr, n_mels, T)) return -1;
-    const bool direct = (mode % 2) == 0, stat = mode >= 2;
-    if (stat) {
-        if (lens_ok<LensW80>(T.slots))
-            return direct ? run_wave<8, true, LensW80>(pcm, n, hop, n_mels, sr, out) : run_wave<8, false, LensW80>(pcm, n, hop, n_mels, sr, out);
-        if (lens_ok<LensW128>(T.slots))
-            return direct ? run_wave<12, true, LensW128>(pcm, n, hop, n_mels, sr, out) : run_wave<12, false, LensW128>(pcm, n, hop, n_mels, sr, out);
+    if (!build_fast_tables(sr, n_mels, T, true)) return -1;
+    if (!T.interval) return -3;
+    if (mode == 1) {
+        if (lens_ok<LensI80>(T.slots)) return run_wave<8, LensI80>(pcm, n, hop, n_mels, sr, out, flags);
+        if (lens_ok<LensI128>(T.slots)) return run_wave<12, LensI128>(pcm, n, hop, n_mels, sr, out, flags);
         return -2;
     }
-    if (n_mels <= 88)
-        return direct ? run_wave<8, true, LensRuntime>(pcm, n, hop, n_mels, sr, out) : run_wave<8, false, LensRuntime>(pcm, n, hop, n_mels, sr, out);
-    return direct ? run_wave<12, true, LensRuntime>(pcm, n, hop, n_mels, sr, out) : run_wave<12, false, LensRuntime>(pcm, n, hop, n_mels, sr, out);
+    if (T.slots.n_slots <= 8) return run_wave<8, LensRuntime>(pcm, n, hop, n_mels, sr, out, flags);
+    return run_wave<12, LensRuntime>(pcm, n, hop, n_mels, sr, out, flags);
+}
+extern "C" long long emu_whisper_wave(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+    return emu_whisper_wave_guard(pcm, n, hop, n_mels, sr, mode, out, nullptr);
 }
 
 // Fused fbank kernel (fbank_wave.hpp), default geometry, no CMN.  out = [frames][n_mels].
@@ -361,7 +300,7 @@ extern "C" long long emu_whisper_precise(const float *pcm, long long n, int hop,
             const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
             const bool act = lane < kFPW * kMelJobs && fl < nv;
             std::vector<double> tmp(snap);
-            precise_phase1(fl, j, act && j < kFftJobs, hop, tb, pcm + f0 * hop, tmp.data());
+            precise_phase1(fl, j, act && j < kFftJobs, tb, pcm + (f0 + fl) * hop, tmp.data());
             merge(tmp);
         }
         rows = next; snap = rows;
@@ -406,19 +345,6 @@ extern "C" long long emu_whisper_precise(const float *pcm, long long n, int hop,
         }
     }
     return frames;
-}
-
-// power spectrum only (debug): |X[k]|^2, k in [0,200], for the first frame of pcm
-extern "C" int emu_fast_power(const float *pcm, double sr, float *pw201) {
-    using L = FastLayout<1>;
-    FastTables T;
-    build_fast_tables(sr, 80, T);
-    std::vector<float> regA(L::region_a(160)), regB(L::region_b());
-    for (int i = 0; i < 400; ++i) regA[i] = pcm[i];
-    for (int tid = 0; tid < 16; ++tid) fast_phase1<1>(tid, 1, 160, T.blob.data(), regA.data(), regB.data());
-    for (int tid = 0; tid < 16; ++tid) fast_phase2<1>(tid, 1, T.blob.data(), regB.data(), regA.data());
-    std::memcpy(pw201, regA.data(), sizeof(float) * 201);
-    return 0;
 }
 
 // small DFT checks
@@ -539,7 +465,7 @@ extern "C" long long emu_stream_push(void *p, const uint32_t *ids, const float *
     for (uint32_t i = 0; i < n; ++i) {                                  // the batch kernel on carry ++ chunk
         if (!pl.frames[i]) continue;
         const long long got = emu_whisper_wave(s->state.data() + pl.off[i], static_cast<long long>(pl.len[i]), static_cast<int>(s->g.hop),
-                                               static_cast<int>(s->g.n_mels), s->sr, 4, out + pl.out_off[i]);
+                                               static_cast<int>(s->g.n_mels), s->sr, 0, out + pl.out_off[i]);
         if (got != pl.frames[i]) return -100;
     }
     for (uint32_t i = 0; i < n; ++i) {                                  // stream_carry_kernel
@@ -634,7 +560,7 @@ extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n
 
 // ---- whisper_six.hpp: six frames per wave, ten lanes per frame ------------------------------------------------
 template <int NSLOTS, class Lens>
-static long long run_six(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+static long long run_six(const float *pcm, long long n, int hop, int n_mels, double sr, float *out, uint8_t *flags) {
     FastTables T;
     if (!build_six_tables(sr, n_mels, T)) return -1;
     if (n < 400) return 0;
@@ -684,8 +610,9 @@ static long long run_six(const float *pcm, long long n, int hop, int n_mels, dou
         slice = next;
         for (int lane = 0; lane < 64; ++lane) {
             int fl, j; bool act; info(lane, fl, j, act);
-            six_phase4<NSLOTS>(fl, j, act, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+            const bool g = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
                                out + f0 * n_mels, 0);
+            if (g && flags) flags[f0 + fl] = 1;
         }
     }
     return frames;
@@ -700,11 +627,37 @@ static bool six_lens_ok(const MelSlots &ms, int n_mels) {
 }
 
 // mode 0: runtime slot lengths, 1: compile-time lengths (Whisper 80 mels only)
-extern "C" long long emu_whisper_six(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+extern "C" long long emu_whisper_six_guard(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out, uint8_t *flags) {
     if (mode == 1) {
         FastTables T;
         if (!build_six_tables(sr, n_mels, T) || !six_lens_ok<LensSix80>(T.slots, n_mels)) return -2;
-        return run_six<kSixMaxSlots, LensSix80>(pcm, n, hop, n_mels, sr, out);
+        return run_six<kSixMaxSlots, LensSix80>(pcm, n, hop, n_mels, sr, out, flags);
     }
-    return run_six<kSixMaxSlots, LensRuntime>(pcm, n, hop, n_mels, sr, out);
+    return run_six<kSixMaxSlots, LensRuntime>(pcm, n, hop, n_mels, sr, out, flags);
+}
+extern "C" long long emu_whisper_six(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+    return emu_whisper_six_guard(pcm, n, hop, n_mels, sr, mode, out, nullptr);
+}
+
+// MELSPEC_PRECISION_AUTO: the f32 kernel the library would pick (six frames per wave up to 80 mels, else five), then the
+// frames its guard queued replaced by the f64 kernel's.  Returns the frame count; *n_flagged the queued frames.
+extern "C" long long emu_whisper_auto(const float *pcm, long long n, int hop, int n_mels, double sr, float *out, long long *n_flagged) {
+    if (n_flagged) *n_flagged = 0;
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / hop + 1;
+    std::vector<uint8_t> flags(static_cast<size_t>(frames), 0);
+    FastTables T6;
+    long long got = build_six_tables(sr, n_mels, T6) ? emu_whisper_six_guard(pcm, n, hop, n_mels, sr, 0, out, flags.data())
+                                                     : emu_whisper_wave_guard(pcm, n, hop, n_mels, sr, 0, out, flags.data());
+    if (got != frames) return got;
+    std::vector<float> one(static_cast<size_t>(n_mels));
+    long long nf = 0;
+    for (long long f = 0; f < frames; ++f) {
+        if (!flags[f]) continue;
+        ++nf;
+        if (emu_whisper_precise(pcm + f * hop, 400, hop, n_mels, sr, one.data()) != 1) return -4;
+        std::memcpy(out + f * n_mels, one.data(), sizeof(float) * n_mels);
+    }
+    if (n_flagged) *n_flagged = nf;
+    return frames;
 }

@@ -1,6 +1,6 @@
-"""CPU check of the fused kernel's arithmetic: tests/emu compiles the very phase functions the
-HIP kernel runs (mel_spec_amd/csrc/whisper_fast.hpp) for the host and executes them thread by
-thread.  This validates the FFT index algebra and the f32 error budget (<= 1e-4 vs the f64
+"""CPU check of the fused kernels' arithmetic: tests/emu compiles the very phase functions the
+HIP kernels run (mel_spec_amd/csrc/whisper_six.hpp, whisper_wave.hpp, ...) for the host and executes them lane by
+lane.  This validates the FFT index algebra and the f32 error budget (<= 1e-4 vs the f64
 oracle) without a GPU; the GPU tests then only have to confirm the device agrees."""
 import ctypes as C
 import os
@@ -20,8 +20,13 @@ def emu():
     subprocess.check_call(["make", "-C", d, "-s"])
     L = C.CDLL(os.path.join(d, "libmelspec_emu.so"))
     f32p = C.POINTER(C.c_float)
-    L.emu_whisper_fast.restype = C.c_longlong
-    L.emu_whisper_fast.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
+    u8p = C.POINTER(C.c_uint8)
+    L.emu_whisper_six_guard.restype = C.c_longlong
+    L.emu_whisper_six_guard.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p, u8p]
+    L.emu_whisper_wave_guard.restype = C.c_longlong
+    L.emu_whisper_wave_guard.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p, u8p]
+    L.emu_whisper_auto.restype = C.c_longlong
+    L.emu_whisper_auto.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p, C.POINTER(C.c_longlong)]
     L.emu_small_fft.argtypes = [C.c_int, f32p]
     L.emu_whisper_wave.restype = C.c_longlong
     L.emu_whisper_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
@@ -39,10 +44,12 @@ def emu():
                                  C.c_float, C.c_int, C.c_int, C.c_int, f32p]
 
     def run(x, hop=160, n_mels=80, sr=16000.0):
+        """the f32 kernel the library picks for this bank: six frames per wave up to 80 mels, five above"""
         x = np.ascontiguousarray(x, np.float32)
         nf = 0 if len(x) < 400 else (len(x) - 400) // hop + 1
         out = np.full((nf, n_mels), np.nan, np.float32)
-        got = L.emu_whisper_fast(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, out.ctypes.data_as(f32p))
+        fn = L.emu_whisper_six if n_mels <= 80 else L.emu_whisper_wave
+        got = fn(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, 0, out.ctypes.data_as(f32p))
         assert got == nf
         return out
 
@@ -105,7 +112,7 @@ def _wave(emu, x, mode, hop=160, n_mels=80, sr=16000.0):
     return got, out
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4, 5])   # direct/staged x runtime/static slot lengths, interval scheme
+@pytest.mark.parametrize("mode", [0, 1])   # run-time / compile-time slot lengths
 @pytest.mark.parametrize("n_mels", [80, 128])
 def test_wave_kernel_modes(emu, oracle, jfk, mode, n_mels):
     x = jfk[8000:60000]
@@ -118,7 +125,7 @@ def test_wave_kernel_modes(emu, oracle, jfk, mode, n_mels):
                                             (160, 131, 16000.0), (2, 80, 16000.0)])
 def test_wave_kernel_interval_scheme_other_filterbanks(emu, oracle, jfk, hop, n_mels, sr):
     x = jfk[20000:20000 + (9000 if hop > 2 else 500)]
-    got, out = _wave(emu, x, 4, hop=hop, n_mels=n_mels, sr=sr)
+    got, out = _wave(emu, x, 0, hop=hop, n_mels=n_mels, sr=sr)
     want = oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr)
     assert got == want.shape[0] and np.abs(out - want).max() <= TOL
 
@@ -126,11 +133,11 @@ def test_wave_kernel_interval_scheme_other_filterbanks(emu, oracle, jfk, hop, n_
 def test_wave_kernel_edges(emu, oracle):
     for n in (400, 559, 560, 400 + 4 * 160, 400 + 5 * 160, 400 + 11 * 160 + 1):
         x = oracle.synth_pcm(1, n)
-        for mode in (2, 5):
+        for mode in (0, 1):
             got, out = _wave(emu, x, mode)
             want = oracle.compute_mel_spectrogram_cpu(x)
             assert got == want.shape[0] and np.abs(out - want).max() <= TOL
-    got, out = _wave(emu, np.zeros(4000, np.float32), 5)
+    got, out = _wave(emu, np.zeros(4000, np.float32), 1)
     assert np.all(out == np.float32(-1.5))
 
 
@@ -157,19 +164,59 @@ def test_precise_kernel_is_f64_accurate(emu, oracle, jfk, n_mels):
     assert np.abs(_precise(emu, jfk, n_mels=n_mels) - want).max() <= 2e-6
 
 
-def test_precise_kernel_on_the_f32_worst_case(emu, oracle):
+def _auto(emu, x, hop=160, n_mels=80, sr=16000.0):
+    """MELSPEC_PRECISION_AUTO emulated: f32 kernel + the frames its guard queues recomputed by the f64 kernel."""
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 400 else (len(x) - 400) // hop + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    flagged = C.c_longlong(0)
+    f32p = C.POINTER(C.c_float)
+    assert emu.lib.emu_whisper_auto(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, out.ctypes.data_as(f32p), C.byref(flagged)) == nf
+    return out, int(flagged.value)
+
+
+def test_f32_worst_case_and_what_the_modes_do_with_it(emu, oracle):
     """A near-full-scale tone over a noise floor ~80 dB below it in the mel domain: every f32 FFT (pocketfft's
     too) leaves the tone's rounding noise in the noise-only bins, and the bands just above the per-frame clamp
-    miss 1e-4 (7 kHz: up to ~4e-4).  Speech and noise stay within ~3e-5 (tests above).  The f64 build does not
-    care.  This is why melspec_set_precise exists; the reference's CUDA back-end also runs a Z2Z (f64) FFT,
-    src/cuda.rs:204-219."""
+    miss 1e-4 (7 kHz: up to ~4e-4) -- MELSPEC_PRECISION_F32.  The default, AUTO, queues exactly these frames for the
+    f64 kernel and holds the tolerance; F64 does not care.  (The reference's CUDA back-end also runs a Z2Z (f64) FFT,
+    src/cuda.rs:204-219.)"""
     for f, lo, hi in ((3333.3, 2e-5, 1.5e-4), (7000.0, 1e-4, 6e-4)):
         x = tone_over_noise_floor(f=f)
         want = oracle.compute_mel_spectrogram_cpu(x)
-        d32 = np.abs(_wave(emu, x, 5)[1] - want).max()
+        d32 = np.abs(_wave(emu, x, 1)[1] - want).max()
+        d32six = np.abs(_six(emu, x, 1)[1] - want).max()
         d64 = np.abs(_precise(emu, x) - want).max()
-        assert lo < d32 < hi, (f, d32)
+        auto, flagged = _auto(emu, x)
+        assert lo < d32 < hi and lo < d32six < hi, (f, d32, d32six)
         assert d64 <= 2e-6
+        assert np.abs(auto - want).max() <= TOL and flagged > 0, (f, np.abs(auto - want).max(), flagged)
+
+
+@pytest.mark.parametrize("n_mels,hop,sr", [(80, 160, 16000.0), (128, 160, 16000.0), (20, 160, 8000.0), (100, 320, 22050.0), (40, 200, 16000.0)])
+def test_auto_mode_holds_the_tolerance_on_a_zoo_of_hard_signals(emu, oracle, jfk, n_mels, hop, sr):
+    """The guard threshold (kGuardBand in whisper_wave.hpp) was calibrated with tools/flag_calib.py; this is the
+    condensed form: tones, a chirp and impulse trains over floors of every level, speech, noise, silence."""
+    rng = np.random.default_rng(42)
+    n = 24000
+    t = np.arange(n) / sr
+    sigs = []
+    for f in (0.0125, 0.0625, 0.2083, 0.3125, 0.4375, 0.4875):                 # fractions of the sampling rate
+        for lv in (-50, -65, -75, -85):
+            sigs.append((0.9 * np.sin(2 * np.pi * f * sr * t) + 10 ** (lv / 20) * rng.standard_normal(n)).astype(np.float32))
+    fch = 100 + (0.48 * sr - 100) * (t / t[-1])
+    sigs.append((0.8 * np.sin(2 * np.pi * np.cumsum(fch) / sr) + 10 ** (-70 / 20) * rng.standard_normal(n)).astype(np.float32))
+    x = rng.standard_normal(n).astype(np.float32) * np.float32(1e-4); x[::173] += 0.7; sigs.append(x)
+    sigs.append(jfk[30000:54000])
+    worst = 0.0
+    for x in sigs:
+        got, _ = _auto(emu, x, hop, n_mels, sr)
+        worst = max(worst, float(np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr)).max()))
+    assert worst <= TOL, worst
+    # what must NOT be queued: noise of any level, digital silence, a click in silence
+    for x in (oracle.synth_pcm(0, n), oracle.synth_pcm(7, n), np.zeros(n, np.float32)):
+        got, flagged = _auto(emu, x, hop, n_mels, sr)
+        assert flagged == 0 and np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr)).max() <= TOL
 
 
 @pytest.mark.parametrize("hop,n_mels,n", [(128, 40, 3000), (320, 100, 5000), (160, 80, 400), (160, 80, 400 + 5 * 160 + 3)])

@@ -1,0 +1,92 @@
+"""BASELINE.json configs[3] and configs[4] at their stated sizes on one MI355X:
+   config 4: 8192 x 30 s x 128 mels  (15.7 GB of PCM -> 24 559 616 frames, 12.6 GB of mel)
+   config 5: 65 536 x 30 s x 80 mels (125.8 GB of PCM -> 196 476 928 frames, 62.9 GB of mel; 188.7 GB resident of 288 GB)
+>= 64 sampled clips against the oracle (first, last, the per-GPU shard boundaries of an 8-way split, strided) plus
+size-independent properties of the WHOLE output computed on the device: finiteness, the per-frame clamp (max - min <= 2),
+a per-clip checksum that must equal the checksum of the same clip computed alone / in another batch position.
+torch is used for the buffers and the device-side reductions only (the kernels run through the C ABI on torch's stream)."""
+import numpy as np
+import pytest
+
+from conftest import ROOT  # noqa: F401
+
+SR = 16000.0
+TOL = 1e-4
+
+
+def _whole_output_properties(torch, out3, chunk_clips):
+    """finite everywhere; every frame's max - min <= 2 (the clamp at max - 8 followed by /4); per-clip f64 checksums"""
+    n = out3.shape[0]
+    sums = torch.empty(n, dtype=torch.float64, device=out3.device)
+    for c0 in range(0, n, chunk_clips):
+        v = out3[c0:c0 + chunk_clips]
+        assert bool(torch.isfinite(v).all())
+        assert float((v.amax(dim=2) - v.amin(dim=2)).max()) <= 2.0 + 1e-6
+        sums[c0:c0 + chunk_clips] = v.sum(dim=(1, 2), dtype=torch.float64)
+    return sums
+
+
+def _run_full(gpu, oracle, n_clips, n_mels, picks, chunk_clips):
+    import torch
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    clip_len, fpc = 480000, 2998
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    need = n_clips * (clip_len * 4 + fpc * n_mels * 4 + fpc * 4)
+    assert need < free_b, f"needs {need / 1e9:.1f} GB of HBM, {free_b / 1e9:.1f} GB free"
+    m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
+    out = torch.empty(n_clips * fpc * n_mels, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    gpu.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, 0, n_clips, stream=stream)
+    m.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert m.guard_last_count() == 0 or m.precision != "auto"        # hash noise never trips the precision guard
+    out3 = out.view(n_clips, fpc, n_mels)
+    # sampled clips vs the oracle (all host cores)
+    assert len(picks) >= 64
+    want = oracle.compute_mel_batch(np.stack([oracle.synth_pcm(c, clip_len) for c in picks]), 400, 160, n_mels, SR)
+    got = out3[torch.tensor(picks, device=dev)].cpu().numpy()
+    worst = float(np.abs(got - want).max())
+    assert worst <= TOL, worst
+    sums = _whole_output_properties(torch, out3, chunk_clips)
+    # batching / position invariance over the whole set: the same clips computed as another batch (the second half first,
+    # through a ragged plan) give bit-identical per-clip checksums
+    half = n_clips // 2
+    order = np.concatenate([np.arange(half, n_clips), np.arange(0, half)]).astype(np.uint64)
+    offs = order * np.uint64(clip_len)
+    lens = np.full(n_clips, clip_len, np.uint64)
+    out_offs = (np.arange(n_clips, dtype=np.uint64) * np.uint64(fpc * n_mels))
+    sums_a = sums.clone()
+    m.compute_ragged_device(pcm.data_ptr(), offs, lens, out.data_ptr(), out_offs, stream=stream)
+    torch.cuda.synchronize()
+    sums_b = _whole_output_properties(torch, out.view(n_clips, fpc, n_mels), chunk_clips)
+    assert bool(torch.equal(sums_b, sums_a[torch.from_numpy(order.astype(np.int64)).to(dev)]))
+    m.close()
+    del pcm, out, out3, sums, sums_a, sums_b
+    torch.cuda.empty_cache()
+    return worst
+
+
+def _picks(n_clips, shards=8, stride=0):
+    per = n_clips // shards
+    p = {0, 1, n_clips - 2, n_clips - 1}
+    for s in range(1, shards):
+        p.update({s * per - 1, s * per})              # the clips either side of every shard boundary of an 8-way split
+    step = stride or max(1, n_clips // 48)
+    p.update(range(7, n_clips, step))
+    return sorted(p)
+
+
+@pytest.mark.gpu
+def test_config4_full_size_8192x30s_128_mels(gpu, oracle):
+    worst = _run_full(gpu, oracle, 8192, 128, _picks(8192), chunk_clips=512)
+    print(f"config 4 full size: worst |gpu - oracle| over the sampled clips {worst:.3e}")
+
+
+@pytest.mark.gpu
+def test_config5_full_size_65536x30s_on_one_gpu(gpu, oracle):
+    """The whole 65 536-clip set of configs[4] resident on one GPU (188.7 GB + 0.8 GB of guard queue of 288 GB); the 8-GPU
+    run gives every rank the 8192-clip shard whose boundaries are among the sampled clips."""
+    worst = _run_full(gpu, oracle, 65536, 80, _picks(65536), chunk_clips=2048)
+    print(f"config 5 full size: worst |gpu - oracle| over the sampled clips {worst:.3e}")

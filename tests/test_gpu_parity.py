@@ -68,13 +68,18 @@ def _tone_over_noise_floor(n=32000, level_db=-70.0, f=3333.3, seed=0):
     return (0.9 * np.sin(2 * np.pi * f * t) + 10 ** (level_db / 20) * rng.standard_normal(n)).astype(np.float32)
 
 
+_ENV_MODE = {"1": "f64", "f": "f32"}.get(os.environ.get("MELSPEC_PRECISE", "")[:1], "auto")   # the suite is also run with MELSPEC_PRECISE=1
+
+
 @pytest.mark.parametrize("n_mels", [80, 128])
-def test_precise_mode(gpu, oracle, jfk, n_mels):
-    """melspec_set_precise: f64 window/FFT/power (the reference's arithmetic, src/stft.rs:98-111)."""
+def test_precision_modes(gpu, oracle, jfk, n_mels):
+    """melspec_set_precision.  F64: window/FFT/power in f64 (the reference's arithmetic, src/stft.rs:98-111).  AUTO, the
+    default: the f32 kernel plus the f64 recompute of the frames its error bound does not cover -- the tone-over-floor
+    signal that the bare f32 FFT misses (F32) is within the tolerance."""
     m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
-    assert m.uses_fast_path and (m.precise == (os.environ.get("MELSPEC_PRECISE") == "1"))   # the suite is also run with MELSPEC_PRECISE=1
+    assert m.uses_fast_path and m.precision == _ENV_MODE
     m.set_precise(True)
-    assert m.precise
+    assert m.precise and m.precision == "f64"
     want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels, SR)
     got = m.compute_mel_spectrogram(jfk)
     assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
@@ -87,9 +92,61 @@ def test_precise_mode(gpu, oracle, jfk, n_mels):
         if n >= 400:
             assert np.abs(m.compute_mel_spectrogram(y) - oracle.compute_mel_spectrogram_cpu(y, 400, 160, n_mels, SR)).max() <= 2e-6
     m.set_precise(False)
-    assert not m.precise
+    assert not m.precise and m.precision == "auto"
+    for f in (3333.3, 7000.0):
+        x = _tone_over_noise_floor(f=f)
+        want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, n_mels, SR)
+        d_auto = np.abs(m.compute_mel_spectrogram(x) - want).max()
+        queued = m.guard_last_count()
+        assert d_auto <= TOL and 0 < queued <= want.shape[0], (f, d_auto, queued)
+    m.set_precision("f32")
     d32 = np.abs(m.compute_mel_spectrogram(x) - want).max()
-    assert 2e-5 < d32 < 2e-4      # the f32 FFT's known worst case (tests/test_emu.py::test_precise_kernel_on_the_f32_worst_case)
+    assert 1e-4 < d32 < 6e-4      # the f32 FFT's known worst case (tests/test_emu.py::test_f32_worst_case_and_what_the_modes_do_with_it)
+    m.set_precision("auto")
+    noise = oracle.synth_pcm(5, 48000)
+    assert np.abs(m.compute_mel_spectrogram(noise) - oracle.compute_mel_spectrogram_cpu(noise, 400, 160, n_mels, SR)).max() <= TOL
+    assert m.guard_last_count() == 0          # noise queues nothing: the bench workload runs at the f32 rate
+    m.close()
+
+
+def _hard_signals(n, sr, seed=42):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    sigs = []
+    for f in (0.0125, 0.2083, 0.4375, 0.4875):
+        for lv in (-50, -65, -75, -85):
+            sigs.append((0.9 * np.sin(2 * np.pi * f * sr * t) + 10 ** (lv / 20) * rng.standard_normal(n)).astype(np.float32))
+    fch = 100 + (0.48 * sr - 100) * (t / t[-1])
+    sigs.append((0.8 * np.sin(2 * np.pi * np.cumsum(fch) / sr) + 10 ** (-70 / 20) * rng.standard_normal(n)).astype(np.float32))
+    x = rng.standard_normal(n).astype(np.float32) * np.float32(1e-4); x[::173] += 0.7
+    sigs.append(x)
+    return sigs
+
+
+@pytest.mark.parametrize("n_mels,hop,sr", [(80, 160, 16000.0), (128, 160, 16000.0), (20, 160, 8000.0), (100, 320, 22050.0)])
+def test_default_mode_holds_the_tolerance_on_hard_signals(gpu, oracle, jfk, n_mels, hop, sr):
+    """AUTO through every batch shape: uniform, ragged, padded and mel-major layouts, the streaming bank."""
+    m = gpu.HipMelSpectrogram(400, hop, sr, n_mels)
+    m.set_precision("auto")
+    sigs = _hard_signals(24000, sr) + [jfk[30000:54000]]
+    want = [oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr) for x in sigs]
+    got = m.compute_batch(np.stack(sigs))
+    assert max(float(np.abs(g - w).max()) for g, w in zip(got, want)) <= TOL
+    assert m.guard_last_count() > 0
+    rag = [x[: 24000 - 777 * i] for i, x in enumerate(sigs)]
+    for g, x in zip(m.compute_ragged(rag), rag):
+        assert np.abs(g - oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, sr)).max() <= TOL
+    for mco in (False, True):
+        img = m.compute_batch_interleaved(np.stack(sigs), mco, 200)
+        for c, w in enumerate(want):
+            g = img[c][: w.shape[0]] if mco else img[c].T[: w.shape[0]]
+            assert np.abs(g - w).max() <= TOL
+    bank = gpu.StreamBank(m, 3, 5000)
+    for s_id, x in enumerate(sigs[:3]):
+        parts = [bank.push([s_id], [x[p:p + 5000]])[0] for p in range(0, len(x), 5000)]
+        st = np.concatenate(parts)
+        assert np.abs(st - oracle.stream_mel(x, 400, hop, n_mels, sr)).max() <= TOL
+    bank.close()
     m.close()
 
 
@@ -103,14 +160,11 @@ def test_precise_mode_batch_and_other_geometry(gpu, oracle):
     g = gpu.HipMelSpectrogram(512, 160, SR, 80)     # fused 512 kernel: always f64
     assert g.precise
     g.set_precise(True)
-    # a bank whose precise tables do not fit in LDS: every attempt is refused and the context keeps working in f32
+    # a bank whose f64 tables do not fit in LDS next to the slices (one 200-bin mel): the generic f64 kernel serves it
     w = gpu.HipMelSpectrogram(400, 160, SR, 1)
     x = oracle.synth_pcm(1, 4000)
-    for _ in range(2):
-        with pytest.raises(gpu.HipRuntimeError):
-            w.set_precise(True)
-        assert not w.precise
-        assert np.abs(w.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_cpu(x, 400, 160, 1, SR)).max() <= TOL
+    assert w.precise and not w.uses_fast_path
+    assert np.abs(w.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_cpu(x, 400, 160, 1, SR)).max() <= 2e-6
     m.close(); g.close(); w.close()
 
 
@@ -140,7 +194,7 @@ def test_silence_and_click(w80, oracle):
     assert np.abs(w80.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_cpu(x)).max() <= TOL
 
 
-@pytest.mark.parametrize("hop,n_mels", [(160, 64), (128, 80), (200, 40), (320, 100), (160, 1), (160, 132)])
+@pytest.mark.parametrize("hop,n_mels", [(160, 64), (128, 80), (200, 40), (320, 100), (160, 8), (160, 131)])
 def test_other_geometries_fast_path(gpu, oracle, jfk, hop, n_mels):
     m = gpu.HipMelSpectrogram(400, hop, SR, n_mels)
     assert m.uses_fast_path
@@ -149,7 +203,7 @@ def test_other_geometries_fast_path(gpu, oracle, jfk, hop, n_mels):
     assert np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, SR)).max() <= TOL
 
 
-@pytest.mark.parametrize("fft,hop,n_mels", [(256, 64, 40), (1024, 256, 80), (400, 160, 200), (100, 50, 20)])
+@pytest.mark.parametrize("fft,hop,n_mels", [(256, 64, 40), (1024, 256, 80), (400, 160, 200), (100, 50, 20), (400, 160, 1), (400, 160, 5), (400, 160, 132)])
 def test_other_geometries_generic_path(gpu, oracle, jfk, fft, hop, n_mels):
     m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
     assert not m.uses_fast_path
@@ -345,12 +399,11 @@ def test_fbank_jfk(gpu, oracle, jfk, golden):
     assert abs(float(raw[0, 0]) - float(np.log(np.float64(np.finfo(np.float32).eps)))) < 1e-4
 
 
-def test_fbank_generic_kernel_agrees(gpu, oracle, jfk, monkeypatch):
+def test_fbank_generic_kernel_agrees(gpu, oracle, jfk):
     """The f64 direct-DFT kernel and the fused kernel are two independent device paths."""
-    monkeypatch.setenv("MELSPEC_FBANK", "generic")
     g = gpu.Fbank(gpu.FbankConfig())
+    g.use_generic(True)
     assert not g.uses_fast_path
-    monkeypatch.delenv("MELSPEC_FBANK")
     f = gpu.Fbank(gpu.FbankConfig())
     x = jfk[:60000]
     a, b, want = g.compute(x), f.compute(x), oracle.fbank_compute(x)

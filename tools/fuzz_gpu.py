@@ -19,7 +19,13 @@ def note(kind, d):
     stats[kind] = (n + 1, max(w, d))
 
 def signal(n):
-    k = rng.integers(0, 4)
+    k = rng.integers(0, 6)
+    if k == 4:      # a line over a quiet noise floor: the f32 FFT's worst case
+        t = np.arange(n)
+        return (rng.uniform(0.05, 1.0) * np.sin(t * rng.uniform(0.01, 3.1)) + 10.0 ** rng.uniform(-5.5, -2.0) * rng.standard_normal(n)).astype(np.float32)
+    if k == 5:      # a chirp over a floor
+        t = np.arange(n)
+        return (0.8 * np.sin(t * t * rng.uniform(1e-6, 3e-5) + 0.01 * t) + 10.0 ** rng.uniform(-5.0, -2.5) * rng.standard_normal(n)).astype(np.float32)
     if k == 0: return rng.standard_normal(n).astype(np.float32) * np.float32(10.0 ** rng.uniform(-4, 0))
     if k == 1: return (np.sin(np.arange(n) * rng.uniform(0.01, 3.0)) * rng.uniform(0.01, 1.0)).astype(np.float32)
     if k == 2: return np.zeros(n, np.float32)
@@ -34,13 +40,11 @@ def case_whisper():
     sr = float(rng.choice([16000.0, 16000.0, 8000.0, 22050.0]))
     m = M.HipMelSpectrogram(fft, hop, sr, n_mels)
     precise = False
-    if m.uses_fast_path and rng.random() < 0.3:
-        try:
-            m.set_precise(True); precise = True
-        except M.HipRuntimeError:
-            pass
-    # f32 FFT: 1e-4 on speech and noise; a line over a >80 dB quieter floor inside one frame reaches 3.8e-4, the soak draws such signals
-    tol = 3e-6 if (precise or not m.uses_fast_path or fft == 512) else 4e-4
+    if m.uses_fast_path and rng.random() < 0.25:
+        m.set_precise(True); precise = True
+    # default mode (AUTO: f32 FFT + f64 recompute of the frames the error bound does not cover): 1e-4 on everything the soak draws,
+    # including lines over a > 80 dB quieter floor inside one frame, where the bare f32 FFT reaches 4.9e-4
+    tol = 3e-6 if (precise or m.precise or fft == 512) else 1e-4
     mode = int(rng.integers(0, 4))
     tag = f"whisper fft={fft} hop={hop} mels={n_mels} sr={sr:.0f} precise={precise} mode={mode}"
     if mode == 0:                                   # ragged batch, host API
