@@ -489,7 +489,9 @@ int launch_fixup_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     q.list = static_cast<const uint32_t *>(c->guard.list.p);
     q.ctl = static_cast<uint32_t *>(c->guard.ctl.p);
     q.fpu = static_cast<uint32_t>(desc.frames_per_unit);
-    // one workgroup per CU is resident; small batches cannot queue more than their own frames
+    // one workgroup per CU is resident; small batches cannot queue more than their own frames.  (The size of this grid does
+    // not matter when the queue is empty: 1 / 8 / 32 / 256 workgroups all cost the bench step the same 9.5 us, the two
+    // dependent-launch gaps on the stream -- profiles/r02_guard.txt.)
     const uint64_t slots = desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);
     const uint64_t blocks = (slots + kPreciseWaves * kFPW - 1) / (kPreciseWaves * kFPW);
     const unsigned grid = grid_for(blocks, c->dev.cus, 1);
