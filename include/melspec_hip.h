@@ -37,6 +37,7 @@ extern "C" {
 #define MELSPEC_ERR_INTERNAL      (-5)
 
 typedef struct melspec_ctx melspec_ctx;      /* Whisper-style log-mel (HipMelSpectrogram) */
+typedef struct melspec_sharded melspec_sharded;   /* one melspec_ctx per GPU of the node, clips split per device */
 typedef struct melspec_fbank melspec_fbank;  /* Kaldi-style fbank (Fbank)                  */
 
 /* ---- library / device ------------------------------------------------------------- */
@@ -97,6 +98,40 @@ int melspec_guard_last_count(melspec_ctx *ctx, uint64_t *frames);
  * Empty/short input -> *n_frames = 0, MELSPEC_OK (src/cuda.rs:91-93). Synchronous. */
 int melspec_compute_host(melspec_ctx *ctx, const float *samples, size_t n_samples,
                          float *out, size_t out_capacity_floats, size_t *n_frames);
+
+/* Additive surface: many host clips in one call.  Clip i = samples + offsets[i] (lengths[i] samples); its frames go to
+ * out + out_offsets[i] floats (NULL: packed back to back in clip order); *total_frames = frames of all clips.
+ * The call is cut into ~16 MiB chunks whose upload, kernels and download overlap on three streams (the reference plugin
+ * chunks at 8192 frames with a synchronise per chunk, src/cuda.rs:150-155,343-351); memory from melspec_host_alloc (or
+ * any pinned memory) is DMA'd in place, pageable memory is staged through pinned buffers by helper threads.
+ * melspec_compute_host takes the same pipeline for clips longer than ~8 MB.  Synchronous. */
+int melspec_compute_batch_host(melspec_ctx *ctx, const float *samples, const uint64_t *offsets, const uint64_t *lengths,
+                               uint32_t n_clips, float *out, const uint64_t *out_offsets, size_t out_capacity_floats,
+                               uint64_t *total_frames);
+/* Pinned host memory (cudaMallocHost of src/cuda.rs:185-199): buffers from here skip the staging copy of the host calls. */
+int melspec_host_alloc(void **p, size_t bytes);
+int melspec_host_free(void *p);
+
+/* ---- the GPUs of one node (additive: the reference binds one device, src/cuda.rs:246-247) ----------------------------
+ * Every frame (Whisper) is independent, so clips are split into contiguous blocks per device, balanced by samples, and no
+ * collective touches the data.  bounds[k] .. bounds[k+1] = the clips of shard k, k < n_shards. */
+int melspec_shard_by_samples(const uint64_t *lengths, uint32_t n_clips, int n_shards, uint32_t *bounds /* [n_shards + 1] */);
+/* One context + stream per listed device (devices == NULL: every gfx950 device; a device may be listed more than once). */
+int melspec_sharded_create(melspec_sharded **out, const int *devices, int n_devices, int fft_size, int hop_size,
+                           double sampling_rate, int n_mels);
+void melspec_sharded_destroy(melspec_sharded *s);
+int melspec_sharded_n_shards(const melspec_sharded *s);
+melspec_ctx *melspec_sharded_ctx(melspec_sharded *s, int shard);   /* for device-resident work on one shard; owned by s */
+/* melspec_compute_batch_host over all devices: one host thread per device drives that device's pipeline on its block of
+ * clips; every shard writes its own part of `out`.  Synchronous. */
+int melspec_sharded_compute_batch_host(melspec_sharded *s, const float *samples, const uint64_t *offsets, const uint64_t *lengths,
+                                       uint32_t n_clips, float *out, const uint64_t *out_offsets, size_t out_capacity_floats,
+                                       uint64_t *total_frames);
+/* Optional consolidation of device-resident results on one device: bytes[i] bytes at srcs[i] (device src_devices[i]) ->
+ * dst + dst_offsets[i] bytes on dst_device, each piece on a stream of its source device (hipMemcpyPeerAsync: the pieces
+ * cross their own xGMI links concurrently).  Synchronous; time it separately from the frames/s figure. */
+int melspec_gather_peer(int dst_device, void *dst, const int *src_devices, const void *const *srcs, const size_t *bytes,
+                        const size_t *dst_offsets, int n);
 
 /* Additive surface (the reference has no multi-clip call): many equal-length clips in
  * one launch, PCM and output resident in HBM.  Clip c = d_pcm[c*clip_stride .. +clip_len).

@@ -61,6 +61,16 @@ SIGNATURES = {
     "melspec_set_precise": (C.c_int, [_vp, C.c_int]),
     "melspec_is_precise": (C.c_int, [_vp]),
     "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "melspec_compute_batch_host": (C.c_int, [_vp, _f32p, _u64p, _u64p, C.c_uint32, _f32p, _u64p, C.c_size_t, _u64p]),
+    "melspec_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "melspec_host_free": (C.c_int, [_vp]),
+    "melspec_shard_by_samples": (C.c_int, [_u64p, C.c_uint32, C.c_int, _u32p]),
+    "melspec_sharded_create": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "melspec_sharded_destroy": (None, [_vp]),
+    "melspec_sharded_n_shards": (C.c_int, [_vp]),
+    "melspec_sharded_ctx": (_vp, [_vp, C.c_int]),
+    "melspec_sharded_compute_batch_host": (C.c_int, [_vp, _f32p, _u64p, _u64p, C.c_uint32, _f32p, _u64p, C.c_size_t, _u64p]),
+    "melspec_gather_peer": (C.c_int, [C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]),
     "melspec_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "melspec_interleaved_width": (C.c_size_t, [_vp, C.c_size_t, C.c_size_t]),
     "melspec_compute_uniform_device_interleaved": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int,

@@ -16,12 +16,14 @@
 #include <atomic>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/melspec_hip.h"
 #include "fast_tables.hpp"
 #include "fbank_tables.hpp"
 #include "melspec_kernels.hpp"
+#include "host_pipe.hpp"
 #include "stream_plan.hpp"
 #include "tga_quant.hpp"
 #include "vad_columns.hpp"
@@ -419,6 +421,7 @@ struct melspec_ctx {
     // scratch
     RaggedScratch ragged;
     DevBuf h2d, d2h;
+    HostPipe pipe;          // chunked H2D / kernels / D2H pipeline of the host entry points (host_pipe.hpp)
 };
 
 namespace {
@@ -751,6 +754,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release(); c->h2d.release(); c->d2h.release();
     c->guard.release();
+    c->pipe.release();
     delete c;
 }
 
@@ -902,6 +906,34 @@ int melspec_synchronize(melspec_ctx *c, void *stream) {
     return MELSPEC_OK;
 }
 
+namespace {
+constexpr uint64_t kPipeChunkSamples = 4u << 20;      // 16 MiB of PCM per chunk
+constexpr uint64_t kPipeMinBytes = 8u << 20;          // smaller calls: one pageable copy each way, one launch (latency path)
+
+// clip (src, n) -> its frames at dst, cut into frame-aligned pieces of at most kPipeChunkSamples samples
+void push_segments(const melspec_ctx *c, const float *src, uint64_t n, float *dst, uint64_t frames, std::vector<HostSeg> &segs) {
+    if (frames == 0) return;
+    const uint64_t fft = static_cast<uint64_t>(c->fft_size), hop = static_cast<uint64_t>(c->hop_size);
+    if (n <= kPipeChunkSamples) { segs.push_back(HostSeg{src, n, dst, frames}); return; }
+    const uint64_t per = (kPipeChunkSamples - fft) / hop + 1;      // frames per piece
+    for (uint64_t f0 = 0; f0 < frames; f0 += per) {
+        const uint64_t nf = frames - f0 < per ? frames - f0 : per;
+        segs.push_back(HostSeg{src + f0 * hop, (nf - 1) * hop + fft, dst + f0 * static_cast<uint64_t>(c->n_mels), nf});
+    }
+}
+
+int run_host_pipe(melspec_ctx *c, const std::vector<HostSeg> &segs) {
+    const char *where = "";
+    const int rc = c->pipe.run(segs, c->n_mels, kPipeChunkSamples, c->stream,
+                               [c](const float *d_in, const uint64_t *offs, const uint64_t *lens, uint32_t n, float *d_out,
+                                   const uint64_t *ooffs, hipStream_t s) {
+                                   return melspec_compute_ragged_device(c, d_in, offs, lens, n, d_out, ooffs, s);
+                               }, &where);
+    if (rc > 0 && where[0] && std::strcmp(where, "kernel launch") != 0) return fail_hip(static_cast<hipError_t>(rc), where);
+    return rc;
+}
+}  // namespace
+
 int melspec_compute_host(melspec_ctx *c, const float *samples, size_t n_samples, float *out,
                          size_t out_capacity_floats, size_t *n_frames) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
@@ -913,6 +945,13 @@ int melspec_compute_host(melspec_ctx *c, const float *samples, size_t n_samples,
     if (out_capacity_floats < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
     HIP_TRY(hipSetDevice(c->dev.device));
     int rc;
+    if ((n_samples + need) * sizeof(float) >= kPipeMinBytes) {       // long clip: frame-aligned pieces through the pipeline
+        std::vector<HostSeg> segs;
+        push_segments(c, samples, n_samples, out, frames, segs);
+        if ((rc = run_host_pipe(c, segs))) return rc;
+        if (n_frames) *n_frames = static_cast<size_t>(frames);
+        return MELSPEC_OK;
+    }
     if ((rc = c->h2d.ensure(n_samples * sizeof(float)))) return rc;
     if ((rc = c->d2h.ensure(need * sizeof(float)))) return rc;
     HIP_TRY(hipMemcpyAsync(c->h2d.p, samples, n_samples * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -923,6 +962,177 @@ int melspec_compute_host(melspec_ctx *c, const float *samples, size_t n_samples,
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (n_frames) *n_frames = static_cast<size_t>(frames);
     return MELSPEC_OK;
+}
+
+int melspec_compute_batch_host(melspec_ctx *c, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
+                               float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_frames) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (total_frames) *total_frames = 0;
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!offsets || !lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    std::vector<HostSeg> segs;
+    segs.reserve(n_clips);
+    uint64_t total = 0, cursor = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        uint64_t f; ctx_num_frames(c, lengths[i], f);
+        const uint64_t oo = out_offsets ? out_offsets[i] : cursor;
+        const uint64_t fl = f * static_cast<uint64_t>(c->n_mels);
+        if (f && oo + fl > out_capacity_floats) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+        if (f && (!samples || !out)) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+        push_segments(c, samples + offsets[i], lengths[i], out + oo, f, segs);
+        cursor += fl; total += f;
+    }
+    if (total_frames) *total_frames = total;
+    if (total == 0) return MELSPEC_OK;
+    HIP_TRY(hipSetDevice(c->dev.device));
+    return run_host_pipe(c, segs);
+}
+
+int melspec_host_alloc(void **p, size_t bytes) {
+    if (!p) return fail(MELSPEC_ERR_INVALID_ARG, "p is NULL");
+    *p = nullptr;
+    HIP_TRY(hipHostMalloc(p, bytes ? bytes : 16, hipHostMallocDefault));
+    return MELSPEC_OK;
+}
+int melspec_host_free(void *p) {
+    if (p) HIP_TRY(hipHostFree(p));
+    return MELSPEC_OK;
+}
+
+// ---- per-clip sharding over the GPUs of one node (independent units, no data-path collective) -------------
+// The reference has no multi-device surface (src/cuda.rs binds one device); this is additive.  One context + stream per
+// device, one host thread per device while a call runs; contiguous blocks of clips per device, balanced by samples.
+
+int melspec_shard_by_samples(const uint64_t *lengths, uint32_t n_clips, int n_shards, uint32_t *bounds) {
+    if (n_shards < 1 || !bounds || (n_clips && !lengths)) return fail(MELSPEC_ERR_INVALID_ARG, "bad shard_by_samples argument");
+    long double total = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) total += static_cast<long double>(lengths[i]);
+    bounds[0] = 0;
+    int r = 1;
+    long double acc = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        acc += static_cast<long double>(lengths[i]);
+        while (r < n_shards && acc >= total * r / n_shards) bounds[r++] = i + 1;      // shard r-1 ends behind clip i
+    }
+    while (r <= n_shards) bounds[r++] = n_clips;
+    return MELSPEC_OK;
+}
+
+}  // extern "C"
+
+struct melspec_sharded {
+    std::vector<melspec_ctx *> ctx;
+};
+
+extern "C" {
+
+int melspec_sharded_create(melspec_sharded **out, const int *devices, int n_devices, int fft_size, int hop_size, double sampling_rate,
+                           int n_mels) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    std::vector<int> devs;
+    if (devices) {
+        if (n_devices < 1) return fail(MELSPEC_ERR_INVALID_ARG, "n_devices must be >= 1");
+        devs.assign(devices, devices + n_devices);
+    } else {
+        const int n = melspec_device_count();
+        if (n < 1) return n;
+        for (int d = 0; d < n; ++d) devs.push_back(d);
+    }
+    melspec_sharded *s = new (std::nothrow) melspec_sharded();
+    if (!s) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    for (int d : devs) {
+        melspec_ctx *c = nullptr;
+        const int rc = melspec_create(&c, d, fft_size, hop_size, sampling_rate, n_mels);
+        if (rc) { melspec_sharded_destroy(s); return rc; }
+        s->ctx.push_back(c);
+    }
+    *out = s;
+    return MELSPEC_OK;
+}
+
+void melspec_sharded_destroy(melspec_sharded *s) {
+    if (!s) return;
+    for (melspec_ctx *c : s->ctx) melspec_destroy(c);
+    delete s;
+}
+
+int melspec_sharded_n_shards(const melspec_sharded *s) { return s ? static_cast<int>(s->ctx.size()) : 0; }
+melspec_ctx *melspec_sharded_ctx(melspec_sharded *s, int shard) {
+    return (s && shard >= 0 && shard < static_cast<int>(s->ctx.size())) ? s->ctx[shard] : nullptr;
+}
+
+int melspec_sharded_compute_batch_host(melspec_sharded *s, const float *samples, const uint64_t *offsets, const uint64_t *lengths,
+                                       uint32_t n_clips, float *out, const uint64_t *out_offsets, size_t out_capacity_floats,
+                                       uint64_t *total_frames) {
+    if (!s || s->ctx.empty()) return fail(MELSPEC_ERR_INVALID_ARG, "sharded object is NULL");
+    if (total_frames) *total_frames = 0;
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!offsets || !lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    const int n = static_cast<int>(s->ctx.size());
+    std::vector<uint32_t> bounds(static_cast<size_t>(n) + 1);
+    int rc = melspec_shard_by_samples(lengths, n_clips, n, bounds.data());
+    if (rc) return rc;
+    // output positions are global (packed in clip order unless given), so every shard writes its own part of `out`
+    std::vector<uint64_t> oo(n_clips);
+    const int nm = s->ctx[0]->n_mels;
+    uint64_t cursor = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        oo[i] = out_offsets ? out_offsets[i] : cursor;
+        cursor += static_cast<uint64_t>(melspec_num_frames(s->ctx[0], lengths[i])) * nm;
+    }
+    std::vector<int> rcs(n, MELSPEC_OK);
+    std::vector<std::string> msgs(n);
+    std::vector<uint64_t> frames(n, 0);
+    auto work = [&](int k) {
+        const uint32_t lo = bounds[k], hi = bounds[k + 1];
+        if (hi == lo) return;
+        rcs[k] = melspec_compute_batch_host(s->ctx[k], samples, offsets + lo, lengths + lo, hi - lo, out, oo.data() + lo,
+                                            out_capacity_floats, &frames[k]);
+        if (rcs[k]) msgs[k] = g_last_error;          // thread-local: carried back to the caller's thread below
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < n; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (auto &t : threads) t.join();
+    uint64_t total = 0;
+    for (int k = 0; k < n; ++k) {
+        if (rcs[k]) { g_last_error = "shard " + std::to_string(k) + ": " + msgs[k]; return rcs[k]; }
+        total += frames[k];
+    }
+    if (total_frames) *total_frames = total;
+    return MELSPEC_OK;
+}
+
+// Consolidation of per-device results on one device (optional, not part of the frames/s figure): piece i =
+// bytes[i] bytes at srcs[i] on src_devices[i] -> dst + dst_offsets[i] on dst_device, every piece on a stream of its source
+// device so that the pieces travel over their own xGMI links at the same time.  Synchronous.
+int melspec_gather_peer(int dst_device, void *dst, const int *src_devices, const void *const *srcs, const size_t *bytes,
+                        const size_t *dst_offsets, int n) {
+    if (n <= 0) return MELSPEC_OK;
+    if (!dst || !src_devices || !srcs || !bytes || !dst_offsets) return fail(MELSPEC_ERR_INVALID_ARG, "NULL argument");
+    std::vector<hipStream_t> streams(n, nullptr);
+    int rc = MELSPEC_OK;
+    for (int i = 0; i < n && !rc; ++i) {
+        if (bytes[i] == 0) continue;
+        hipError_t e = hipSetDevice(src_devices[i]);
+        if (e == hipSuccess && src_devices[i] != dst_device) {
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, src_devices[i], dst_device);
+            if (can) { const hipError_t pe = hipDeviceEnablePeerAccess(dst_device, 0); if (pe != hipSuccess) (void)hipGetLastError(); }   // already enabled is fine
+        }
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(static_cast<char *>(dst) + dst_offsets[i], dst_device, srcs[i], src_devices[i], bytes[i], streams[i]);
+        if (e != hipSuccess) rc = fail_hip(e, "melspec_gather_peer");
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!streams[i]) continue;
+        (void)hipSetDevice(src_devices[i]);
+        const hipError_t e = hipStreamSynchronize(streams[i]);
+        if (e != hipSuccess && !rc) rc = fail_hip(e, "melspec_gather_peer: hipStreamSynchronize");
+        (void)hipStreamDestroy(streams[i]);
+    }
+    return rc;
 }
 
 // ---- host-side table builders ------------------------------------------------------------

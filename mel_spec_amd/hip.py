@@ -91,6 +91,28 @@ class DeviceBuffer:
             pass
 
 
+class HostBuffer:
+    """Pinned host memory (melspec_host_alloc) as a numpy f32 array: the host pipeline DMA's it in place."""
+
+    def __init__(self, n_floats: int):
+        p = C.c_void_p()
+        _check(lib().melspec_host_alloc(C.byref(p), max(int(n_floats), 1) * 4))
+        self._p = p
+        self.array = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(max(int(n_floats), 1),))[:int(n_floats)]
+
+    def free(self) -> None:
+        if self._p is not None and self._p.value:
+            self.array = None
+            lib().melspec_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def synth_pcm_device(buf_ptr: int, clip_stride: int, clip_len: int, first_clip: int, n_clips: int,
                      seed: int = 0x4D454C53, stream: int = 0) -> None:
     _check(lib().melspec_synth_pcm_device(C.c_void_p(buf_ptr), clip_stride, clip_len, first_clip, n_clips, seed,
@@ -219,8 +241,24 @@ class HipMelSpectrogram:
                                                  C.c_void_p(d_out), warmup, iters, C.byref(ms)))
         return float(ms.value)
 
+    def compute_batch_host(self, flat: np.ndarray, offsets, lengths, out: np.ndarray | None = None, out_offsets=None):
+        """melspec_compute_batch_host: clip i = flat[offsets[i] : offsets[i] + lengths[i]] -> its frames at out[out_offsets[i]:]
+        (floats; None = packed).  Returns (out, total_frames).  flat / out may be pinned (HostBuffer.array)."""
+        x = flat if isinstance(flat, np.ndarray) and flat.dtype == np.float32 and flat.flags.c_contiguous else _f32(flat).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        frames = np.array([self.num_frames(int(n)) for n in ln], dtype=np.uint64)
+        if out is None:
+            out = np.empty(int(frames.sum()) * self.n_mels, np.float32)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        total = C.c_uint64(0)
+        _check(lib().melspec_compute_batch_host(self._h, _fp(x.reshape(-1)), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
+                                                _fp(out.reshape(-1)), None if oo is None else oo.ctypes.data_as(u64p), out.size, C.byref(total)))
+        return out, int(total.value)
+
     def compute_batch(self, clips) -> np.ndarray:
-        """[n_clips, clip_len] host f32 -> [n_clips, frames, n_mels] host f32 in one launch."""
+        """[n_clips, clip_len] host f32 -> [n_clips, frames, n_mels] host f32 through the chunked host pipeline."""
         x = _f32(clips)
         assert x.ndim == 2
         n_clips, clip_len = x.shape
@@ -228,35 +266,21 @@ class HipMelSpectrogram:
         out = np.empty((n_clips, nf, self.n_mels), np.float32)
         if out.size == 0:
             return out
-        din, dout = DeviceBuffer(x.nbytes), DeviceBuffer(out.nbytes)
-        try:
-            din.upload(x)
-            self.compute_uniform_device(din.ptr, clip_len, clip_len, n_clips, dout.ptr)
-            self.synchronize()
-            out = dout.download(out.shape)
-        finally:
-            din.free(); dout.free()
+        offs = np.arange(n_clips, dtype=np.uint64) * np.uint64(clip_len)
+        self.compute_batch_host(x.reshape(-1), offs, np.full(n_clips, clip_len, np.uint64), out.reshape(-1))
         return out
 
     def compute_ragged(self, clips) -> list:
-        """List of 1-D host arrays of any lengths -> list of [frames_i, n_mels] arrays, one launch."""
+        """List of 1-D host arrays of any lengths -> list of [frames_i, n_mels] arrays, one call of the host pipeline."""
         arrs = [_f32(c).reshape(-1) for c in clips]
         lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
         offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
         frames = [self.num_frames(int(n)) for n in lens]
-        total_out = sum(frames) * self.n_mels
         flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
-        din, dout = DeviceBuffer(max(flat.nbytes, 16)), DeviceBuffer(max(total_out * 4, 16))
-        try:
-            din.upload(flat)
-            self.compute_ragged_device(din.ptr, offs, lens, dout.ptr)
-            self.synchronize()
-            host = dout.download((total_out,)) if total_out else np.zeros(0, np.float32)
-        finally:
-            din.free(); dout.free()
+        out, _ = self.compute_batch_host(flat, offs, lens)
         res, cur = [], 0
         for f in frames:
-            res.append(host[cur:cur + f * self.n_mels].reshape(f, self.n_mels).copy())
+            res.append(out[cur:cur + f * self.n_mels].reshape(f, self.n_mels))
             cur += f * self.n_mels
         return res
 

@@ -19,19 +19,94 @@ def shard_range(n_items: int, rank: int, world_size: int) -> tuple[int, int]:
 
 
 def shard_by_samples(lengths, world_size: int) -> list[tuple[int, int]]:
-    """Contiguous clip ranges balanced by total samples (ragged batches)."""
-    total = float(sum(lengths))
-    bounds, acc, lo, r = [], 0.0, 0, 1
-    for i, n in enumerate(lengths):
-        acc += n
-        while r < world_size and acc >= total * r / world_size:
-            bounds.append((lo, i + 1))
-            lo = i + 1
-            r += 1
-    bounds.append((lo, len(lengths)))
-    while len(bounds) < world_size:
-        bounds.append((len(lengths), len(lengths)))
-    return bounds[:world_size]
+    """Contiguous clip ranges balanced by total samples (ragged batches): melspec_shard_by_samples, host logic of the
+    library (runs without a GPU)."""
+    import ctypes as C
+    import numpy as np
+    from ._lib import lib
+    if world_size < 1:
+        raise ValueError("world_size must be >= 1")
+    ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+    bounds = np.zeros(world_size + 1, np.uint32)
+    rc = lib().melspec_shard_by_samples(ln.ctypes.data_as(C.POINTER(C.c_uint64)), ln.shape[0], world_size,
+                                        bounds.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc:
+        raise ValueError("melspec_shard_by_samples failed")
+    return [(int(bounds[k]), int(bounds[k + 1])) for k in range(world_size)]
+
+
+class ShardedMelSpectrogram:
+    """HipMelSpectrogram over the GPUs of one node (melspec_sharded_*): one context + stream per device, one host thread per
+    device while a call runs, contiguous blocks of clips per device balanced by samples, no collective.  `devices`: list of
+    device indices (None = every gfx950 device; listing a device twice gives it two contexts -- how the 1-GPU tests exercise
+    the multi-context path)."""
+
+    def __init__(self, fft_size: int, hop_size: int, sampling_rate: float, n_mels: int, devices=None):
+        import ctypes as C
+        from ._lib import lib
+        from .hip import _check
+        self._h = None
+        h = C.c_void_p()
+        if devices is None:
+            _check(lib().melspec_sharded_create(C.byref(h), None, 0, fft_size, hop_size, float(sampling_rate), n_mels), construct=True)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().melspec_sharded_create(C.byref(h), arr, len(devices), fft_size, hop_size, float(sampling_rate), n_mels), construct=True)
+        self._h = h
+        self.n_mels, self.fft_size, self.hop_size = n_mels, fft_size, hop_size
+        self.n_shards = int(lib().melspec_sharded_n_shards(h))
+
+    def num_frames(self, n: int) -> int:
+        return 0 if n < self.fft_size else (n - self.fft_size) // self.hop_size + 1
+
+    def compute_ragged(self, clips) -> list:
+        """list of 1-D host arrays -> list of [frames_i, n_mels] arrays; shard k computes clips bounds[k]:bounds[k+1]"""
+        import ctypes as C
+        import numpy as np
+        from ._lib import lib
+        from .hip import _check, _f32, _fp
+        arrs = [_f32(c).reshape(-1) for c in clips]
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
+        frames = [self.num_frames(int(n)) for n in lens]
+        flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
+        out = np.empty(max(sum(frames) * self.n_mels, 1), np.float32)
+        total = C.c_uint64(0)
+        u64p = C.POINTER(C.c_uint64)
+        _check(lib().melspec_sharded_compute_batch_host(self._h, _fp(flat), offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p), len(arrs),
+                                                        _fp(out), None, out.size, C.byref(total)))
+        assert int(total.value) == sum(frames)
+        res, cur = [], 0
+        for f in frames:
+            res.append(out[cur:cur + f * self.n_mels].reshape(f, self.n_mels))
+            cur += f * self.n_mels
+        return res
+
+    def close(self) -> None:
+        if self._h is not None:
+            from ._lib import lib
+            lib().melspec_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def gather_peer(dst_device: int, dst_ptr: int, pieces) -> None:
+    """melspec_gather_peer: pieces = [(src_device, src_ptr, n_bytes, dst_offset_bytes), ...], copied concurrently (one
+    stream per source device, hipMemcpyPeerAsync over xGMI)."""
+    import ctypes as C
+    from ._lib import lib
+    from .hip import _check
+    n = len(pieces)
+    devs = (C.c_int * n)(*[p[0] for p in pieces])
+    srcs = (C.c_void_p * n)(*[p[1] for p in pieces])
+    sizes = (C.c_size_t * n)(*[p[2] for p in pieces])
+    offs = (C.c_size_t * n)(*[p[3] for p in pieces])
+    _check(lib().melspec_gather_peer(dst_device, C.c_void_p(dst_ptr), devs, srcs, sizes, offs, n))
 
 
 def timed_steps(step, synchronize, steps: int, warmup: int, dist=None, device=None):

@@ -639,3 +639,48 @@ def test_nemo_normalisation_of_a_silent_clip_matches_the_reference_fold(gpu, ora
     assert np.abs(want[:, :valid]).max() > 0.1            # the artefact is there in the reference
     assert np.abs(got - want).max() <= 1e-6
     fe.close()
+
+
+def test_host_pipeline_pageable_and_pinned_memory(gpu, w80, oracle, jfk):
+    """melspec_compute_batch_host: several ~16 MiB chunks in flight (upload / kernels / download on three streams), clips longer
+    than a chunk cut at frame boundaries, scattered output offsets; pageable memory (staged by the helper threads) and pinned
+    memory (DMA in place) must give the bits the device-resident path gives."""
+    rng = np.random.default_rng(5)
+    lens = [int(n) for n in rng.integers(0, 400000, 150)] + [5_000_000, 399, 400, 0, 9_000_001]
+    clips = [oracle.synth_pcm(i, n) if i % 3 else np.resize(jfk, n).astype(np.float32) for i, n in enumerate(lens)]
+    flat = np.concatenate(clips)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    frames = np.array([w80.num_frames(n) for n in lens], dtype=np.uint64)
+    # outputs in reverse clip order with a gap of 7 floats between them
+    sizes = frames * 80 + 7
+    ooff = (np.cumsum(sizes[::-1])[::-1] - sizes).astype(np.uint64)
+    total = int(sizes.sum())
+    # device-resident reference result of the same ragged batch
+    din, dout = gpu.DeviceBuffer(flat.nbytes), gpu.DeviceBuffer(total * 4)
+    din.upload(flat)
+    w80.compute_ragged_device(din.ptr, offs, np.array(lens, np.uint64), dout.ptr, ooff)
+    w80.synchronize()
+    ref = dout.download((total,))
+    din.free(); dout.free()
+    mask = np.zeros(total, bool)
+    for f, o in zip(frames, ooff):
+        mask[int(o):int(o) + int(f) * 80] = True
+    out = np.full(total, np.nan, np.float32)
+    _, tf = w80.compute_batch_host(flat, offs, lens, out, ooff)
+    assert tf == int(frames.sum()) and np.array_equal(out[mask], ref[mask]) and np.all(np.isnan(out[~mask]))
+    hin, hout = gpu.HostBuffer(flat.size), gpu.HostBuffer(total)
+    hin.array[:] = flat
+    hout.array[:] = np.nan
+    w80.compute_batch_host(hin.array, offs, lens, hout.array, ooff)
+    assert np.array_equal(hout.array[mask], ref[mask]) and np.all(np.isnan(hout.array[~mask]))
+    for i in (0, 7, 150, 154):                       # and against the oracle, including both clips longer than a chunk
+        want = oracle.compute_mel_spectrogram_cpu(clips[i], 400, 160, 80, SR)
+        got = out[int(ooff[i]):int(ooff[i]) + want.size].reshape(want.shape)
+        assert np.abs(got - want).max() <= TOL
+    # the single-clip entry point takes the same pipeline for long clips (compute_mel_spectrogram of ~9 M samples)
+    long_clip = clips[154]
+    assert np.abs(w80.compute_mel_spectrogram(long_clip) - oracle.compute_mel_spectrogram_cpu(long_clip, 400, 160, 80, SR)).max() <= TOL
+    hin.free(); hout.free()
+    # capacity and argument errors come back as codes, not crashes
+    with pytest.raises(gpu.HipRuntimeError):
+        w80.compute_batch_host(flat, offs, lens, np.empty(10, np.float32), ooff)

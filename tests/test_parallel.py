@@ -26,13 +26,66 @@ def test_shard_range_partitions_exactly():
 
 
 def test_shard_by_samples_balances_ragged():
+    """melspec_shard_by_samples (host logic of the library, no GPU needed): what ShardedMelSpectrogram splits by."""
     lengths = [480000] * 10 + [16000] * 300 + [160000] * 50
-    for w in (2, 4, 8):
+    for w in (1, 2, 4, 8):
         b = shard_by_samples(lengths, w)
         assert len(b) == w and b[0][0] == 0 and b[-1][1] == len(lengths)
         assert all(x[1] == y[0] for x, y in zip(b, b[1:]))
         loads = [sum(lengths[lo:hi]) for lo, hi in b]
         assert max(loads) <= sum(lengths) / w + max(lengths)
+    # degenerate inputs: fewer clips than shards, empty clips, nothing at all
+    assert shard_by_samples([5, 5], 4)[-1][1] == 2 and sum(hi - lo for lo, hi in shard_by_samples([5, 5], 4)) == 2
+    assert shard_by_samples([], 3) == [(0, 0)] * 3
+    b = shard_by_samples([0, 0, 7, 0], 2)
+    assert b[0][0] == 0 and b[-1][1] == 4 and b[0][1] == b[1][0]
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        ln = rng.integers(0, 500000, int(rng.integers(1, 400))).tolist()
+        w = int(rng.integers(1, 9))
+        b = shard_by_samples(ln, w)
+        assert b[0][0] == 0 and b[-1][1] == len(ln) and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+        assert max(sum(ln[lo:hi]) for lo, hi in b) <= sum(ln) / w + max(ln)
+
+
+def test_sharded_object_without_a_gpu_reports_unavailable():
+    """The spawn path needs devices; on a box without one construction fails like CudaError::Unavailable (src/cuda.rs:10-25)
+    and nothing falls back to the CPU."""
+    import mel_spec_amd as M
+    if M._lib.lib().melspec_device_count() >= 1:
+        pytest.skip("a GPU is visible: covered by the -m gpu test below")
+    with pytest.raises(M.HipUnavailable):
+        M.ShardedMelSpectrogram(400, 160, 16000.0, 80, devices=[0, 0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0, 0], None])
+def test_sharded_mel_spectrogram_on_the_devices_of_this_box(gpu, oracle, jfk, devices):
+    """One context + stream + host thread per listed device; a device listed several times gets several contexts, which is
+    how a 1-GPU box runs the multi-shard path (threads, per-shard pipelines, disjoint output ranges)."""
+    rng = np.random.default_rng(11)
+    clips = [jfk[int(a):int(a) + int(n)] for a, n in zip(rng.integers(0, 60000, 37), rng.integers(0, 90000, 37))]
+    clips += [oracle.synth_pcm(3, 3_000_000), np.zeros(399, np.float32), oracle.synth_pcm(5, 400)]      # a clip longer than a pipeline chunk
+    sh = gpu.ShardedMelSpectrogram(400, 160, 16000.0, 80, devices=devices)
+    assert sh.n_shards == (len(devices) if devices else gpu.device_count())
+    got = sh.compute_ragged(clips)
+    for g, x in zip(got, clips):
+        want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, 80, 16000.0)
+        assert g.shape == want.shape and (g.size == 0 or np.abs(g - want).max() <= 1e-4)
+    sh.close()
+
+
+@pytest.mark.gpu
+def test_gather_peer_consolidates_device_results(gpu):
+    """melspec_gather_peer with every piece on device 0 (the only one of this box): the offsets / sizes / streams path."""
+    a = gpu.DeviceBuffer(4096 * 4); b = gpu.DeviceBuffer(1000 * 4); dst = gpu.DeviceBuffer(6000 * 4)
+    xa, xb = np.arange(4096, dtype=np.float32), -np.arange(1000, dtype=np.float32)
+    a.upload(xa); b.upload(xb)
+    gpu.gather_peer(0, dst.ptr, [(0, a.ptr, 4096 * 4, 0), (0, b.ptr, 1000 * 4, 5000 * 4)])
+    got = dst.download((6000,))
+    assert np.array_equal(got[:4096], xa) and np.array_equal(got[5000:], xb)
+    for x in (a, b, dst):
+        x.free()
 
 
 WORKER = r'''
