@@ -108,6 +108,26 @@ int melspec_compute_host(melspec_ctx *ctx, const float *samples, size_t n_sample
 int melspec_compute_batch_host(melspec_ctx *ctx, const float *samples, const uint64_t *offsets, const uint64_t *lengths,
                                uint32_t n_clips, float *out, const uint64_t *out_offsets, size_t out_capacity_floats,
                                uint64_t *total_frames);
+/* ---- STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) ---------------------------------------------------
+ * The complex spectrum of every frame instead of its mel row (callers such as examples/vad_ten_eval/src/main.rs:232-256 feed
+ * it to dense mel code of their own).  Always computed in f64 like the reference (frame_windows + forward FFT); stored as
+ * interleaved (re, im) pairs of float (MELSPEC_STFT_F32) or double (MELSPEC_STFT_F64), `bins` per frame:
+ * full == 0: n_fft/2 + 1 (the input is real); full != 0: n_fft, the reference's Vec<Complex<f64>> layout, upper half =
+ * conjugate mirror.  d_out = [clip][frame][bins]; out offsets / capacities count complex elements. */
+#define MELSPEC_STFT_F32 0
+#define MELSPEC_STFT_F64 1
+size_t melspec_stft_bins(const melspec_ctx *ctx, int full);
+int melspec_stft_uniform_device(melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len, uint32_t n_clips,
+                                void *d_out, int dtype, int full, void *stream);
+int melspec_stft_ragged_device(melspec_ctx *ctx, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                               uint32_t n_clips, void *d_out, const uint64_t *h_out_offsets, int dtype, int full, void *stream);
+/* compute_all_cpu(samples) on the GPU: host PCM in, host [frames][bins] complex out.  Synchronous. */
+int melspec_stft_host(melspec_ctx *ctx, const float *samples, size_t n_samples, void *out, size_t out_capacity_complex,
+                      int dtype, int full, size_t *n_frames);
+
+/* The context's scratch only grows (pipeline buffers sized by the largest chunk, the precision guard's queue of 4 B per frame of
+ * the largest batch, ragged plans): this waits for the context's queued work and gives all of it back.  The next call re-allocates. */
+int melspec_release_scratch(melspec_ctx *ctx);
 /* Pinned host memory (cudaMallocHost of src/cuda.rs:185-199): buffers from here skip the staging copy of the host calls. */
 int melspec_host_alloc(void **p, size_t bytes);
 int melspec_host_free(void *p);
@@ -279,6 +299,10 @@ size_t melspec_stream_frames_after(const melspec_stream *st, uint32_t id, uint32
  * frames_out[i] how many entry i emitted.  Synchronous. */
 int melspec_stream_push_host(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
                              float *out, size_t out_capacity_floats, uint32_t *frames_out);
+/* The same push emitting what Spectrogram::add itself returns (src/stft.rs:48-86): the spectrum of every completed frame,
+ * [frame][bins] complex per entry (melspec_stft_bins; dtype MELSPEC_STFT_F32 / _F64), instead of its mel row. */
+int melspec_stream_push_host_stft(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                                  void *out, size_t out_capacity_complex, uint32_t *frames_out, int dtype, int full);
 /* Spectrogram::add with fewer than hop samples (src/stft.rs:57-60): the pending samples of each listed
  * stream are zero-padded to a hop, idx advances by the real samples only, at most one frame each. */
 int melspec_stream_flush_host(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,

@@ -62,6 +62,11 @@ SIGNATURES = {
     "melspec_is_precise": (C.c_int, [_vp]),
     "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_compute_batch_host": (C.c_int, [_vp, _f32p, _u64p, _u64p, C.c_uint32, _f32p, _u64p, C.c_size_t, _u64p]),
+    "melspec_release_scratch": (C.c_int, [_vp]),
+    "melspec_stft_bins": (C.c_size_t, [_vp, C.c_int]),
+    "melspec_stft_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _vp]),
+    "melspec_stft_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, C.c_int, C.c_int, _vp]),
+    "melspec_stft_host": (C.c_int, [_vp, _f32p, C.c_size_t, _vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "melspec_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "melspec_host_free": (C.c_int, [_vp]),
     "melspec_shard_by_samples": (C.c_int, [_u64p, C.c_uint32, C.c_int, _u32p]),
@@ -111,6 +116,7 @@ SIGNATURES = {
     "melspec_stream_reset": (C.c_int, [_vp, _u32p, C.c_uint32]),
     "melspec_stream_frames_after": (C.c_size_t, [_vp, C.c_uint32, C.c_uint32]),
     "melspec_stream_push_host": (C.c_int, [_vp, _u32p, _f32p, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p]),
+    "melspec_stream_push_host_stft": (C.c_int, [_vp, _u32p, _f32p, _u32p, C.c_uint32, _vp, C.c_size_t, _u32p, C.c_int, C.c_int]),
     "melspec_stream_flush_host": (C.c_int, [_vp, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p]),
     "melspec_stream_input_ptr": (_vp, [_vp, C.c_uint32]),
     "melspec_stream_push_device": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, _vp, _u64p, _u32p, _vp]),

@@ -124,6 +124,8 @@ inline bool host_ptr_is_pinned(const void *p) {
 struct HostPipe {
     static constexpr int kBuf = 2;
     static constexpr size_t kDirectPieces = 32;          // more DMA requests than this per chunk: gather through staging instead
+    static constexpr uint64_t kDirectBytes = 32u << 20;  // calls up to this size (PCM + mel): no pipeline, see run()
+    static constexpr uint64_t kMinChunkSamples = 1u << 18;
     hipStream_t s_in = nullptr, s_out = nullptr;
     void *d_in[kBuf] = {}, *d_out[kBuf] = {};
     size_t d_in_cap[kBuf] = {}, d_out_cap[kBuf] = {};
@@ -200,6 +202,14 @@ struct HostPipe {
                                 host_ptr_is_pinned(segs.back().dst + segs.back().frames * static_cast<uint64_t>(n_mels) - 1);
         struct Chunk { size_t first, count; uint64_t samples, out_floats; bool staged_out; };
         std::vector<Chunk> chunks;
+        uint64_t total_samples = 0, total_out = 0;
+        for (const HostSeg &sg : segs) { total_samples += sg.n; total_out += sg.frames * static_cast<uint64_t>(n_mels); }
+        // small calls: one chunk, copied by the runtime straight from / to the caller's memory on the compute stream (its
+        // pageable path is as fast as pinned DMA up to a few tens of MB and there is nothing to overlap); large calls: at least
+        // eight chunks in the pipeline
+        const bool direct = (total_samples + total_out) * sizeof(float) <= kDirectBytes;
+        if (direct) chunk_samples = ~0ull;
+        else if (total_samples / 8 < chunk_samples) chunk_samples = total_samples / 8 > kMinChunkSamples ? total_samples / 8 : kMinChunkSamples;
         for (size_t i = 0; i < segs.size();) {
             Chunk c{i, 0, 0, 0, false};
             while (i < segs.size() && (c.count == 0 || (c.samples + segs[i].n <= chunk_samples && c.count < 65536))) {
@@ -237,6 +247,26 @@ struct HostPipe {
             pool->run(jobs);
             return 0;
         };
+        if (direct && chunks.size() == 1 && pieces_of(chunks[0], false).size() <= kDirectPieces && pieces_of(chunks[0], true).size() <= kDirectPieces) {
+            const Chunk &c = chunks[0];
+            MS_PIPE_TRY(grow_dev(d_in[0], d_in_cap[0], static_cast<size_t>(c.samples) * sizeof(float) + 16));
+            MS_PIPE_TRY(grow_dev(d_out[0], d_out_cap[0], static_cast<size_t>(c.out_floats) * sizeof(float) + 16));
+            for (const Piece &p : pieces_of(c, false))
+                MS_PIPE_TRY(hipMemcpyAsync(static_cast<char *>(d_in[0]) + p.dev_off, p.host, p.bytes, hipMemcpyHostToDevice, compute));
+            uint64_t so = 0, oo = 0;
+            for (size_t i = c.first; i < c.first + c.count; ++i) {
+                offs.push_back(so); lens.push_back(segs[i].n); ooffs.push_back(oo);
+                so += segs[i].n;
+                oo += segs[i].frames * static_cast<uint64_t>(n_mels);
+            }
+            const int rc = launch(static_cast<const float *>(d_in[0]), offs.data(), lens.data(), static_cast<uint32_t>(c.count),
+                                  static_cast<float *>(d_out[0]), ooffs.data(), compute);
+            if (rc) { *where = "kernel launch"; (void)hipStreamSynchronize(compute); return rc; }
+            for (const Piece &p : pieces_of(c, true))
+                MS_PIPE_TRY(hipMemcpyAsync(const_cast<char *>(p.host), static_cast<const char *>(d_out[0]) + p.dev_off, p.bytes, hipMemcpyDeviceToHost, compute));
+            MS_PIPE_TRY(hipStreamSynchronize(compute));
+            return 0;
+        }
         for (size_t k = 0; k < chunks.size(); ++k) {
             Chunk &c = chunks[k];
             const int b = static_cast<int>(k % kBuf);

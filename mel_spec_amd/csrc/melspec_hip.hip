@@ -420,7 +420,6 @@ struct melspec_ctx {
     GenericTables gt;
     // scratch
     RaggedScratch ragged;
-    DevBuf h2d, d2h;
     HostPipe pipe;          // chunked H2D / kernels / D2H pipeline of the host entry points (host_pipe.hpp)
 };
 
@@ -752,7 +751,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release(); c->h2d.release(); c->d2h.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release();
     c->guard.release();
     c->pipe.release();
     delete c;
@@ -908,7 +907,6 @@ int melspec_synchronize(melspec_ctx *c, void *stream) {
 
 namespace {
 constexpr uint64_t kPipeChunkSamples = 4u << 20;      // 16 MiB of PCM per chunk
-constexpr uint64_t kPipeMinBytes = 8u << 20;          // smaller calls: one pageable copy each way, one launch (latency path)
 
 // clip (src, n) -> its frames at dst, cut into frame-aligned pieces of at most kPipeChunkSamples samples
 void push_segments(const melspec_ctx *c, const float *src, uint64_t n, float *dst, uint64_t frames, std::vector<HostSeg> &segs) {
@@ -945,21 +943,11 @@ int melspec_compute_host(melspec_ctx *c, const float *samples, size_t n_samples,
     if (out_capacity_floats < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
     HIP_TRY(hipSetDevice(c->dev.device));
     int rc;
-    if ((n_samples + need) * sizeof(float) >= kPipeMinBytes) {       // long clip: frame-aligned pieces through the pipeline
-        std::vector<HostSeg> segs;
-        push_segments(c, samples, n_samples, out, frames, segs);
-        if ((rc = run_host_pipe(c, segs))) return rc;
-        if (n_frames) *n_frames = static_cast<size_t>(frames);
-        return MELSPEC_OK;
-    }
-    if ((rc = c->h2d.ensure(n_samples * sizeof(float)))) return rc;
-    if ((rc = c->d2h.ensure(need * sizeof(float)))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h2d.p, samples, n_samples * sizeof(float), hipMemcpyHostToDevice, c->stream));
-    rc = melspec_compute_uniform_device(c, static_cast<const float *>(c->h2d.p), n_samples, n_samples, 1,
-                                        static_cast<float *>(c->d2h.p), c->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->d2h.p, need * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // one clip, or frame-aligned pieces of a long one, through the host pipeline (host_pipe.hpp; calls up to 32 MB take its
+    // single-chunk path: one copy each way by the runtime, one launch, one synchronise)
+    std::vector<HostSeg> segs;
+    push_segments(c, samples, n_samples, out, frames, segs);
+    if ((rc = run_host_pipe(c, segs))) return rc;
     if (n_frames) *n_frames = static_cast<size_t>(frames);
     return MELSPEC_OK;
 }
@@ -986,6 +974,136 @@ int melspec_compute_batch_host(melspec_ctx *c, const float *samples, const uint6
     if (total == 0) return MELSPEC_OK;
     HIP_TRY(hipSetDevice(c->dev.device));
     return run_host_pipe(c, segs);
+}
+
+// ---- STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) / Spectrogram::add (src/stft.rs:48-86) -----------------
+size_t melspec_stft_bins(const melspec_ctx *c, int full) {
+    return !c ? 0 : static_cast<size_t>(full ? c->fft_size : c->fft_size / 2 + 1);
+}
+
+namespace {
+int launch_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipStream_t s) {
+    if (desc.n_units == 0) return MELSPEC_OK;
+    const int words = bins * 2 * (dtype == MELSPEC_STFT_F64 ? 2 : 1);
+    if (c->fast) {
+        static std::atomic<uint64_t> attr_done{0};
+        if (!device_done(attr_done)) {
+            int rc = allow_big_lds(&whisper400_stft_kernel<float>, "hipFuncSetAttribute(whisper400_stft_kernel<float>)");
+            if (!rc) rc = allow_big_lds(&whisper400_stft_kernel<double>, "hipFuncSetAttribute(whisper400_stft_kernel<double>)");
+            if (rc) return rc;
+            mark_device_done(attr_done);
+        }
+        StftParams p{};
+        p.b = desc;
+        p.d_blob = static_cast<const uint32_t *>(c->d_blob64.p);
+        p.blob_words = PreciseBlob::kCount * 2;                    // the f64 tables only, not the mel section behind them
+        p.hop = c->hop_size; p.bins = bins; p.words_per_frame = words;
+        const size_t lds = static_cast<size_t>(p.blob_words) * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double);
+        const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
+        const unsigned grid = grid_for_xcd(blocks, c->dev.cus, 1);
+        if (dtype == MELSPEC_STFT_F64) hipLaunchKernelGGL(whisper400_stft_kernel<double>, dim3(grid), dim3(kPreciseWaves * 64), lds, s, p);
+        else hipLaunchKernelGGL(whisper400_stft_kernel<float>, dim3(grid), dim3(kPreciseWaves * 64), lds, s, p);
+        HIP_TRY(hipGetLastError());
+        return MELSPEC_OK;
+    }
+    GenericStftParams g{};
+    g.b = desc;
+    g.n_fft = c->fft_size; g.hop = c->hop_size; g.bins = bins; g.words_per_frame = words; g.f64 = dtype == MELSPEC_STFT_F64;
+    g.d_win = static_cast<const double *>(c->gt.win.p);
+    g.d_tw = static_cast<const double *>(c->gt.tw.p);
+    const size_t lds = sizeof(double) * 3 * static_cast<size_t>(c->fft_size);
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&generic_stft_kernel<kGenericNT>, "hipFuncSetAttribute(generic_stft_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    hipLaunchKernelGGL(generic_stft_kernel<kGenericNT>, dim3(grid_for(desc.n_units, c->dev.cus, 8)), dim3(kGenericNT), lds, s, g);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+int stft_args(const melspec_ctx *c, int dtype) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    return MELSPEC_OK;
+}
+}  // namespace
+
+int melspec_stft_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len, uint32_t n_clips,
+                                void *d_out, int dtype, int full, void *stream) {
+    int rc = stft_args(c, dtype);
+    if (rc) return rc;
+    if (n_clips == 0) return MELSPEC_OK;
+    uint64_t fpc; ctx_num_frames(c, clip_len, fpc);
+    if (fpc == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    const int bins = static_cast<int>(melspec_stft_bins(c, full));
+    const int words = bins * 2 * (dtype == MELSPEC_STFT_F64 ? 2 : 1);
+    const BatchPlan pl = plan_uniform(d_pcm, static_cast<float *>(d_out), clip_stride, fpc, n_clips, words, c->fast ? kFPW : 1);
+    return launch_stft(c, pl.desc, bins, dtype, stream ? static_cast<hipStream_t>(stream) : c->stream);
+}
+
+int melspec_stft_ragged_device(melspec_ctx *c, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths, uint32_t n_clips,
+                               void *d_out, const uint64_t *h_out_offsets, int dtype, int full, void *stream) {
+    int rc = stft_args(c, dtype);
+    if (rc) return rc;
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!h_offsets || !h_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    std::vector<uint64_t> frames(n_clips), oo;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) { ctx_num_frames(c, h_lengths[i], frames[i]); total += frames[i]; }
+    if (total == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const int bins = static_cast<int>(melspec_stft_bins(c, full));
+    const int words = bins * 2 * (dtype == MELSPEC_STFT_F64 ? 2 : 1);
+    if (h_out_offsets) {                          // complex elements -> 32-bit words
+        oo.resize(n_clips);
+        for (uint32_t i = 0; i < n_clips; ++i) oo[i] = h_out_offsets[i] * static_cast<uint64_t>(words / bins);
+    }
+    BatchPlan pl;
+    RaggedSlot *slot = nullptr;
+    rc = plan_ragged(c->ragged, s, d_pcm, static_cast<float *>(d_out), h_offsets, frames, h_out_offsets ? oo.data() : nullptr, n_clips, words,
+                     c->fast ? kFPW : 1, pl, slot);
+    if (!rc) rc = launch_stft(c, pl.desc, bins, dtype, s);
+    plan_ragged_done(slot, s);
+    return rc;
+}
+
+int melspec_stft_host(melspec_ctx *c, const float *samples, size_t n_samples, void *out, size_t out_capacity_complex, int dtype, int full,
+                      size_t *n_frames) {
+    int rc = stft_args(c, dtype);
+    if (rc) return rc;
+    if (n_frames) *n_frames = 0;
+    uint64_t frames; ctx_num_frames(c, n_samples, frames);
+    if (frames == 0) return MELSPEC_OK;
+    if (!samples || !out) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+    const uint64_t need = frames * melspec_stft_bins(c, full);
+    if (out_capacity_complex < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    const size_t esz = dtype == MELSPEC_STFT_F64 ? 16 : 8;
+    DevBuf din, dout;
+    auto done = [&](int code) { din.release(); dout.release(); return code; };
+    if ((rc = din.ensure(n_samples * sizeof(float))) || (rc = dout.ensure(need * esz))) return done(rc);
+    if (hipMemcpyAsync(din.p, samples, n_samples * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "hipMemcpyAsync failed"));
+    if ((rc = melspec_stft_uniform_device(c, static_cast<const float *>(din.p), n_samples, n_samples, 1, dout.p, dtype, full, c->stream))) return done(rc);
+    if (hipMemcpyAsync(out, dout.p, need * esz, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "hipMemcpyAsync failed"));
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return done(fail(MELSPEC_ERR_INTERNAL, "hipStreamSynchronize failed"));
+    if (n_frames) *n_frames = static_cast<size_t>(frames);
+    return done(MELSPEC_OK);
+}
+
+int melspec_release_scratch(melspec_ctx *c) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->guard.used) HIP_TRY(hipStreamSynchronize(c->guard.last_stream));
+    c->pipe.release();
+    c->guard.release();
+    c->ragged.release();
+    return MELSPEC_OK;
 }
 
 int melspec_host_alloc(void **p, size_t bytes) {
@@ -1363,9 +1481,15 @@ void stream_commit(melspec_stream *st, const uint32_t *ids, const uint32_t *lens
     stream_commit_push(st->geom, st->book, ids, lens, n, flush);
 }
 
+// what a push emits per frame: the mel row (Spectrogram::add + MelSpectrogram::add) or the spectrum (Spectrogram::add alone)
+struct StreamEmit {
+    bool stft = false;
+    int dtype = MELSPEC_STFT_F32, full = 0;
+};
+
 // scatter (optional) -> frames -> carry update, all on one stream
-int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float *d_src, float *d_out, const uint64_t *h_out_off,
-               hipStream_t s) {
+int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float *d_src, void *d_out, const uint64_t *h_out_off,
+               hipStream_t s, const StreamEmit &emit = StreamEmit()) {
     melspec_ctx *c = st->ctx;
     HIP_TRY(hipSetDevice(c->dev.device));
     if (pl.total_frames && !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");      // before anything is queued
@@ -1395,8 +1519,16 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
         hipLaunchKernelGGL(stream_scatter_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e, d_src);
         HIP_TRY(hipGetLastError());
     }
-    if (pl.total_frames) {
-        rc = melspec_compute_ragged_device(c, state, pl.off.data(), pl.len.data(), n, d_out, h_out_off ? h_out_off : pl.out_off.data(), s);
+    if (pl.total_frames && emit.stft) {
+        std::vector<uint64_t> oo(n);            // complex elements, entries back to back
+        uint64_t cur = 0;
+        const uint64_t bins = melspec_stft_bins(c, emit.full);
+        for (uint32_t i = 0; i < n; ++i) { oo[i] = cur; cur += pl.frames[i] * bins; }
+        rc = melspec_stft_ragged_device(c, state, pl.off.data(), pl.len.data(), n, d_out, h_out_off ? h_out_off : oo.data(), emit.dtype, emit.full, s);
+        if (rc) return rc;
+    } else if (pl.total_frames) {
+        rc = melspec_compute_ragged_device(c, state, pl.off.data(), pl.len.data(), n, static_cast<float *>(d_out),
+                                           h_out_off ? h_out_off : pl.out_off.data(), s);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(stream_carry_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e);
@@ -1480,15 +1612,17 @@ int melspec_stream_push_device(melspec_stream *st, const uint32_t *ids, const ui
 }
 
 static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
-                                 bool flush, float *out, size_t out_capacity_floats, uint32_t *h_frames) {
+                                 bool flush, void *out, size_t out_capacity, uint32_t *h_frames, const StreamEmit &emit = StreamEmit()) {
     if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
     if (n == 0) return MELSPEC_OK;
     if (!ids || (!flush && !lens)) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
     StreamPlan pl;
     int rc = stream_plan(st, ids, lens, n, flush, pl);
     if (rc) return rc;
-    const uint64_t need = pl.total_frames * st->ctx->n_mels;
-    if (need > out_capacity_floats) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    // elements the caller receives: floats (mel rows) or complex values (spectra)
+    const uint64_t need = pl.total_frames * (emit.stft ? melspec_stft_bins(st->ctx, emit.full) : static_cast<uint64_t>(st->ctx->n_mels));
+    const size_t esz = emit.stft ? (emit.dtype == MELSPEC_STFT_F64 ? 16 : 8) : sizeof(float);
+    if (need > out_capacity) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
     if (need && !out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += pl.entries[i].len;
@@ -1496,12 +1630,12 @@ static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const 
     hipStream_t s = st->ctx->stream;
     HIP_TRY(hipSetDevice(st->ctx->dev.device));
     if ((rc = st->staging.ensure(total * sizeof(float) + 16))) return rc;
-    if ((rc = st->out.ensure(need * sizeof(float) + 16))) return rc;
+    if ((rc = st->out.ensure(need * esz + 16))) return rc;
     if (total) HIP_TRY(hipMemcpyAsync(st->staging.p, samples, total * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = stream_run(st, pl, n, total ? static_cast<const float *>(st->staging.p) : nullptr, static_cast<float *>(st->out.p), nullptr, s);
+    rc = stream_run(st, pl, n, total ? static_cast<const float *>(st->staging.p) : nullptr, st->out.p, nullptr, s, emit);
     if (rc) return rc;
     if (need) {
-        HIP_TRY(hipMemcpyAsync(out, st->out.p, need * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(out, st->out.p, need * esz, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     stream_commit(st, ids, lens, n, flush);
@@ -1512,6 +1646,13 @@ static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const 
 int melspec_stream_push_host(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
                              float *out, size_t out_capacity_floats, uint32_t *h_frames) {
     return stream_push_host_impl(st, ids, samples, lens, n, false, out, out_capacity_floats, h_frames);
+}
+
+int melspec_stream_push_host_stft(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                                  void *out, size_t out_capacity_complex, uint32_t *h_frames, int dtype, int full) {
+    if (st) { const int rc = stft_args(st->ctx, dtype); if (rc) return rc; }
+    StreamEmit e; e.stft = true; e.dtype = dtype; e.full = full;
+    return stream_push_host_impl(st, ids, samples, lens, n, false, out, out_capacity_complex, h_frames, e);
 }
 
 int melspec_stream_flush_host(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,

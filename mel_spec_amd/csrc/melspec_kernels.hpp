@@ -601,6 +601,94 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
     }
 }
 
+// STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) -- the complex spectrum itself, f64 phases 1-2 of the
+// precise kernel, a contiguous run of units per wave.  Output [clip][frame][bins] complex<T>; BatchDesc's "floats" are
+// 32-bit words of that layout (floats per frame = bins * 2 * sizeof(T) / 4).
+struct StftParams {
+    BatchDesc b;
+    const uint32_t *d_blob;   // the f64 table part of the precise blob
+    int blob_words;
+    int hop;
+    int bins;                 // 201 (half spectrum) or 400 (the reference's full layout)
+    int words_per_frame;
+};
+
+template <class T>
+__global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_stft_kernel(const StftParams p) {
+    constexpr int WAVES = kPreciseWaves;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    __syncthreads();
+    const double *tb = reinterpret_cast<const double *>(ldsw);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    double *rows = reinterpret_cast<double *>(ldsw + p.blob_words) + wave * PreciseLayout::slice_doubles();
+    const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+    const bool in = lane < kFPW * kMelJobs;
+    ClipRun cr;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    for (; cr.unit < cr.end; ++cr.unit) {
+        cr.enter(p.b);
+        const uint64_t f0 = (cr.unit - cr.c_start) * kFPW;
+        const uint64_t left = cr.c_frames - f0;
+        const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv;
+        precise_phase1(fl, j, act && j < kFftJobs, tb, src + fl * p.hop, rows);
+        __builtin_amdgcn_wave_barrier();
+        T *out = reinterpret_cast<T *>(cr.c_out + (f0 + (uint64_t)fl) * (uint64_t)p.words_per_frame);
+        precise_phase2_spectrum<T>(fl, j, act, tb, rows, out, p.bins);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The same for any n_fft: one frame per workgroup, direct f64 DFT of bins 0..n_fft/2 from an LDS twiddle table (the
+// arithmetic of generic_frame_kernel below), the upper half mirrored for the full layout.
+struct GenericStftParams {
+    BatchDesc b;             // units == frames
+    int n_fft, hop, bins, words_per_frame, f64;
+    const double *d_win;     // [n_fft]
+    const double *d_tw;      // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void generic_stft_kernel(const GenericStftParams p) {
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    double *tw = ldsd;                       // 2*n_fft
+    double *xw = tw + 2 * p.n_fft;           // n_fft
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * p.n_fft; i += NT) tw[i] = p.d_tw[i];
+    for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const float *x = loc.pcm + loc.unit * (uint64_t)p.hop;
+        __syncthreads();
+        for (int i = tid; i < p.n_fft; i += NT) xw[i] = (double)x[i] * p.d_win[i];     // src/stft.rs:160-165
+        __syncthreads();
+        float *o = loc.out + loc.unit * (uint64_t)p.words_per_frame;
+        for (int k = tid; k <= p.n_fft / 2; k += NT) {
+            double re = 0.0, im = 0.0;
+            int idx = 0;
+            for (int n = 0; n < p.n_fft; ++n) {
+                re += xw[n] * tw[2 * idx];
+                im += xw[n] * tw[2 * idx + 1];
+                idx += k;
+                if (idx >= p.n_fft) idx -= p.n_fft;
+            }
+            const int mk = p.n_fft - k;
+            const bool mirror = p.bins == p.n_fft && k > 0 && mk > k;
+            if (p.f64) {
+                double *od = reinterpret_cast<double *>(o);
+                od[2 * k] = re; od[2 * k + 1] = im;
+                if (mirror) { od[2 * mk] = re; od[2 * mk + 1] = -im; }
+            } else {
+                o[2 * k] = (float)re; o[2 * k + 1] = (float)im;
+                if (mirror) { o[2 * mk] = (float)re; o[2 * mk + 1] = (float)-im; }
+            }
+        }
+    }
+}
+
 // The f64 recompute of the frames the f32 kernels queued (MELSPEC_PRECISION_AUTO): launched behind every guarded f32
 // launch on the same stream with the same BatchDesc.  Every frame slot of a wave takes its own queue entry -- the five
 // frames of a wave need not be neighbours -- and overwrites that frame's column of the output.  An empty queue (noise,

@@ -78,4 +78,43 @@ MS_DEV void precise_phase2(int fl, int j, bool active, const double *MS_RESTRICT
     }
 }
 
+// STFT export (Spectrogram::compute_all_cpu, src/stft.rs:89-115): phase 2 with the spectrum itself as the result.
+// Lane (frame, j) holds 2*X[k] and 2*conj(X[200-k]) for k = j + 20q, q < 10 -- between the eleven lanes every bin 0..200
+// (the Nyquist bin is the partner of k = 0).  out: this lane's frame in global memory, `bins` complex values of type T
+// (201: the half spectrum; 400: the reference's full layout, the upper half being the conjugate mirror X[400-k] = conj X[k]).
+template <class T>
+MS_DEV void precise_phase2_spectrum(int fl, int j, bool active, const double *MS_RESTRICT tb, const double *MS_RESTRICT rows,
+                                    T *MS_RESTRICT out, int bins) {
+    if (!active) return;
+    const int brow = (j == 0) ? 20 : 20 - j;
+    const double *ua = rows + fl * PreciseLayout::kXStride + j * PreciseLayout::kXRow;
+    const double *va = rows + fl * PreciseLayout::kXStride + brow * PreciseLayout::kXRow;
+    cd u[10], v[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        u[i] = ldc(ua + 2 * i);
+        v[i] = ldc(va + 2 * i);
+    }
+    fft10(u);
+    fft10(v);
+    const double *tw = tb + PreciseBlob::kTw2 + j * 20;
+    const bool full = bins > 201;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        const cd zk = u[q], zm = v[9 - q];
+        const cd S = {zk.re + zm.re, zk.im - zm.im};
+        const cd D = {zk.re - zm.re, zk.im + zm.im};
+        const cd wd = cmul(ldc(tw + 2 * q), D);
+        const double ar = 0.5 * (S.re + wd.im), ai = 0.5 * (S.im - wd.re);      // X[k]
+        const double br = 0.5 * (S.re - wd.im), bi = -0.5 * (S.im + wd.re);     // X[200 - k]
+        const int k = j + 20 * q, m = 200 - k;
+        stc(out + 2 * k, cpx<T>{static_cast<T>(ar), static_cast<T>(ai)});
+        stc(out + 2 * m, cpx<T>{static_cast<T>(br), static_cast<T>(bi)});
+        if (full) {
+            if (k > 0) stc(out + 2 * (400 - k), cpx<T>{static_cast<T>(ar), static_cast<T>(-ai)});
+            if (m < 200) stc(out + 2 * (400 - m), cpx<T>{static_cast<T>(br), static_cast<T>(-bi)});
+        }
+    }
+}
+
 }  // namespace melspec

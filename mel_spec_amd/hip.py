@@ -181,6 +181,39 @@ class HipMelSpectrogram:
     def precise(self) -> bool:
         return bool(lib().melspec_is_precise(self._h))
 
+    def stft_bins(self, full: bool = False) -> int:
+        return int(lib().melspec_stft_bins(self._h, int(full)))
+
+    def compute_all(self, samples, dtype=np.complex128, full: bool = True) -> np.ndarray:
+        """Spectrogram::compute_all_cpu on the GPU (melspec_stft_host): [frames][bins] complex64 / complex128; full = the
+        reference's n_fft-bin layout, else the n_fft/2 + 1 non-redundant bins."""
+        x = _f32(samples).reshape(-1)
+        dt = np.dtype(dtype)
+        assert dt in (np.dtype(np.complex64), np.dtype(np.complex128))
+        nf, bins = self.num_frames(x.shape[0]), self.stft_bins(full)
+        out = np.zeros((nf, bins), dt)
+        got = C.c_size_t(0)
+        _check(lib().melspec_stft_host(self._h, _fp(x), x.shape[0], out.ctypes.data_as(C.c_void_p), out.size, int(dt == np.dtype(np.complex128)),
+                                       int(full), C.byref(got)))
+        assert got.value == nf
+        return out
+
+    def stft_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int, f64: bool = False, full: bool = False,
+                            stream: int = 0) -> None:
+        _check(lib().melspec_stft_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips, C.c_void_p(d_out), int(f64), int(full),
+                                                 C.c_void_p(stream)))
+
+    def stft_ragged_device(self, d_pcm: int, offsets, lengths, d_out: int, out_offsets=None, f64: bool = False, full: bool = False, stream: int = 0) -> None:
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        _check(lib().melspec_stft_ragged_device(self._h, C.c_void_p(d_pcm), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
+                                                C.c_void_p(d_out), None if oo is None else oo.ctypes.data_as(u64p), int(f64), int(full), C.c_void_p(stream)))
+
+    def release_scratch(self) -> None:
+        _check(lib().melspec_release_scratch(self._h))
+
     def plain_kernel_name(self) -> str:
         return (lib().melspec_plain_kernel_name(self._h) or b"").decode()
 

@@ -66,6 +66,23 @@ class StreamBank:
         assert int(frames.sum()) == cap
         return self._collect(out, frames)
 
+    def push_stft(self, ids: Sequence[int], chunks: Sequence, dtype=np.complex128, full: bool = True) -> List[np.ndarray]:
+        """push() emitting what Spectrogram::add returns (src/stft.rs:48-86): [k_i, bins] complex spectra per stream."""
+        a = _u32(ids)
+        xs = [_f32(c).ravel() for c in chunks]
+        lens = _u32([x.shape[0] for x in xs])
+        flat = np.concatenate(xs) if xs else np.zeros(0, np.float32)
+        dt = np.dtype(dtype)
+        bins = self._mel.stft_bins(full)
+        cap = sum(self.frames_after(int(s), int(n)) for s, n in zip(a, lens))
+        out = np.empty((cap, bins), dt)
+        frames = np.zeros(a.shape[0], np.uint32)
+        _check(lib().melspec_stream_push_host_stft(self._h, a.ctypes.data_as(_u32p), _fp(flat), lens.ctypes.data_as(_u32p), a.shape[0],
+                                                   out.ctypes.data_as(C.c_void_p), out.size, frames.ctypes.data_as(_u32p),
+                                                   int(dt == np.dtype(np.complex128)), int(full)))
+        assert int(frames.sum()) == cap
+        return self._collect(out, frames)
+
     def flush(self, ids: Sequence[int]) -> List[np.ndarray]:
         """Spectrogram::add with the pending (< hop) samples: zero-padded, at most one more frame per stream."""
         a = _u32(ids)

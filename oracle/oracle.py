@@ -130,6 +130,18 @@ def fft_forward(z: np.ndarray) -> np.ndarray:
     return z
 
 
+def compute_all_cpu(samples, fft_size=400, hop_size=160) -> np.ndarray:
+    """Spectrogram::compute_all_cpu (src/stft.rs:89-115): frame_windows (periodic Hann, no padding, src/stft.rs:147-169),
+    then the forward complex FFT of every frame -> [frames][fft_size] complex128 (the reference's Vec<Vec<Complex<f64>>>)."""
+    x = _f32(samples).astype(np.float64)
+    nf = num_frames(x.shape[0], fft_size, hop_size)
+    w = hann_window(fft_size)
+    out = np.empty((nf, fft_size), np.complex128)
+    for f in range(nf):
+        out[f] = fft_forward(x[f * hop_size:f * hop_size + fft_size] * w)
+    return out
+
+
 def mel_filterbank(sr: float, n_fft: int, n_mels: int, f_min=None, f_max=None, htk=False, norm=True) -> np.ndarray:
     """mel() of src/mel.rs:547-589 -> dense f64 [n_mels, n_fft//2+1]."""
     out = np.empty((n_mels, n_fft // 2 + 1), np.float64)

@@ -347,6 +347,39 @@ extern "C" long long emu_whisper_precise(const float *pcm, long long n, int hop,
     return frames;
 }
 
+// STFT export on the f64 phases (precise_phase2_spectrum): out = [frames][bins] complex128, bins = 201 or 400
+extern "C" long long emu_stft400(const float *pcm, long long n, int hop, int bins, double *out) {
+    FastTables T;
+    if (!build_fast_tables(16000.0, 80, T, true) || !T.interval) return -1;
+    PreciseTables P;
+    if (!build_precise_tables(T, P)) return -2;
+    const double *tb = reinterpret_cast<const double *>(P.blob.data());
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / hop + 1;
+    std::vector<double> rows(PreciseLayout::slice_doubles());
+    for (long long f0 = 0; f0 < frames; f0 += kFPW) {
+        const int nv = static_cast<int>(std::min<long long>(kFPW, frames - f0));
+        std::fill(rows.begin(), rows.end(), 1.0e30);
+        std::vector<double> snap(rows), next(rows);
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            std::vector<double> tmp(snap);
+            precise_phase1(fl, j, act && j < kFftJobs, tb, pcm + (f0 + fl) * hop, tmp.data());
+            const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
+            uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
+            for (size_t i = 0; i < tmp.size() * 2; ++i) if (a[i] != b0[i]) d[i] = a[i];
+        }
+        rows = next;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
+            const bool act = lane < kFPW * kMelJobs && fl < nv;
+            precise_phase2_spectrum<double>(fl, j, act, tb, rows.data(), out + (f0 + fl) * 2 * bins, bins);
+        }
+    }
+    return frames;
+}
+
 // small DFT checks
 extern "C" void emu_small_fft(int n, float *interleaved) {
     if (n == 10) { cf x[10]; std::memcpy(x, interleaved, sizeof x); fft10(x); std::memcpy(interleaved, x, sizeof x); }

@@ -684,3 +684,81 @@ def test_host_pipeline_pageable_and_pinned_memory(gpu, w80, oracle, jfk):
     # capacity and argument errors come back as codes, not crashes
     with pytest.raises(gpu.HipRuntimeError):
         w80.compute_batch_host(flat, offs, lens, np.empty(10, np.float32), ooff)
+
+
+def _stream_spectra(x, n_fft, hop):
+    """What the reference's Spectrogram::add loop returns for a stream (src/stft.rs:48-86): one spectrum per completed hop once
+    idx >= n_fft, i.e. compute_all_cpu of samples[off:], off = ceil(n_fft/hop)*hop - n_fft (the alignment rust_jfk_golden.npy pins)."""
+    off = -(-n_fft // hop) * hop - n_fft
+    return off
+
+
+@pytest.mark.parametrize("fft,hop", [(400, 160), (400, 128), (512, 160), (256, 64), (100, 33)])
+def test_stft_export_matches_compute_all_cpu(gpu, oracle, jfk, fft, hop):
+    """Row a3: Spectrogram::compute_all_cpu (src/stft.rs:89-115) -- the complex spectrum of every frame.  f64 output within
+    1e-10 of the frame norm, f32 output within 1e-6 (the arithmetic is f64 either way); half (n_fft/2+1 bins) and the
+    reference's full n_fft-bin layout; uniform and ragged device batches; edge lengths."""
+    m = gpu.HipMelSpectrogram(fft, hop, SR, 80 if fft >= 256 else 20)
+    x = jfk[30000:30000 + 9 * fft + 7 * hop + 5]
+    want = oracle.compute_all_cpu(x, fft, hop)
+    norm = np.linalg.norm(want, axis=1, keepdims=True)
+    for full in (True, False):
+        bins = m.stft_bins(full)
+        assert bins == (fft if full else fft // 2 + 1)
+        g64 = m.compute_all(x, np.complex128, full)
+        g32 = m.compute_all(x, np.complex64, full)
+        assert g64.shape == (want.shape[0], bins)
+        assert (np.abs(g64 - want[:, :bins]) / norm).max() <= 1e-10
+        assert (np.abs(g32 - want[:, :bins]) / norm).max() <= 1e-6
+    for n in (0, fft - 1, fft, fft + hop - 1, fft + hop, fft + 5 * hop):
+        y = oracle.synth_pcm(4, n)
+        g = m.compute_all(y)
+        w = oracle.compute_all_cpu(y, fft, hop)
+        assert g.shape == w.shape and (g.size == 0 or np.abs(g - w).max() <= 1e-10 * np.abs(w).max())
+    # device batches: 7 equal clips, then the same PCM as a ragged batch with reversed output order
+    clip, n_clips = 5 * fft + 11 * hop, 7
+    pcm = np.stack([oracle.synth_pcm(c, clip) if c % 2 else np.resize(jfk[c * 1000:], clip) for c in range(n_clips)]).astype(np.float32)
+    nf, bins = m.num_frames(clip), m.stft_bins(False)
+    din, dout = gpu.DeviceBuffer(pcm.nbytes), gpu.DeviceBuffer(n_clips * nf * bins * 16)
+    din.upload(pcm)
+    m.stft_uniform_device(din.ptr, clip, clip, n_clips, dout.ptr, f64=True, full=False)
+    m.synchronize()
+    got = dout.download((n_clips, nf, bins), np.complex128)
+    for c in range(n_clips):
+        w = oracle.compute_all_cpu(pcm[c], fft, hop)[:, :bins]
+        assert np.abs(got[c] - w).max() <= 1e-10 * np.abs(w).max()
+    lens = np.array([clip, fft, clip - hop, 0, clip, fft - 1, clip], np.uint64)
+    offs = np.arange(n_clips, dtype=np.uint64) * np.uint64(clip)
+    fr = np.array([m.num_frames(int(v)) for v in lens], np.uint64)
+    ooff = (np.cumsum((fr * bins)[::-1])[::-1] - fr * bins).astype(np.uint64)
+    m.stft_ragged_device(din.ptr, offs, lens, dout.ptr, ooff, f64=False, full=False)
+    m.synchronize()
+    flat = dout.download((int((fr * bins).sum()),), np.complex64)
+    for c in range(n_clips):
+        if fr[c]:
+            w = oracle.compute_all_cpu(pcm[c][:int(lens[c])], fft, hop)[:, :bins]
+            g = flat[int(ooff[c]):int(ooff[c]) + w.size].reshape(w.shape)
+            assert np.abs(g - w).max() <= 1e-6 * np.abs(w).max()
+    din.free(); dout.free(); m.close()
+
+
+@pytest.mark.parametrize("fft,hop", [(400, 160), (512, 160)])
+def test_streaming_stft_is_what_spectrogram_add_returns(gpu, oracle, jfk, fft, hop):
+    """Spectrogram::add (src/stft.rs:48-86) through the stream bank: pushes of any size emit the spectra of samples[off:]'s frames,
+    off = ceil(n_fft/hop)*hop - n_fft (80 / 128: the alignment rust_jfk_golden.npy pins)."""
+    m = gpu.HipMelSpectrogram(fft, hop, SR, 80)
+    x = jfk[:40000]
+    off = -(-fft // hop) * hop - fft
+    want = oracle.compute_all_cpu(x[off:], fft, hop)
+    bank = gpu.StreamBank(m, 2, 4500)
+    rng = np.random.default_rng(2)
+    got, pos = [], 0
+    while pos < len(x):
+        k = int(rng.integers(0, 4501))
+        got.append(bank.push_stft([1], [x[pos:pos + k]])[0])
+        pos += k
+    got = np.concatenate(got)
+    n = got.shape[0]
+    assert want.shape[0] - 1 <= n <= want.shape[0] and got.shape[1] == fft
+    assert np.abs(got - want[:n]).max() <= 1e-10 * np.abs(want).max()
+    bank.close(); m.close()
