@@ -125,7 +125,6 @@ struct HostPipe {
     static constexpr int kBuf = 2;
     static constexpr size_t kDirectPieces = 32;          // more DMA requests than this per chunk: gather through staging instead
     static constexpr uint64_t kDirectBytes = 32u << 20;  // calls up to this size (PCM + mel): no pipeline, see run()
-    static constexpr uint64_t kMinChunkSamples = 1u << 18;
     hipStream_t s_in = nullptr, s_out = nullptr;
     void *d_in[kBuf] = {}, *d_out[kBuf] = {};
     size_t d_in_cap[kBuf] = {}, d_out_cap[kBuf] = {};
@@ -205,11 +204,10 @@ struct HostPipe {
         uint64_t total_samples = 0, total_out = 0;
         for (const HostSeg &sg : segs) { total_samples += sg.n; total_out += sg.frames * static_cast<uint64_t>(n_mels); }
         // small calls: one chunk, copied by the runtime straight from / to the caller's memory on the compute stream (its
-        // pageable path is as fast as pinned DMA up to a few tens of MB and there is nothing to overlap); large calls: at least
-        // eight chunks in the pipeline
+        // pageable path is as fast as pinned DMA up to a few tens of MB and there is nothing to overlap).  Larger calls: chunks
+        // of chunk_samples (16 MiB of PCM; cutting 64 x 10 s into 8 chunks instead of 3 lost 12 %: per-chunk launches and events)
         const bool direct = (total_samples + total_out) * sizeof(float) <= kDirectBytes;
         if (direct) chunk_samples = ~0ull;
-        else if (total_samples / 8 < chunk_samples) chunk_samples = total_samples / 8 > kMinChunkSamples ? total_samples / 8 : kMinChunkSamples;
         for (size_t i = 0; i < segs.size();) {
             Chunk c{i, 0, 0, 0, false};
             while (i < segs.size() && (c.count == 0 || (c.samples + segs[i].n <= chunk_samples && c.count < 65536))) {
