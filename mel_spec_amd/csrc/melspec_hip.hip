@@ -1290,6 +1290,11 @@ struct melspec_fbank {
     hipStream_t stream = nullptr;
     bool fast = false;          // fused 512-point kernel (default Kaldi geometry) vs generic f64 kernel
     bool use_generic = false;   // melspec_fbank_use_generic: the direct-DFT kernel as the on-device cross-check
+    // clip counter of fbank512_clip_kernel (never reset; clip_base = its value when the next launch starts), used in stream order
+    DevBuf clip_ctr;
+    uint32_t clip_base = 0;
+    hipStream_t clip_stream = nullptr;
+    bool clip_used = false;
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -1361,7 +1366,7 @@ void melspec_fbank_destroy(melspec_fbank *fb) {
     if (!fb) return;
     if (fb->dev.device >= 0) (void)hipSetDevice(fb->dev.device);
     if (fb->stream) { (void)hipStreamSynchronize(fb->stream); (void)hipStreamDestroy(fb->stream); }
-    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release();
+    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->clip_ctr.release();
     delete fb;
 }
 
@@ -1403,6 +1408,35 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         fp.use_log = fb->cfg.use_log_fbank;
         fp.use_power = fb->cfg.use_power;
         fp.slots = fb->ft.slots;
+        // many clips + CMN: workgroup-per-clip kernel with the normalisation inside (lab builds: MELSPEC_FB_CLIP=0 keeps the two-kernel path)
+        static const bool clip_on = lab_int("MELSPEC_FB_CLIP", 1, 0, 1) != 0;
+        if (clip_on && fb->cfg.apply_cmn && fb->waves == 8 && n_clips >= static_cast<uint32_t>(fb->dev.cus) && nm <= 89) {
+            if (fb->clip_used && fb->clip_stream != s) HIP_TRY(hipStreamSynchronize(fb->clip_stream));
+            if (!fb->clip_ctr.p) {
+                if ((rc = fb->clip_ctr.ensure(64))) return rc;
+                HIP_TRY(hipMemsetAsync(fb->clip_ctr.p, 0, 64, s));
+                fb->clip_base = 0;
+            }
+            fb->clip_used = true; fb->clip_stream = s;
+            static std::atomic<uint64_t> attr_done{0};
+            if (!device_done(attr_done)) {
+                rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi80>, "hipFuncSetAttribute(fbank512_clip_kernel)");
+                if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensRuntime>, "hipFuncSetAttribute(fbank512_clip_kernel)");
+                if (rc) return rc;
+                mark_device_done(attr_done);
+            }
+            FbankClipParams q{};
+            q.f = fp;
+            q.clip_ctr = static_cast<uint32_t *>(fb->clip_ctr.p);
+            q.clip_base = fb->clip_base;
+            const unsigned grid = grid_for_xcd(n_clips, fb->dev.cus, 1);
+            fb->clip_base += n_clips + grid;          // every workgroup ends with exactly one failed grab
+            const size_t lds = fb->fast_lds + 16 + 128 * sizeof(float);
+            if (fb_lens_match<LensKaldi80>(fb->ft.slots)) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(grid), dim3(512), lds, s, q);
+            else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime>), dim3(grid), dim3(512), lds, s, q);
+            HIP_TRY(hipGetLastError());
+            return MELSPEC_OK;
+        }
         if (fb_lens_match<LensKaldi80>(fb->ft.slots))
             rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi80>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         else
