@@ -345,10 +345,11 @@ MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const
 
 MS_DEV float fast_ln(float x) { return fast_log2(x) * 0.69314718055994531f; }
 
-// floor, ln, store (src/fbank.rs:207-221).  out_tile = &out[first frame of the tile][0]
+// floor, ln, store (src/fbank.rs:207-221).  out_tile = &out[first frame of the tile][0].  vals (optional): the stored
+// features of this lane, mel j + 15 i of frame fl (for the in-order column sums of the CMN, fbank512_clip_kernel).
 template <int NSLOTS = kFbSlots>
 MS_DEV void fb_phase3_store(int fl, int j, bool active, int n_mels, float floor_v, bool use_log,
-                            const float (&rise)[NSLOTS], const float (&fnext)[NSLOTS], float *out_tile) {
+                            const float (&rise)[NSLOTS], const float (&fnext)[NSLOTS], float *out_tile, float *vals = nullptr) {
     if (!active || j >= kFbOwn) return;
     float *o = out_tile + static_cast<long long>(fl) * n_mels + j;
 #pragma unroll
@@ -357,7 +358,9 @@ MS_DEV void fb_phase3_store(int fl, int j, bool active, int n_mels, float floor_
         if (m < n_mels) {
             float e = rise[i] + fnext[i];
             e = __builtin_fmaxf(e, floor_v);
-            o[kFbOwn * i] = use_log ? fast_ln(e) : e;
+            const float v = use_log ? fast_ln(e) : e;
+            o[kFbOwn * i] = v;
+            if (vals) vals[i] = v;
         }
     }
 }

@@ -1408,8 +1408,9 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         fp.use_log = fb->cfg.use_log_fbank;
         fp.use_power = fb->cfg.use_power;
         fp.slots = fb->ft.slots;
+#ifdef MELSPEC_LAB
         // many clips + CMN: workgroup-per-clip kernel with the normalisation inside (lab builds: MELSPEC_FB_CLIP=0 keeps the two-kernel path)
-        static const bool clip_on = lab_int("MELSPEC_FB_CLIP", 1, 0, 1) != 0;
+        static const bool clip_on = lab_int("MELSPEC_FB_CLIP", 0, 0, 1) != 0;
         if (clip_on && fb->cfg.apply_cmn && fb->waves == 8 && n_clips >= static_cast<uint32_t>(fb->dev.cus) && nm <= 89) {
             if (fb->clip_used && fb->clip_stream != s) HIP_TRY(hipStreamSynchronize(fb->clip_stream));
             if (!fb->clip_ctr.p) {
@@ -1431,12 +1432,14 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
             q.clip_base = fb->clip_base;
             const unsigned grid = grid_for_xcd(n_clips, fb->dev.cus, 1);
             fb->clip_base += n_clips + grid;          // every workgroup ends with exactly one failed grab
-            const size_t lds = fb->fast_lds + 16 + 128 * sizeof(float);
+            const size_t lds = fb->fast_lds + (4 + 8 + 8) * 4 + 96 * 4 + 5 * 4 * 92 * 4;      // counters, sums, ring (fbank512_clip_kernel)
+            if (lds > kLdsLimit) return fail(MELSPEC_ERR_INTERNAL, "fbank512_clip_kernel: LDS");
             if (fb_lens_match<LensKaldi80>(fb->ft.slots)) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(grid), dim3(512), lds, s, q);
             else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime>), dim3(grid), dim3(512), lds, s, q);
             HIP_TRY(hipGetLastError());
             return MELSPEC_OK;
         }
+#endif
         if (fb_lens_match<LensKaldi80>(fb->ft.slots))
             rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi80>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         else
@@ -1452,8 +1455,21 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         CmnParams cp{};
         cp.b = pl.desc;
         cp.n_mels = nm;
+        // rows staged per chunk: what fits one workgroup's LDS next to the means; two workgroups per CU when a whole clip fits half of it
+        const size_t head = static_cast<size_t>((nm + 3) & ~3) * sizeof(float);
+        size_t budget = kLdsLimit - head - 256;
+        if (fpc * static_cast<uint64_t>(nm) * sizeof(float) + head <= kLdsLimit / 2 - 256) budget = kLdsLimit / 2 - head - 256;
+        uint64_t rows = budget / (static_cast<size_t>(nm) * sizeof(float));
+        if (rows > fpc) rows = fpc;
+        cp.rows_per_chunk = nm <= 512 ? static_cast<int>(rows) : 0;
+        static std::atomic<uint64_t> cmn_attr{0};
+        if (!device_done(cmn_attr)) {
+            if ((rc = allow_big_lds(&cmn_kernel<512>, "hipFuncSetAttribute(cmn_kernel)"))) return rc;
+            mark_device_done(cmn_attr);
+        }
+        const size_t lds = head + (cp.rows_per_chunk ? static_cast<size_t>(cp.rows_per_chunk) * nm : 512) * sizeof(float);
         const unsigned grid = grid_for(n_clips, fb->dev.cus, 8);
-        hipLaunchKernelGGL(cmn_kernel<512>, dim3(grid), dim3(512), 0, s, cp);
+        hipLaunchKernelGGL(cmn_kernel<512>, dim3(grid), dim3(512), lds, s, cp);
         HIP_TRY(hipGetLastError());
     }
     return MELSPEC_OK;

@@ -911,14 +911,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     }
 }
 
+#ifdef MELSPEC_LAB
+// LAB ONLY (measured slower than the two-kernel path, profiles/r02_fbank.txt; kept for the next attempt).
 // Kaldi fbank with CMN in one launch (Fbank::compute incl. src/fbank.rs:224-233), for batches of many clips: a workgroup owns
-// whole clips.  Its eight waves take the clip's units from an LDS counter (whoever is free takes the next one: the two
-// waves that later fold and the odd unit counts balance out), store the un-normalised features, meet at one barrier per
-// clip, then lanes m < n_mels fold column m over the frames IN THE REFERENCE'S ORDER (ndarray's mean() of a strided column is
-// a left fold in f32 and its rounding error is part of the reference's output: ~1e-5 of a feature at 1000 frames, more on
-// longer clips) with 32 rows in flight, and all threads subtract -- while the clip's rows (319 KB at 10 s) are still in this
-// XCD's L2 / the Infinity Cache, instead of cmn_kernel's second grid-wide pass over everything (2 reads + 1 write of the
-// whole output: measured 2.0 x the algorithmic traffic, 0.2 of config 3's 0.92 ms).  Clips are handed out by a global
+// whole clips.  Its eight waves take the clip's units from an LDS counter (whoever is free takes the next one).  The column
+// sums of the CMN must be accumulated IN THE REFERENCE'S ORDER -- ndarray's mean() of a strided column is a left fold in f32 and
+// its rounding error is part of the reference's output: ~1e-5 of a feature at 1000 frames, more on longer clips -- so a wave
+// that has stored unit u waits until units 0..u-1 have been added, adds its four rows to the 80 running sums in LDS frame by
+// frame, and passes the turn on (units are taken in order and take the same time, so the wait is short; the sums never
+// re-read the features).  At the end of the clip: one barrier, mean = sum / frames, and all threads subtract while the clip's
+// rows (319 KB at 10 s) are still in this XCD's L2 -- instead of cmn_kernel's second grid-wide pass (2 reads + 1 write of
+// the whole output: measured 2.0 x the algorithmic traffic, 0.2 of config 3's 0.92 ms).  Clips are handed out by a global
 // counter that is never reset: the host passes the value it will have when this launch starts (every workgroup ends with
 // exactly one failed grab, so a launch advances it by n_clips + gridDim.x).
 struct FbankClipParams {
@@ -936,8 +939,13 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += NT) ldsw[i] = p.d_blob[i];
-    unsigned *ctl = ldsw + p.blob_words + WAVES * L::slice_elems() * 2;      // [0] next unit of the clip, [1] this clip, [2] the next clip
-    float *mean_s = reinterpret_cast<float *>(ctl + 4);                       // [n_mels]
+    constexpr unsigned kRing = 5;          // parked units (what fits behind the slices: 5 x 4 rows x 92 floats)
+    constexpr int kRingRow = 92;
+    unsigned *ctl = ldsw + p.blob_words + WAVES * L::slice_elems() * 2;      // [0] next unit of the clip, [1] next unit of the sum chain, [2] the next clip, [3] chain lock
+    unsigned *ready = ctl + 4;                                                // [kRing] unit + 1 parked in the slot
+    unsigned *nvs = ready + 8;                                                // [kRing] its valid frames
+    float *sum_s = reinterpret_cast<float *>(nvs + 8);                        // [n_mels <= 92] running column sums, then the means
+    float *ring = sum_s + 96;                                                 // [kRing][4][kRingRow]
     if (tid == 0) ctl[2] = atomicAdd(q.clip_ctr, 1u) - q.clip_base;
     __syncthreads();
     const T *tblob = reinterpret_cast<const T *>(ldsw);
@@ -961,8 +969,12 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
         if (clip >= p.b.n_clips) break;
         if (tid == 0) {
             ctl[0] = 0;
+            ctl[1] = 0;
+            ctl[3] = 0;
             ctl[2] = atomicAdd(q.clip_ctr, 1u) - q.clip_base;      // the next clip: its round trip hides behind this clip's units
         }
+        if (tid < 8) ready[tid] = 0;
+        if (tid < nm) sum_s[tid] = 0.0f;
         const float *pcm;
         float *out;
         uint64_t frames;
@@ -976,7 +988,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             frames = scalar64(p.b.d_frames[clip]);
         }
         const uint32_t units = static_cast<uint32_t>((frames + kFbFPW - 1) / kFbFPW);
-        __syncthreads();                              // ctl[0] is reset
+        __syncthreads();                              // counters and sums are reset
         for (;;) {
             unsigned u = 0;
             if (lane == 0) u = atomicAdd(&ctl[0], 1u);
@@ -1010,50 +1022,85 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             }
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(2);
-            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS], vals[NSLOTS];
             fb_phase3_sums<T, NSLOTS, Lens>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
 #pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-            fb_phase3_store<NSLOTS>(fl, j, act, nm, p.floor_v, use_log, rise, fnext, out + f0 * (uint64_t)nm);
+            for (int i = 0; i < NSLOTS; ++i) { fnext[i] = wave_shift_down1(fprev[i]); vals[i] = 0.0f; }
+            fb_phase3_store<NSLOTS>(fl, j, act, nm, p.floor_v, use_log, rise, fnext, out + f0 * (uint64_t)nm, vals);
+            // The CMN's column sums, frame by frame in clip order, without making the waves finish in order: the unit's rows
+            // are parked in a ring of kRing slots in LDS, and whoever finds the next unit of the chain parked (trylock) adds it
+            // and every parked successor to the running sums.  A wave only ever waits when it is kRing units ahead of the chain.
+            MS_PRIO(0);
+            const unsigned slot = u % kRing;
+            if (u >= kRing && lane == 0) {
+                // bounded (~0.1 s): a chain that never moves would be a bug, and a wrong sum is caught by the parity tests while a hung
+                // GPU is not recoverable
+                for (unsigned spin = 0; spin < (1u << 21) && __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + kRing <= u; ++spin)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            float *rs = ring + slot * (kFbFPW * kRingRow);
+            if (act && j < kFbOwn) {
+#pragma unroll
+                for (int i = 0; i < NSLOTS; ++i)
+                    if (j + kFbOwn * i < nm) rs[fl * kRingRow + j + kFbOwn * i] = vals[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                nvs[slot] = static_cast<unsigned>(nv);
+                __hip_atomic_store(&ready[slot], u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (;;) {
+                // (a ballot, not readfirstlane of a value set under `if (lane == 0)`: with the latter the compiler folded this loop
+                // into the lane-0 block above and ran the adds below with lane 0 masked off)
+                bool got = false;
+                if (lane == 0) got = atomicCAS(&ctl[3], 0u, 1u) == 0u;
+                if (__builtin_amdgcn_ballot_w64(got) == 0) break;
+                unsigned fn = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                for (;;) {
+                    const unsigned sl = fn % kRing;
+                    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != fn + 1) break;
+                    const int nv2 = __builtin_amdgcn_readfirstlane(nvs[sl]);
+                    const float *rr = ring + sl * (kFbFPW * kRingRow);
+                    float r0[kFbFPW], r1[kFbFPW];
+#pragma unroll
+                    for (int f = 0; f < kFbFPW; ++f) {
+                        r0[f] = (lane < nm && f < nv2) ? rr[f * kRingRow + lane] : 0.0f;
+                        r1[f] = (lane + 64 < nm && f < nv2) ? rr[f * kRingRow + lane + 64] : 0.0f;
+                    }
+                    float s0 = lane < nm ? sum_s[lane] : 0.0f, s1 = lane + 64 < nm ? sum_s[lane + 64] : 0.0f;
+#pragma unroll
+                    for (int f = 0; f < kFbFPW; ++f)
+                        if (f < nv2) { s0 += r0[f]; s1 += r1[f]; }
+                    if (lane < nm) sum_s[lane] = s0;
+                    if (lane + 64 < nm) sum_s[lane + 64] = s1;
+                    ++fn;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) __hip_atomic_store(&ctl[1], fn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // the slot is free again
+                }
+                if (lane == 0) __hip_atomic_store(&ctl[3], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // a unit parked between the last look and the unlock is nobody's: look once more
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ready[fn % kRing], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != fn + 1) break;
+            }
             __builtin_amdgcn_wave_barrier();
         }
         MS_PRIO(0);
-        if (frames == 0) continue;                    // wave-uniform and workgroup-uniform
-        __syncthreads();                              // every row of the clip is stored (and visible to this workgroup)
-        if (tid < nm) {
-            constexpr int kB = 32;
-            const float *col = out + tid;
-            float s = 0.0f;
-            float cur[kB], nxt[kB];
-            const uint64_t last = frames - 1;
-#pragma unroll
-            for (int i = 0; i < kB; ++i) cur[i] = col[((uint64_t)i < last ? (uint64_t)i : last) * nm];
-            for (uint64_t f = 0; f < frames; f += kB) {
-#pragma unroll
-                for (int i = 0; i < kB; ++i) { const uint64_t r = f + kB + i; nxt[i] = col[(r < last ? r : last) * nm]; }
-                if (f + kB <= frames) {
-#pragma unroll
-                    for (int i = 0; i < kB; ++i) s += cur[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < kB; ++i) if (f + i < frames) s += cur[i];
-                }
-#pragma unroll
-                for (int i = 0; i < kB; ++i) cur[i] = nxt[i];
-            }
-            mean_s[tid] = f32_div_rn(s, (float)frames);
-        }
+        if (frames == 0) continue;                    // workgroup-uniform
+        __syncthreads();                              // every unit of the clip is stored (visible to this workgroup) and summed
+        if (tid < nm) sum_s[tid] = f32_div_rn(sum_s[tid], (float)frames);
         __syncthreads();
         {
             const int G = NT / nm;                    // row groups (n_mels <= 89: at least 5)
             const int g = tid / nm, m = tid - g * nm;
             if (g < G) {
-                const float mean = mean_s[m];
+                const float mean = sum_s[m];
                 for (uint64_t f = g; f < frames; f += G) out[f * nm + m] -= mean;
             }
         }
     }
 }
+#endif  // MELSPEC_LAB
 
 // Per-feature normalisation of the NeMo frontend (normalize_per_feature, src/mel.rs:721-749): for every (clip, mel) row the
 // mean over the valid frames, the unbiased variance, (v - mean) / (sqrt(var) + 1e-5) -- in the reference's f32 and in the
@@ -1403,19 +1450,27 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
 
 // CMN (src/fbank.rs:224-233): per clip and mel column subtract the f32 mean over the clip's frames.  The reference's
 // `column(m).mean()` (ndarray on a strided view) is a left fold in f32 followed by one division, and its rounding error
-// (~1e-5 of a feature value at 1000 frames, more on longer clips) is part of its output, so the sum runs in that order:
-// one workgroup per clip, thread m folds column m over the frames (16 rows in flight: the row reads are coalesced over
-// the columns), then every thread subtracts.
+// (~1e-5 of a feature value at 1000 frames, more on longer clips) is part of its output, so the sum runs in that order.
+// One workgroup per clip.  The fold is a chain of `frames` dependent adds per column and must not wait on memory: all 512
+// threads stage the clip's rows in LDS, a chunk of up to rows_per_chunk at a time (coalesced 16-byte loads, every load of a
+// chunk in flight together), lanes m < n_mels fold the chunk in frame order from LDS, and when the whole clip has been
+// folded every thread subtracts -- the last chunk straight from its LDS copy, the earlier ones re-read (L2 / Infinity
+// Cache).  (r01: 80 threads folded from global memory with 16 rows in flight and everything was read twice: 0.2 ms of
+// config 3's 0.92.)  rows_per_chunk == 0 (no LDS given): the r01 form, for banks wider than the staging allows.
 struct CmnParams {
     BatchDesc b;   // only the clip geometry is used
     int n_mels;
+    int rows_per_chunk;
 };
 
 template <int NT>
 __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
-    __shared__ float mean_s[NT];
+    extern __shared__ __attribute__((aligned(16))) float cmn_lds[];
+    float *mean_s = cmn_lds;                 // [n_mels rounded up to 4]
     const int nm = p.n_mels;
+    float *rows = cmn_lds + ((nm + 3) & ~3);
     const int tid = threadIdx.x;
+    const int R = p.rows_per_chunk;
     for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x) {
         float *o;
         uint64_t frames;
@@ -1427,6 +1482,73 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
             frames = p.b.d_frames[clip];
         }
         if (frames == 0) continue;
+        if (R > 0) {
+            float s = 0.0f;
+            uint64_t f0 = 0;
+            const bool vec = ((reinterpret_cast<uintptr_t>(o) & 15) == 0) && (nm % 4 == 0);
+            for (;; f0 += R) {
+                const int nr = frames - f0 < (uint64_t)R ? (int)(frames - f0) : R;
+                const float *src = o + f0 * nm;
+                const int total = nr * nm;
+                __syncthreads();                                   // the previous chunk has been folded
+                if (vec) {
+                    // eight 16-byte loads per thread in flight (a plain copy loop leaves one: ~40 memory round trips per chunk)
+                    constexpr int kU = 8;
+                    const int nq = total / 4;
+                    for (int q0 = tid; q0 < nq; q0 += NT * kU) {
+                        f4 v[kU];
+#pragma unroll
+                        for (int k = 0; k < kU; ++k) {
+                            const int q = q0 + k * NT;
+                            v[k] = *reinterpret_cast<const f4 *>(src + 4 * (q < nq ? q : q0));
+                        }
+#pragma unroll
+                        for (int k = 0; k < kU; ++k) {
+                            const int q = q0 + k * NT;
+                            if (q < nq) *reinterpret_cast<f4 *>(rows + 4 * q) = v[k];
+                        }
+                    }
+                } else {
+                    for (int i = tid; i < total; i += NT) rows[i] = src[i];
+                }
+                __syncthreads();
+                if (tid < nm) {
+                    const float *col = rows + tid;
+                    int r = 0;
+                    for (; r + 16 <= nr; r += 16) {
+                        float v[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = col[(r + i) * nm];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) s += v[i];
+                    }
+                    for (; r < nr; ++r) s += col[r * nm];
+                }
+                if (f0 + nr >= frames) break;
+            }
+            if (tid < nm) mean_s[tid] = f32_div_rn(s, (float)frames);
+            __syncthreads();
+            // the last chunk from LDS, the earlier ones from memory
+            const int nr = (int)(frames - f0);
+            const int G = NT / nm;
+            const int g = tid / nm, m = tid - g * nm;
+            if (g < G) {
+                const float mean = mean_s[m];
+                for (int r = g; r < nr; r += G) o[(f0 + r) * nm + m] = rows[r * nm + m] - mean;
+                // earlier chunks: 8 rows per thread in flight
+                uint64_t f = g;
+                for (; f + 7 * (uint64_t)G < f0; f += 8 * (uint64_t)G) {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = o[(f + k * (uint64_t)G) * nm + m];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[(f + k * (uint64_t)G) * nm + m] = v[k] - mean;
+                }
+                for (; f < f0; f += G) o[f * nm + m] -= mean;
+            }
+            __syncthreads();                                       // mean_s / rows are reused by the next clip
+            continue;
+        }
         for (int m0 = 0; m0 < nm; m0 += NT) {                 // column chunks when n_mels > NT
             const int cols = nm - m0 < NT ? nm - m0 : NT;
             const int G = NT / cols;                           // frame groups per column
@@ -1444,11 +1566,11 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
                     for (int i = 0; i < kB; ++i) s += v[i];
                 }
                 for (; f < frames; ++f) s += col[f * nm];
-                mean_s[tid] = f32_div_rn(s, (float)frames);
+                rows[tid] = f32_div_rn(s, (float)frames);
             }
             __syncthreads();
             if (g < G) {
-                const float mean = mean_s[tid - g * cols];
+                const float mean = rows[tid - g * cols];
                 for (uint64_t f = g; f < frames; f += G) o[f * nm + m] -= mean;
             }
             __syncthreads();
