@@ -72,10 +72,10 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
  * an f64 FFT too, cufftExecZ2Z src/cuda.rs:204-219).  Every mode but F32 is within 1e-4 of the f64 reference on every input.
  *   AUTO (default)  f32 FFT; in the same pass every frame is checked against an error bound -- a mel band within two
  *                   decades of the per-frame clamp (max - 8, src/mel.rs:645-654) is where the f32 FFT's rounding noise can
- *                   exceed 1e-4 -- and the frames that fail it are recomputed with the f64 kernel by a second launch on the
- *                   same stream.  Noise-like input queues nothing (the bench workload runs at the f32 rate); a line over a
- *                   quiet floor or speech with > 60 dB of in-frame dynamic range queues most frames, and F64 is then the
- *                   faster choice because it skips the f32 pass.
+ *                   exceed 1e-4 -- and a frame that fails it is recomputed in f64 on the spot by the wavefront that owns it
+ *                   (same launch).  Noise-like input never takes that branch (the bench workload runs at the f32 rate); a
+ *                   line over a quiet floor or speech with > 60 dB of in-frame dynamic range takes it on most frames
+ *                   (~2 us per frame and wavefront), and F64 -- the dedicated f64 kernel on everything -- is then faster.
  *   F64             window, FFT and |X|^2 in f64 for every frame: ~4e-7 from the reference, about 60 % of the f32 rate.
  *   F32             the f32 kernel alone: ~3e-5 on speech and noise, up to ~5e-4 on a line over a floor 70..90 dB down.
  * Geometries on the generic kernel and the fused n_fft = 512 kernel always compute in f64. */
@@ -89,8 +89,8 @@ int melspec_set_precise(melspec_ctx *ctx, int on);
 int melspec_is_precise(const melspec_ctx *ctx);
 /* Name of the kernel(s) a plain [clip][frame][mel] batch of this context runs on (for profiles and bench lines). */
 const char *melspec_plain_kernel_name(const melspec_ctx *ctx);
-/* Frames the last AUTO call on this context recomputed in f64 (waits for that call). */
-int melspec_guard_last_count(melspec_ctx *ctx, uint64_t *frames);
+/* Frames the AUTO mode of this context has recomputed in f64 since it was created (synchronises the device). */
+int melspec_guard_count(melspec_ctx *ctx, uint64_t *frames);
 
 /* compute_mel_spectrogram(&mut self, samples: &[f32]) -> Vec<Vec<f32>> (src/cuda.rs:88-101)
  * == Spectrogram::compute_mel_spectrogram_cpu (src/stft.rs:119-138) on the GPU.

@@ -56,7 +56,7 @@ SIGNATURES = {
     "melspec_uses_fast_path": (C.c_int, [_vp]),
     "melspec_set_precision": (C.c_int, [_vp, C.c_int]),
     "melspec_precision": (C.c_int, [_vp]),
-    "melspec_guard_last_count": (C.c_int, [_vp, _u64p]),
+    "melspec_guard_count": (C.c_int, [_vp, _u64p]),
     "melspec_plain_kernel_name": (C.c_char_p, [_vp]),
     "melspec_set_precise": (C.c_int, [_vp, C.c_int]),
     "melspec_is_precise": (C.c_int, [_vp]),

@@ -378,12 +378,10 @@ bool fb_lens_match(const MelSlots &ms) {
 // ------------------------------------------------------------------------------------
 // Whisper log-mel context
 // ------------------------------------------------------------------------------------
-// Queue of the precision guard (GuardSink in melspec_kernels.hpp): u32 frame ids + three control words.
-struct GuardQueue {
-    DevBuf list, ctl;
-    hipStream_t last_stream = nullptr;   // the queue is stream-ordered: a call on another stream first waits for this one
-    bool used = false;
-    void release() { list.release(); ctl.release(); used = false; last_stream = nullptr; }
+// MELSPEC_PRECISION_AUTO state (FixSink in melspec_kernels.hpp): the f64 tables of the in-kernel recompute and its counter.
+struct FixState {
+    DevBuf tab, count;
+    void release() { tab.release(); count.release(); }
 };
 
 struct melspec_ctx {
@@ -415,7 +413,7 @@ struct melspec_ctx {
     PreciseTables pt;
     DevBuf d_blob64;
     size_t precise_lds = 0;
-    GuardQueue guard;
+    FixState fix;
     // generic path
     GenericTables gt;
     // scratch
@@ -477,63 +475,7 @@ int launch_precise(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
     return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stream) : launch_precise_t<12, LensRuntime>(c, desc, stream);
 }
 
-// the f64 recompute of the frames an f32 launch queued (MELSPEC_PRECISION_AUTO), behind that launch on the same stream
-template <int NSLOTS, class Lens>
-int launch_fixup_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    static std::atomic<uint64_t> attr_done{0};
-    if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_fixup_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_fixup_kernel)");
-        if (rc) return rc;
-        mark_device_done(attr_done);
-    }
-    FixupParams q{};
-    q.pp = precise_params(c, desc);
-    q.list = static_cast<const uint32_t *>(c->guard.list.p);
-    q.ctl = static_cast<uint32_t *>(c->guard.ctl.p);
-    q.fpu = static_cast<uint32_t>(desc.frames_per_unit);
-    // one workgroup per CU is resident; small batches cannot queue more than their own frames.  (The size of this grid does
-    // not matter when the queue is empty: 1 / 8 / 32 / 256 workgroups all cost the bench step the same 9.5 us, the two
-    // dependent-launch gaps on the stream -- profiles/r02_guard.txt.)
-    const uint64_t slots = desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);
-    const uint64_t blocks = (slots + kPreciseWaves * kFPW - 1) / (kPreciseWaves * kFPW);
-    const unsigned grid = grid_for(blocks, c->dev.cus, 1);
-    hipLaunchKernelGGL((whisper400_fixup_kernel<NSLOTS, Lens>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, q);
-    HIP_TRY(hipGetLastError());
-    return MELSPEC_OK;
-}
-
-int launch_fixup(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
-    if (c->ft.slots.n_slots <= 8)
-        return c->lens_kind == 1 ? launch_fixup_t<8, LensI80>(c, desc, stream) : launch_fixup_t<8, LensRuntime>(c, desc, stream);
-    return c->lens_kind == 2 ? launch_fixup_t<12, LensI128>(c, desc, stream) : launch_fixup_t<12, LensRuntime>(c, desc, stream);
-}
-
-// Sizes the queue for this batch and orders it behind the previous user.  guard.list stays null when the queue cannot be
-// used (ids would not fit 32 bits): the caller then runs the f64 kernel on the whole batch.
-int guard_prepare(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, GuardSink &sink) {
-    sink = GuardSink{};
-    const uint64_t slots = desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);
-    if (slots >= 0xffffffffull) return MELSPEC_OK;
-    GuardQueue &g = c->guard;
-    if (g.used && g.last_stream != stream) HIP_TRY(hipStreamSynchronize(g.last_stream));
-    if (slots * sizeof(uint32_t) > g.list.cap) {
-        if (g.used) HIP_TRY(hipStreamSynchronize(g.last_stream));       // a launch in flight may still write the old list
-        int rc = g.list.ensure(static_cast<size_t>(slots) * sizeof(uint32_t));
-        if (rc) return rc;
-    }
-    if (!g.ctl.p) {
-        int rc = g.ctl.ensure(64);
-        if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(g.ctl.p, 0, 64, stream));
-    }
-    g.used = true;
-    g.last_stream = stream;
-    sink.list = static_cast<uint32_t *>(g.list.p);
-    sink.ctl = static_cast<uint32_t *>(g.ctl.p);
-    return MELSPEC_OK;
-}
-
-FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf &blob, melspec_ctx *c, const GuardSink &sink) {
+FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf &blob, melspec_ctx *c, const FixSink &sink) {
     FastParams fp{};
     fp.b = desc;
     fp.d_blob = static_cast<const float *>(blob.p);
@@ -542,13 +484,13 @@ FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf
     fp.n_mels = c->n_mels;
     fp.slice_floats = WaveLayout::slice_floats();
     fp.slots = ft.slots;
-    fp.guard = sink;
+    fp.fix = sink;
     return fp;
 }
 
 // 5-frame f32 kernels: plain batches (uniform, ragged) on contiguous runs of units per wave, layouts round-robin
 template <int NSLOTS, class Lens>
-int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, hipStream_t stream) {
+int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_wave_kernel<NSLOTS, Lens>, "hipFuncSetAttribute(whisper400_wave_kernel)");
@@ -570,14 +512,14 @@ int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, 
     return MELSPEC_OK;
 }
 
-int launch_wave(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, hipStream_t stream) {
+int launch_wave(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipStream_t stream) {
     if (c->ft.slots.n_slots <= 8)
         return c->lens_kind == 1 ? launch_wave_t<8, LensI80>(c, desc, sink, stream) : launch_wave_t<8, LensRuntime>(c, desc, sink, stream);
     return c->lens_kind == 2 ? launch_wave_t<12, LensI128>(c, desc, sink, stream) : launch_wave_t<12, LensRuntime>(c, desc, sink, stream);
 }
 
 template <class Lens>
-int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const GuardSink &sink, hipStream_t stream) {
+int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_kernel)");
@@ -626,22 +568,14 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, stream);
-    GuardSink sink{};
+    FixSink sink{};
     if (c->precision == MELSPEC_PRECISION_AUTO) {
-        int rc = guard_prepare(c, desc, stream, sink);
-        if (rc) return rc;
-        if (!sink.list) {                         // ids do not fit the queue: f64 on everything (units of 5 frames)
-            if (desc.frames_per_unit != kFPW) return fail(MELSPEC_ERR_UNSUPPORTED, "batch too large for one launch in MELSPEC_PRECISION_AUTO");
-            return launch_precise(c, desc, stream);
-        }
+        sink.tab = static_cast<const double *>(c->fix.tab.p);
+        sink.count = static_cast<unsigned *>(c->fix.count.p);
     }
-    int rc;
     if (c->six && desc.frames_per_unit == kSixFrames)
-        rc = c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
-    else
-        rc = launch_wave(c, desc, sink, stream);
-    if (rc || !sink.list) return rc;
-    return launch_fixup(c, desc, stream);
+        return c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
+    return launch_wave(c, desc, sink, stream);
 }
 
 template <class Lens>
@@ -729,6 +663,8 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
         if ((rc = upload(c->d_blob64, c->pt.blob))) return bail(rc);
+        if ((rc = upload(c->fix.tab, build_fix_tables()))) return bail(rc);
+        if ((rc = upload(c->fix.count, std::vector<uint32_t>(16, 0u)))) return bail(rc);
     }
     if (!c->fast) {          // the generic kernel also serves the layouts the fused 512 build does not store
         const int bins = fft_size / 2 + 1;
@@ -752,7 +688,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release();
-    c->guard.release();
+    c->fix.release();
     c->pipe.release();
     delete c;
 }
@@ -789,21 +725,21 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
         return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";
     const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
     if (c->six)
-        return c->six_static ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix80> + whisper400_fixup_kernel" : "melspec::whisper400_six_runs_kernel<9, LensSix80>")
-                             : (fix ? "melspec::whisper400_six_runs_kernel<9, LensRuntime> + whisper400_fixup_kernel" : "melspec::whisper400_six_runs_kernel<9, LensRuntime>");
-    if (c->ft.slots.n_slots <= 8) return fix ? "melspec::whisper400_wave_runs_kernel<8, .> + whisper400_fixup_kernel" : "melspec::whisper400_wave_runs_kernel<8, .>";
-    return fix ? "melspec::whisper400_wave_runs_kernel<12, .> + whisper400_fixup_kernel" : "melspec::whisper400_wave_runs_kernel<12, .>";
+        return c->six_static ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix80> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix80>")
+                             : (fix ? "melspec::whisper400_six_runs_kernel<9, LensRuntime> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensRuntime>");
+    if (c->ft.slots.n_slots <= 8) return fix ? "melspec::whisper400_wave_runs_kernel<8, .> (precision guard on)" : "melspec::whisper400_wave_runs_kernel<8, .>";
+    return fix ? "melspec::whisper400_wave_runs_kernel<12, .> (precision guard on)" : "melspec::whisper400_wave_runs_kernel<12, .>";
 }
 
-int melspec_guard_last_count(melspec_ctx *c, uint64_t *frames) {
+int melspec_guard_count(melspec_ctx *c, uint64_t *frames) {
     if (!c || !frames) return fail(MELSPEC_ERR_INVALID_ARG, "ctx/frames is NULL");
     *frames = 0;
-    if (!c->guard.used) return MELSPEC_OK;
+    if (!c->fix.count.p) return MELSPEC_OK;
     HIP_TRY(hipSetDevice(c->dev.device));
-    HIP_TRY(hipStreamSynchronize(c->guard.last_stream));
-    uint32_t ctl[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpy(ctl, c->guard.ctl.p, sizeof(ctl), hipMemcpyDeviceToHost));
-    *frames = ctl[2];
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpy(&n, c->fix.count.p, sizeof(n), hipMemcpyDeviceToHost));
+    *frames = n;
     return MELSPEC_OK;
 }
 
@@ -1099,9 +1035,7 @@ int melspec_release_scratch(melspec_ctx *c) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
     HIP_TRY(hipSetDevice(c->dev.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->guard.used) HIP_TRY(hipStreamSynchronize(c->guard.last_stream));
     c->pipe.release();
-    c->guard.release();
     c->ragged.release();
     return MELSPEC_OK;
 }

@@ -14,6 +14,7 @@
 #include "fbank_wave.hpp"
 #include "whisper_wave_f64.hpp"
 #include "whisper_six.hpp"
+#include "whisper_fix64.hpp"
 #include "stream_plan.hpp"
 
 // Issue priority of the wave (s_setprio 0..3).  The persistent kernels raise it as a unit progresses (loads + first FFT
@@ -109,12 +110,12 @@ __device__ __forceinline__ unsigned xcd_logical_block() {
 // consecutive frames of one clip (5 or 6) and belongs to one wavefront; the waves of a workgroup share only the
 // table blob.  LDS: [table blob][WAVES x private slice].  No workgroup barrier in the unit loop.
 // ------------------------------------------------------------------------------------
-// Where the f32 kernels queue the frames whose result the precision guard does not trust (wave_phase4): u32 ids
-// `unit * frames_per_unit + frame_in_unit`, appended with one atomic per wave that has any.  list == nullptr: guard off
-// (MELSPEC_PRECISION_F32).  whisper400_fixup_kernel consumes the list behind the launch and resets the counter.
-struct GuardSink {
-    uint32_t *list;
-    uint32_t *ctl;      // [0] entries queued, [1] workgroups of the fix-up kernel that are done, [2] entries of the last call
+// MELSPEC_PRECISION_AUTO: the f32 kernels recompute the frames their precision guard does not trust (wave_phase4) in f64 on the
+// spot (whisper_fix64.hpp).  tab == nullptr: guard off (MELSPEC_PRECISION_F32).  count: frames recomputed since the context was
+// created (statistics; one atomic per recomputed frame).
+struct FixSink {
+    const double *tab;      // FixTables in global memory
+    unsigned *count;
 };
 
 struct FastParams {
@@ -125,7 +126,7 @@ struct FastParams {
     int n_mels;
     int slice_floats;  // floats per wave (5-frame kernels)
     MelSlots slots;
-    GuardSink guard;
+    FixSink fix;
 };
 
 // One-lane-down shift across the whole wave (lane l receives lane l+1's value).
@@ -134,21 +135,75 @@ __device__ __forceinline__ float wave_shift_down1(float v) {
                                                                  0xf, 0xf, false));
 }
 
-// Queue the frames of this wave's unit that have a guarded lane.  LANES lanes per frame (lane = LANES * fl + j); slot0 = the
-// id of the unit's frame 0.  The common case -- no lane set -- is one v_cmp, one s_cbranch.
-template <int LANES>
-__device__ __forceinline__ void guard_append(bool lane_flag, int lane, int fl, int j, uint64_t slot0, const GuardSink &g) {
-    const uint64_t any = __builtin_amdgcn_ballot_w64(lane_flag);
-    if (any == 0) return;
-    const uint64_t mine = (any >> (LANES * fl)) & ((1ull << LANES) - 1);
-    const bool lead = j == 0 && fl * LANES < 64 && mine != 0;
-    const uint64_t lb = __builtin_amdgcn_ballot_w64(lead);
-    const int first = __builtin_ctzll(lb);
-    unsigned base = 0;
-    if (lane == first) base = atomicAdd(g.ctl, static_cast<unsigned>(__builtin_popcountll(lb)));
-    base = __builtin_amdgcn_readlane(base, first);
-    const unsigned rank = __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(lb >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(lb), 0u));
-    if (lead) g.list[base + rank] = static_cast<uint32_t>(slot0 + fl);
+constexpr int kSixFixOff = 1408;      // float offset of the f64 scratch (400 doubles) inside a six-frame slice: behind power rows and maxima
+constexpr int kWaveFixOff = 1104;     // the same inside a five-frame slice
+static_assert(kSixFixOff >= SixLayout::kPmaxOff + kSixFrames * SixLayout::kPmaxStride && kSixFixOff + 2 * FixTables::kScratchDoubles <= SixLayout::slice_floats(), "six-frame slice");
+static_assert(kWaveFixOff >= WaveLayout::kPmaxOff + kFPW * WaveLayout::kPmaxStride && kWaveFixOff + 2 * FixTables::kScratchDoubles <= WaveLayout::slice_floats(), "five-frame slice");
+
+// f64 power row of frame `f` of the unit (whisper_fix64.hpp): every lane of the wave takes part
+__device__ __forceinline__ void fix_power_row(int lane, const float *frame, const double *tab, float *slice, int scratch_off, float *prow) {
+    double *z = reinterpret_cast<double *>(slice + scratch_off);
+    fix_step1(lane, frame, tab, z);
+    __builtin_amdgcn_wave_barrier();
+    fix_step2(lane, tab, z);
+    __builtin_amdgcn_wave_barrier();
+    fix_step3(lane, z);
+    __builtin_amdgcn_wave_barrier();
+    fix_step4(lane, tab, z, prow);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The frames of this wave's unit with a guarded lane (`any` = ballot of wave_phase4's result), one after the other: f64 power
+// row, then the kernel's own phases 3-4 for that frame alone.  Six frames x ten lanes.
+template <int NSLOTS, class Lens, bool LAYOUT>
+__device__ __noinline__ void six_fix_unit(uint64_t any, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+                                          const FixSink &fix, const float *src, float *out_tile, long long row_w) {
+    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
+    const bool in = lane < kSixFrames * kSixLanes;
+    const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
+    for (int f = 0; f < kSixFrames; ++f) {
+        if (((any >> (kSixLanes * f)) & ((1ull << kSixLanes) - 1)) == 0) continue;            // wave-uniform
+        fix_power_row(lane, src + f * hop, fix.tab, slice, kSixFixOff, slice + f * SixLayout::kPStride);
+        const bool act = in && fl == f;
+        int st[NSLOTS];
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
+        float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS], vals[NSLOTS];
+        six_phase3_sums<NSLOTS, Lens>(fl, j, act, ms, blob, slice, st, rise, fprev);
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+        six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
+        __builtin_amdgcn_wave_barrier();
+        six_phase4<NSLOTS, LAYOUT, false>(fl, j, act, act, n_mels, slice, vals, out_tile, row_w);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) atomicAdd(fix.count, 1u);
+    }
+}
+
+// The same for the five-frame kernels (12 lanes per frame in phases 3-4).
+template <int NSLOTS, class Lens, bool LAYOUT>
+__device__ __noinline__ void wave_fix_unit(uint64_t any, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+                                           const FixSink &fix, const float *src, float *out_tile, long long row_w) {
+    const int fl3 = lane / 12, j3 = lane - fl3 * 12;
+    const bool in3 = lane < kFPW * 12;
+    const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
+    for (int f = 0; f < kFPW; ++f) {
+        if (((any >> (12 * f)) & 0xfffull) == 0) continue;                                     // wave-uniform
+        fix_power_row(lane, src + f * hop, fix.tab, slice, kWaveFixOff, slice + f * WaveLayout::kPStride);
+        const bool act3 = in3 && fl3 == f;
+        int st[NSLOTS];
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
+        float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS], vals[NSLOTS];
+        wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, ms, blob, slice, st, rise, fprev);
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+        wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
+        __builtin_amdgcn_wave_barrier();
+        wave_phase4<NSLOTS, LAYOUT, false>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w);
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) atomicAdd(fix.count, 1u);
+    }
 }
 
 // Sub-group barrier of the mel-major stores (BatchDesc::sync_rounds = gsize + 16 * across, gsize in {2, 4, 8}): only the
@@ -217,7 +272,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;               // 12 lanes per frame in phases 3-4
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
-    const bool guard = p.guard.list != nullptr;
+    const bool guard = p.fix.tab != nullptr;
 
     RoundSync<WAVES> rs(p.b.sync_rounds, wave, arrive);
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
@@ -252,13 +307,14 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         }
         __builtin_amdgcn_wave_barrier();
         rs.template before_stores<0>(lane);
-        bool flag;
-        if (p.b.mel_major)
-            flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
-        else
-            flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
-        if (guard) guard_append<12>(flag, lane, fl3, j3, unit * kFPW, p.guard);
+        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
+        const long long row_w = p.b.mel_major ? (long long)width : 0;
+        const bool flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, out_tile, row_w);
         __builtin_amdgcn_wave_barrier();
+        if (guard) {
+            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            if (any) wave_fix_unit<NSLOTS, Lens, true>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, row_w);
+        }
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
         rs.after_round();
@@ -289,7 +345,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     SixLayout::row_offsets(j, uoff, voff);
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    const bool guard = p.guard.list != nullptr;
+    const bool guard = p.fix.tab != nullptr;
     RoundSync<kSixWaves> rs(p.b.sync_rounds, wave, arrive);
     for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
         const uint64_t unit = first + rs.slot;
@@ -325,13 +381,14 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         }
         __builtin_amdgcn_wave_barrier();
         rs.template before_stores<3>(lane);
-        bool flag;
-        if (p.b.mel_major)
-            flag = six_phase4<NSLOTS, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0, (long long)width);
-        else
-            flag = six_phase4<NSLOTS, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
-        if (guard) guard_append<kSixLanes>(flag, lane, fl, j, unit * kSixFrames, p.guard);
+        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
+        const long long row_w = p.b.mel_major ? (long long)width : 0;
+        const bool flag = six_phase4<NSLOTS, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, out_tile, row_w);
         __builtin_amdgcn_wave_barrier();
+        if (guard) {
+            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            if (any) six_fix_unit<NSLOTS, Lens, true>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, row_w);
+        }
         rs.after_round();
     }
 }
@@ -416,7 +473,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     SixLayout::row_offsets(j, uoff, voff);
     const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    const bool guard = p.guard.list != nullptr;
+    const bool guard = p.fix.tab != nullptr;
 
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) return;
@@ -446,9 +503,13 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
             six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        const bool flag = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
-        if (guard) guard_append<kSixLanes>(flag, lane, fl, j, cr.unit * kSixFrames, p.guard);
+        float *out_tile = cr.c_out + f0 * (uint64_t)n_mels;
+        const bool flag = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice, vals, out_tile, 0);
         __builtin_amdgcn_wave_barrier();
+        if (guard) {
+            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            if (any) six_fix_unit<NSLOTS, Lens, false>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, 0);
+        }
     }
 }
 
@@ -473,7 +534,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
-    const bool guard = p.guard.list != nullptr;
+    const bool guard = p.fix.tab != nullptr;
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
     for (; cr.unit < cr.end; ++cr.unit) {
@@ -502,9 +563,13 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
             wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         }
         __builtin_amdgcn_wave_barrier();
-        const bool flag = wave_phase4<NSLOTS, false, true>(fl3, j3, act3, act3, n_mels, slice, vals, cr.c_out + f0 * (uint64_t)n_mels, 0);
-        if (guard) guard_append<12>(flag, lane, fl3, j3, cr.unit * kFPW, p.guard);
+        float *out_tile = cr.c_out + f0 * (uint64_t)n_mels;
+        const bool flag = wave_phase4<NSLOTS, false, true>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, 0);
         __builtin_amdgcn_wave_barrier();
+        if (guard) {
+            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            if (any) wave_fix_unit<NSLOTS, Lens, false>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, 0);
+        }
     }
 }
 
@@ -685,98 +750,6 @@ __global__ __launch_bounds__(NT) void generic_stft_kernel(const GenericStftParam
                 o[2 * k] = (float)re; o[2 * k + 1] = (float)im;
                 if (mirror) { o[2 * mk] = (float)re; o[2 * mk + 1] = (float)-im; }
             }
-        }
-    }
-}
-
-// The f64 recompute of the frames the f32 kernels queued (MELSPEC_PRECISION_AUTO): launched behind every guarded f32
-// launch on the same stream with the same BatchDesc.  Every frame slot of a wave takes its own queue entry -- the five
-// frames of a wave need not be neighbours -- and overwrites that frame's column of the output.  An empty queue (noise,
-// music, most of what is not a line over a quiet floor) costs one load per workgroup.  The last workgroup to finish resets
-// the queue for the next call.
-struct FixupParams {
-    PreciseParams pp;
-    const uint32_t *list;
-    uint32_t *ctl;
-    uint32_t fpu;         // frames per unit of the f32 kernel that queued (how an id splits into unit and frame)
-};
-
-template <int NSLOTS, class Lens>
-__global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_fixup_kernel(const FixupParams q) {
-    constexpr int WAVES = kPreciseWaves;
-    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
-    const PreciseParams &p = q.pp;
-    const int tid = threadIdx.x;
-    const uint32_t count = __builtin_amdgcn_readfirstlane(q.ctl[0]);
-    if (count != 0) {
-        for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
-        __syncthreads();
-        const double *tb = reinterpret_cast<const double *>(ldsw);
-        const float *fblob = reinterpret_cast<const float *>(ldsw + p.mel_off_words) - FastBlob::kMelStart;
-        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int lane = tid & 63;
-        double *rows = reinterpret_cast<double *>(ldsw + p.blob_words) + wave * PreciseLayout::slice_doubles();
-        float *slice = reinterpret_cast<float *>(rows);
-        const int fl = lane / kMelJobs, j = lane - fl * kMelJobs;
-        const bool in = lane < kFPW * kMelJobs;
-        const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
-        const int fl3 = lane / 12, j3 = lane - fl3 * 12;
-        const bool in3 = lane < kFPW * 12;
-        int st[NSLOTS];
-        {
-            const int *starts = reinterpret_cast<const int *>(fblob + FastBlob::kMelStart);
-#pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12 + j3] : 0;
-        }
-        const bool uniform = p.b.d_unit_prefix == nullptr;
-        for (uint64_t g = ((uint64_t)blockIdx.x * WAVES + wave) * kFPW; g < count; g += (uint64_t)gridDim.x * WAVES * kFPW) {
-            // phases 1-2 see the wave as 5 x 11 lanes, phases 3-4 as 5 x 12: a lane resolves the entry of either role
-            const bool act = in && g + fl < count, act3 = in3 && g + fl3 < count;
-            const float *frame = nullptr;
-            if (act && j < kFftJobs) {
-                const uint32_t e = q.list[g + fl];
-                const uint64_t unit = e / q.fpu;
-                const UnitLoc loc = locate_unit(p.b, unit);
-                frame = loc.pcm + (loc.unit * q.fpu + (e - unit * q.fpu)) * (uint64_t)p.hop;
-            }
-            float *out_tile = nullptr;
-            long long row_w = 0;
-            if (act3) {
-                const uint32_t e = q.list[g + fl3];
-                const uint64_t unit = e / q.fpu;
-                const UnitLoc loc = locate_unit(p.b, unit);
-                const uint64_t f = loc.unit * q.fpu + (e - unit * q.fpu);
-                if (p.b.mel_major) {
-                    row_w = static_cast<long long>(uniform ? p.b.out_width : loc.frames);
-                    out_tile = loc.out + f - fl3;                                  // wave_phase4 adds the frame slot back
-                } else {
-                    out_tile = loc.out + f * (uint64_t)n_mels - (uint64_t)fl3 * n_mels;
-                }
-            }
-            MS_PRIO(0);
-            precise_phase1(fl, j, act && j < kFftJobs, tb, frame, rows);
-            __builtin_amdgcn_wave_barrier();
-            MS_PRIO(1);
-            precise_phase2(fl, j, act, tb, rows);
-            __builtin_amdgcn_wave_barrier();
-            MS_PRIO(2);
-            float vals[NSLOTS], rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
-            wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, fblob, slice, st, rise, fprev);
-#pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-            wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
-            __builtin_amdgcn_wave_barrier();
-            wave_phase4<NSLOTS, true>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w);
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(q.ctl + 1, 1u) == gridDim.x - 1) {      // every other workgroup has read ctl[0] and finished
-            q.ctl[2] = count;
-            q.ctl[0] = 0;
-            q.ctl[1] = 0;
         }
     }
 }

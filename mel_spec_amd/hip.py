@@ -217,11 +217,18 @@ class HipMelSpectrogram:
     def plain_kernel_name(self) -> str:
         return (lib().melspec_plain_kernel_name(self._h) or b"").decode()
 
-    def guard_last_count(self) -> int:
-        """frames the last "auto" call recomputed in f64 (waits for that call)"""
+    def guard_count(self) -> int:
+        """frames the "auto" mode of this context has recomputed in f64 since it was created (synchronises the device)"""
         n = C.c_uint64(0)
-        _check(lib().melspec_guard_last_count(self._h, C.byref(n)))
+        _check(lib().melspec_guard_count(self._h, C.byref(n)))
         return int(n.value)
+
+    def guard_last_count(self) -> int:
+        """the same since the previous call of this method"""
+        total = self.guard_count()
+        last = total - getattr(self, "_guard_seen", 0)
+        self._guard_seen = total
+        return last
 
     def compute_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int,
                                stream: int = 0) -> None:

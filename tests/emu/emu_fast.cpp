@@ -11,6 +11,7 @@
 
 #include "../../mel_spec_amd/csrc/fast_tables.hpp"
 #include "../../mel_spec_amd/csrc/whisper_wave.hpp"
+#include "../../mel_spec_amd/csrc/whisper_fix64.hpp"
 #include "../../mel_spec_amd/csrc/fbank_tables.hpp"
 #include "../../mel_spec_amd/csrc/tga_quant.hpp"
 #include "../../mel_spec_amd/csrc/vad_columns.hpp"
@@ -672,24 +673,122 @@ extern "C" long long emu_whisper_six(const float *pcm, long long n, int hop, int
     return emu_whisper_six_guard(pcm, n, hop, n_mels, sr, mode, out, nullptr);
 }
 
+// The in-kernel f64 recompute of one frame (whisper_fix64.hpp + the f32 phases 3-4 of the kernel that owns the frame), as
+// six_fix_unit / wave_fix_unit run it: frame slot f of a unit, the other slots idle.
+static void emu_fix_power_row(const float *frame, const std::vector<double> &tab, float *prow) {
+    std::vector<double> z(FixTables::kScratchDoubles, 1.0e30), nxt;
+    auto step = [&](auto fn) {
+        nxt = z;
+        for (int lane = 0; lane < 64; ++lane) {
+            std::vector<double> tmp(z);
+            fn(lane, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (std::memcmp(&tmp[i], &z[i], sizeof(double)) != 0) nxt[i] = tmp[i];
+        }
+        z = nxt;
+    };
+    step([&](int lane, double *zz) { fix_step1(lane, frame, tab.data(), zz); });
+    step([&](int lane, double *zz) { fix_step2(lane, tab.data(), zz); });
+    step([&](int lane, double *zz) { fix_step3(lane, zz); });
+    for (int lane = 0; lane < 64; ++lane) fix_step4(lane, tab.data(), z.data(), prow);
+}
+
+template <int NSLOTS>
+static int emu_fix_frame_six(const float *frame, int n_mels, double sr, float *out_row) {
+    FastTables T;
+    if (!build_six_tables(sr, n_mels, T)) return -1;
+    const std::vector<double> tab = build_fix_tables();
+    const int f = 3;                                             // any slot: exercise a non-zero one
+    std::vector<float> slice(SixLayout::slice_floats(), 1.0e30f);
+    emu_fix_power_row(frame, tab, slice.data() + f * SixLayout::kPStride);
+    const int *starts = reinterpret_cast<const int *>(T.blob.data() + SixBlob::kMelStart);
+    std::vector<float> rise(64 * NSLOTS), fprev(65 * NSLOTS, 0.0f), vals(64 * NSLOTS);
+    std::vector<float> tile(static_cast<size_t>(kSixFrames) * n_mels, 0.0f);
+    auto info = [&](int lane, int &fl, int &j, bool &act) { fl = lane / kSixLanes; j = lane - fl * kSixLanes; act = lane < kSixFrames * kSixLanes && fl == f; };
+    for (int lane = 0; lane < 64; ++lane) {
+        int fl, j; bool act; info(lane, fl, j, act);
+        int st[NSLOTS];
+        for (int i = 0; i < NSLOTS; ++i) st[i] = lane < kSixFrames * kSixLanes ? starts[i * kSixLanes + j] : 0;
+        six_phase3_sums<NSLOTS, LensRuntime>(fl, j, act, T.slots, T.blob.data(), slice.data(), st,
+                                             *reinterpret_cast<float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                             *reinterpret_cast<float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane) * NSLOTS]));
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        int fl, j; bool act; info(lane, fl, j, act);
+        six_phase3_finish<NSLOTS>(fl, j, act, n_mels, *reinterpret_cast<const float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                  *reinterpret_cast<const float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane + 1) * NSLOTS]), slice.data(),
+                                  *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        int fl, j; bool act; info(lane, fl, j, act);
+        six_phase4<NSLOTS, false, false>(fl, j, act, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+                                         tile.data(), 0);
+    }
+    std::memcpy(out_row, tile.data() + static_cast<size_t>(f) * n_mels, sizeof(float) * n_mels);
+    return 0;
+}
+
+template <int NSLOTS>
+static int emu_fix_frame_wave(const float *frame, int n_mels, double sr, float *out_row) {
+    FastTables T;
+    if (!build_fast_tables(sr, n_mels, T, true) || !T.interval) return -1;
+    const std::vector<double> tab = build_fix_tables();
+    const int f = 2;
+    std::vector<float> slice(WaveLayout::slice_floats(), 1.0e30f);
+    emu_fix_power_row(frame, tab, slice.data() + f * WaveLayout::kPStride);
+    const int *starts = reinterpret_cast<const int *>(T.blob.data() + FastBlob::kMelStart);
+    std::vector<float> rise(64 * NSLOTS), fprev(65 * NSLOTS, 0.0f), vals(64 * NSLOTS);
+    std::vector<float> tile(static_cast<size_t>(kFPW) * n_mels, 0.0f);
+    for (int lane = 0; lane < 64; ++lane) {
+        const int fl = lane / 12, j = lane - fl * 12;
+        const bool act = lane < kFPW * 12 && fl == f;
+        int st[NSLOTS];
+        for (int i = 0; i < NSLOTS; ++i) st[i] = lane < kFPW * 12 ? starts[i * 12 + j] : 0;
+        wave_phase3i_sums<NSLOTS, LensRuntime>(fl, j, act, T.slots, T.blob.data(), slice.data(), st,
+                                               *reinterpret_cast<float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                               *reinterpret_cast<float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane) * NSLOTS]));
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        const int fl = lane / 12, j = lane - fl * 12;
+        const bool act = lane < kFPW * 12 && fl == f;
+        wave_phase3i_finish<NSLOTS>(fl, j, act, n_mels, *reinterpret_cast<const float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                    *reinterpret_cast<const float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane + 1) * NSLOTS]), slice.data(),
+                                    *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+        const int fl = lane / 12, j = lane - fl * 12;
+        const bool act = lane < kFPW * 12 && fl == f;
+        wave_phase4<NSLOTS, false, false>(fl, j, act, act, n_mels, slice.data(), *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+                                          tile.data(), 0);
+    }
+    std::memcpy(out_row, tile.data() + static_cast<size_t>(f) * n_mels, sizeof(float) * n_mels);
+    return 0;
+}
+
+// one 400-sample frame through the in-kernel f64 recompute; six != 0: as the six-frame kernel runs it
+extern "C" int emu_fix_frame(const float *frame, int n_mels, double sr, int six, float *out_row) {
+    if (six) return emu_fix_frame_six<kSixMaxSlots>(frame, n_mels, sr, out_row);
+    FastTables T;
+    if (!build_fast_tables(sr, n_mels, T, true) || !T.interval) return -1;
+    return T.slots.n_slots <= 8 ? emu_fix_frame_wave<8>(frame, n_mels, sr, out_row) : emu_fix_frame_wave<12>(frame, n_mels, sr, out_row);
+}
+
 // MELSPEC_PRECISION_AUTO: the f32 kernel the library would pick (six frames per wave up to 80 mels, else five), then the
-// frames its guard queued replaced by the f64 kernel's.  Returns the frame count; *n_flagged the queued frames.
+// frames its guard trips recomputed by the in-kernel f64 path.  Returns the frame count; *n_flagged the recomputed frames.
 extern "C" long long emu_whisper_auto(const float *pcm, long long n, int hop, int n_mels, double sr, float *out, long long *n_flagged) {
     if (n_flagged) *n_flagged = 0;
     if (n < 400) return 0;
     const long long frames = (n - 400) / hop + 1;
     std::vector<uint8_t> flags(static_cast<size_t>(frames), 0);
     FastTables T6;
-    long long got = build_six_tables(sr, n_mels, T6) ? emu_whisper_six_guard(pcm, n, hop, n_mels, sr, 0, out, flags.data())
-                                                     : emu_whisper_wave_guard(pcm, n, hop, n_mels, sr, 0, out, flags.data());
+    const bool six = build_six_tables(sr, n_mels, T6);
+    long long got = six ? emu_whisper_six_guard(pcm, n, hop, n_mels, sr, 0, out, flags.data())
+                        : emu_whisper_wave_guard(pcm, n, hop, n_mels, sr, 0, out, flags.data());
     if (got != frames) return got;
-    std::vector<float> one(static_cast<size_t>(n_mels));
     long long nf = 0;
     for (long long f = 0; f < frames; ++f) {
         if (!flags[f]) continue;
         ++nf;
-        if (emu_whisper_precise(pcm + f * hop, 400, hop, n_mels, sr, one.data()) != 1) return -4;
-        std::memcpy(out + f * n_mels, one.data(), sizeof(float) * n_mels);
+        if (emu_fix_frame(pcm + f * hop, n_mels, sr, six ? 1 : 0, out + f * n_mels) != 0) return -4;
     }
     if (n_flagged) *n_flagged = nf;
     return frames;

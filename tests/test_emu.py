@@ -355,3 +355,19 @@ def test_six_frame_kernel_edges_and_coverage(emu, oracle, four_tone):
     assert np.abs(_six(emu, four_tone, 1)[1] - oracle.compute_mel_spectrogram_cpu(four_tone)).max() <= TOL
     assert _six(emu, np.zeros(4000, np.float32), 0, n_mels=81)[0] == -1           # 82 intervals > 9 slots of 9: not covered
     assert _six(emu, np.zeros(4000, np.float32), 1, n_mels=64)[0] == -2           # compile-time lengths are Whisper-80 only
+
+
+@pytest.mark.parametrize("n_mels,six", [(80, 1), (80, 0), (128, 0), (40, 1)])
+def test_in_kernel_f64_recompute_is_f64_accurate(emu, oracle, jfk, n_mels, six):
+    """whisper_fix64.hpp: one frame recomputed by a whole wavefront (200 = 8 x 25 Good-Thomas, 25 = 5 x 5), as the f32 kernels
+    run it for the frames their precision guard trips -- within 2e-6 of the oracle on speech, a tone over a floor, noise, silence."""
+    emu.lib.emu_fix_frame.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_double, C.c_int, C.POINTER(C.c_float)]
+    f32p = C.POINTER(C.c_float)
+    frames = [jfk[20000 + 160 * i:20400 + 160 * i] for i in range(0, 60, 7)]
+    frames += [tone_over_noise_floor(f=7000.0)[1000:1400], tone_over_noise_floor(f=333.3, level_db=-85.0)[555:955], oracle.synth_pcm(2, 400), np.zeros(400, np.float32)]
+    for x in frames:
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.full(n_mels, np.nan, np.float32)
+        assert emu.lib.emu_fix_frame(x.ctypes.data_as(f32p), n_mels, 16000.0, six, out.ctypes.data_as(f32p)) == 0
+        want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, n_mels)[0]
+        assert np.abs(out - want).max() <= 2e-6
