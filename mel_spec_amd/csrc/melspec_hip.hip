@@ -380,8 +380,10 @@ bool fb_lens_match(const MelSlots &ms) {
 // ------------------------------------------------------------------------------------
 // MELSPEC_PRECISION_AUTO state (FixSink in melspec_kernels.hpp): the f64 tables of the in-kernel recompute and its counter.
 struct FixState {
-    DevBuf tab, count;
-    void release() { tab.release(); count.release(); }
+    DevBuf tab, count, list;
+    hipStream_t last_stream = nullptr;    // the note list is used in stream order: a call on another stream first waits for this one
+    bool used = false;
+    void release() { tab.release(); count.release(); list.release(); used = false; last_stream = nullptr; }
 };
 
 struct melspec_ctx {
@@ -570,8 +572,18 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, stream);
     FixSink sink{};
     if (c->precision == MELSPEC_PRECISION_AUTO) {
-        sink.tab = static_cast<const double *>(c->fix.tab.p);
-        sink.count = static_cast<unsigned *>(c->fix.count.p);
+        FixState &fx = c->fix;
+        if (fx.used && fx.last_stream != stream) HIP_TRY(hipStreamSynchronize(fx.last_stream));
+        const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
+        if (need > fx.list.cap) {
+            if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
+            int rc = fx.list.ensure(need);
+            if (rc) return rc;
+        }
+        fx.used = true; fx.last_stream = stream;
+        sink.tab = static_cast<const double *>(fx.tab.p);
+        sink.count = static_cast<unsigned *>(fx.count.p);
+        sink.list = static_cast<uint64_t *>(fx.list.p);
     }
     if (c->six && desc.frames_per_unit == kSixFrames)
         return c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
@@ -1037,6 +1049,8 @@ int melspec_release_scratch(melspec_ctx *c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->pipe.release();
     c->ragged.release();
+    c->fix.list.release();
+    c->fix.used = false;
     return MELSPEC_OK;
 }
 

@@ -116,6 +116,8 @@ __device__ __forceinline__ unsigned xcd_logical_block() {
 struct FixSink {
     const double *tab;      // FixTables in global memory
     unsigned *count;
+    uint64_t *list;         // one entry per unit of the launch (+ a round of slack): every wave notes the units it has to revisit in
+                            // the part of it that its own units index, so no two waves share an entry
 };
 
 struct FastParams {
@@ -133,6 +135,11 @@ struct FastParams {
 __device__ __forceinline__ float wave_shift_down1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */,
                                                                  0xf, 0xf, false));
+}
+
+__device__ __forceinline__ uint64_t scalar64(uint64_t v) {
+    // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
 constexpr int kSixFixOff = 1408;      // float offset of the f64 scratch (400 doubles) inside a six-frame slice: behind power rows and maxima
@@ -153,16 +160,27 @@ __device__ __forceinline__ void fix_power_row(int lane, const float *frame, cons
     __builtin_amdgcn_wave_barrier();
 }
 
-// The frames of this wave's unit with a guarded lane (`any` = ballot of wave_phase4's result), one after the other: f64 power
-// row, then the kernel's own phases 3-4 for that frame alone.  Six frames x ten lanes.
+// ballot of wave_phase4's result -> one bit per frame of the unit (LANES lanes per frame)
+template <int LANES, int FRAMES>
+__device__ __forceinline__ unsigned frame_mask(uint64_t any) {
+    unsigned m = 0;
+#pragma unroll
+    for (int f = 0; f < FRAMES; ++f) m |= ((any >> (LANES * f)) & ((1ull << LANES) - 1)) ? (1u << f) : 0u;
+    return m;
+}
+
+// The frames `mask` of a unit, one after the other: f64 power row, then the kernel's own phases 3-4 for that frame alone.
+// The f32 kernels do not call this inside their unit loop -- with the f64 code in the loop body the register allocator gives the
+// hot path 5 % (a call) to 40 % (inlined) away -- but note the unit (FixSink::list) and come back to it when their run is done.
+// Six frames x ten lanes.
 template <int NSLOTS, class Lens, bool LAYOUT>
-__device__ __noinline__ void six_fix_unit(uint64_t any, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+__device__ __forceinline__ void six_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
                                           const FixSink &fix, const float *src, float *out_tile, long long row_w) {
     const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
     const bool in = lane < kSixFrames * kSixLanes;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
     for (int f = 0; f < kSixFrames; ++f) {
-        if (((any >> (kSixLanes * f)) & ((1ull << kSixLanes) - 1)) == 0) continue;            // wave-uniform
+        if (!((mask >> f) & 1u)) continue;                                                         // wave-uniform
         fix_power_row(lane, src + f * hop, fix.tab, slice, kSixFixOff, slice + f * SixLayout::kPStride);
         const bool act = in && fl == f;
         int st[NSLOTS];
@@ -182,13 +200,13 @@ __device__ __noinline__ void six_fix_unit(uint64_t any, int lane, int hop, int n
 
 // The same for the five-frame kernels (12 lanes per frame in phases 3-4).
 template <int NSLOTS, class Lens, bool LAYOUT>
-__device__ __noinline__ void wave_fix_unit(uint64_t any, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+__device__ __forceinline__ void wave_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
                                            const FixSink &fix, const float *src, float *out_tile, long long row_w) {
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
     for (int f = 0; f < kFPW; ++f) {
-        if (((any >> (12 * f)) & 0xfffull) == 0) continue;                                     // wave-uniform
+        if (!((mask >> f) & 1u)) continue;                                                         // wave-uniform
         fix_power_row(lane, src + f * hop, fix.tab, slice, kWaveFixOff, slice + f * WaveLayout::kPStride);
         const bool act3 = in3 && fl3 == f;
         int st[NSLOTS];
@@ -275,6 +293,10 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
     const bool guard = p.fix.tab != nullptr;
 
     RoundSync<WAVES> rs(p.b.sync_rounds, wave, arrive);
+    // this wave's notes: one slot per round, rounds * (its rank among all waves) onwards
+    const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * WAVES - 1) / ((uint64_t)gridDim.x * WAVES);
+    uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * WAVES + rs.slot) * rounds : nullptr;
+    unsigned noted = 0;
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
         const uint64_t unit = first + rs.slot;
         const bool have = unit < p.b.n_units;
@@ -313,11 +335,27 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         __builtin_amdgcn_wave_barrier();
         if (guard) {
             const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
-            if (any) wave_fix_unit<NSLOTS, Lens, true>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, row_w);
+            if (any != 0) {
+                if (lane == 0) notes[noted] = (unit << 8) | frame_mask<12, kFPW>(any);
+                ++noted;
+            }
         }
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
         rs.after_round();
+    }
+    // the units whose frames tripped the precision guard, again, in f64 (no barrier of the rounds involved any more)
+    for (unsigned k = 0; k < noted; ++k) {
+        uint64_t e = 0;
+        if (lane == 0) e = notes[k];
+        e = scalar64(e);
+        const uint64_t unit = e >> 8;
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * kFPW;
+        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
+        wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
 }
 
@@ -347,6 +385,9 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
     const bool guard = p.fix.tab != nullptr;
     RoundSync<kSixWaves> rs(p.b.sync_rounds, wave, arrive);
+    const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * kSixWaves - 1) / ((uint64_t)gridDim.x * kSixWaves);
+    uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * kSixWaves + rs.slot) * rounds : nullptr;
+    unsigned noted = 0;
     for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
         const uint64_t unit = first + rs.slot;
         const bool have = unit < p.b.n_units;
@@ -387,9 +428,24 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         __builtin_amdgcn_wave_barrier();
         if (guard) {
             const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
-            if (any) six_fix_unit<NSLOTS, Lens, true>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, row_w);
+            if (any != 0) {
+                if (lane == 0) notes[noted] = (unit << 8) | frame_mask<kSixLanes, kSixFrames>(any);
+                ++noted;
+            }
         }
         rs.after_round();
+    }
+    for (unsigned k = 0; k < noted; ++k) {
+        uint64_t e = 0;
+        if (lane == 0) e = notes[k];
+        e = scalar64(e);
+        const uint64_t unit = e >> 8;
+        const UnitLoc loc = locate_unit(p.b, unit);
+        const uint64_t f0 = loc.unit * kSixFrames;
+        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
+        six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+                                         loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
 }
 
@@ -399,10 +455,6 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
 // mel-major layouts keep, their stores want adjacent units in adjacent waves): ragged batches lose the two dependent
 // look-ups in front of every unit's PCM loads (-6 %), uniform ones the 64-bit division per unit and a wave re-reads its own
 // frame-tail halo (cfg2 -1.6 %, 8192 x 30 s -1.7 %).  The unit body is the same.
-__device__ __forceinline__ uint64_t scalar64(uint64_t v) {
-    // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
-}
 
 // A wave's contiguous run of units of a ragged batch and the clip it is in (everything wave-uniform, in scalar registers).
 struct ClipRun {
@@ -477,6 +529,8 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
 
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) return;
+    uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;        // this wave's notes: the entries its own run indexes
+    unsigned noted = 0;
     for (; cr.unit < cr.end; ++cr.unit) {
         cr.enter(p.b);
         const uint64_t f0 = (cr.unit - cr.c_start) * kSixFrames;
@@ -508,8 +562,21 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         __builtin_amdgcn_wave_barrier();
         if (guard) {
             const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
-            if (any) six_fix_unit<NSLOTS, Lens, false>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, 0);
+            if (any != 0) {
+                if (lane == 0) notes[noted] = (cr.unit << 8) | frame_mask<kSixLanes, kSixFrames>(any);
+                ++noted;
+            }
         }
+    }
+    // the units whose frames tripped the precision guard, again, in f64
+    for (unsigned k = 0; k < noted; ++k) {
+        uint64_t e = 0;
+        if (lane == 0) e = notes[k];
+        e = scalar64(e);
+        const UnitLoc loc = locate_unit(p.b, e >> 8);
+        const uint64_t f0 = loc.unit * kSixFrames;
+        six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+                                          loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
 }
 
@@ -537,6 +604,8 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     const bool guard = p.fix.tab != nullptr;
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;
+    unsigned noted = 0;
     for (; cr.unit < cr.end; ++cr.unit) {
         cr.enter(p.b);
         const uint64_t f0 = (cr.unit - cr.c_start) * kFPW;
@@ -568,8 +637,20 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
         __builtin_amdgcn_wave_barrier();
         if (guard) {
             const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
-            if (any) wave_fix_unit<NSLOTS, Lens, false>(any, lane, p.hop, n_mels, p.slots, blob, slice, p.fix, src, out_tile, 0);
+            if (any != 0) {
+                if (lane == 0) notes[noted] = (cr.unit << 8) | frame_mask<12, kFPW>(any);
+                ++noted;
+            }
         }
+    }
+    for (unsigned k = 0; k < noted; ++k) {
+        uint64_t e = 0;
+        if (lane == 0) e = notes[k];
+        e = scalar64(e);
+        const UnitLoc loc = locate_unit(p.b, e >> 8);
+        const uint64_t f0 = loc.unit * kFPW;
+        wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+                                           loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
 }
 
