@@ -177,6 +177,14 @@ int melspec_compute_ragged_device(melspec_ctx *ctx, const float *d_pcm, const ui
                                   const uint64_t *h_lengths, uint32_t n_clips, float *d_out,
                                   const uint64_t *h_out_offsets, void *stream);
 
+/* The same batch with its clip table in DEVICE memory (a segmenter or VAD on the GPU produces it; nothing is copied back):
+ * d_offsets / d_lengths in samples, d_out_offsets in floats (NULL: the clips' frames packed back to back in clip order).  The plan
+ * the host would build is built by a kernel on `stream`.  max_total_frames: an upper bound of the frames of all clips together (the
+ * capacity of d_out in frames) -- it sizes the launch and the scratch; the true count stays on the device.  Asynchronous. */
+int melspec_compute_ragged_device_desc(melspec_ctx *ctx, const float *d_pcm, const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                       uint32_t n_clips, float *d_out, const uint64_t *d_out_offsets, uint64_t max_total_frames,
+                                       void *stream);
+
 /* Benchmark helper (the reference's #[ignore] Instant-timed benches, src/cuda.rs:547-613): runs
  * `warmup` untimed and `iters` timed melspec_compute_uniform_device calls on the context's own
  * stream between two HIP events and returns the average milliseconds per call. */
@@ -234,6 +242,13 @@ int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n
 /* Many equal-length clips, device resident; CMN (src/fbank.rs:224-233) is per clip. */
 int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride,
                                          uint64_t clip_len, uint32_t n_clips, float *d_out, void *stream);
+/* Fbank::compute for clips of any length in one launch (src/fbank.rs:141 is per clip): host or device clip tables, as
+ * melspec_compute_ragged_device / _desc; offsets of the output in floats; CMN per clip. */
+int melspec_fbank_compute_ragged_device(melspec_fbank *fb, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                                        uint32_t n_clips, float *d_out, const uint64_t *h_out_offsets, void *stream);
+int melspec_fbank_compute_ragged_device_desc(melspec_fbank *fb, const float *d_pcm, const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                             uint32_t n_clips, float *d_out, const uint64_t *d_out_offsets, uint64_t max_total_frames,
+                                             void *stream);
 int melspec_fbank_synchronize(melspec_fbank *fb, void *stream);
 
 /* ---- NeMo/Parakeet log-mel frontend: replaces BatchLogMelSpectrogram (src/mel.rs:171-418) ------- */

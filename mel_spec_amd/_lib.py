@@ -81,6 +81,7 @@ SIGNATURES = {
     "melspec_compute_uniform_device_interleaved": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int,
                                                              C.c_uint64, _vp]),
     "melspec_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
+    "melspec_compute_ragged_device_desc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),
     "melspec_time_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _f32p]),
     "melspec_synchronize": (C.c_int, [_vp, _vp]),
     "melspec_mel_filterbank": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _f64p]),
@@ -95,6 +96,8 @@ SIGNATURES = {
     "melspec_fbank_use_generic": (C.c_int, [_vp, C.c_int]),
     "melspec_fbank_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_fbank_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_fbank_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
+    "melspec_fbank_compute_ragged_device_desc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),
     "melspec_fbank_synchronize": (C.c_int, [_vp, _vp]),
     "melspec_blm_default_config": (None, [C.POINTER(BlmConfigC)]),
     "melspec_blm_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(BlmConfigC)]),

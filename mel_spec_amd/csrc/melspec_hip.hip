@@ -292,6 +292,47 @@ void plan_ragged_done(RaggedSlot *sl, hipStream_t stream) {
     if (sl && sl->ev && hipEventRecord(sl->ev, stream) == hipSuccess) sl->pending = true;
 }
 
+// Ragged plan built on the device from descriptors that live there (plan_ragged_device_kernel).  One buffer per object, used in
+// stream order (a call on another stream first waits for the stream that used it last).
+struct DevicePlan {
+    DevBuf buf;
+    hipStream_t last = nullptr;
+    bool used = false;
+    void release() { buf.release(); used = false; last = nullptr; }
+};
+
+int plan_ragged_device(DevicePlan &dp, hipStream_t stream, const float *d_pcm, float *d_out, const uint64_t *d_off, const uint64_t *d_len,
+                       const uint64_t *d_out_off, uint32_t n_clips, uint64_t frame_len, uint64_t frame_shift, uint32_t words_per_frame,
+                       int frames_per_unit, uint64_t max_total_frames, BatchPlan &pl) {
+    // every clip with frames has at most frames / fpu + 1 units
+    const uint64_t max_units = max_total_frames / frames_per_unit + n_clips;
+    const uint64_t max_blocks = max_units / kUnitBlock + 2;
+    const size_t words64 = static_cast<size_t>(n_clips) * 4 + 1;
+    const size_t bytes = words64 * sizeof(uint64_t) + static_cast<size_t>(max_blocks) * sizeof(uint32_t) + 16;
+    if (dp.used && dp.last != stream) HIP_TRY(hipStreamSynchronize(dp.last));
+    if (bytes > dp.buf.cap && dp.used) HIP_TRY(hipStreamSynchronize(dp.last));
+    int rc = dp.buf.ensure(bytes);
+    if (rc) return rc;
+    dp.used = true; dp.last = stream;
+    PlanParams q{};
+    q.d_off = d_off; q.d_len = d_len; q.d_out_off = d_out_off; q.n_clips = n_clips;
+    q.frame_len = frame_len; q.frame_shift = frame_shift; q.words_per_frame = words_per_frame;
+    q.frames_per_unit = static_cast<uint32_t>(frames_per_unit);
+    q.plan = static_cast<uint64_t *>(dp.buf.p);
+    q.max_blocks = max_blocks;
+    hipLaunchKernelGGL(plan_ragged_device_kernel, dim3(1), dim3(1024), 0, stream, q);
+    HIP_TRY(hipGetLastError());
+    const uint64_t *d = q.plan;
+    BatchDesc &b = pl.desc;
+    b = BatchDesc{};
+    b.pcm = d_pcm; b.out = d_out; b.n_clips = n_clips; b.n_units = max_units; b.frames_per_unit = frames_per_unit;
+    b.d_off = d; b.d_frames = d + n_clips; b.d_out_off = d + 2 * n_clips; b.d_unit_prefix = d + 3 * n_clips;
+    b.d_unit_block = reinterpret_cast<const uint32_t *>(d + words64);
+    b.d_n_units = d + 4 * static_cast<size_t>(n_clips);        // prefix[n_clips]
+    pl.total_frames = max_total_frames;
+    return MELSPEC_OK;
+}
+
 unsigned grid_for(uint64_t units, int cus, int per_cu) {
     const uint64_t cap = static_cast<uint64_t>(cus > 0 ? cus : 256) * per_cu;
     const uint64_t g = units < cap ? units : cap;
@@ -420,6 +461,7 @@ struct melspec_ctx {
     GenericTables gt;
     // scratch
     RaggedScratch ragged;
+    DevicePlan dplan;
     HostPipe pipe;          // chunked H2D / kernels / D2H pipeline of the host entry points (host_pipe.hpp)
 };
 
@@ -701,6 +743,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release();
     c->fix.release();
+    c->dplan.release();
     c->pipe.release();
     delete c;
 }
@@ -819,6 +862,20 @@ int melspec_compute_ragged_device(melspec_ctx *c, const float *d_pcm, const uint
     if (!rc) rc = launch_ctx(c, pl.desc, s);
     plan_ragged_done(slot, s);
     return rc;
+}
+
+int melspec_compute_ragged_device_desc(melspec_ctx *c, const float *d_pcm, const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                       uint32_t n_clips, float *d_out, const uint64_t *d_out_offsets, uint64_t max_total_frames, void *stream) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (n_clips == 0 || max_total_frames == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out || !d_offsets || !d_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    BatchPlan pl;
+    int rc = plan_ragged_device(c->dplan, s, d_pcm, d_out, d_offsets, d_lengths, d_out_offsets, n_clips, static_cast<uint64_t>(c->fft_size),
+                                static_cast<uint64_t>(c->hop_size), static_cast<uint32_t>(c->n_mels), ctx_frames_per_unit(c), max_total_frames, pl);
+    if (rc) return rc;
+    return launch_ctx(c, pl.desc, s);
 }
 
 int melspec_time_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
@@ -1239,6 +1296,8 @@ struct melspec_fbank {
     bool fast = false;          // fused 512-point kernel (default Kaldi geometry) vs generic f64 kernel
     bool use_generic = false;   // melspec_fbank_use_generic: the direct-DFT kernel as the on-device cross-check
     // clip counter of fbank512_clip_kernel (never reset; clip_base = its value when the next launch starts), used in stream order
+    RaggedScratch ragged;
+    DevicePlan dplan;
     DevBuf clip_ctr;
     uint32_t clip_base = 0;
     hipStream_t clip_stream = nullptr;
@@ -1314,7 +1373,7 @@ void melspec_fbank_destroy(melspec_fbank *fb) {
     if (!fb) return;
     if (fb->dev.device >= 0) (void)hipSetDevice(fb->dev.device);
     if (fb->stream) { (void)hipStreamSynchronize(fb->stream); (void)hipStreamDestroy(fb->stream); }
-    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->clip_ctr.release();
+    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->clip_ctr.release(); fb->ragged.release(); fb->dplan.release();
     delete fb;
 }
 
@@ -1329,6 +1388,8 @@ int melspec_fbank_use_generic(melspec_fbank *fb, int on) {
     return MELSPEC_OK;
 }
 
+static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips, uint64_t fpc, hipStream_t s);
+
 int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                          uint32_t n_clips, float *d_out, void *stream) {
     if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
@@ -1341,6 +1402,13 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
     const int nm = fb->cfg.num_mel_bins;
     const bool fused = fb->fast && !fb->use_generic;
     const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, nm, fused ? kFbFPW : 1);
+    return fbank_launch(fb, pl, n_clips, fpc, s);
+}
+
+// kernels of one batch (uniform or ragged plan): fused 512-point kernel or the generic one, then CMN per clip
+static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips, uint64_t fpc /* frames of the longest clip (LDS budget of the CMN) */, hipStream_t s) {
+    const int nm = fb->cfg.num_mel_bins;
+    const bool fused = fb->fast && !fb->use_generic;
     const double floor_v = fb->cfg.energy_floor > 0.0 ? fb->cfg.energy_floor : static_cast<double>(FLT_EPSILON);
     int rc = MELSPEC_OK;
     if (fused) {
@@ -1421,6 +1489,47 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
         HIP_TRY(hipGetLastError());
     }
     return MELSPEC_OK;
+}
+
+// Fbank::compute per clip of any length (src/fbank.rs:141): clip c = d_pcm[h_offsets[c] .. + h_lengths[c]) -> its frames at
+// d_out + h_out_offsets[c] floats (NULL: packed); CMN per clip.
+int melspec_fbank_compute_ragged_device(melspec_fbank *fb, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                                        uint32_t n_clips, float *d_out, const uint64_t *h_out_offsets, void *stream) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!h_offsets || !h_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    std::vector<uint64_t> frames(n_clips);
+    uint64_t total = 0, longest = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) { frames[i] = fbank_frames(fb, h_lengths[i]); total += frames[i]; longest = std::max(longest, frames[i]); }
+    if (total == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fb->stream;
+    const bool fused = fb->fast && !fb->use_generic;
+    BatchPlan pl;
+    RaggedSlot *slot = nullptr;
+    int rc = plan_ragged(fb->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, fb->cfg.num_mel_bins, fused ? kFbFPW : 1, pl, slot);
+    if (!rc) rc = fbank_launch(fb, pl, n_clips, longest, s);
+    plan_ragged_done(slot, s);
+    return rc;
+}
+
+// The same with the clip table in device memory (see melspec_compute_ragged_device_desc).
+int melspec_fbank_compute_ragged_device_desc(melspec_fbank *fb, const float *d_pcm, const uint64_t *d_offsets, const uint64_t *d_lengths,
+                                             uint32_t n_clips, float *d_out, const uint64_t *d_out_offsets, uint64_t max_total_frames,
+                                             void *stream) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    if (n_clips == 0 || max_total_frames == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out || !d_offsets || !d_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fb->stream;
+    const bool fused = fb->fast && !fb->use_generic;
+    BatchPlan pl;
+    int rc = plan_ragged_device(fb->dplan, s, d_pcm, d_out, d_offsets, d_lengths, d_out_offsets, n_clips, static_cast<uint64_t>(fb->frame_len),
+                                static_cast<uint64_t>(fb->frame_shift), static_cast<uint32_t>(fb->cfg.num_mel_bins), fused ? kFbFPW : 1,
+                                max_total_frames, pl);
+    if (rc) return rc;
+    return fbank_launch(fb, pl, n_clips, max_total_frames, s);
 }
 
 int melspec_fbank_synchronize(melspec_fbank *fb, void *stream) {

@@ -50,7 +50,11 @@ struct BatchDesc {
     const uint64_t *d_out_off;   // ragged: first output float of clip c
     const uint64_t *d_unit_prefix;  // ragged: first unit of clip c, [n_clips+1]
     const uint32_t *d_unit_block;   // ragged: clip that holds unit k * kUnitBlock
+    const uint64_t *d_n_units;      // ragged batches planned on the device (plan_ragged_device_kernel): the unit count lives here and
+                                    // n_units above is the host's upper bound (grid and scratch sizes)
 };
+
+__device__ __forceinline__ uint64_t batch_n_units(const BatchDesc &b) { return b.d_n_units ? *b.d_n_units : b.n_units; }
 
 constexpr uint32_t kUnitBlock = 16;   // granularity of BatchDesc::d_unit_block
 
@@ -478,9 +482,11 @@ struct ClipRun {
     }
     // false: this wave has no units
     __device__ __forceinline__ bool init(const BatchDesc &b, uint64_t wave_id, uint64_t waves) {
-        const uint64_t run = (b.n_units + waves - 1) / waves;
+        const uint64_t nu = b.d_n_units ? ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(*b.d_n_units >> 32)) << 32 |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)*b.d_n_units)) : b.n_units;
+        const uint64_t run = (nu + waves - 1) / waves;
         unit = wave_id * run;
-        end = unit + run < b.n_units ? unit + run : b.n_units;
+        end = unit + run < nu ? unit + run : nu;
         if (unit >= end) return false;
         if (b.d_unit_prefix == nullptr) {
             clip = static_cast<uint32_t>(unit / b.units_per_clip);
@@ -805,7 +811,8 @@ __global__ __launch_bounds__(NT) void generic_stft_kernel(const GenericStftParam
     double *xw = tw + 2 * p.n_fft;           // n_fft
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * p.n_fft; i += NT) tw[i] = p.d_tw[i];
-    for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
+    const uint64_t n_units = batch_n_units(p.b);
+    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         const UnitLoc loc = locate_unit(p.b, unit);
         const float *x = loc.pcm + loc.unit * (uint64_t)p.hop;
         __syncthreads();
@@ -1428,7 +1435,8 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * p.n_fft; i += NT) tw[i] = p.d_tw[i];
 
-    for (uint64_t unit = blockIdx.x; unit < p.b.n_units; unit += gridDim.x) {
+    const uint64_t n_units = batch_n_units(p.b);
+    for (uint64_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
         const UnitLoc loc = locate_unit(p.b, unit);
         if (loc.unit >= loc.frames) {       // zero column of a padded layout (uniform batches only)
             float *z = p.b.mel_major ? loc.out + loc.unit : loc.out + loc.unit * (uint64_t)p.n_mels;
@@ -1663,6 +1671,61 @@ __global__ __launch_bounds__(256) void stream_carry_kernel(float *state, uint64_
         __syncthreads();
         if (i < e.keep) dst[i] = v;
         __syncthreads();
+    }
+}
+
+// Ragged batch whose descriptors live in device memory (melspec_*_ragged_device_desc): the plan the host builds for
+// melspec_compute_ragged_device (plan_ragged in melspec_hip.hip), built by one workgroup instead -- per-clip frame counts,
+// the prefix of units per clip, packed output offsets when none are given, the clip of every 16th unit -- so that a caller
+// whose clip table is produced on the GPU (a VAD, a segmenter) never copies it back.  Layout of `plan` as plan_ragged's:
+// [off n][frames n][out_off n][prefix n+1] u64, then the block table (u32).
+struct PlanParams {
+    const uint64_t *d_off, *d_len, *d_out_off;     // d_out_off may be null: outputs packed in clip order
+    uint32_t n_clips;
+    uint64_t frame_len, frame_shift;               // frames(n) = n < frame_len ? 0 : (n - frame_len) / frame_shift + 1
+    uint32_t words_per_frame;                      // output words (floats) per frame
+    uint32_t frames_per_unit;
+    uint64_t *plan;
+    uint64_t max_blocks;                           // capacity of the block table
+};
+
+__global__ __launch_bounds__(1024) void plan_ragged_device_kernel(const PlanParams q) {
+    __shared__ uint64_t part_units[1024], part_out[1024];
+    const uint32_t n = q.n_clips, tid = threadIdx.x;
+    uint64_t *off = q.plan, *fr = off + n, *oo = fr + n, *pre = oo + n;
+    uint32_t *blk = reinterpret_cast<uint32_t *>(pre + n + 1);
+    const uint32_t per = (n + 1023) / 1024, c0 = tid * per, c1 = c0 + per < n ? c0 + per : n;
+    uint64_t su = 0, so = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint64_t len = q.d_len[c];
+        const uint64_t f = len < q.frame_len ? 0 : (len - q.frame_len) / q.frame_shift + 1;
+        off[c] = q.d_off[c];
+        fr[c] = f;
+        su += (f + q.frames_per_unit - 1) / q.frames_per_unit;
+        so += f * q.words_per_frame;
+    }
+    part_units[tid] = su; part_out[tid] = so;
+    __syncthreads();
+    if (tid == 0) {                                  // 1024 partials: a serial scan is 2 us
+        uint64_t au = 0, ao = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const uint64_t u = part_units[i], o = part_out[i];
+            part_units[i] = au; part_out[i] = ao;
+            au += u; ao += o;
+        }
+        pre[n] = au;
+    }
+    __syncthreads();
+    su = part_units[tid]; so = part_out[tid];
+    for (uint32_t c = c0; c < c1; ++c) {
+        const uint64_t f = fr[c];
+        const uint64_t u = (f + q.frames_per_unit - 1) / q.frames_per_unit;
+        pre[c] = su;
+        oo[c] = q.d_out_off ? q.d_out_off[c] : so;
+        // the clip of every 16th unit inside [su, su + u)
+        for (uint64_t k = (su + kUnitBlock - 1) / kUnitBlock; k * kUnitBlock < su + u && k < q.max_blocks; ++k) blk[k] = c;
+        su += u;
+        so += f * q.words_per_frame;
     }
 }
 

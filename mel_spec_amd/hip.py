@@ -270,6 +270,13 @@ class HipMelSpectrogram:
             self._h, C.c_void_p(d_pcm), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
             C.c_void_p(d_out), None if oo is None else oo.ctypes.data_as(u64p), C.c_void_p(stream)))
 
+    def compute_ragged_device_desc(self, d_pcm: int, d_offsets: int, d_lengths: int, n_clips: int, d_out: int, d_out_offsets: int,
+                                   max_total_frames: int, stream: int = 0) -> None:
+        """melspec_compute_ragged_device_desc: the clip table (u64 offsets / lengths / output offsets) lives in device memory"""
+        _check(lib().melspec_compute_ragged_device_desc(self._h, C.c_void_p(d_pcm), C.c_void_p(d_offsets), C.c_void_p(d_lengths), n_clips,
+                                                        C.c_void_p(d_out), C.c_void_p(d_out_offsets) if d_out_offsets else None,
+                                                        max_total_frames, C.c_void_p(stream)))
+
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_synchronize(self._h, C.c_void_p(stream)))
 
@@ -387,6 +394,42 @@ class Fbank:
     @property
     def uses_fast_path(self) -> bool:
         return bool(lib().melspec_fbank_uses_fast_path(self._h))
+
+    def compute_ragged_device(self, d_pcm: int, offsets, lengths, d_out: int, out_offsets=None, stream: int = 0) -> None:
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        _check(lib().melspec_fbank_compute_ragged_device(self._h, C.c_void_p(d_pcm), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
+                                                         C.c_void_p(d_out), None if oo is None else oo.ctypes.data_as(u64p), C.c_void_p(stream)))
+
+    def compute_ragged_device_desc(self, d_pcm: int, d_offsets: int, d_lengths: int, n_clips: int, d_out: int, d_out_offsets: int,
+                                   max_total_frames: int, stream: int = 0) -> None:
+        _check(lib().melspec_fbank_compute_ragged_device_desc(self._h, C.c_void_p(d_pcm), C.c_void_p(d_offsets), C.c_void_p(d_lengths), n_clips,
+                                                              C.c_void_p(d_out), C.c_void_p(d_out_offsets) if d_out_offsets else None,
+                                                              max_total_frames, C.c_void_p(stream)))
+
+    def compute_ragged(self, clips) -> list:
+        """list of 1-D host arrays of any lengths -> list of [frames_i, num_mel_bins] arrays (Fbank::compute per clip), one launch"""
+        arrs = [_f32(c).reshape(-1) for c in clips]
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
+        frames = [self.num_frames(int(n)) for n in lens]
+        total = sum(frames) * self.num_mel_bins
+        flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
+        din, dout = DeviceBuffer(max(flat.nbytes, 16)), DeviceBuffer(max(total * 4, 16))
+        try:
+            din.upload(flat)
+            self.compute_ragged_device(din.ptr, offs, lens, dout.ptr)
+            self.synchronize()
+            out = dout.download((max(total, 1),))[:total]
+        finally:
+            din.free(); dout.free()
+        res, cur = [], 0
+        for f in frames:
+            res.append(out[cur:cur + f * self.num_mel_bins].reshape(f, self.num_mel_bins))
+            cur += f * self.num_mel_bins
+        return res
 
     def use_generic(self, on: bool = True) -> None:
         """run on the generic f64 direct-DFT kernel (the on-device cross-check of the fused kernel)"""

@@ -782,3 +782,83 @@ def test_streaming_stft_is_what_spectrogram_add_returns(gpu, oracle, jfk, fft, h
     assert want.shape[0] - 1 <= n <= want.shape[0] and got.shape[1] == fft
     assert np.abs(got - want[:n]).max() <= 1e-10 * np.abs(want).max()
     bank.close(); m.close()
+
+
+def _ragged_set(oracle, jfk, seed, n=57, fft=400):
+    rng = np.random.default_rng(seed)
+    lens = [int(v) for v in rng.integers(0, 70000, n)] + [fft - 1, fft, 0, 123457]
+    return [(jfk[(i * 977) % 60000:][:m] if i % 2 else oracle.synth_pcm(i, m)).astype(np.float32) for i, m in enumerate(lens)]
+
+
+@pytest.mark.parametrize("fft,hop,n_mels,mode", [(400, 160, 80, "auto"), (400, 160, 128, "auto"), (400, 160, 80, "f64"), (512, 160, 80, "auto"), (256, 100, 40, "auto")])
+def test_ragged_batch_with_the_clip_table_in_device_memory(gpu, oracle, jfk, fft, hop, n_mels, mode):
+    """melspec_compute_ragged_device_desc: offsets / lengths / output offsets are device arrays and the plan is built by a kernel;
+    same bits as the host-table call, packed and scattered outputs, a generous and a tight frame bound."""
+    m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
+    if m.uses_fast_path and fft == 400:
+        m.set_precision(mode)
+    clips = _ragged_set(oracle, jfk, 3, fft=fft)
+    lens = np.array([len(c) for c in clips], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    frames = np.array([m.num_frames(int(v)) for v in lens], np.uint64)
+    total = int(frames.sum())
+    flat = np.concatenate(clips)
+    din, dout, dref = gpu.DeviceBuffer(flat.nbytes), gpu.DeviceBuffer((total * n_mels + 1000) * 4), gpu.DeviceBuffer((total * n_mels + 1000) * 4)
+    din.upload(flat)
+    d_off, d_len, d_oo = gpu.DeviceBuffer(offs.nbytes), gpu.DeviceBuffer(lens.nbytes), gpu.DeviceBuffer(offs.nbytes)
+    d_off.upload(offs.view(np.float32)); d_len.upload(lens.view(np.float32))
+    m.compute_ragged_device(din.ptr, offs, lens, dref.ptr)
+    m.synchronize()
+    ref = dref.download((total * n_mels,))
+    for bound in (total, total + 5000):
+        m.compute_ragged_device_desc(din.ptr, d_off.ptr, d_len.ptr, len(clips), dout.ptr, 0, bound)
+        m.synchronize()
+        assert np.array_equal(dout.download((total * n_mels,)), ref)
+    # scattered outputs: reverse order with gaps
+    sizes = frames * n_mels + 9
+    ooff = (np.cumsum(sizes[::-1])[::-1] - sizes).astype(np.uint64)
+    d_oo.upload(ooff.view(np.float32))
+    big = gpu.DeviceBuffer(int(sizes.sum()) * 4)
+    m.compute_ragged_device_desc(din.ptr, d_off.ptr, d_len.ptr, len(clips), big.ptr, d_oo.ptr, total)
+    m.synchronize()
+    got = big.download((int(sizes.sum()),))
+    cur = 0
+    for c, f in enumerate(frames):
+        n = int(f) * n_mels
+        assert np.array_equal(got[int(ooff[c]):int(ooff[c]) + n], ref[cur:cur + n])
+        cur += n
+    want = oracle.compute_mel_spectrogram_cpu(clips[-1], fft, hop, n_mels, SR)
+    assert np.abs(ref[cur - want.size:cur].reshape(want.shape) - want).max() <= TOL
+    for b in (din, dout, dref, d_off, d_len, d_oo, big):
+        b.free()
+    m.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(num_mel_bins=40, apply_cmn=False), dict(frame_shift_ms=6.3125)])
+def test_fbank_ragged_batches(gpu, oracle, jfk, kw):
+    """Fbank::compute is per clip of any length (src/fbank.rs:141): many clips of different lengths in one launch, host and device
+    clip tables, CMN per clip; against the oracle clip by clip."""
+    fb = gpu.Fbank(gpu.FbankConfig(**kw))
+    oc = oracle.fbank_default_config()
+    for k_, v in kw.items():
+        setattr(oc, k_, type(getattr(oc, k_))(v))
+    clips = _ragged_set(oracle, jfk, 8, n=33)
+    got = fb.compute_ragged(clips)
+    for g, x in zip(got, clips):
+        want = oracle.fbank_compute(x, oc)
+        assert g.shape == want.shape and (g.size == 0 or np.abs(g - want).max() <= TOL)
+    # device clip table
+    lens = np.array([len(c) for c in clips], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    total = sum(g.shape[0] for g in got)
+    nm = fb.num_mel_bins
+    flat = np.concatenate(clips)
+    din, dout = gpu.DeviceBuffer(flat.nbytes), gpu.DeviceBuffer(max(total * nm, 1) * 4)
+    d_off, d_len = gpu.DeviceBuffer(offs.nbytes), gpu.DeviceBuffer(lens.nbytes)
+    din.upload(flat); d_off.upload(offs.view(np.float32)); d_len.upload(lens.view(np.float32))
+    fb.compute_ragged_device_desc(din.ptr, d_off.ptr, d_len.ptr, len(clips), dout.ptr, 0, total + 77)
+    fb.synchronize()
+    assert np.array_equal(dout.download((total * nm,)), np.concatenate([g.reshape(-1) for g in got]))
+    for b in (din, dout, d_off, d_len):
+        b.free()
+    fb.close()
