@@ -178,7 +178,7 @@ __device__ __forceinline__ unsigned frame_mask(uint64_t any) {
 // hot path 5 % (a call) to 40 % (inlined) away -- but note the unit (FixSink::list) and come back to it when their run is done.
 // Six frames x ten lanes.
 template <int NSLOTS, class Lens, bool LAYOUT>
-__device__ __forceinline__ void six_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+__device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
                                           const FixSink &fix, const float *src, float *out_tile, long long row_w) {
     const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
     const bool in = lane < kSixFrames * kSixLanes;
@@ -198,13 +198,14 @@ __device__ __forceinline__ void six_fix_unit(unsigned mask, int lane, int hop, i
         __builtin_amdgcn_wave_barrier();
         six_phase4<NSLOTS, LAYOUT, false>(fl, j, act, act, n_mels, slice, vals, out_tile, row_w);
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) atomicAdd(fix.count, 1u);
     }
+    return static_cast<unsigned>(__builtin_popcount(mask));      // frames recomputed (the caller adds them up: one atomic per wave, not per
+                                                                  // frame -- a million atomics on one address took 10 ms)
 }
 
 // The same for the five-frame kernels (12 lanes per frame in phases 3-4).
 template <int NSLOTS, class Lens, bool LAYOUT>
-__device__ __forceinline__ void wave_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
+__device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
                                            const FixSink &fix, const float *src, float *out_tile, long long row_w) {
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
@@ -224,8 +225,9 @@ __device__ __forceinline__ void wave_fix_unit(unsigned mask, int lane, int hop, 
         __builtin_amdgcn_wave_barrier();
         wave_phase4<NSLOTS, LAYOUT, false>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w);
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) atomicAdd(fix.count, 1u);
     }
+    return static_cast<unsigned>(__builtin_popcount(mask));      // frames recomputed (the caller adds them up: one atomic per wave, not per
+                                                                  // frame -- a million atomics on one address took 10 ms)
 }
 
 // Sub-group barrier of the mel-major stores (BatchDesc::sync_rounds = gsize + 16 * across, gsize in {2, 4, 8}): only the
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         rs.after_round();
     }
     // the units whose frames tripped the precision guard, again, in f64 (no barrier of the rounds involved any more)
+    unsigned redone = 0;
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
@@ -358,9 +361,10 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
                                           loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
+    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
 }
 
 // ------------------------------------------------------------------------------------
@@ -439,6 +443,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         }
         rs.after_round();
     }
+    unsigned redone = 0;
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
@@ -448,9 +453,10 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         const uint64_t f0 = loc.unit * kSixFrames;
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
+    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
 }
 
 // Plain [frame][mel] output, uniform and ragged batches, on the six-frame build -- the default kernel of the bench workload.
@@ -575,15 +581,17 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         }
     }
     // the units whose frames tripped the precision guard, again, in f64
+    unsigned redone = 0;
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
         e = scalar64(e);
         const UnitLoc loc = locate_unit(p.b, e >> 8);
         const uint64_t f0 = loc.unit * kSixFrames;
-        six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
                                           loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
+    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
 }
 
 // The same for the 5-frame kernel (81..131 mels): interval mel scheme, direct PCM reads, 8-wave workgroups.
@@ -649,15 +657,17 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
             }
         }
     }
+    unsigned redone = 0;
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
         e = scalar64(e);
         const UnitLoc loc = locate_unit(p.b, e >> 8);
         const uint64_t f0 = loc.unit * kFPW;
-        wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
                                            loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
+    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
 }
 
 // ------------------------------------------------------------------------------------

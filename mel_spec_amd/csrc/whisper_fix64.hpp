@@ -1,12 +1,14 @@
 // whisper_fix64.hpp -- the f64 recompute of ONE frame by a whole wavefront, inside the f32 kernels (MELSPEC_PRECISION_AUTO).
 //
 // The f32 kernels check every frame against an error bound in phase 4 (wave_phase4: a mel band within kGuardBand decades of the
-// per-frame clamp).  A frame that fails it is recomputed right there, by the wave that owns it, before the wave moves on: window,
-// 400-point real FFT, Hermitian split and |X|^2 in f64 (the reference's arithmetic, src/stft.rs:98-111), then the kernel's own
-// f32 mel / log10 / clamp phases on the new power row.  No second launch, no queue: noise-like input never takes the branch (the
-// bench workload pays one ballot per unit), a frame that does costs the wave ~2 us.  Contexts whose input trips the guard on
-// most frames (a line over a quiet floor, speech with > 60 dB of in-frame dynamic range) are better served by
-// MELSPEC_PRECISION_F64, which runs the dedicated f64 kernel (whisper_wave_f64.hpp) on everything.
+// per-frame clamp).  A wave notes the units that have such frames and, when its run of units is done, recomputes those frames
+// itself: window, 400-point real FFT, Hermitian split and |X|^2 in f64 (the reference's arithmetic, src/stft.rs:98-111), then the
+// kernel's own f32 mel / log10 / clamp phases on the new power row.  No second launch (two dependent launches cost the 0.3 ms
+// bench step 9.5 us), no cross-wave queue: noise-like input notes nothing (the bench workload pays one ballot per unit and runs
+// at the f32 rate), a recomputed frame costs its wave ~6 us (three dependent trips to the global tables; keeping the tables in
+// 60 VGPRs per lane was tried and spills both the tail and the hot loop).  Measured (tools/guard_bench.py, 1024 x 10 s, 80 mels):
+// noise 0.307 ms; speech, 66 % of the frames recomputed: 1.57 ms; a tone over a -70 dB floor, 100 %: 1.87 ms -- against 0.50 ms
+// for MELSPEC_PRECISION_F64, the dedicated f64 kernel (whisper_wave_f64.hpp) on everything, which is the mode for such input.
 //
 // Register budget is what shapes it: the f32 kernels live at <= 128 VGPRs (four waves per SIMD), so no lane may hold a 20-point
 // f64 DFT (80 VGPRs of data).  The complex-200 transform is spread over the lanes instead, 200 = 8 x 25 by Good-Thomas (no
