@@ -275,7 +275,8 @@ typedef struct melspec_blm melspec_blm;
 void melspec_blm_default_config(melspec_blm_config *cfg);                 /* BatchLogMelConfig::default (src/mel.rs:189-208) */
 /* BatchLogMelSpectrogram::new (src/mel.rs:248-280); validate_batch_config's messages (src/mel.rs:656-683) come
  * back through melspec_last_error with MELSPEC_ERR_INVALID_ARG (== BatchLogMelError::InvalidConfig).
- * Only n_fft = 512 / win_length = 400 (the NeMo/Parakeet geometry) is covered: else MELSPEC_ERR_UNSUPPORTED. */
+ * n_fft = 512 / win_length = 400 (the NeMo/Parakeet geometry) runs on the fused 512-point kernel, every other validated
+ * config (n_fft <= 4096) on the generic f64 kernel (two orders of magnitude slower, same results). */
 int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *cfg);
 void melspec_blm_destroy(melspec_blm *b);
 size_t melspec_blm_num_frames(const melspec_blm *b, size_t n_samples);    /* valid frames (src/mel.rs:387-395) */

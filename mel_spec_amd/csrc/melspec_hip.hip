@@ -347,13 +347,14 @@ unsigned grid_for_xcd(uint64_t units, int cus, int per_cu) {
     return (g + 7u) & ~7u;
 }
 
-int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, bool fbank, int use_log, int use_power,
-                   double preemph, double floor_v, int cus, hipStream_t stream) {
+int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int flavour /* 0 Whisper, 1 Kaldi fbank, 2 NeMo */, int use_log, int use_power,
+                   double preemph, double floor_v, int cus, hipStream_t stream, long long clip_len = 0, int pad = 0) {
     if (desc.n_units == 0) return MELSPEC_OK;
     GenericParams gp{};
     gp.b = desc;
     gp.n_fft = gt.n_fft; gp.frame_len = gt.frame_len; gp.hop = hop; gp.n_bins = gt.n_bins; gp.n_mels = gt.n_mels;
-    gp.fbank = fbank ? 1 : 0; gp.use_log = use_log; gp.use_power = use_power; gp.preemph = preemph; gp.floor_v = floor_v;
+    gp.fbank = flavour; gp.use_log = use_log; gp.use_power = use_power; gp.preemph = preemph; gp.floor_v = floor_v;
+    gp.clip_len = clip_len; gp.pad = pad;
     gp.d_win = static_cast<const double *>(gt.win.p);
     gp.d_tw = static_cast<const double *>(gt.tw.p);
     gp.d_mstart = static_cast<const int *>(gt.mstart.p);
@@ -610,7 +611,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         return c->ft512.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorWhisper, kFbSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream)
                                                   : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
     }
-    if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, false, 1, 1, 0.0, 0.0, c->dev.cus, stream);
+    if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, 0, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, stream);
     FixSink sink{};
     if (c->precision == MELSPEC_PRECISION_AUTO) {
@@ -1463,7 +1464,7 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         if (rc) return rc;
         // the CMN pass below walks clips, not units
     } else {
-        rc = launch_generic(fb->gt, pl.desc, fb->frame_shift, true, fb->cfg.use_log_fbank, fb->cfg.use_power,
+        rc = launch_generic(fb->gt, pl.desc, fb->frame_shift, 1, fb->cfg.use_log_fbank, fb->cfg.use_power,
                             fb->cfg.preemphasis, floor_v, fb->dev.cus, s);
     }
     if (rc) return rc;
@@ -2110,6 +2111,8 @@ struct melspec_blm {
     DeviceInfo dev;
     melspec_blm_config cfg{};
     hipStream_t stream = nullptr;
+    bool fast = false;          // fused 512-point kernel (n_fft 512 / win_length 400) vs the generic f64 kernel (any validated config)
+    GenericTables gt;
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -2153,8 +2156,8 @@ int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *
     if (!std::isfinite(cfg->log_zero_guard) || cfg->log_zero_guard <= 0.0f)
         return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: log_zero_guard must be finite and > 0");
     if (cfg->pad_to < 0) return fail(MELSPEC_ERR_INVALID_ARG, "invalid log-mel config: pad_to must be >= 0");
-    if (cfg->n_fft != 512 || cfg->win_length != 400)
-        return fail(MELSPEC_ERR_UNSUPPORTED, "only n_fft = 512 with win_length = 400 is covered by the fused kernel");
+    if (cfg->n_fft > kMaxGenericFft || cfg->n_mels > kMaxGenericMels)
+        return fail(MELSPEC_ERR_UNSUPPORTED, "n_fft must be <= 4096 and n_mels <= 1024");
     DeviceInfo info;
     int rc = pick_device(device, info);
     if (rc) return rc;
@@ -2165,13 +2168,37 @@ int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *
     if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
     if (hipStreamCreate(&b->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
     const double f_max = cfg->f_max > 0.0 ? cfg->f_max : cfg->sample_rate / 2.0;   // src/mel.rs:254
-    if (!build_blm_fast_tables<double>(cfg->sample_rate, cfg->n_mels, cfg->f_min, f_max, cfg->htk != 0, cfg->norm != 0, b->ft))
-        return bail(fail(MELSPEC_ERR_UNSUPPORTED, "filterbank outside the fused kernel's coverage (n_mels <= 149, triangular bank)"));
-    const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double);
-    b->waves = fused512_waves(b->ft.blob.size() * 4, slice_bytes);
-    b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(b->waves) * slice_bytes;
-    if (b->fast_lds > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "tables do not fit in LDS"));
-    if ((rc = upload(b->d_blob, b->ft.blob))) return bail(rc);
+    // the NeMo / Parakeet geometry (n_fft 512, win_length 400) runs on the fused 512-point kernel; every other validated config
+    // (src/mel.rs:248-280 accepts them all) on the generic f64 kernel
+    b->fast = cfg->n_fft == 512 && cfg->win_length == 400 &&
+              build_blm_fast_tables<double>(cfg->sample_rate, cfg->n_mels, cfg->f_min, f_max, cfg->htk != 0, cfg->norm != 0, b->ft);
+    if (b->fast) {
+        const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double);
+        b->waves = fused512_waves(b->ft.blob.size() * 4, slice_bytes);
+        b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(b->waves) * slice_bytes;
+        if (b->fast_lds > kLdsLimit) b->fast = false;
+    }
+    if (b->fast) {
+        if ((rc = upload(b->d_blob, b->ft.blob))) return bail(rc);
+    } else {
+        // the reference's f32 tables: symmetric Hann(win_length) centred in the n_fft frame (src/mel.rs:708-719), f32 weights
+        const int N = cfg->n_fft, bins = N / 2 + 1;
+        std::vector<double> win(static_cast<size_t>(N), 0.0);
+        if (cfg->win_length > 1) {
+            const int offset = (N - cfg->win_length) / 2;
+            const float pi_f32 = 3.14159265358979323846f;
+            for (int i = 0; i < cfg->win_length; ++i) {
+                const float phase = (2.0f * pi_f32 * static_cast<float>(i)) / (static_cast<float>(cfg->win_length) - 1.0f);
+                win[offset + i] = static_cast<double>(0.5f - (0.5f * std::cos(phase)));
+            }
+        }
+        std::vector<double> dense = mel_filterbank(static_cast<double>(cfg->sample_rate), N, cfg->n_mels, cfg->f_min > 0.0 ? cfg->f_min : -1.0, f_max,
+                                                   cfg->htk != 0, cfg->norm != 0);
+        for (double &w : dense) w = static_cast<double>(static_cast<float>(w));
+        if ((rc = b->gt.build(N, N, bins, win, dense, cfg->n_mels, bins))) return bail(rc);
+        if (b->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
+        if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
+    }
     *out = b;
     return MELSPEC_OK;
 }
@@ -2180,7 +2207,7 @@ void melspec_blm_destroy(melspec_blm *b) {
     if (!b) return;
     if (b->dev.device >= 0) (void)hipSetDevice(b->dev.device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    b->d_blob.release(); b->h2d.release(); b->d2h.release();
+    b->d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release();
     delete b;
 }
 
@@ -2197,6 +2224,13 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
     HIP_TRY(hipSetDevice(b->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
     const int nm = b->cfg.n_mels;
+    int rc;
+    if (!b->fast) {
+        const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, valid, n_clips, nm, 1, cols, true);
+        rc = launch_generic(b->gt, pl.desc, b->cfg.hop_length, 2, 1, 1, static_cast<double>(b->cfg.preemphasis), static_cast<double>(b->cfg.log_zero_guard),
+                            b->dev.cus, s, static_cast<long long>(clip_len), b->cfg.center ? b->cfg.n_fft / 2 : 0);
+        if (rc) return rc;
+    } else {
     const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, valid, n_clips, nm, kFbFPW, cols, true);
     FbankFastParams fp{};
     fp.b = pl.desc;
@@ -2211,12 +2245,12 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
     fp.clip_len = static_cast<long long>(clip_len);
     fp.org0 = b->cfg.center ? -200 : 56;      // tap 0 of the window sits at position (512-400)/2 of the frame
     fp.slots = b->ft.slots;
-    int rc;
     if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
     else if (fb_lens_match<LensSlaney80>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kFbSlots, LensSlaney80>(b->waves, fp, b->fast_lds, b->dev.cus, s);
     else rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
                                               : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
     if (rc) return rc;
+    }
     if (b->cfg.normalize_per_feature && valid > 0) {
         BlmNormParams np{};
         np.out = d_out; np.clip_stride = cols * static_cast<uint64_t>(nm); np.row_w = cols; np.valid = valid;

@@ -1406,9 +1406,11 @@ struct GenericParams {
     int hop;
     int n_bins;            // bins whose power is needed: n_fft/2 (Whisper) or n_fft/2+1 (fbank)
     int n_mels;
-    int fbank;             // 0: Whisper log10 + per-frame norm; 1: Kaldi fbank
+    int fbank;             // 0: Whisper log10 + per-frame norm; 1: Kaldi fbank; 2: NeMo BatchLogMelSpectrogram (src/mel.rs:321-385)
     int use_log, use_power;
-    double preemph, floor_v;
+    double preemph, floor_v;   // NeMo: preemph = the f32 coefficient, floor_v = log_zero_guard
+    long long clip_len;    // NeMo (uniform batches): samples per clip
+    int pad;               // NeMo: n_fft / 2 when centred (zero padding either side, src/mel.rs:685-694), else 0
     const double *d_win;   // [frame_len]
     const double *d_tw;    // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
     const int *d_mstart;   // [n_mels]
@@ -1460,6 +1462,18 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
         if (!p.fbank) {
             // frame_windows: x[start+i] as f64 * window[i]   (src/stft.rs:160-165)
             for (int i = tid; i < p.frame_len; i += NT) xw[i] = (double)x[i] * p.d_win[i];
+        } else if (p.fbank == 2) {
+            // whole-clip pre-emphasis in f32 with the reference's two roundings (src/mel.rs:696-706), zero centre padding, window
+            const float coeff = (float)p.preemph;
+            for (int i = tid; i < p.frame_len; i += NT) {
+                const long long sidx = (long long)start + i - p.pad;
+                float v = 0.0f;
+                if (sidx >= 0 && sidx < p.clip_len) {
+                    v = loc.pcm[sidx];
+                    if (coeff != 0.0f && sidx > 0) v = v - f32_mul_rn(coeff, loc.pcm[sidx - 1]);
+                }
+                xw[i] = (double)v * p.d_win[i];
+            }
         } else {
             // DC removal, pre-emphasis, Povey window   (src/fbank.rs:164-190)
             double part = 0.0;
@@ -1498,6 +1512,8 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
             double v;
             if (!p.fbank) {
                 v = log10(e > 1e-10 ? e : 1e-10);          // src/mel.rs:166
+            } else if (p.fbank == 2) {
+                v = log(e + p.floor_v);                    // src/mel.rs:365-368
             } else {
                 v = e > p.floor_v ? e : p.floor_v;           // src/fbank.rs:210-218
                 if (p.use_log) v = log(v);
@@ -1514,6 +1530,8 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
                 const double v = mv[m] > lo ? mv[m] : lo;
                 o[m * ostep] = (float)((v + 4.0) / 4.0);
             }
+        } else if (p.fbank == 2) {
+            for (int m = tid; m < p.n_mels; m += NT) o[m * ostep] = (float)mv[m];      // feature-major rows (src/mel.rs:366)
         } else {
             for (int m = tid; m < p.n_mels; m += NT) o[m] = (float)mv[m];
         }

@@ -523,8 +523,30 @@ def test_nemo_frontend_reference_shape_and_errors(gpu):
                      (dict(hop_length=0), "hop_length must be > 0"), (dict(log_zero_guard=0.0), "log_zero_guard must be finite and > 0")):
         with pytest.raises(gpu.BatchLogMelError, match=msg):      # validate_batch_config, src/mel.rs:656-683
             gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**bad))
-    with pytest.raises(gpu.HipUnavailable):
-        gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_fft=1024, win_length=800))   # outside the fused kernel
+
+
+@pytest.mark.parametrize("kw", [dict(n_fft=1024, win_length=800, hop_length=256), dict(n_fft=400, win_length=400, hop_length=160, n_mels=64),
+                                dict(n_fft=512, win_length=320, hop_length=160, preemphasis=0.97, normalize_per_feature=True),
+                                dict(n_fft=256, win_length=200, hop_length=80, center=False, pad_to=16, n_mels=40, sample_rate=8000),
+                                dict(n_fft=300, win_length=1, hop_length=77, n_mels=20)])
+def test_nemo_frontend_any_validated_geometry(gpu, oracle, jfk, kw):
+    """BatchLogMelSpectrogram::new accepts every config validate_batch_config lets through (src/mel.rs:248-280,656-683): what is not
+    the NeMo / Parakeet geometry of the fused kernel (n_fft 512, win_length 400) runs on the generic f64 kernel."""
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+    cfg = oracle.blm_default_config(**kw)
+    for x in (jfk[30000:47000], oracle.synth_pcm(3, 5003), oracle.synth_pcm(4, max(1, kw["n_fft"] - 1)), np.zeros(0, np.float32)):
+        want, valid = oracle.blm_compute(x, cfg, True)
+        got = fe.compute(x)
+        assert got.shape == want.shape
+        if want.size:
+            tol = 2e-3 if kw.get("normalize_per_feature") else TOL
+            assert np.abs(got - want).max() <= tol, kw
+    clips = np.stack([oracle.synth_pcm(c, 9000) for c in range(5)])
+    got = fe.compute_batch(clips)
+    for c in range(5):
+        want, _ = oracle.blm_compute(clips[c], cfg, True)
+        assert np.abs(got[c] - want).max() <= (2e-3 if kw.get("normalize_per_feature") else TOL)
+    fe.close()
 
 
 def test_nemo_frontend_batch(gpu, oracle):
