@@ -62,6 +62,9 @@ void melspec_destroy(melspec_ctx *ctx);   /* Drop (src/cuda.rs:142-148,366-375) 
 
 /* frame_windows' count: len < fft ? 0 : (len - fft)/hop + 1 (src/stft.rs:153-157). */
 size_t melspec_num_frames(const melspec_ctx *ctx, size_t n_samples);
+/* CudaMelSpectrogram::max_frames_per_batch (src/cuda.rs:84-86, 150-155: the reference chunks at 8192 frames / 64 MiB): frames
+ * per chunk of the host pipeline here (16 MiB of PCM: 26 212 at 400/160).  The device entry points take any batch in one launch. */
+size_t melspec_max_frames_per_batch(const melspec_ctx *ctx);
 int melspec_fft_size(const melspec_ctx *ctx);
 int melspec_hop_size(const melspec_ctx *ctx);
 int melspec_n_mels(const melspec_ctx *ctx);

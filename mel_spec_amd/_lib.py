@@ -50,6 +50,7 @@ SIGNATURES = {
     "melspec_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
     "melspec_destroy": (None, [_vp]),
     "melspec_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
+    "melspec_max_frames_per_batch": (C.c_size_t, [_vp]),
     "melspec_fft_size": (C.c_int, [_vp]),
     "melspec_hop_size": (C.c_int, [_vp]),
     "melspec_n_mels": (C.c_int, [_vp]),

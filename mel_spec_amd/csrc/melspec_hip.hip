@@ -55,6 +55,7 @@ constexpr int kGenericNT = 256;
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
+constexpr uint64_t kPipeChunkSamples = 4u << 20;      // host pipeline: 16 MiB of PCM per chunk (host_pipe.hpp)
 
 // Tuning switches exist only in -DMELSPEC_LAB builds (mel_spec_amd.build.build(lab=True), used by tools/): the product
 // library runs the measured defaults below and reads no environment variable except MELSPEC_PRECISE (melspec_create).
@@ -754,6 +755,11 @@ size_t melspec_num_frames(const melspec_ctx *c, size_t n_samples) {
     uint64_t f; ctx_num_frames(c, n_samples, f);
     return static_cast<size_t>(f);
 }
+size_t melspec_max_frames_per_batch(const melspec_ctx *c) {
+    // frames of one chunk of the host pipeline (16 MiB of PCM); the device entry points have no limit
+    if (!c || kPipeChunkSamples < static_cast<uint64_t>(c->fft_size)) return 0;
+    return static_cast<size_t>((kPipeChunkSamples - c->fft_size) / c->hop_size + 1);
+}
 int melspec_fft_size(const melspec_ctx *c) { return c ? c->fft_size : 0; }
 int melspec_hop_size(const melspec_ctx *c) { return c ? c->hop_size : 0; }
 int melspec_n_mels(const melspec_ctx *c) { return c ? c->n_mels : 0; }
@@ -912,7 +918,6 @@ int melspec_synchronize(melspec_ctx *c, void *stream) {
 }
 
 namespace {
-constexpr uint64_t kPipeChunkSamples = 4u << 20;      // 16 MiB of PCM per chunk
 
 // clip (src, n) -> its frames at dst, cut into frame-aligned pieces of at most kPipeChunkSamples samples
 void push_segments(const melspec_ctx *c, const float *src, uint64_t n, float *dst, uint64_t frames, std::vector<HostSeg> &segs) {

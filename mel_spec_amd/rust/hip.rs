@@ -7,10 +7,22 @@
 use std::ffi::{c_char, c_int, c_void, CStr};
 use std::fmt;
 
+/// Same split as `CudaError` (src/cuda.rs:10-25): construction problems are `Unavailable(&'static str)` so that callers and
+/// tests can skip (src/cuda.rs:512-518), per-call problems are `Runtime(String)` with the library's message.
 #[derive(Debug)]
 pub enum HipError {
     Runtime(String),
-    Unavailable(String),
+    Unavailable(&'static str),
+}
+
+/// The library reports construction failures as codes (include/melspec_hip.h); `Unavailable` wants a `&'static str`.
+fn unavailable(rc: c_int) -> HipError {
+    HipError::Unavailable(match rc {
+        -1 => "fft_size, hop_size, and n_mels must be non-zero", // src/cuda.rs:45-49
+        -2 => "no gfx950 (MI355X) device visible to the HIP runtime",
+        -4 => "geometry outside what the HIP kernels cover",
+        _ => "HIP backend failed to initialise",
+    })
 }
 
 impl fmt::Display for HipError {
@@ -38,6 +50,28 @@ unsafe extern "C" {
                                       d_out: *mut f32, stream: *mut c_void) -> c_int;
     fn melspec_synchronize(ctx: *mut Ctx, stream: *mut c_void) -> c_int;
     fn melspec_set_precise(ctx: *mut Ctx, on: c_int) -> c_int;
+    fn melspec_set_precision(ctx: *mut Ctx, mode: c_int) -> c_int;
+    fn melspec_max_frames_per_batch(ctx: *const Ctx) -> usize;
+    fn melspec_compute_batch_host(ctx: *mut Ctx, samples: *const f32, offsets: *const u64, lengths: *const u64, n_clips: u32,
+                                  out: *mut f32, out_offsets: *const u64, cap: usize, total_frames: *mut u64) -> c_int;
+    fn melspec_stft_bins(ctx: *const Ctx, full: c_int) -> usize;
+    fn melspec_stft_host(ctx: *mut Ctx, samples: *const f32, n: usize, out: *mut c_void, cap: usize, dtype: c_int, full: c_int,
+                         frames: *mut usize) -> c_int;
+    // Fbank (src/fbank.rs:85-247)
+    fn melspec_fbank_create(out: *mut *mut FbankHandle, device: c_int, cfg: *const FbankConfigC) -> c_int;
+    fn melspec_fbank_destroy(fb: *mut FbankHandle);
+    fn melspec_fbank_num_frames(fb: *const FbankHandle, n: usize) -> usize;
+    fn melspec_fbank_compute_host(fb: *mut FbankHandle, samples: *const f32, n: usize, out: *mut f32, cap: usize, frames: *mut usize) -> c_int;
+    // BatchLogMelSpectrogram (src/mel.rs:171-418)
+    fn melspec_blm_create(out: *mut *mut BlmHandle, device: c_int, cfg: *const BlmConfigC) -> c_int;
+    fn melspec_blm_destroy(b: *mut BlmHandle);
+    fn melspec_blm_padded_frames(b: *const BlmHandle, n: usize) -> usize;
+    fn melspec_blm_num_frames(b: *const BlmHandle, n: usize) -> usize;
+    fn melspec_blm_compute_host(b: *mut BlmHandle, samples: *const f32, n: usize, out: *mut f32, cap: usize, rows: *mut usize, cols: *mut usize) -> c_int;
+    // vad_boundaries (src/vad.rs:251-340)
+    fn melspec_vad_mask_len(n_mels: c_int, width: usize) -> usize;
+    fn melspec_vad_boundaries_host(device: c_int, image: *const f32, n_mels: c_int, width: usize, settings: *const VadSettingsC,
+                                   raw: *mut u8, smoothed: *mut u8, longest_run: *mut u32) -> c_int;
     fn melspec_last_error() -> *const c_char;
     // src/quant.rs on the device (tga_8bit / parse_tga_8bit / quantize / dequantize)
     fn melspec_tga_create(out: *mut *mut Tga, device: c_int) -> c_int;
@@ -58,6 +92,56 @@ struct Tga {
     _private: [u8; 0],
 }
 #[repr(C)]
+struct FbankHandle {
+    _private: [u8; 0],
+}
+#[repr(C)]
+struct BlmHandle {
+    _private: [u8; 0],
+}
+/// melspec_fbank_config (include/melspec_hip.h): FbankConfig (src/fbank.rs:25-44) without `dither` and `use_energy`, which
+/// `Fbank::compute` never reads.
+#[repr(C)]
+struct FbankConfigC {
+    sample_rate: f64,
+    num_mel_bins: i32,
+    frame_length_ms: f64,
+    frame_shift_ms: f64,
+    energy_floor: f64,
+    use_log_fbank: i32,
+    use_power: i32,
+    preemphasis: f64,
+    apply_cmn: i32,
+    low_freq: f64,
+    high_freq: f64,
+}
+/// melspec_blm_config == BatchLogMelConfig (src/mel.rs:171-187); f_max <= 0 encodes None.
+#[repr(C)]
+struct BlmConfigC {
+    sample_rate: i32,
+    n_fft: i32,
+    win_length: i32,
+    hop_length: i32,
+    n_mels: i32,
+    f_min: f64,
+    f_max: f64,
+    htk: i32,
+    norm: i32,
+    preemphasis: f32,
+    center: i32,
+    log_zero_guard: f32,
+    pad_to: i32,
+    normalize_per_feature: i32,
+}
+/// melspec_vad_settings == DetectionSettings (src/vad.rs:5-11)
+#[repr(C)]
+struct VadSettingsC {
+    min_energy: f64,
+    min_y: c_int,
+    min_x: c_int,
+    min_mel: c_int,
+}
+#[repr(C)]
 struct Stream {
     _private: [u8; 0],
 }
@@ -76,9 +160,63 @@ impl HipMelSpectrogram {
         let mut ctx = std::ptr::null_mut();
         let rc = unsafe { melspec_create(&mut ctx, -1, fft_size as c_int, hop_size as c_int, sampling_rate, n_mels as c_int) };
         if rc != 0 {
-            return Err(HipError::Unavailable(last_error()));
+            return Err(unavailable(rc));
         }
         Ok(Self { ctx, n_mels })
+    }
+
+    /// `CudaMelSpectrogram::max_frames_per_batch` (src/cuda.rs:84-86): frames per chunk of the host pipeline.
+    pub fn max_frames_per_batch(&self) -> usize {
+        unsafe { melspec_max_frames_per_batch(self.ctx) }
+    }
+
+    /// 0: f32 FFT + f64 recompute of the frames its error bound does not cover (default, within 1e-4 on every input),
+    /// 1: f64 on every frame (the mode for batches of speech / tonal input), 2: f32 only.
+    pub fn set_precision(&mut self, mode: i32) -> Result<(), HipError> {
+        match unsafe { melspec_set_precision(self.ctx, mode as c_int) } {
+            0 => Ok(()),
+            _ => Err(HipError::Runtime(last_error())),
+        }
+    }
+
+    /// Additive: many clips in one call through the chunked H2D / kernels / D2H pipeline; `Vec<Vec<Vec<f32>>>` = clip, frame, mel.
+    pub fn compute_batch(&mut self, clips: &[&[f32]]) -> Result<Vec<Vec<Vec<f32>>>, HipError> {
+        let lens: Vec<u64> = clips.iter().map(|c| c.len() as u64).collect();
+        let mut offs = Vec::with_capacity(clips.len());
+        let mut flat = Vec::with_capacity(lens.iter().sum::<u64>() as usize);
+        for c in clips {
+            offs.push(flat.len() as u64);
+            flat.extend_from_slice(c);
+        }
+        let frames: Vec<usize> = clips.iter().map(|c| unsafe { melspec_num_frames(self.ctx, c.len()) }).collect();
+        let mut out = vec![0.0f32; frames.iter().sum::<usize>() * self.n_mels];
+        let mut total = 0u64;
+        let rc = unsafe {
+            melspec_compute_batch_host(self.ctx, flat.as_ptr(), offs.as_ptr(), lens.as_ptr(), clips.len() as u32, out.as_mut_ptr(),
+                                       std::ptr::null(), out.len(), &mut total)
+        };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        let mut cur = 0usize;
+        Ok(frames.iter().map(|&f| {
+            let rows = out[cur..cur + f * self.n_mels].chunks(self.n_mels).map(|r| r.to_vec()).collect();
+            cur += f * self.n_mels;
+            rows
+        }).collect())
+    }
+
+    /// `Spectrogram::compute_all_cpu` (src/stft.rs:89-115): the full `fft_size`-bin complex spectrum of every frame, f64.
+    pub fn compute_all(&mut self, samples: &[f32]) -> Result<Vec<Vec<num::Complex<f64>>>, HipError> {
+        let frames = unsafe { melspec_num_frames(self.ctx, samples.len()) };
+        let bins = unsafe { melspec_stft_bins(self.ctx, 1) };
+        let mut flat = vec![num::Complex::<f64>::new(0.0, 0.0); frames * bins];
+        let mut got = 0usize;
+        let rc = unsafe { melspec_stft_host(self.ctx, samples.as_ptr(), samples.len(), flat.as_mut_ptr() as *mut c_void, flat.len(), 1, 1, &mut got) };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        Ok(flat.chunks(bins).take(got).map(|r| r.to_vec()).collect())
     }
 
     /// f64 window/FFT/power like `Spectrogram::compute_mel_spectrogram_cpu` and the CUDA backend's Z2Z FFT.
@@ -168,8 +306,9 @@ pub struct HipTga {
 impl HipTga {
     pub fn new() -> Result<Self, HipError> {
         let mut q = std::ptr::null_mut();
-        if unsafe { melspec_tga_create(&mut q, -1) } != 0 {
-            return Err(HipError::Unavailable(last_error()));
+        let rc = unsafe { melspec_tga_create(&mut q, -1) };
+        if rc != 0 {
+            return Err(unavailable(rc));
         }
         Ok(Self { q })
     }
@@ -214,8 +353,9 @@ pub struct HipStream<'a> {
 impl<'a> HipStream<'a> {
     pub fn new(mel: &'a mut HipMelSpectrogram, max_chunk: usize) -> Result<Self, HipError> {
         let mut st = std::ptr::null_mut();
-        if unsafe { melspec_stream_create(&mut st, mel.ctx, 1, max_chunk as u32) } != 0 {
-            return Err(HipError::Unavailable(last_error()));
+        let rc = unsafe { melspec_stream_create(&mut st, mel.ctx, 1, max_chunk as u32) };
+        if rc != 0 {
+            return Err(unavailable(rc));
         }
         Ok(Self { st, n_mels: mel.n_mels, _mel: std::marker::PhantomData })
     }
@@ -235,4 +375,133 @@ impl Drop for HipStream<'_> {
     fn drop(&mut self) {
         unsafe { melspec_stream_destroy(self.st) }
     }
+}
+
+/// `Fbank` (src/fbank.rs:85-247) on the GPU: same constructor argument, same `compute` signature and result type.
+pub struct HipFbank {
+    fb: *mut FbankHandle,
+    num_mel_bins: usize,
+}
+impl HipFbank {
+    pub fn new(config: crate::fbank::FbankConfig) -> Result<Self, HipError> {
+        let c = FbankConfigC {
+            sample_rate: config.sample_rate,
+            num_mel_bins: config.num_mel_bins as i32,
+            frame_length_ms: config.frame_length_ms,
+            frame_shift_ms: config.frame_shift_ms,
+            energy_floor: config.energy_floor,
+            use_log_fbank: config.use_log_fbank as i32,
+            use_power: config.use_power as i32,
+            preemphasis: config.preemphasis,
+            apply_cmn: config.apply_cmn as i32,
+            low_freq: config.low_freq,
+            high_freq: config.high_freq,
+        };
+        let mut fb = std::ptr::null_mut();
+        let rc = unsafe { melspec_fbank_create(&mut fb, -1, &c) };
+        if rc != 0 {
+            return Err(unavailable(rc));
+        }
+        Ok(Self { fb, num_mel_bins: config.num_mel_bins })
+    }
+    /// `Fbank::compute(&self, samples) -> Array2<f32>` (frames, num_mel_bins), src/fbank.rs:141-236
+    pub fn compute(&mut self, samples: &[f32]) -> Result<ndarray::Array2<f32>, HipError> {
+        let frames = unsafe { melspec_fbank_num_frames(self.fb, samples.len()) };
+        let mut flat = vec![0.0f32; frames * self.num_mel_bins];
+        let mut got = 0usize;
+        let rc = unsafe { melspec_fbank_compute_host(self.fb, samples.as_ptr(), samples.len(), flat.as_mut_ptr(), flat.len(), &mut got) };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        Ok(ndarray::Array2::from_shape_vec((got, self.num_mel_bins), flat).expect("shape"))
+    }
+}
+impl Drop for HipFbank {
+    fn drop(&mut self) {
+        unsafe { melspec_fbank_destroy(self.fb) }
+    }
+}
+
+/// `BatchLogMelSpectrogram` (src/mel.rs:239-396) on the GPU.  Invalid configs come back as
+/// `BatchLogMelError::InvalidConfig` with the reference's messages (validate_batch_config, src/mel.rs:656-683).
+pub struct HipBatchLogMel {
+    b: *mut BlmHandle,
+    n_mels: usize,
+}
+impl HipBatchLogMel {
+    pub fn new(config: crate::mel::BatchLogMelConfig) -> Result<Self, crate::mel::BatchLogMelError> {
+        let c = BlmConfigC {
+            sample_rate: config.sample_rate as i32,
+            n_fft: config.n_fft as i32,
+            win_length: config.win_length as i32,
+            hop_length: config.hop_length as i32,
+            n_mels: config.n_mels as i32,
+            f_min: config.f_min,
+            f_max: config.f_max.unwrap_or(-1.0),
+            htk: config.htk as i32,
+            norm: config.norm as i32,
+            preemphasis: config.preemphasis,
+            center: config.center as i32,
+            log_zero_guard: config.log_zero_guard,
+            pad_to: config.pad_to as i32,
+            normalize_per_feature: config.normalize_per_feature as i32,
+        };
+        let mut b = std::ptr::null_mut();
+        if unsafe { melspec_blm_create(&mut b, -1, &c) } != 0 {
+            return Err(crate::mel::BatchLogMelError::InvalidConfig(last_error()));
+        }
+        Ok(Self { b, n_mels: config.n_mels })
+    }
+    /// `compute(&self, samples) -> Array2<f32>` (n_mels, padded frames), src/mel.rs:299-302; the second value is
+    /// `BatchLogMelOutput::valid_frames` (src/mel.rs:387-395).
+    pub fn compute(&mut self, samples: &[f32]) -> Result<(ndarray::Array2<f32>, usize), HipError> {
+        let cols = unsafe { melspec_blm_padded_frames(self.b, samples.len()) };
+        let valid = unsafe { melspec_blm_num_frames(self.b, samples.len()) };
+        let mut flat = vec![0.0f32; self.n_mels * cols];
+        let (mut rows, mut got_cols) = (0usize, 0usize);
+        let rc = unsafe { melspec_blm_compute_host(self.b, samples.as_ptr(), samples.len(), flat.as_mut_ptr(), flat.len(), &mut rows, &mut got_cols) };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        Ok((ndarray::Array2::from_shape_vec((self.n_mels, got_cols), flat).expect("shape"), valid))
+    }
+}
+impl Drop for HipBatchLogMel {
+    fn drop(&mut self) {
+        unsafe { melspec_blm_destroy(self.b) }
+    }
+}
+
+/// `vad_boundaries(frames, settings) -> EdgeInfo` (src/vad.rs:251-340) with the Sobel stencil and the majority vote on the GPU.
+/// `frames`: the mel images of `interleave_frames(.., false, ..)` / `to_array2`, concatenated along time like the reference does.
+pub fn hip_vad_boundaries(frames: &[ndarray::Array2<f64>], settings: &crate::vad::DetectionSettings) -> Result<crate::vad::EdgeInfo, HipError> {
+    use std::collections::HashSet;
+    let Some(first) = frames.first() else {
+        return Ok(crate::vad::EdgeInfo::new(Vec::new(), Vec::new(), HashSet::new()));
+    };
+    let height = first.nrows();
+    let width: usize = frames.iter().map(|f| f.ncols()).sum();
+    let mut image = vec![0.0f32; height * width];
+    let mut x0 = 0usize;
+    for f in frames {
+        for y in 0..height {
+            for x in 0..f.ncols() {
+                image[y * width + x0 + x] = f[[y, x]] as f32;
+            }
+        }
+        x0 += f.ncols();
+    }
+    let n = unsafe { melspec_vad_mask_len(height as c_int, width) };
+    let (mut raw, mut smoothed, mut run) = (vec![0u8; n.max(1)], vec![0u8; n.max(1)], 0u32);
+    let s = VadSettingsC { min_energy: settings.min_energy, min_y: settings.min_y as c_int, min_x: settings.min_x as c_int, min_mel: settings.min_mel as c_int };
+    let rc = unsafe { melspec_vad_boundaries_host(-1, image.as_ptr(), height as c_int, width, &s, raw.as_mut_ptr(), smoothed.as_mut_ptr(), &mut run) };
+    if rc != 0 {
+        return Err(HipError::Runtime(last_error()));
+    }
+    let (mut hit, mut miss) = (Vec::new(), Vec::new());
+    for (x, &m) in smoothed.iter().take(n).enumerate() {
+        if m != 0 { hit.push(x) } else { miss.push(x) }
+    }
+    // gradient_positions is only read by as_image (src/vad.rs:523-529), which is outside the accelerated path
+    Ok(crate::vad::EdgeInfo::new(miss, hit, HashSet::new()))
 }
