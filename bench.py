@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive host API figure (never `value`)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the consolidation of the outputs on rank 0")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn the ranks (gloo), plan every rank's shard, run the timing protocol on a "
+                                                            "sleep and print the JSON line -- the CPU test of the launch path")
     return ap.parse_args()
 
 
@@ -112,11 +114,42 @@ def cpu_baseline(clip_len: int, n_mels: int, target_s: float, pool: int) -> dict
     }
 
 
+def dry_run(args) -> None:
+    """The launch path without a GPU: ranks over gloo, the shard plan of every rank, the barrier / MAX-over-ranks protocol."""
+    import torch
+    import torch.distributed as dist
+    from mel_spec_amd.parallel import shard_range, timed_steps
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    cfg_clips, cfg_seconds, cfg_mels, scaling = CONFIGS[args.config]
+    total = args.clips or cfg_clips
+    lo, hi = (rank * total, (rank + 1) * total) if scaling == "weak" else shard_range(total, rank, world)
+    elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), lambda: None, 3, 1, dist if world > 1 else None, None)
+    mine = torch.tensor([lo, hi], dtype=torch.int64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": scaling, "config": args.config,
+                          "shards": [[int(t[0]), int(t[1])] for t in allr], "max_over_ranks_s": elapsed}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     args = parse_args()
     launched = "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         respawn_under_torchrun(args)          # does not return
+    if args.dry_run:
+        return dry_run(args)
     import numpy as np
     import torch
     import mel_spec_amd as M

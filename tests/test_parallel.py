@@ -129,3 +129,24 @@ def test_two_rank_gloo_run_covers_every_clip_once(tmp_path, oracle):
     assert int(line[1]) == sum(o.shape[0] for o in want)
     assert abs(float(line[2]) - float(sum(np.float64(o).sum() for o in want))) < 1e-6
     assert line[3] == "True"
+
+
+@pytest.mark.parametrize("gpus,config", [(2, 2), (2, 5), (1, 5)])
+def test_bench_spawns_its_ranks(gpus, config):
+    """`python bench.py --gpus N` as the driver runs it, without a launcher: bench.py re-executes itself under
+    torch.distributed.run, every rank plans its shard (config 5: shard_range over the 65 536 clips), the barrier / MAX protocol
+    runs, rank 0 prints one JSON line with n_gpus == N.  --dry-run keeps it off the GPU (gloo)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--config", str(config), "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == gpus and line["dry_run"] is True
+    sh = line["shards"]
+    assert len(sh) == gpus
+    if config == 5:
+        assert line["scaling"] == "strong" and sh[0][0] == 0 and sh[-1][1] == 65536 and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+    else:
+        assert line["scaling"] == "weak" and sh == [[1024 * r, 1024 * (r + 1)] for r in range(gpus)]
+    assert line["max_over_ranks_s"] >= 0.002 * gpus * 3 * 0.9
