@@ -10,6 +10,7 @@
 // CudaError::Runtime (per call).  Objects are move-only and single-threaded, like `&mut self`.
 #pragma once
 #include <cstddef>
+#include <cstdint>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -74,6 +75,45 @@ public:
     // f64 window/FFT/power like the reference's CPU and CUDA paths (melspec_set_precise)
     void set_precise(bool on) { detail::check(melspec_set_precise(ctx_, on ? 1 : 0), false); }
     bool precise() const { return melspec_is_precise(ctx_) != 0; }
+    // MELSPEC_PRECISION_AUTO (default) / _F64 / _F32
+    void set_precision(int mode) { detail::check(melspec_set_precision(ctx_, mode), false); }
+    int precision() const { return melspec_precision(ctx_); }
+    // CudaMelSpectrogram::max_frames_per_batch (src/cuda.rs:84-86): frames per chunk of the host pipeline
+    std::size_t max_frames_per_batch() const { return melspec_max_frames_per_batch(ctx_); }
+
+    // additive: many host clips in one call through the chunked H2D / kernels / D2H pipeline -> [clip][frame][mel]
+    std::vector<std::vector<std::vector<float>>> compute_batch(const std::vector<std::vector<float>> &clips) {
+        std::vector<std::uint64_t> offs, lens;
+        std::vector<float> flat;
+        for (const auto &c : clips) { offs.push_back(flat.size()); lens.push_back(c.size()); flat.insert(flat.end(), c.begin(), c.end()); }
+        const std::size_t nm = n_mels();
+        std::size_t total = 0;
+        for (const auto &c : clips) total += num_frames(c.size());
+        std::vector<float> out(total * nm + 1);
+        std::uint64_t got = 0;
+        if (flat.empty()) flat.push_back(0.0f);
+        detail::check(melspec_compute_batch_host(ctx_, flat.data(), offs.data(), lens.data(), static_cast<std::uint32_t>(clips.size()),
+                                                 out.data(), nullptr, out.size(), &got), false);
+        std::vector<std::vector<std::vector<float>>> res(clips.size());
+        std::size_t cur = 0;
+        for (std::size_t c = 0; c < clips.size(); ++c) {
+            const std::size_t f = num_frames(clips[c].size());
+            res[c].resize(f);
+            for (std::size_t i = 0; i < f; ++i, cur += nm) res[c][i].assign(out.begin() + cur, out.begin() + cur + nm);
+        }
+        return res;
+    }
+
+    // Spectrogram::compute_all_cpu (src/stft.rs:89-115): [frame][fft_size] interleaved (re, im) doubles
+    std::vector<std::vector<double>> compute_all(const std::vector<float> &samples) {
+        const std::size_t frames = num_frames(samples.size()), bins = melspec_stft_bins(ctx_, 1);
+        std::vector<double> flat(frames * bins * 2 + 2);
+        std::size_t got = 0;
+        detail::check(melspec_stft_host(ctx_, samples.data(), samples.size(), flat.data(), frames * bins, MELSPEC_STFT_F64, 1, &got), false);
+        std::vector<std::vector<double>> out(got);
+        for (std::size_t f = 0; f < got; ++f) out[f].assign(flat.begin() + f * bins * 2, flat.begin() + (f + 1) * bins * 2);
+        return out;
+    }
     melspec_ctx *raw() { return ctx_; }
 
 private:

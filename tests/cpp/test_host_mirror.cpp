@@ -69,6 +69,18 @@ int main() {
         std::printf("precise max delta %.3g\n", md);
         if (!(md <= 2e-6f)) { std::puts("FAIL: precise tolerance"); return 1; }
         hip.set_precise(false);
+        if (hip.precision() != MELSPEC_PRECISION_AUTO || hip.max_frames_per_batch() == 0) { std::puts("FAIL: precision / max_frames_per_batch"); return 1; }
+        // additive batch call and the STFT export through the same header
+        const auto batch = hip.compute_batch({samples, std::vector<float>(samples.begin(), samples.begin() + 4000), std::vector<float>(399, 0.0f)});
+        if (batch.size() != 3 || batch[0].size() != 98 || batch[1].size() != 23 || !batch[2].empty()) { std::puts("FAIL: batch shape"); return 1; }
+        float bd = 0.0f;
+        for (size_t f = 0; f < 98; ++f)
+            for (size_t m = 0; m < 80; ++m) bd = std::fmax(bd, std::fabs(batch[0][f][m] - cpu[f * 80 + m]));
+        if (!(bd <= 1e-4f)) { std::puts("FAIL: batch tolerance"); return 1; }
+        const auto spec = hip.compute_all(samples);
+        if (spec.size() != 98 || spec[0].size() != 800) { std::puts("FAIL: stft shape"); return 1; }
+        for (size_t k = 1; k < 200; ++k)            // real input: X[400 - k] = conj X[k]
+            if (std::fabs(spec[5][2 * k] - spec[5][2 * (400 - k)]) > 1e-9 || std::fabs(spec[5][2 * k + 1] + spec[5][2 * (400 - k) + 1]) > 1e-9) { std::puts("FAIL: stft symmetry"); return 1; }
 
         melspec::RingBuffer rb(hip, 16000);
         std::vector<float> want(100 * 80);
