@@ -291,6 +291,10 @@ int melspec_blm_compute_host(melspec_blm *b, const float *samples, size_t n_samp
 /* Many equal-length clips resident in HBM; d_out = [clip][n_mels][cols]. */
 int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                        uint32_t n_clips, float *d_out, void *stream);
+/* Clips of any length in one launch: clip c = d_pcm[h_offsets[c] .. + h_lengths[c]) -> [n_mels][cols_c] at d_out + h_out_offsets[c]
+ * floats (NULL: packed in clip order), cols_c = melspec_blm_padded_frames(b, h_lengths[c]).  Fused kernel (n_fft 512 / win_length 400). */
+int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                                      uint32_t n_clips, float *d_out, const uint64_t *h_out_offsets, void *stream);
 int melspec_blm_synchronize(melspec_blm *b, void *stream);
 
 /* ---- streaming: Spectrogram::add + RingBuffer::maybe_mel (src/stft.rs:48-86, src/rb.rs:60-121) ---- */

@@ -107,6 +107,7 @@ SIGNATURES = {
     "melspec_blm_padded_frames": (C.c_size_t, [_vp, C.c_size_t]),
     "melspec_blm_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "melspec_blm_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_blm_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
     "melspec_blm_synchronize": (C.c_int, [_vp, _vp]),
     "melspec_malloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "melspec_free": (C.c_int, [_vp]),

@@ -54,6 +54,7 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kGenericNT = 256;
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
+constexpr int kNemoSync = 18;               // RoundSync mode of the NeMo feature-major store: pairs of waves four apart
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
 constexpr uint64_t kPipeChunkSamples = 4u << 20;      // host pipeline: 16 MiB of PCM per chunk (host_pipe.hpp)
 
@@ -2118,6 +2119,8 @@ struct melspec_blm {
     hipStream_t stream = nullptr;
     bool fast = false;          // fused 512-point kernel (n_fft 512 / win_length 400) vs the generic f64 kernel (any validated config)
     GenericTables gt;
+    RaggedScratch ragged;
+    DevBuf aux;                 // ragged batches: per-clip sample counts and valid frames
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -2180,7 +2183,7 @@ int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *
     if (b->fast) {
         const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double);
         b->waves = fused512_waves(b->ft.blob.size() * 4, slice_bytes);
-        b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(b->waves) * slice_bytes;
+        b->fast_lds = b->ft.blob.size() * 4 + static_cast<size_t>(b->waves) * slice_bytes + 64;      // + RoundSync counters
         if (b->fast_lds > kLdsLimit) b->fast = false;
     }
     if (b->fast) {
@@ -2212,7 +2215,7 @@ void melspec_blm_destroy(melspec_blm *b) {
     if (!b) return;
     if (b->dev.device >= 0) (void)hipSetDevice(b->dev.device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    b->d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release();
+    b->d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release(); b->ragged.release(); b->aux.release();
     delete b;
 }
 
@@ -2239,6 +2242,8 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
     const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, valid, n_clips, nm, kFbFPW, cols, true);
     FbankFastParams fp{};
     fp.b = pl.desc;
+    // feature-major store: waves holding adjacent units are kept in step (RoundSync); measured best for this kernel, see DESIGN 4.2b
+    if (fp.b.sync_rounds < 0) fp.b.sync_rounds = kNemoSync;
     fp.d_blob = static_cast<const uint32_t *>(b->d_blob.p);
     fp.blob_words = static_cast<int>(b->ft.blob.size());
     fp.mel_off_words = b->ft.mel_off_words;
@@ -2295,6 +2300,70 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         HIP_TRY(hipGetLastError());
     }
     return MELSPEC_OK;
+}
+
+// BatchLogMelSpectrogram::compute per clip of any length (src/mel.rs:299-385) in one launch: clip c = d_pcm[h_offsets[c] .. + h_lengths[c])
+// -> [n_mels][cols_c] floats at d_out + h_out_offsets[c] (NULL: packed in clip order), cols_c = melspec_blm_padded_frames(len_c).
+// Fused kernel only (n_fft 512 / win_length 400).
+int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                                      uint32_t n_clips, float *d_out, const uint64_t *h_out_offsets, void *stream) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!h_offsets || !h_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    if (!b->fast) return fail(MELSPEC_ERR_UNSUPPORTED, "ragged batches need the fused kernel (n_fft = 512, win_length = 400)");
+    std::vector<uint64_t> cols(n_clips), aux(2 * static_cast<size_t>(n_clips));
+    uint64_t total = 0, longest = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        const uint64_t valid = blm_valid_frames(b, h_lengths[i]);
+        cols[i] = blm_padded(b, valid);
+        aux[i] = h_lengths[i];
+        aux[n_clips + i] = valid;
+        total += cols[i];
+        longest = std::max(longest, valid);
+    }
+    if (total == 0) return MELSPEC_OK;
+    if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
+    const int nm = b->cfg.n_mels;
+    int rc = b->aux.ensure(aux.size() * sizeof(uint64_t));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->aux.p, aux.data(), aux.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));    // pageable source: staged before the call returns
+    BatchPlan pl;
+    RaggedSlot *slot = nullptr;
+    rc = plan_ragged(b->ragged, s, d_pcm, d_out, h_offsets, cols, h_out_offsets, n_clips, nm, kFbFPW, pl, slot);
+    if (!rc) {
+        FbankFastParams fp{};
+        fp.b = pl.desc;
+        fp.b.mel_major = 1;
+        fp.b.sync_rounds = kNemoSync;
+        fp.d_blob = static_cast<const uint32_t *>(b->d_blob.p);
+        fp.blob_words = static_cast<int>(b->ft.blob.size());
+        fp.mel_off_words = b->ft.mel_off_words;
+        fp.shift = b->cfg.hop_length;
+        fp.n_mels = nm;
+        fp.preemph = b->cfg.preemphasis;
+        fp.floor_v = b->cfg.log_zero_guard;
+        fp.use_log = 1; fp.use_power = 1;
+        fp.org0 = b->cfg.center ? -200 : 56;
+        fp.d_len = static_cast<const uint64_t *>(b->aux.p);
+        fp.d_valid = fp.d_len + n_clips;
+        fp.slots = b->ft.slots;
+        if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+        else if (fb_lens_match<LensSlaney80>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kFbSlots, LensSlaney80>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+        else rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
+                                                  : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+        if (!rc && b->cfg.normalize_per_feature && longest > 0) {
+            BlmNormParams np{};
+            np.out = d_out; np.n_clips = n_clips; np.n_mels = nm; np.rows_per_group = 0;
+            np.d_out_off = pl.desc.d_out_off; np.d_cols = pl.desc.d_frames; np.d_valid = fp.d_valid;
+            const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
+            hipLaunchKernelGGL(blm_normalize_kernel, dim3(grid_for((rows + kBlmNormThreads - 1) / kBlmNormThreads, b->dev.cus, 4)), dim3(kBlmNormThreads), 0, s, np);
+            if (hipGetLastError() != hipSuccess) rc = fail(MELSPEC_ERR_INTERNAL, "blm_normalize_kernel launch failed");
+        }
+    }
+    plan_ragged_done(slot, s);
+    return rc;
 }
 
 int melspec_blm_synchronize(melspec_blm *b, void *stream) {

@@ -63,6 +63,7 @@ struct UnitLoc {
     float *out;         // first output float of the clip
     uint64_t frames;    // frames in the clip
     uint64_t unit;      // unit index inside the clip
+    uint32_t clip;      // the clip
 };
 
 __device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit) {
@@ -73,6 +74,7 @@ __device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit
         r.pcm = b.pcm + clip * b.clip_stride;
         r.out = b.out + clip * b.out_stride;
         r.frames = b.frames_per_clip;
+        r.clip = static_cast<uint32_t>(clip);
     } else {
         // d_unit_block[k] = clip that holds unit k * kUnitBlock.  The records of that clip and of the next one are fetched
         // together (second round trip); only clips shorter than a block of units need the walk (third and later trips).
@@ -93,6 +95,7 @@ __device__ __forceinline__ UnitLoc locate_unit(const BatchDesc &b, uint64_t unit
         r.pcm = b.pcm + off0;
         r.out = b.out + oo0;
         r.frames = fr0;
+        r.clip = lo;
     }
     return r;
 }
@@ -507,7 +510,7 @@ struct ClipRun {
     }
     __device__ __forceinline__ UnitLoc loc() const {
         UnitLoc r;
-        r.unit = unit - c_start; r.pcm = c_pcm; r.out = c_out; r.frames = c_frames;
+        r.unit = unit - c_start; r.pcm = c_pcm; r.out = c_out; r.frames = c_frames; r.clip = clip;
         return r;
     }
     // before each unit: the run may have entered the next clip that has frames
@@ -868,6 +871,8 @@ struct FbankFastParams {
     int use_log, use_power;
     long long clip_len;     // NeMo (uniform batches): samples per clip, for the centre padding
     int org0;               // NeMo: clip index of tap 0 of frame 0 (-200 centred, +56 not centred)
+    const uint64_t *d_len;  // NeMo, ragged batches: samples of clip c (BatchDesc::d_frames then holds the PADDED column count of the
+    const uint64_t *d_valid;//   clip -- what the units cover and the row width -- and d_valid its valid frames)
     MelSlots slots;
 };
 
@@ -885,6 +890,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    // NeMo: the feature-major store gives every wave 16 bytes of each mel row per unit; the units are walked in workgroup-uniform
+    // rounds and the waves that hold adjacent units are kept in step before their stores (RoundSync, as in the mel-major Whisper kernels)
+    constexpr bool ROUNDS = FLAVOR == kFlavorNemo;
+    unsigned *arrive = ldsw + p.blob_words + WAVES * L::slice_elems() * (sizeof(T) / 4);
+    if (ROUNDS && tid < WAVES) arrive[tid] = 0;
     __syncthreads();
     const T *tblob = reinterpret_cast<const T *>(ldsw);
     const float *mel = reinterpret_cast<const float *>(ldsw + p.mel_off_words);
@@ -906,16 +916,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     static_assert(!(RUNS && FLAVOR == kFlavorNemo), "the feature-major store wants adjacent units in adjacent waves");
     ClipRun cr;
     if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
-    for (uint64_t unit = (uint64_t)xcd_logical_block() * WAVES + wave;; unit += (uint64_t)gridDim.x * WAVES) {
+    RoundSync<WAVES> rs(ROUNDS ? p.b.sync_rounds : 0, wave, arrive);
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + (ROUNDS ? 0 : wave);; first += (uint64_t)gridDim.x * WAVES) {
+        const uint64_t unit = ROUNDS ? first + rs.slot : first;
         if (RUNS) {
             if (cr.unit >= cr.end) break;
             cr.enter(p.b);
-        } else if (unit >= p.b.n_units) {
+        } else if (first >= p.b.n_units) {
             break;
         }
-        const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, unit);
+        const bool have = !ROUNDS || unit < p.b.n_units;       // a wave without a unit idles through the round
+        const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFbFPW;
-        const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
+        // valid frames of the clip (NeMo ragged: loc.frames is the padded width there)
+        const uint64_t vframes = (FLAVOR == kFlavorNemo && p.d_valid) ? p.d_valid[loc.clip] : loc.frames;
+        const uint64_t left = (have && f0 < vframes) ? vframes - f0 : 0;
         const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
         const bool act = in && fl < nv;
         MS_PRIO(0);
@@ -936,10 +951,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         } else if (FLAVOR == kFlavorWhisper) {
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
         } else {
+            const long long clip_len = p.d_len ? (long long)p.d_len[loc.clip] : p.clip_len;
             const long long org = (long long)(f0 + (uint64_t)fl) * p.shift + p.org0;
-            const bool inside = org >= 1 && org + 400 <= (long long)p.clip_len;
+            const bool inside = org >= 1 && org + 400 <= clip_len;
             const bool all_inside = __builtin_amdgcn_ballot_w64(act && !inside) == 0;
-            nemo_phase1<T>(fl, j, act, all_inside, loc.pcm, org, p.clip_len, static_cast<float>(p.preemph), tblob, slice);
+            nemo_phase1<T>(fl, j, act, all_inside, loc.pcm, org, clip_len, static_cast<float>(p.preemph), tblob, slice);
         }
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(1);
@@ -972,12 +988,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             else
                 w512_phase4<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, slice_f, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
         } else {
-            const uint64_t wleft = p.b.out_width - f0;
+            const uint64_t row_w = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+            const uint64_t wleft = have ? row_w - f0 : 0;
             const int ns = wleft < (uint64_t)kFbFPW ? (int)wleft : kFbFPW;
-            nemo_phase3_store<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, p.floor_v, rise, fnext, loc.out + f0,
-                                      (long long)p.b.out_width);
+            rs.template before_stores<2>(lane);
+            nemo_phase3_store<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, p.floor_v, rise, fnext, loc.out + f0, (long long)row_w);
         }
         __builtin_amdgcn_wave_barrier();
+        if (ROUNDS) rs.after_round();
         if (RUNS) ++cr.unit;
     }
 }
@@ -1190,6 +1208,8 @@ struct BlmNormParams {
     int rows_per_group;     // rows staged per workgroup round (<= 64), 0: rows too long for LDS
     int lds_stride;         // floats between staged rows: 4 * odd (16-byte aligned rows whose per-lane walks spread over the banks)
     int vec;                // rows are 16-byte aligned: float4 loads and stores
+    // ragged batches (rows_per_group == 0 form only): per clip the first output float, the row width and the valid frames
+    const uint64_t *d_out_off, *d_cols, *d_valid;
 };
 
 constexpr int kBlmNormThreads = 256;
@@ -1293,10 +1313,19 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
     const int tid = threadIdx.x;
     if (p.rows_per_group == 0) {
         for (uint64_t row = (uint64_t)blockIdx.x * kBlmNormThreads + tid; row < rows; row += (uint64_t)gridDim.x * kBlmNormThreads) {
-            float *r = blm_row(p, row);
+            float *r;
+            uint64_t valid = p.valid;
+            if (p.d_out_off) {
+                const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
+                r = p.out + p.d_out_off[clip] + m * p.d_cols[clip];
+                valid = p.d_valid[clip];
+                if (valid == 0) continue;
+            } else {
+                r = blm_row(p, row);
+            }
             float mean, sd;
-            blm_row_stats_slow(r, p.valid, mean, sd);
-            for (uint64_t k = 0; k < p.valid; ++k) r[k] = f32_div_rn(r[k] - mean, sd);
+            blm_row_stats_slow(r, valid, mean, sd);
+            for (uint64_t k = 0; k < valid; ++k) r[k] = f32_div_rn(r[k] - mean, sd);
         }
         return;
     }

@@ -547,6 +547,31 @@ class BatchLogMelSpectrogram:
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_blm_synchronize(self._h, C.c_void_p(stream)))
 
+    def compute_ragged(self, clips) -> list:
+        """list of 1-D host arrays of any lengths -> list of [n_mels, cols_i] arrays (BatchLogMelSpectrogram::compute per clip), one launch"""
+        arrs = [_f32(c).reshape(-1) for c in clips]
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
+        cols = [self.padded_frames(int(n)) for n in lens]
+        nm = self.config.n_mels
+        total = sum(cols) * nm
+        flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
+        din, dout = DeviceBuffer(max(flat.nbytes, 16)), DeviceBuffer(max(total * 4, 16))
+        u64p = C.POINTER(C.c_uint64)
+        try:
+            din.upload(flat)
+            _check(lib().melspec_blm_compute_ragged_device(self._h, C.c_void_p(din.ptr), offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p), len(arrs),
+                                                           C.c_void_p(dout.ptr), None, None))
+            self.synchronize()
+            out = dout.download((max(total, 1),))[:total]
+        finally:
+            din.free(); dout.free()
+        res, cur = [], 0
+        for c in cols:
+            res.append(out[cur:cur + c * nm].reshape(nm, c))
+            cur += c * nm
+        return res
+
     def compute_batch(self, clips) -> np.ndarray:
         x = _f32(clips)
         n_clips, clip_len = x.shape

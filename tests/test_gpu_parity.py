@@ -884,3 +884,23 @@ def test_fbank_ragged_batches(gpu, oracle, jfk, kw):
     for b in (din, dout, d_off, d_len):
         b.free()
     fb.close()
+
+
+@pytest.mark.parametrize("kw", [dict(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), dict(center=False, n_mels=64, pad_to=16),
+                                dict(preemphasis=0.5, normalize_per_feature=True)])
+def test_nemo_frontend_ragged_batches(gpu, oracle, jfk, kw):
+    """BatchLogMelSpectrogram::compute is per clip (src/mel.rs:299-385): clips of different lengths in one launch -- per-clip centre
+    padding, valid frames, pad_to-rounded row widths and per-feature normalisation."""
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+    cfg = oracle.blm_default_config(**kw)
+    rng = np.random.default_rng(6)
+    lens = [int(v) for v in rng.integers(1, 40000, 21)] + [1, 159, 160, 511, 512, 0, 30001]
+    clips = [(jfk[(i * 1511) % 50000:][:m] if i % 2 else oracle.synth_pcm(i, m)).astype(np.float32) for i, m in enumerate(lens)]
+    got = fe.compute_ragged(clips)
+    tol = 2e-3 if kw.get("normalize_per_feature") else TOL
+    for g, x in zip(got, clips):
+        want, valid = oracle.blm_compute(x, cfg, True)
+        assert g.shape == want.shape, (len(x), g.shape, want.shape)
+        if want.size:
+            assert np.abs(g - want).max() <= tol, (kw, len(x), float(np.abs(g - want).max()))
+    fe.close()
