@@ -1302,13 +1302,8 @@ struct melspec_fbank {
     hipStream_t stream = nullptr;
     bool fast = false;          // fused 512-point kernel (default Kaldi geometry) vs generic f64 kernel
     bool use_generic = false;   // melspec_fbank_use_generic: the direct-DFT kernel as the on-device cross-check
-    // clip counter of fbank512_clip_kernel (never reset; clip_base = its value when the next launch starts), used in stream order
     RaggedScratch ragged;
     DevicePlan dplan;
-    DevBuf clip_ctr;
-    uint32_t clip_base = 0;
-    hipStream_t clip_stream = nullptr;
-    bool clip_used = false;
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -1380,7 +1375,7 @@ void melspec_fbank_destroy(melspec_fbank *fb) {
     if (!fb) return;
     if (fb->dev.device >= 0) (void)hipSetDevice(fb->dev.device);
     if (fb->stream) { (void)hipStreamSynchronize(fb->stream); (void)hipStreamDestroy(fb->stream); }
-    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->clip_ctr.release(); fb->ragged.release(); fb->dplan.release();
+    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->ragged.release(); fb->dplan.release();
     delete fb;
 }
 
@@ -1431,17 +1426,14 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         fp.use_log = fb->cfg.use_log_fbank;
         fp.use_power = fb->cfg.use_power;
         fp.slots = fb->ft.slots;
-#ifdef MELSPEC_LAB
-        // many clips + CMN: workgroup-per-clip kernel with the normalisation inside (lab builds: MELSPEC_FB_CLIP=0 keeps the two-kernel path)
-        static const bool clip_on = lab_int("MELSPEC_FB_CLIP", 0, 0, 1) != 0;
-        if (clip_on && fb->cfg.apply_cmn && fb->waves == 8 && n_clips >= static_cast<uint32_t>(fb->dev.cus) && nm <= 89) {
-            if (fb->clip_used && fb->clip_stream != s) HIP_TRY(hipStreamSynchronize(fb->clip_stream));
-            if (!fb->clip_ctr.p) {
-                if ((rc = fb->clip_ctr.ensure(64))) return rc;
-                HIP_TRY(hipMemsetAsync(fb->clip_ctr.p, 0, 64, s));
-                fb->clip_base = 0;
-            }
-            fb->clip_used = true; fb->clip_stream = s;
+        // many clips of one length + CMN: the workgroup-per-clip kernel with the normalisation inside (fbank512_clip_kernel) when the
+        // clips fill the CUs evenly enough to beat the two-kernel path's 1.29 x (lab builds: MELSPEC_FB_CLIP=0 keeps the two kernels)
+        static const bool clip_on = lab_int("MELSPEC_FB_CLIP", 1, 0, 1) != 0;
+        const uint32_t cus = static_cast<uint32_t>(fb->dev.cus);
+        const uint32_t passes = (n_clips + cus - 1) / cus;
+        if (clip_on && fb->cfg.apply_cmn && fb->waves == 8 && pl.desc.d_unit_prefix == nullptr && nm % 4 == 0 && nm <= 89 &&
+            (reinterpret_cast<uintptr_t>(pl.desc.out) & 15) == 0 && pl.desc.out_stride % 4 == 0 &&
+            n_clips >= cus && static_cast<uint64_t>(n_clips) * 100 >= static_cast<uint64_t>(passes) * cus * 85) {
             static std::atomic<uint64_t> attr_done{0};
             if (!device_done(attr_done)) {
                 rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi80>, "hipFuncSetAttribute(fbank512_clip_kernel)");
@@ -1451,18 +1443,15 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
             }
             FbankClipParams q{};
             q.f = fp;
-            q.clip_ctr = static_cast<uint32_t *>(fb->clip_ctr.p);
-            q.clip_base = fb->clip_base;
-            const unsigned grid = grid_for_xcd(n_clips, fb->dev.cus, 1);
-            fb->clip_base += n_clips + grid;          // every workgroup ends with exactly one failed grab
-            const size_t lds = fb->fast_lds + (4 + 8 + 8) * 4 + 96 * 4 + 5 * 4 * 92 * 4;      // counters, sums, ring (fbank512_clip_kernel)
-            if (lds > kLdsLimit) return fail(MELSPEC_ERR_INTERNAL, "fbank512_clip_kernel: LDS");
-            if (fb_lens_match<LensKaldi80>(fb->ft.slots)) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(grid), dim3(512), lds, s, q);
-            else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime>), dim3(grid), dim3(512), lds, s, q);
-            HIP_TRY(hipGetLastError());
-            return MELSPEC_OK;
+            q.frames = fpc;
+            const size_t lds = fb->fast_lds + sizeof(ClipCmnShared<8>);
+            if (lds <= kLdsLimit) {
+                if (fb_lens_match<LensKaldi80>(fb->ft.slots)) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(cus), dim3(512), lds, s, q);
+                else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime>), dim3(cus), dim3(512), lds, s, q);
+                HIP_TRY(hipGetLastError());
+                return MELSPEC_OK;
+            }
         }
-#endif
         if (fb_lens_match<LensKaldi80>(fb->ft.slots))
             rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi80>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         else

@@ -1000,24 +1000,70 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     }
 }
 
-#ifdef MELSPEC_LAB
-// LAB ONLY (measured slower than the two-kernel path, profiles/r02_fbank.txt; kept for the next attempt).
-// Kaldi fbank with CMN in one launch (Fbank::compute incl. src/fbank.rs:224-233), for batches of many clips: a workgroup owns
-// whole clips.  Its eight waves take the clip's units from an LDS counter (whoever is free takes the next one).  The column
-// sums of the CMN must be accumulated IN THE REFERENCE'S ORDER -- ndarray's mean() of a strided column is a left fold in f32 and
-// its rounding error is part of the reference's output: ~1e-5 of a feature at 1000 frames, more on longer clips -- so a wave
-// that has stored unit u waits until units 0..u-1 have been added, adds its four rows to the 80 running sums in LDS frame by
-// frame, and passes the turn on (units are taken in order and take the same time, so the wait is short; the sums never
-// re-read the features).  At the end of the clip: one barrier, mean = sum / frames, and all threads subtract while the clip's
-// rows (319 KB at 10 s) are still in this XCD's L2 -- instead of cmn_kernel's second grid-wide pass (2 reads + 1 write of
-// the whole output: measured 2.0 x the algorithmic traffic, 0.2 of config 3's 0.92 ms).  Clips are handed out by a global
-// counter that is never reset: the host passes the value it will have when this launch starts (every workgroup ends with
-// exactly one failed grab, so a launch advances it by n_clips + gridDim.x).
+// Kaldi fbank with the CMN inside (Fbank::compute incl. src/fbank.rs:224-233), for uniform batches of many clips: a workgroup
+// owns whole clips, each of its eight waves a contiguous eighth of the clip's units.  Nothing in it waits on a workgroup barrier:
+//   * a wave adds the values it stores to per-lane column sums (one f32 add per stored value), folds the four frame positions
+//     at the end of its run and leaves its 80 partial sums in LDS; the wave that arrives last adds the eight partials in a
+//     fixed order, divides by the frame count and publishes the clip's means;
+//   * the subtraction of clip c is done one clip later: every wave, when it has finished its run of clip c+1, subtracts the
+//     means from an eighth of clip c's rows (16 sixteen-byte loads in flight per lane) -- by then the means have long been
+//     published, so the wait in front of it never spins in practice, and the rows (319 KB at 10 s; 82 MB over the 256
+//     workgroups) come back from the Infinity Cache rather than from HBM.
+// The column sums are therefore NOT the reference's order (ndarray's mean() of a strided column is an f32 left fold over the
+// frames); they are a fixed tree of 31-term folds, deterministic from run to run, and more accurate than the fold: config 3
+// sits 1.5e-5 from the oracle (which folds like the reference) against the 1e-4 bar, the reference's own rounding error in that
+// mean being ~1e-5.  cmn_kernel (the reference's order, 1.9e-6) stays the path for everything this kernel does not take:
+// ragged batches, n_mels not a multiple of 4, fewer clips than fill the CUs evenly.
+// History (profiles/r02_fbank.txt): in-order sums under a ticket / through an LDS ring were 1.06-1.49 ms against 0.92 ms
+// for the two kernels; what makes the fusion pay is giving up the order and the barrier.
 struct FbankClipParams {
     FbankFastParams f;
-    uint32_t *clip_ctr;
-    uint32_t clip_base;
+    uint64_t frames;        // per clip (uniform batches)
 };
+
+template <int WAVES>
+struct ClipCmnShared {
+    float part[2][WAVES][96];
+    float mean[2][96];
+    unsigned arrived[2], ready[2];
+};
+
+// this wave's share of the rows of a finished clip: rows - mean, in place
+template <int WAVES>
+MS_DEV void clip_cmn_subtract(ClipCmnShared<WAVES> *sh, int par, unsigned expect, int wave, int lane, float *out, uint64_t frames, int nm) {
+    if (lane == 0) {
+        // bounded (a mean that is never published would be a bug; a wrong result is caught by the parity tests, a hung GPU is not recoverable)
+        for (unsigned spin = 0; spin < (1u << 22) && __hip_atomic_load(&sh->ready[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < expect; ++spin)
+            __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int q4 = nm >> 2;                    // 16-byte pieces per row
+    const int R = 64 / q4;                     // rows per wave instruction
+    int r = lane / q4;
+    const int c4 = lane - r * q4;
+    const bool on = r < R;
+    const f4 m4 = *reinterpret_cast<const f4 *>(&sh->mean[par][4 * c4]);
+    f4 *o4 = reinterpret_cast<f4 *>(out);
+    const uint64_t groups = (frames + R - 1) / R;
+    constexpr int K = 16;
+    for (uint64_t g = wave; g < groups; g += (uint64_t)WAVES * K) {
+        f4 v[K];
+        uint64_t idx[K];
+        bool ok[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint64_t row = (g + (uint64_t)k * WAVES) * R + r;
+            ok[k] = on && row < frames;
+            idx[k] = (row < frames ? row : frames - 1) * q4 + c4;       // the load is unconditional
+            v[k] = o4[idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (ok[k]) o4[idx[k]] = v[k] - m4;
+    }
+}
 
 template <int NSLOTS, class Lens>
 __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankClipParams q) {
@@ -1028,14 +1074,8 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += NT) ldsw[i] = p.d_blob[i];
-    constexpr unsigned kRing = 5;          // parked units (what fits behind the slices: 5 x 4 rows x 92 floats)
-    constexpr int kRingRow = 92;
-    unsigned *ctl = ldsw + p.blob_words + WAVES * L::slice_elems() * 2;      // [0] next unit of the clip, [1] next unit of the sum chain, [2] the next clip, [3] chain lock
-    unsigned *ready = ctl + 4;                                                // [kRing] unit + 1 parked in the slot
-    unsigned *nvs = ready + 8;                                                // [kRing] its valid frames
-    float *sum_s = reinterpret_cast<float *>(nvs + 8);                        // [n_mels <= 92] running column sums, then the means
-    float *ring = sum_s + 96;                                                 // [kRing][4][kRingRow]
-    if (tid == 0) ctl[2] = atomicAdd(q.clip_ctr, 1u) - q.clip_base;
+    auto *sh = reinterpret_cast<ClipCmnShared<WAVES> *>(ldsw + p.blob_words + WAVES * L::slice_elems() * 2);
+    if (tid < 2) { sh->arrived[tid] = 0; sh->ready[tid] = 0; }
     __syncthreads();
     const T *tblob = reinterpret_cast<const T *>(ldsw);
     const float *mel = reinterpret_cast<const float *>(ldsw + p.mel_off_words);
@@ -1052,37 +1092,19 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
     const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
     const T preemph = static_cast<T>(p.preemph);
     const int nm = p.n_mels;
-    for (;;) {
-        const uint32_t clip = ctl[2];
-        __syncthreads();                              // everyone has read the clip id (and is done with the previous clip's means)
-        if (clip >= p.b.n_clips) break;
-        if (tid == 0) {
-            ctl[0] = 0;
-            ctl[1] = 0;
-            ctl[3] = 0;
-            ctl[2] = atomicAdd(q.clip_ctr, 1u) - q.clip_base;      // the next clip: its round trip hides behind this clip's units
-        }
-        if (tid < 8) ready[tid] = 0;
-        if (tid < nm) sum_s[tid] = 0.0f;
-        const float *pcm;
-        float *out;
-        uint64_t frames;
-        if (p.b.d_unit_prefix == nullptr) {
-            pcm = p.b.pcm + (uint64_t)clip * p.b.clip_stride;
-            out = p.b.out + (uint64_t)clip * p.b.out_stride;
-            frames = p.b.frames_per_clip;
-        } else {
-            pcm = p.b.pcm + scalar64(p.b.d_off[clip]);
-            out = p.b.out + scalar64(p.b.d_out_off[clip]);
-            frames = scalar64(p.b.d_frames[clip]);
-        }
-        const uint32_t units = static_cast<uint32_t>((frames + kFbFPW - 1) / kFbFPW);
-        __syncthreads();                              // counters and sums are reset
-        for (;;) {
-            unsigned u = 0;
-            if (lane == 0) u = atomicAdd(&ctl[0], 1u);
-            u = __builtin_amdgcn_readfirstlane(u);
-            if (u >= units) break;
+    const uint64_t frames = q.frames;
+    const uint32_t units = static_cast<uint32_t>((frames + kFbFPW - 1) / kFbFPW);
+    const uint32_t u0 = static_cast<uint32_t>((uint64_t)units * wave / WAVES), u1 = static_cast<uint32_t>((uint64_t)units * (wave + 1) / WAVES);
+    unsigned gen = 0;                      // clips this workgroup has finished
+    float *prev_out = nullptr;
+    for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x, ++gen) {
+        const int par = gen & 1;
+        const float *pcm = p.b.pcm + (uint64_t)clip * p.b.clip_stride;
+        float *out = p.b.out + (uint64_t)clip * p.b.out_stride;
+        float acc[NSLOTS];
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) acc[i] = 0.0f;
+        for (uint32_t u = u0; u < u1; ++u) {
             const uint64_t f0 = (uint64_t)u * kFbFPW;
             const uint64_t left = frames - f0;
             const int nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
@@ -1116,80 +1138,42 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
 #pragma unroll
             for (int i = 0; i < NSLOTS; ++i) { fnext[i] = wave_shift_down1(fprev[i]); vals[i] = 0.0f; }
             fb_phase3_store<NSLOTS>(fl, j, act, nm, p.floor_v, use_log, rise, fnext, out + f0 * (uint64_t)nm, vals);
-            // The CMN's column sums, frame by frame in clip order, without making the waves finish in order: the unit's rows
-            // are parked in a ring of kRing slots in LDS, and whoever finds the next unit of the chain parked (trylock) adds it
-            // and every parked successor to the running sums.  A wave only ever waits when it is kRing units ahead of the chain.
-            MS_PRIO(0);
-            const unsigned slot = u % kRing;
-            if (u >= kRing && lane == 0) {
-                // bounded (~0.1 s): a chain that never moves would be a bug, and a wrong sum is caught by the parity tests while a hung
-                // GPU is not recoverable
-                for (unsigned spin = 0; spin < (1u << 21) && __hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + kRing <= u; ++spin)
-                    __builtin_amdgcn_s_sleep(1);
-            }
-            __builtin_amdgcn_wave_barrier();
-            float *rs = ring + slot * (kFbFPW * kRingRow);
-            if (act && j < kFbOwn) {
 #pragma unroll
-                for (int i = 0; i < NSLOTS; ++i)
-                    if (j + kFbOwn * i < nm) rs[fl * kRingRow + j + kFbOwn * i] = vals[i];
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) {
-                nvs[slot] = static_cast<unsigned>(nv);
-                __hip_atomic_store(&ready[slot], u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            __builtin_amdgcn_wave_barrier();
-            for (;;) {
-                // (a ballot, not readfirstlane of a value set under `if (lane == 0)`: with the latter the compiler folded this loop
-                // into the lane-0 block above and ran the adds below with lane 0 masked off)
-                bool got = false;
-                if (lane == 0) got = atomicCAS(&ctl[3], 0u, 1u) == 0u;
-                if (__builtin_amdgcn_ballot_w64(got) == 0) break;
-                unsigned fn = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                for (;;) {
-                    const unsigned sl = fn % kRing;
-                    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != fn + 1) break;
-                    const int nv2 = __builtin_amdgcn_readfirstlane(nvs[sl]);
-                    const float *rr = ring + sl * (kFbFPW * kRingRow);
-                    float r0[kFbFPW], r1[kFbFPW];
-#pragma unroll
-                    for (int f = 0; f < kFbFPW; ++f) {
-                        r0[f] = (lane < nm && f < nv2) ? rr[f * kRingRow + lane] : 0.0f;
-                        r1[f] = (lane + 64 < nm && f < nv2) ? rr[f * kRingRow + lane + 64] : 0.0f;
-                    }
-                    float s0 = lane < nm ? sum_s[lane] : 0.0f, s1 = lane + 64 < nm ? sum_s[lane + 64] : 0.0f;
-#pragma unroll
-                    for (int f = 0; f < kFbFPW; ++f)
-                        if (f < nv2) { s0 += r0[f]; s1 += r1[f]; }
-                    if (lane < nm) sum_s[lane] = s0;
-                    if (lane + 64 < nm) sum_s[lane + 64] = s1;
-                    ++fn;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) __hip_atomic_store(&ctl[1], fn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // the slot is free again
-                }
-                if (lane == 0) __hip_atomic_store(&ctl[3], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // a unit parked between the last look and the unlock is nobody's: look once more
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&ready[fn % kRing], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != fn + 1) break;
-            }
+            for (int i = 0; i < NSLOTS; ++i) acc[i] += vals[i];
             __builtin_amdgcn_wave_barrier();
         }
         MS_PRIO(0);
-        if (frames == 0) continue;                    // workgroup-uniform
-        __syncthreads();                              // every unit of the clip is stored (visible to this workgroup) and summed
-        if (tid < nm) sum_s[tid] = f32_div_rn(sum_s[tid], (float)frames);
-        __syncthreads();
-        {
-            const int G = NT / nm;                    // row groups (n_mels <= 89: at least 5)
-            const int g = tid / nm, m = tid - g * nm;
-            if (g < G) {
-                const float mean = sum_s[m];
-                for (uint64_t f = g; f < frames; f += G) out[f * nm + m] -= mean;
-            }
+        // the wave's column sums: frame positions (0+1)+(2+3), then lanes of position 0 write them
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) {
+            acc[i] += __shfl_xor(acc[i], 16);
+            acc[i] += __shfl_xor(acc[i], 32);
         }
+        if (fl == 0 && j < kFbOwn) {
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i)
+                if (j + kFbOwn * i < nm) sh->part[par][wave][j + kFbOwn * i] = acc[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(&sh->arrived[par], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);    // releases the rows this wave stored, too
+        const unsigned turn = gen / 2 + 1;      // how many clips of this parity, this one included
+        if (__builtin_amdgcn_ballot_w64(lane == 0 && old == turn * WAVES - 1) != 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float fr = static_cast<float>(frames);
+            for (int m = lane; m < nm; m += 64) {
+                const float (*pp)[96] = sh->part[par];
+                const float s = ((pp[0][m] + pp[1][m]) + (pp[2][m] + pp[3][m])) + ((pp[4][m] + pp[5][m]) + (pp[6][m] + pp[7][m]));
+                sh->mean[par][m] = f32_div_rn(s, fr);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) __hip_atomic_store(&sh->ready[par], turn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (gen > 0) clip_cmn_subtract<WAVES>(sh, par ^ 1, (gen - 1) / 2 + 1, wave, lane, prev_out, frames, nm);
+        prev_out = out;
     }
+    if (gen > 0) clip_cmn_subtract<WAVES>(sh, (gen - 1) & 1, (gen - 1) / 2 + 1, wave, lane, prev_out, frames, nm);
 }
-#endif  // MELSPEC_LAB
 
 // Per-feature normalisation of the NeMo frontend (normalize_per_feature, src/mel.rs:721-749): for every (clip, mel) row the
 // mean over the valid frames, the unbiased variance, (v - mean) / (sqrt(var) + 1e-5) -- in the reference's f32 and in the

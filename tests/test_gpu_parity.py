@@ -456,22 +456,24 @@ def test_fbank_batch_config3_sampled(gpu, oracle):
     pcm.free(); out.free()
 
 
-@pytest.mark.parametrize("n_mels,clip_len", [(80, 11357), (40, 4000), (64, 400), (80, 399 + 160 * 3)])
-def test_fbank_clip_kernel_equals_the_two_kernel_path(gpu, oracle, jfk, n_mels, clip_len):
-    """Batches of >= one clip per CU take fbank512_clip_kernel (a workgroup per clip, CMN inside: the left fold of
-    src/fbank.rs:224-233 in the reference's order); smaller batches the fused kernel + cmn_kernel.  Same bits either way,
-    and both within the tolerance of the oracle."""
+@pytest.mark.parametrize("n_mels,clip_len", [(80, 11357), (40, 4000), (64, 400), (80, 399 + 160 * 3), (80, 160000)])
+def test_fbank_clip_kernel_against_the_two_kernel_path(gpu, oracle, jfk, n_mels, clip_len):
+    """Uniform batches that fill the CUs evenly take fbank512_clip_kernel (a workgroup per clip, CMN inside, the column sums as
+    a fixed tree instead of the left fold of src/fbank.rs:224-233); smaller ones the fused kernel + cmn_kernel (the reference's
+    order).  The two differ by the rounding of the mean only, both sit within the tolerance of the oracle, and the clip kernel
+    gives the same bits on every run."""
     fb = gpu.Fbank(gpu.FbankConfig(num_mel_bins=n_mels))
     oc = oracle.fbank_default_config(); oc.num_mel_bins = n_mels
-    n_clips = 300
-    x = np.stack([(jfk[c * 500:c * 500 + clip_len] if c % 2 else oracle.synth_pcm(c, clip_len)) for c in range(n_clips)]).astype(np.float32)
+    n_clips = 512          # two clips per CU of an MI355X
+    src = np.concatenate([jfk, jfk])
+    x = np.stack([(src[c * 300:c * 300 + clip_len] if c % 2 else oracle.synth_pcm(c, clip_len)) for c in range(n_clips)]).astype(np.float32)
     big = fb.compute_batch(x)
     small = fb.compute_batch(x[:40])
-    assert np.array_equal(big[:40], small)
+    assert np.abs(big[:40] - small).max() <= 5e-5
     if big.shape[1]:
-        for c in (0, 1, 150, 299):
+        for c in (0, 1, 150, n_clips - 1):
             assert np.abs(big[c] - oracle.fbank_compute(x[c], oc)).max() <= TOL
-    # again on the same object: the clip counter carries on from where the first launch left it
+        assert np.abs(big.mean(axis=1)).max() < 1e-4
     assert np.array_equal(fb.compute_batch(x), big)
     fb.close()
 
