@@ -1444,6 +1444,8 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
             FbankClipParams q{};
             q.f = fp;
             q.frames = fpc;
+            static const int clip_skip = lab_int("MELSPEC_FB_CLIP_SKIP", 0, 0, 15);
+            q.lab_skip = clip_skip;
             const size_t lds = fb->fast_lds + sizeof(ClipCmnShared<8>);
             if (lds <= kLdsLimit) {
                 if (fb_lens_match<LensKaldi80>(fb->ft.slots)) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(cus), dim3(512), lds, s, q);
@@ -2254,15 +2256,20 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         BlmNormParams np{};
         np.out = d_out; np.clip_stride = cols * static_cast<uint64_t>(nm); np.row_w = cols; np.valid = valid;
         np.n_clips = n_clips; np.n_mels = nm;
+        static const int fold_sel = lab_int("MELSPEC_NORM_FOLD", -1, -1, 12);
+        np.fold_sel = fold_sel;
+        static const int norm_skip = lab_int("MELSPEC_NORM_SKIP", 0, 0, 7);
+        np.lab_skip = norm_skip;
+        static const int norm_stagger = lab_int("MELSPEC_NORM_STAGGER", 1, 0, 1);
+        np.stagger = norm_stagger;
         const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
         // four workgroups of <= 38 KB per CU measured best (1024 x 10 s x 128 mels, ms per call incl. the 0.72 ms mel kernel: 150 KB x 1: 1.72,
         // 76 x 2: 1.45, 50 x 3: 1.34, 38 x 4: 1.28, 25 x 6: 1.68); MELSPEC_NORM_KB / MELSPEC_NORM_PER_CU override
-        size_t stride = (static_cast<size_t>(valid) + 31) & ~static_cast<size_t>(31);      // whole groups of 32 floats ...
+        size_t stride = (static_cast<size_t>(valid) + 3 + 31) & ~static_cast<size_t>(31);  // whole groups of 32 floats (a row starts up to 3 floats into its first granule) ...
         if ((stride / 4) % 2 == 0) stride += 4;                                              // ... and 4 * odd
-        np.vec = (cols % 4 == 0 && reinterpret_cast<uintptr_t>(d_out) % 16 == 0) ? 1 : 0;
         static const int norm_kb = lab_int("MELSPEC_NORM_KB", 38, 8, 158);
         static const int norm_per_cu = lab_int("MELSPEC_NORM_PER_CU", 4, 1, 16);
-        const size_t budget = static_cast<size_t>(norm_kb) * 1024 - 64 * 2 * sizeof(float);
+        const size_t budget = static_cast<size_t>(norm_kb) * 1024 - (64 * 2 + kBlmNormThreads) * sizeof(float);
         size_t per = budget / (stride * sizeof(float));
         int per_cu = norm_per_cu;
         if (per < 4) {                            // long rows (> ~25 s): one workgroup per CU with the whole LDS, up to ~6 min per row
@@ -2282,7 +2289,7 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
             const unsigned g2 = grid_for((rows + kBlmNormThreads - 1) / kBlmNormThreads, b->dev.cus, 4);
             hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), 0, s, np);
         } else {
-            const size_t lds = (per * stride + 2 * per) * sizeof(float);
+            const size_t lds = (per * stride + 2 * per + kBlmNormThreads) * sizeof(float);
             const unsigned g2 = grid_for((rows + per - 1) / per, b->dev.cus, per_cu);
             hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), lds, s, np);
         }
@@ -2344,6 +2351,7 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
                                                   : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
         if (!rc && b->cfg.normalize_per_feature && longest > 0) {
             BlmNormParams np{};
+            np.fold_sel = -1;
             np.out = d_out; np.n_clips = n_clips; np.n_mels = nm; np.rows_per_group = 0;
             np.d_out_off = pl.desc.d_out_off; np.d_cols = pl.desc.d_frames; np.d_valid = fp.d_valid;
             const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;

@@ -937,7 +937,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         if (FLAVOR == kFlavorKaldi) {
             const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
             // frame mean (src/fbank.rs:165-166): 16 partial sums of 24-26 samples through LDS, fixed tree
-            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
+            FbColumnIn cin;
+            const bool patch = f0 + fl == 0 && j == 0;          // the first sample of a clip has nothing in front of it
+            fb_column_load(frame, j, patch, cin);
+            slice[L::kSumOff + lane] = act ? fb_column_sum<T>(cin, j) : T(0);
             __builtin_amdgcn_wave_barrier();
             T mean = 0;
             if (act) {
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
                 mean = (a + b) / T(400);
             }
             __builtin_amdgcn_wave_barrier();
-            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+            if (act) fb_column_rest<T>(cin, j, preemph, mean, patch, tblob, slice + fl * L::kXStride + 2 * j);
         } else if (FLAVOR == kFlavorWhisper) {
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
         } else {
@@ -964,7 +967,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             fb_phase2_dft<T>(fl, j, act, slice, own);
 #pragma unroll
             for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
-            fb_phase2_split<T>(fl, j, act, use_power, tblob, own, part, slice);
+            if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
+            else fb_phase2_split<T, false>(fl, j, act, tblob, own, part, slice);
         }
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(2);
@@ -1019,6 +1023,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
 struct FbankClipParams {
     FbankFastParams f;
     uint64_t frames;        // per clip (uniform batches)
+    int lab_skip;           // lab builds, timing ablations (wrong results): 1 = no subtraction, 2 = its loads only, 4 = its stores only
 };
 
 template <int WAVES>
@@ -1028,42 +1033,80 @@ struct ClipCmnShared {
     unsigned arrived[2], ready[2];
 };
 
-// this wave's share of the rows of a finished clip: rows - mean, in place
+// The subtraction of a finished clip, one wave's share: groups of R = 64 / (n_mels / 4) rows (one 16-byte piece per lane), group
+// g belongs to wave g % WAVES, the wave's groups are numbered by `slot` (g = wave + WAVES * slot).
 template <int WAVES>
-MS_DEV void clip_cmn_subtract(ClipCmnShared<WAVES> *sh, int par, unsigned expect, int wave, int lane, float *out, uint64_t frames, int nm) {
-    if (lane == 0) {
-        // bounded (a mean that is never published would be a bug; a wrong result is caught by the parity tests, a hung GPU is not recoverable)
-        for (unsigned spin = 0; spin < (1u << 22) && __hip_atomic_load(&sh->ready[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < expect; ++spin)
-            __builtin_amdgcn_s_sleep(2);
-    }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+struct ClipCmnSub {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int q4 = nm >> 2;                    // 16-byte pieces per row
-    const int R = 64 / q4;                     // rows per wave instruction
-    int r = lane / q4;
-    const int c4 = lane - r * q4;
-    const bool on = r < R;
-    const f4 m4 = *reinterpret_cast<const f4 *>(&sh->mean[par][4 * c4]);
-    f4 *o4 = reinterpret_cast<f4 *>(out);
-    const uint64_t groups = (frames + R - 1) / R;
-    constexpr int K = 16;
-    for (uint64_t g = wave; g < groups; g += (uint64_t)WAVES * K) {
-        f4 v[K];
-        uint64_t idx[K];
-        bool ok[K];
+    f4 *o4 = nullptr;          // the finished clip's rows
+    f4 m4;                     // this lane's four column means
+    uint32_t frames = 0, q4 = 0, R = 1, r = 0, c4 = 0, slots = 0, next = 0;
+    bool lane_on = false, have_mean = false;
+    int lab = 0;               // lab builds: 2 = loads only, 4 = stores only
+
+    MS_DEV void begin(float *out, uint64_t frames_, int nm, int wave, int lane) {
+        o4 = reinterpret_cast<f4 *>(out);
+        frames = static_cast<uint32_t>(frames_);
+        q4 = static_cast<uint32_t>(nm) >> 2;
+        R = 64u / q4;
+        r = static_cast<uint32_t>(lane) / q4;
+        c4 = static_cast<uint32_t>(lane) - r * q4;
+        lane_on = r < R;
+        const uint32_t groups = (frames + R - 1) / R;
+        slots = groups > static_cast<uint32_t>(wave) ? (groups - wave + WAVES - 1) / WAVES : 0;
+        next = 0;
+        have_mean = false;
+    }
+    // wave-uniform; never waits
+    MS_DEV bool poll(ClipCmnShared<WAVES> *sh, int par, unsigned expect, int lane) {
+        if (have_mean) return true;
+        bool ok = false;
+        if (lane == 0) ok = __hip_atomic_load(&sh->ready[par], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= expect;
+        if (__builtin_amdgcn_ballot_w64(ok) == 0) return false;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        m4 = *reinterpret_cast<const f4 *>(&sh->mean[par][4 * c4]);
+        have_mean = true;
+        return true;
+    }
+    MS_DEV void wait(ClipCmnShared<WAVES> *sh, int par, unsigned expect, int lane) {
+        // bounded (a mean that is never published would be a bug; a wrong result is caught by the parity tests, a hung GPU is not recoverable)
+        for (unsigned spin = 0; spin < (1u << 22) && !poll(sh, par, expect, lane); ++spin) __builtin_amdgcn_s_sleep(2);
+    }
+    // the load of one slot (unconditional: rows past the clip re-read its last row); returns the piece's index
+    MS_DEV uint32_t load(int wave, uint32_t slot, f4 &v, bool &ok) const {
+        const uint32_t row = (static_cast<uint32_t>(wave) + WAVES * slot) * R + r;
+        ok = lane_on && slot < slots && row < frames;
+        const uint32_t idx = (row < frames ? row : frames - 1) * q4 + c4;
+        if (lab & 4) v = m4; else v = o4[idx];
+        return idx;
+    }
+    MS_DEV void store(uint32_t idx, const f4 &v, bool ok) const {
+        if (lab & 2) { asm volatile("" :: "v"(v)); return; }
+        if (ok) o4[idx] = v - m4;
+    }
+    // everything that is left, 8 loads in flight, the next batch's loads issued before this batch's stores
+    MS_DEV void finish(int wave) {
+        constexpr int K = 8;
+        if (next >= slots) return;
+        f4 v[K], w[K];
+        uint32_t iv[K], iw[K];
+        bool kv[K], kw[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const uint64_t row = (g + (uint64_t)k * WAVES) * R + r;
-            ok[k] = on && row < frames;
-            idx[k] = (row < frames ? row : frames - 1) * q4 + c4;       // the load is unconditional
-            v[k] = o4[idx[k]];
+        for (int k = 0; k < K; ++k) iv[k] = load(wave, next + k, v[k], kv[k]);
+        next += K;
+        while (next < slots) {                       // wave-uniform
+#pragma unroll
+            for (int k = 0; k < K; ++k) iw[k] = load(wave, next + k, w[k], kw[k]);
+            next += K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) store(iv[k], v[k], kv[k]);
+#pragma unroll
+            for (int k = 0; k < K; ++k) { v[k] = w[k]; iv[k] = iw[k]; kv[k] = kw[k]; }
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (ok[k]) o4[idx[k]] = v[k] - m4;
+        for (int k = 0; k < K; ++k) store(iv[k], v[k], kv[k]);
     }
-}
+};
 
 template <int NSLOTS, class Lens>
 __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankClipParams q) {
@@ -1096,9 +1139,11 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
     const uint32_t units = static_cast<uint32_t>((frames + kFbFPW - 1) / kFbFPW);
     const uint32_t u0 = static_cast<uint32_t>((uint64_t)units * wave / WAVES), u1 = static_cast<uint32_t>((uint64_t)units * (wave + 1) / WAVES);
     unsigned gen = 0;                      // clips this workgroup has finished
-    float *prev_out = nullptr;
+    ClipCmnSub<WAVES> sub;                 // the previous clip's subtraction
+    sub.lab = q.lab_skip & 6;
     for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x, ++gen) {
         const int par = gen & 1;
+        const unsigned prev_turn = (gen + 1) / 2;      // == (gen - 1) / 2 + 1 for gen > 0
         const float *pcm = p.b.pcm + (uint64_t)clip * p.b.clip_stride;
         float *out = p.b.out + (uint64_t)clip * p.b.out_stride;
         float acc[NSLOTS];
@@ -1111,7 +1156,10 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             const bool act = fl < nv;
             MS_PRIO(0);
             const float *frame = pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
+            FbColumnIn cin;
+            const bool patch = f0 + fl == 0 && j == 0;          // the first sample of a clip has nothing in front of it
+            fb_column_load(frame, j, patch, cin);
+            slice[L::kSumOff + lane] = act ? fb_column_sum<T>(cin, j) : T(0);
             __builtin_amdgcn_wave_barrier();
             T mean = 0;
             if (act) {
@@ -1121,7 +1169,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
                 mean = (a + b) / T(400);
             }
             __builtin_amdgcn_wave_barrier();
-            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+            if (act) fb_column_rest<T>(cin, j, preemph, mean, patch, tblob, slice + fl * L::kXStride + 2 * j);
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(1);
             {
@@ -1129,7 +1177,8 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
                 fb_phase2_dft<T>(fl, j, act, slice, own);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
-                fb_phase2_split<T>(fl, j, act, use_power, tblob, own, part, slice);
+                if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
+            else fb_phase2_split<T, false>(fl, j, act, tblob, own, part, slice);
             }
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(2);
@@ -1143,6 +1192,13 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             __builtin_amdgcn_wave_barrier();
         }
         MS_PRIO(0);
+        // this wave's share of the previous clip's subtraction (its means were published a whole run ago: the wait does not spin).
+        // Spreading it over the units of the run -- two pieces loaded after phase 1, stored at the end of the unit -- was measured
+        // and is slower (+0.08 ms against +0.07 ms, profiles/r02_fbank.txt): the cost is the extra traffic, not this wave's stall
+        if (gen > 0 && !(q.lab_skip & 1)) {
+            sub.wait(sh, par ^ 1, prev_turn, lane);
+            sub.finish(wave);
+        }
         // the wave's column sums: frame positions (0+1)+(2+3), then lanes of position 0 write them
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) {
@@ -1169,10 +1225,12 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) __hip_atomic_store(&sh->ready[par], turn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        if (gen > 0) clip_cmn_subtract<WAVES>(sh, par ^ 1, (gen - 1) / 2 + 1, wave, lane, prev_out, frames, nm);
-        prev_out = out;
+        sub.begin(out, frames, nm, wave, lane);        // this clip is the next one to subtract
     }
-    if (gen > 0) clip_cmn_subtract<WAVES>(sh, (gen - 1) & 1, (gen - 1) / 2 + 1, wave, lane, prev_out, frames, nm);
+    if (gen > 0 && !(q.lab_skip & 1)) {
+        sub.wait(sh, (gen - 1) & 1, (gen - 1) / 2 + 1, lane);
+        sub.finish(wave);
+    }
 }
 
 // Per-feature normalisation of the NeMo frontend (normalize_per_feature, src/mel.rs:721-749): for every (clip, mel) row the
@@ -1191,7 +1249,9 @@ struct BlmNormParams {
     int n_mels;
     int rows_per_group;     // rows staged per workgroup round (<= 64), 0: rows too long for LDS
     int lds_stride;         // floats between staged rows: 4 * odd (16-byte aligned rows whose per-lane walks spread over the banks)
-    int vec;                // rows are 16-byte aligned: float4 loads and stores
+    int fold_sel;           // the wave that folds = (blockIdx.x >> fold_sel) & 3; < 0: wave 0
+    int lab_skip;           // lab builds, timing ablations (wrong results): 1 no folds, 2 no stores, 4 no loads
+    int stagger;            // 1: first round of a different length per workgroup (0 in lab builds: all workgroups in step)
     // ragged batches (rows_per_group == 0 form only): per clip the first output float, the row width and the valid frames
     const uint64_t *d_out_off, *d_cols, *d_valid;
 };
@@ -1203,77 +1263,50 @@ __device__ __forceinline__ float *blm_row(const BlmNormParams &p, uint64_t row) 
     return p.out + clip * p.clip_stride + m * p.row_w;
 }
 
-// mean and standard deviation (+1e-5) of one row, left folds in f32 exactly like the reference (no FMA contraction of
-// c * c + s).  The fold is a chain of `valid` dependent adds per pass and nothing else should be on its critical path:
-// the row is read 32 floats at a time (eight 16-byte reads) and the next 32 are in flight while the current ones are added.
-// row: 16-byte aligned, readable up to the next multiple of 32 floats past `valid` (the excess is never added).
-__device__ __forceinline__ void blm_row_stats_lds(const float *row, uint32_t valid, float &mean, float &sd) {
+// The mean of one row as the reference computes it: `iter().sum::<f32>() / n`, an f32 LEFT FOLD (src/mel.rs:721-749).  Its rounding
+// error (~1e-4 for 1000 values near -10) divided by a small standard deviation is visible in the output, so the order is kept: a
+// chain of `valid` dependent adds by one lane, and nothing else on its critical path -- the row is read 32 floats at a time (eight
+// 16-byte reads) into two register sets filled in turn (a copy "cur = nxt" per group is one v_mov per element: as many
+// instructions as the adds).  A lone wave issues one VALU instruction per ~5.6 cycles and a dependent add takes 10.5
+// (tools/dep_add.hip): ~4.4 us per 1001-frame row.
+// row: 16-byte aligned; the row's values are row[head .. head + valid), head < 4 (the piece of the 16-byte granule in front of the
+// row belongs to its neighbour); readable up to the next multiple of 32 floats past head + valid (the excess is never added).
+__device__ __forceinline__ float blm_row_mean_lds(const float *row, uint32_t head, uint32_t valid) {
     constexpr int kQ = 8;                      // float4s per group
-    const uint32_t groups = (valid + 4 * kQ - 1) / (4 * kQ);
+    const uint32_t lo = head, hi = head + valid;
+    const uint32_t groups = (hi + 4 * kQ - 1) / (4 * kQ);
     auto fetch = [&](uint32_t g, f4 (&v)[kQ]) {
 #pragma unroll
         for (int i = 0; i < kQ; ++i) v[i] = *reinterpret_cast<const f4 *>(row + (g * kQ + i) * 4);
     };
     float s = 0.0f;
-    {
-        f4 cur[kQ], nxt[kQ];
-        fetch(0, cur);
-        for (uint32_t g = 0; g < groups; ++g) {
-            fetch(g + 1 < groups ? g + 1 : g, nxt);
-            const uint32_t k0 = g * 4 * kQ;
-            if (k0 + 4 * kQ <= valid) {
+    auto consume = [&](const f4 (&c)[kQ], uint32_t g) {
+        const uint32_t k0 = g * 4 * kQ;
+        if (k0 >= lo && k0 + 4 * kQ <= hi) {
 #pragma unroll
-                for (int i = 0; i < kQ; ++i) { s += cur[i].x; s += cur[i].y; s += cur[i].z; s += cur[i].w; }
-            } else {
-#pragma unroll
-                for (int i = 0; i < kQ; ++i) {
-                    if (k0 + 4 * i + 0 < valid) s += cur[i].x;
-                    if (k0 + 4 * i + 1 < valid) s += cur[i].y;
-                    if (k0 + 4 * i + 2 < valid) s += cur[i].z;
-                    if (k0 + 4 * i + 3 < valid) s += cur[i].w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < kQ; ++i) cur[i] = nxt[i];
-        }
-    }
-    mean = f32_div_rn(s, static_cast<float>(valid));
-    float q = 0.0f;
-    {
-        f4 cur[kQ], nxt[kQ];
-        fetch(0, cur);
-        for (uint32_t g = 0; g < groups; ++g) {
-            fetch(g + 1 < groups ? g + 1 : g, nxt);
-            const uint32_t k0 = g * 4 * kQ;
-            // a lone wave issues one VALU instruction per ~5.6 cycles and a dependent add takes 10.5 (tools/dep_add.hip): the
-            // centring and squaring go through the packed f32 ops (two elements per instruction, same IEEE results) so that
-            // the pass is bound by its chain of adds, not by instruction issue
-            float sq[4 * kQ];
+            for (int i = 0; i < kQ; ++i) { s += c[i].x; s += c[i].y; s += c[i].z; s += c[i].w; }
+        } else {
 #pragma unroll
             for (int i = 0; i < kQ; ++i) {
-                typedef float v2f __attribute__((ext_vector_type(2)));
-                const v2f m2 = {mean, mean};
-                v2f a = {cur[i].x, cur[i].y}, b = {cur[i].z, cur[i].w};
-                a = a - m2; b = b - m2;
-                v2f sa = a * a, sb = b * b;
-                asm("" : "+v"(sa), "+v"(sb));            // products rounded on their own (no contraction into the adds below)
-                sq[4 * i] = sa.x; sq[4 * i + 1] = sa.y; sq[4 * i + 2] = sb.x; sq[4 * i + 3] = sb.y;
+                const uint32_t k = k0 + 4 * i;
+                if (k + 0 >= lo && k + 0 < hi) s += c[i].x;
+                if (k + 1 >= lo && k + 1 < hi) s += c[i].y;
+                if (k + 2 >= lo && k + 2 < hi) s += c[i].z;
+                if (k + 3 >= lo && k + 3 < hi) s += c[i].w;
             }
-            if (k0 + 4 * kQ <= valid) {
-#pragma unroll
-                for (int i = 0; i < 4 * kQ; ++i) q += sq[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4 * kQ; ++i)
-                    if (k0 + i < valid) q += sq[i];
-            }
-#pragma unroll
-            for (int i = 0; i < kQ; ++i) cur[i] = nxt[i];
         }
+    };
+    f4 a[kQ], b[kQ];
+    fetch(0, a);
+    uint32_t g = 0;
+    for (; g + 1 < groups; g += 2) {
+        fetch(g + 1, b);
+        consume(a, g);
+        fetch(g + 2 < groups ? g + 2 : g + 1, a);
+        consume(b, g + 1);
     }
-    float denom = static_cast<float>(valid) - 1.0f;
-    denom = denom < 1.0f ? 1.0f : denom;
-    sd = __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
+    if (g < groups) consume(a, g);
+    return f32_div_rn(s, static_cast<float>(valid));
 }
 
 // the same from HBM, one value at a time (rows too long for LDS)
@@ -1315,93 +1348,124 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
     }
     const int R = p.rows_per_group, S = p.lds_stride;
     float *stat = tile + (size_t)R * S;      // [R][2]
-    // rows of one clip are contiguous and so are the clips (clip_stride == n_mels * row_w): row r starts at out + r * row_w.
-    // vec: 16-byte aligned rows -> one float4 per thread and row, kRowsAtOnce rows in flight (a load inside a per-row `if`
-    // would be one memory round trip per row; rows past the group re-read its last row instead)
-    const bool vec = p.vec != 0;
+    const int fold_wave = p.fold_sel < 0 ? 0 : static_cast<int>((blockIdx.x >> p.fold_sel) & 3u);
+    // Rows of one clip are contiguous and so are the clips (clip_stride == n_mels * row_w): row r starts at out + r * row_w, at
+    // any 4-byte alignment (1001 columns for a 10 s clip without pad_to).  Global memory is accessed in whole 16-byte granules
+    // all the same: a row whose first float sits `a` floats into its granule is staged from the granule's start, at the same
+    // offset `a` in its 16-byte aligned LDS row; the granules a row shares with its neighbours are loaded by both and stored
+    // float by float.  kRowsAtOnce rows in flight per thread (a load inside a per-row `if` would be one memory round trip per
+    // row; rows past the group re-read its last row, granules past the row its last granule).
     constexpr int kRowsAtOnce = 9;
-    const uint64_t nq = (p.valid + 3) / 4;
-    for (uint64_t row0 = (uint64_t)blockIdx.x * R; row0 < rows; row0 += (uint64_t)gridDim.x * R) {
-        const int nr = rows - row0 < (uint64_t)R ? (int)(rows - row0) : R;
-        float *base = p.out + row0 * p.row_w;
-        if (vec) {
-            // row pointers advance by increments (rows past the group repeat its last row): no 64-bit multiply per row
-            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
-                const float *g0 = base + (uint64_t)rr0 * p.row_w;
-                float *t0 = tile + (size_t)rr0 * S;
-                for (uint64_t q = tid; q < nq; q += kBlmNormThreads) {
-                    f4 v[kRowsAtOnce];
-                    const float *g = g0 + 4 * q;
+    const uint32_t valid = static_cast<uint32_t>(p.valid);
+    const uint32_t out_f = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p.out) >> 2) & 3u;
+    const uint32_t nq_max = (valid + 6) / 4;            // granules of a row at the worst alignment
+    // A workgroup owns a contiguous range of rows and walks it in rounds of R.  All workgroups marching through "load, fold,
+    // store" in step would leave HBM idle during the folds (measured: the three phases added up, 0.10 + 0.19 + 0.13 ms), so the
+    // first round is short by a different amount in every workgroup and the rounds of the workgroups sharing a CU overlap.
+    const uint64_t per_wg = (rows + gridDim.x - 1) / gridDim.x;
+    const uint64_t row_begin = (uint64_t)blockIdx.x * per_wg;
+    const uint64_t row_end = row_begin + per_wg < rows ? row_begin + per_wg : rows;
+    float *part = stat + 2 * R;              // [R][PP] partial sums of squares
+    const int PP = kBlmNormThreads / R;      // threads per row in the variance pass
+    int first = p.stagger ? 1 + static_cast<int>((blockIdx.x * 5u + (blockIdx.x >> 8) * 3u) % static_cast<unsigned>(R)) : R;
+    for (uint64_t row0 = row_begin; row0 < row_end;) {
+        const int want = first;
+        first = R;
+        const int nr = row_end - row0 < (uint64_t)want ? (int)(row_end - row0) : want;
+        const uint64_t e00 = row0 * p.row_w;
+        for (int rr0 = 0; rr0 < ((p.lab_skip & 4) ? 0 : nr); rr0 += kRowsAtOnce) {
+            for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
+                f4 v[kRowsAtOnce];
+                uint32_t to[kRowsAtOnce];
+                uint64_t e0 = e00 + (uint64_t)rr0 * p.row_w;
+                uint32_t t = static_cast<uint32_t>(rr0) * S;
 #pragma unroll
-                    for (int i = 0; i < kRowsAtOnce; ++i) {
-                        v[i] = *reinterpret_cast<const f4 *>(g);
-                        if (rr0 + i + 1 < nr) g += p.row_w;
-                    }
-                    float *t = t0 + 4 * q;
-#pragma unroll
-                    for (int i = 0; i < kRowsAtOnce; ++i) {
-                        *reinterpret_cast<f4 *>(t) = v[i];          // S is a multiple of 4: one 16-byte write
-                        if (rr0 + i + 1 < nr) t += S;
-                    }
+                for (int i = 0; i < kRowsAtOnce; ++i) {
+                    const uint32_t a = (out_f + static_cast<uint32_t>(e0)) & 3u;
+                    const uint32_t nq = (a + valid + 3) >> 2;
+                    const uint32_t qq = q < nq ? q : nq - 1;
+                    v[i] = *reinterpret_cast<const f4 *>(p.out + e0 - a + 4 * qq);
+                    to[i] = t + 4 * qq;
+                    if (rr0 + i + 1 < nr) { e0 += p.row_w; t += S; }
                 }
+#pragma unroll
+                for (int i = 0; i < kRowsAtOnce; ++i) *reinterpret_cast<f4 *>(tile + to[i]) = v[i];
             }
-        } else {
-            for (int rr = 0; rr < nr; ++rr) {
-                const float *src = base + (uint64_t)rr * p.row_w;
-                float *dst = tile + (size_t)rr * S;
-                for (uint64_t k = tid; k < p.valid; k += kBlmNormThreads) dst[k] = src[k];
+        }
+        __syncthreads();
+        // the means: a few lanes of ONE wave (fold_sel: which one; measured without effect)
+        const int ft = tid - 64 * fold_wave;
+        if (ft >= 0 && ft < nr) {
+            const uint32_t a = (out_f + static_cast<uint32_t>(e00 + (uint64_t)ft * p.row_w)) & 3u;
+            stat[2 * ft] = (p.lab_skip & 1) ? 0.0f : blm_row_mean_lds(tile + (size_t)ft * S, a, valid);
+        }
+        __syncthreads();
+        // the unbiased variance: sum of (v - mean)^2 as a fixed tree over all threads, PP strided partial sums per row added in
+        // order.  The reference folds this sum left to right as well; unlike the mean, the order is immaterial here -- either
+        // sum is within ~1e-6 (relative) of the exact one, 5e-7 of the standard deviation, and the output moves by |out| * 5e-7.
+        {
+            const int r = tid / PP, pt = tid - r * PP;
+            if (r < nr) {
+                const uint32_t a = (out_f + static_cast<uint32_t>(e00 + (uint64_t)r * p.row_w)) & 3u;
+                const float *row = tile + (size_t)r * S + a;
+                const float mean = stat[2 * r];
+                float acc = 0.0f;
+                for (uint32_t k = pt; k < valid; k += PP) {
+                    const float c = row[k] - mean;
+                    acc += c * c;
+                }
+                part[r * PP + pt] = acc;
             }
         }
         __syncthreads();
         if (tid < nr) {
-            const float *row = tile + (size_t)tid * S;
-            float mean, sd;
-            blm_row_stats_lds(row, static_cast<uint32_t>(p.valid), mean, sd);
-            stat[2 * tid] = mean;
-            stat[2 * tid + 1] = sd;
+            float q = 0.0f;
+            for (int i = 0; i < PP; ++i) q += part[tid * PP + i];
+            float denom = static_cast<float>(valid) - 1.0f;
+            denom = denom < 1.0f ? 1.0f : denom;
+            stat[2 * tid + 1] = (p.lab_skip & 1) ? 1.0f : __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
         }
         __syncthreads();
-        if (vec) {
-            for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
-                float *g0 = base + (uint64_t)rr0 * p.row_w;
-                const float *t0 = tile + (size_t)rr0 * S;
-                for (uint64_t q = tid; q < nq; q += kBlmNormThreads) {
-                    f4 v[kRowsAtOnce];
-                    float mean[kRowsAtOnce], sd[kRowsAtOnce];
-                    const float *t = t0 + 4 * q;
-                    const float *st = stat + 2 * rr0;
+        const uint32_t row_w = static_cast<uint32_t>(p.row_w);
+        for (int rr0 = 0; rr0 < ((p.lab_skip & 2) ? 0 : nr); rr0 += kRowsAtOnce) {
+            for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
+                f4 v[kRowsAtOnce];
+                float mean[kRowsAtOnce], sd[kRowsAtOnce];
+                uint32_t t = static_cast<uint32_t>(rr0) * S + 4 * q;
+                const float *st = stat + 2 * rr0;
 #pragma unroll
-                    for (int i = 0; i < kRowsAtOnce; ++i) {           // every LDS read first (rows past the group: its last row again)
-                        v[i] = *reinterpret_cast<const f4 *>(t);
-                        mean[i] = st[0]; sd[i] = st[1];
-                        if (rr0 + i + 1 < nr) { t += S; st += 2; }
-                    }
-                    float *g = g0 + 4 * q;
+                for (int i = 0; i < kRowsAtOnce; ++i) {           // every LDS read first (rows past the group: its last row again)
+                    v[i] = *reinterpret_cast<const f4 *>(tile + t);
+                    mean[i] = st[0]; sd[i] = st[1];
+                    if (rr0 + i + 1 < nr) { t += S; st += 2; }
+                }
+                uint64_t e0 = e00 + (uint64_t)rr0 * p.row_w;
 #pragma unroll
-                    for (int i = 0; i < kRowsAtOnce; ++i) {
-                        f4 o;                                         // columns past the valid frames keep their zeros
-                        o.x = f32_div_rn(v[i].x - mean[i], sd[i]);
-                        o.y = f32_div_rn(v[i].y - mean[i], sd[i]);
-                        o.z = f32_div_rn(v[i].z - mean[i], sd[i]);
-                        o.w = f32_div_rn(v[i].w - mean[i], sd[i]);
-                        if (4 * q + 0 >= p.valid) o.x = 0.0f;
-                        if (4 * q + 1 >= p.valid) o.y = 0.0f;
-                        if (4 * q + 2 >= p.valid) o.z = 0.0f;
-                        if (4 * q + 3 >= p.valid) o.w = 0.0f;
-                        *reinterpret_cast<f4 *>(g) = o;
-                        if (rr0 + i + 1 < nr) g += p.row_w;
+                for (int i = 0; i < kRowsAtOnce; ++i) {
+                    const uint32_t a = (out_f + static_cast<uint32_t>(e0)) & 3u;
+                    const int c0 = static_cast<int>(4 * q) - static_cast<int>(a);       // column of the granule's first float
+                    float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)                   // columns past the valid frames keep their zeros
+                        o[e] = (c0 + e >= 0 && static_cast<uint32_t>(c0 + e) < valid) ? f32_div_rn(o[e] - mean[i], sd[i]) : 0.0f;
+                    float *g = p.out + e0 + c0;
+                    const bool mine = rr0 + i < nr && 4 * q < a + valid;                 // granules that hold valid frames of a row of the group
+                    if (mine) {
+                        if (c0 >= 0 && static_cast<uint32_t>(c0 + 3) < row_w) {
+                            f4 w = {o[0], o[1], o[2], o[3]};
+                            *reinterpret_cast<f4 *>(g) = w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c0 + e >= 0 && static_cast<uint32_t>(c0 + e) < row_w) g[e] = o[e];
+                        }
                     }
+                    if (rr0 + i + 1 < nr) e0 += p.row_w;
                 }
             }
-        } else {
-            for (int rr = 0; rr < nr; ++rr) {
-                float *dstg = base + (uint64_t)rr * p.row_w;
-                const float *src = tile + (size_t)rr * S;
-                const float mean = stat[2 * rr], sd = stat[2 * rr + 1];
-                for (uint64_t k = tid; k < p.valid; k += kBlmNormThreads) dstg[k] = f32_div_rn(src[k] - mean, sd);
-            }
         }
         __syncthreads();
+        row0 += nr;
     }
 }
 

@@ -167,8 +167,9 @@ static long long run_fbank(const float *pcm, long long n, int shift, int n_mels,
             cpx<T> part[8];
             const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);          // what partner16() fetches on the device
             for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
-            fb_phase2_split<T>(fl, j, act, use_power != 0, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]),
-                               part, tmp.data());
+            const auto &mine = *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]);
+            if (use_power != 0) fb_phase2_split<T, true>(fl, j, act, tblob, mine, part, tmp.data());
+            else fb_phase2_split<T, false>(fl, j, act, tblob, mine, part, tmp.data());
             // power rows are f32 written into the T-typed slice: compare bytes
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
@@ -247,7 +248,7 @@ extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_
             cpx<T> part[8];
             const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);          // what partner16() fetches on the device
             for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
-            fb_phase2_split<T>(fl, j, act, true, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]),
+            fb_phase2_split<T, true>(fl, j, act, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]),
                                part, tmp.data());
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
@@ -562,7 +563,7 @@ extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n
             cpx<T> part[8];
             const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);
             for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
-            fb_phase2_split<T>(fl, j, act, true, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]), part, tmp.data());
+            fb_phase2_split<T, true>(fl, j, act, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]), part, tmp.data());
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
             for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];

@@ -11,6 +11,6 @@ fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, 
 out = M.DeviceBuffer(n_clips * fe.padded_frames(clip_len) * 128 * 4)
 for _ in range(2):
     fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); fe.synchronize()
-fb = M.Fbank(M.FbankConfig(apply_cmn=False))
+fb = M.Fbank()        # CMN on: the clip kernel (or, MELSPEC_FB_CLIP=0 in lab builds, the fused kernel + cmn_kernel)
 for _ in range(2):
     fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); fb.synchronize()

@@ -1,0 +1,18 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/probe_f.txt
+: > $O
+LAB=$PWD/mel_spec_amd/libmelspec_hip_lab.so
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "nemo" 2>&1 | tail -5 >> $O
+echo "== normaliser: product" >> $O
+NEMO_ONLY=norm timeout 200 python tools/nemo_probe.py 2>&1 | grep n_mels >> $O
+for st in 0 1; do for kp in "38 4" "30 5" "50 3"; do
+  set -- $kp
+  echo "MELSPEC_NORM_STAGGER=$st MELSPEC_NORM_KB=$1 MELSPEC_NORM_PER_CU=$2" >> $O
+  NEMO_ONLY=norm MELSPEC_LIB=$LAB MELSPEC_NORM_STAGGER=$st MELSPEC_NORM_KB=$1 MELSPEC_NORM_PER_CU=$2 timeout 200 python tools/nemo_probe.py 2>&1 | grep normalize >> $O
+done; done
+for k in 1 2 4 7; do
+  echo "MELSPEC_NORM_SKIP=$k" >> $O
+  NEMO_ONLY=norm MELSPEC_LIB=$LAB MELSPEC_NORM_SKIP=$k timeout 200 python tools/nemo_probe.py 2>&1 | grep normalize >> $O
+done
+cat $O
