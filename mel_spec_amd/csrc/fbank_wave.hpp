@@ -125,49 +125,8 @@ MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_
     fb_column_finish<T>(x, n2, tblob, xo);
 }
 
-// The same in three steps for the kernels, so that a unit pays ONE memory round trip for its samples: load (13 pairs and the
-// sample in front of each), the lane's share of the frame sum from those registers (the order of fb_partial_sum), and -- once the
-// frame mean has come back through LDS -- fb_column's arithmetic on the same registers.  (fb_partial_sum + fb_column read and
-// convert the samples twice: 26 v_cvt_f64_f32, 13 loads and a second dependent round trip per unit.)
-struct FbColumnIn {
-    f2 c[13];
-    float prev[13];
-};
-MS_DEV void fb_column_load(const float *frame, int n2, bool patch_first, FbColumnIn &in) {
-#pragma unroll
-    for (int n1 = 0; n1 < 13; ++n1) {
-        const int i = (n1 < 12 || n2 < 8) ? 32 * n1 + 2 * n2 : 0;
-        in.c[n1] = load2_unaligned(frame + i);
-        in.prev[n1] = frame[(n1 == 0 && patch_first) ? 0 : i - 1];
-    }
-}
-template <class T>
-MS_DEV T fb_column_sum(const FbColumnIn &in, int n2) {
-    T s = 0;
-#pragma unroll
-    for (int n1 = 0; n1 < 12; ++n1) s += static_cast<T>(in.c[n1].x) + static_cast<T>(in.c[n1].y);
-    if (n2 < 8) s += static_cast<T>(in.c[12].x) + static_cast<T>(in.c[12].y);
-    return s;
-}
-template <class T>
-MS_DEV void fb_column_rest(const FbColumnIn &in, int n2, T preemph, T mean, bool patch_first, const T *tblob, T *xo /* &row[0][n2] */) {
-    cpx<T> x[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        x[n1] = {T(0), T(0)};
-        if (n1 < 12 || (n1 == 12 && n2 < 8)) {
-            const int i = 32 * n1 + 2 * n2;
-            const T b0 = static_cast<T>(in.c[n1].x) - mean, b1 = static_cast<T>(in.c[n1].y) - mean;
-            const T pe = b0 - preemph * (static_cast<T>(in.prev[n1]) - mean);
-            const T y0 = (n1 == 0 && patch_first) ? b0 : pe;
-            const T y1 = b1 - preemph * b0;
-            const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
-            x[n1] = {y0 * w.re, y1 * w.im};
-        }
-    }
-    fb_column_finish<T>(x, n2, tblob, xo);
-}
-
+// (Loading the samples once for both the frame sum and the column -- one round trip, 26 conversions and 13 loads fewer per unit --
+// was measured: no difference, 0.733 ms either way, and 20 more VGPRs.  The second read hits L1 and two waves hide it.)
 // phase 1 (after the frame mean is known): lane t does column n2 = t (13 non-zero inputs for t < 8, else 12).
 template <class T>
 MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this frame's first sample */, bool clip_start,
@@ -271,6 +230,7 @@ MS_DEV void nemo_phase1(int fl, int t, bool active, bool all_inside, const float
 // followed by row_ror:1 (lane i <- i-1).  Frames occupy whole rows, so source and destination lanes always
 // share their EXEC state.
 #if defined(__HIP_DEVICE_COMPILE__)
+// (One ds_bpermute_b32 per dword instead of the two DPP moves was measured too: Whisper-512 0.58 ms against 0.55 ms.)
 MS_DEV int dpp_partner16(int x) {
     // bound_ctrl: every lane has a source lane in its row, so no "old" value (and no v_mov to set one up) is needed
     const int m = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, true);

@@ -54,7 +54,7 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kGenericNT = 256;
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
-constexpr int kNemoSync = 18;               // RoundSync mode of the NeMo feature-major store: pairs of waves four apart
+constexpr int kNemoSync = 2;                // RoundSync mode of the NeMo feature-major store: pairs of adjacent waves (profiles/r02_nemo.txt)
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
 constexpr uint64_t kPipeChunkSamples = 4u << 20;      // host pipeline: 16 MiB of PCM per chunk (host_pipe.hpp)
 
@@ -2260,7 +2260,7 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         np.fold_sel = fold_sel;
         static const int norm_skip = lab_int("MELSPEC_NORM_SKIP", 0, 0, 7);
         np.lab_skip = norm_skip;
-        static const int norm_stagger = lab_int("MELSPEC_NORM_STAGGER", 1, 0, 1);
+        static const int norm_stagger = lab_int("MELSPEC_NORM_STAGGER", 1, 0, 3);
         np.stagger = norm_stagger;
         const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
         // four workgroups of <= 38 KB per CU measured best (1024 x 10 s x 128 mels, ms per call incl. the 0.72 ms mel kernel: 150 KB x 1: 1.72,

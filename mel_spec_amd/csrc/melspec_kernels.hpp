@@ -937,10 +937,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         if (FLAVOR == kFlavorKaldi) {
             const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
             // frame mean (src/fbank.rs:165-166): 16 partial sums of 24-26 samples through LDS, fixed tree
-            FbColumnIn cin;
-            const bool patch = f0 + fl == 0 && j == 0;          // the first sample of a clip has nothing in front of it
-            fb_column_load(frame, j, patch, cin);
-            slice[L::kSumOff + lane] = act ? fb_column_sum<T>(cin, j) : T(0);
+            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
             __builtin_amdgcn_wave_barrier();
             T mean = 0;
             if (act) {
@@ -950,7 +947,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
                 mean = (a + b) / T(400);
             }
             __builtin_amdgcn_wave_barrier();
-            if (act) fb_column_rest<T>(cin, j, preemph, mean, patch, tblob, slice + fl * L::kXStride + 2 * j);
+            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
         } else if (FLAVOR == kFlavorWhisper) {
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
         } else {
@@ -1156,10 +1153,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             const bool act = fl < nv;
             MS_PRIO(0);
             const float *frame = pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            FbColumnIn cin;
-            const bool patch = f0 + fl == 0 && j == 0;          // the first sample of a clip has nothing in front of it
-            fb_column_load(frame, j, patch, cin);
-            slice[L::kSumOff + lane] = act ? fb_column_sum<T>(cin, j) : T(0);
+            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
             __builtin_amdgcn_wave_barrier();
             T mean = 0;
             if (act) {
@@ -1169,7 +1163,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
                 mean = (a + b) / T(400);
             }
             __builtin_amdgcn_wave_barrier();
-            if (act) fb_column_rest<T>(cin, j, preemph, mean, patch, tblob, slice + fl * L::kXStride + 2 * j);
+            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(1);
             {
@@ -1367,7 +1361,12 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
     const uint64_t row_end = row_begin + per_wg < rows ? row_begin + per_wg : rows;
     float *part = stat + 2 * R;              // [R][PP] partial sums of squares
     const int PP = kBlmNormThreads / R;      // threads per row in the variance pass
-    int first = p.stagger ? 1 + static_cast<int>((blockIdx.x * 5u + (blockIdx.x >> 8) * 3u) % static_cast<unsigned>(R)) : R;
+    int first = p.stagger == 1 ? 1 + static_cast<int>((blockIdx.x * 5u + (blockIdx.x >> 8) * 3u) % static_cast<unsigned>(R)) : R;
+    if (p.stagger >= 2) {
+        // start the workgroups that share a CU a quarter of a round (~6 us) apart
+        const unsigned d = p.stagger == 2 ? (blockIdx.x >> 8) & 3u : (blockIdx.x * 2654435761u) >> 30;
+        for (unsigned i = 0; i < 2 * d; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     for (uint64_t row0 = row_begin; row0 < row_end;) {
         const int want = first;
         first = R;
