@@ -2291,7 +2291,28 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         } else {
             const size_t lds = (per * stride + 2 * per + kBlmNormThreads) * sizeof(float);
             const unsigned g2 = grid_for((rows + per - 1) / per, b->dev.cus, per_cu);
+#ifdef MELSPEC_LAB
+            static const int norm_dbg = lab_int("MELSPEC_NORM_DBG", 0, 0, 1);
+            static uint64_t *d_dbg = nullptr;
+            static int dbg_calls = 0;
+            if (norm_dbg) {
+                if (!d_dbg) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_dbg), 64 * 8 * 8));
+                HIP_TRY(hipMemsetAsync(d_dbg, 0, 64 * 8 * 8, s));
+                np.dbg = d_dbg;
+            }
+#endif
             hipLaunchKernelGGL(blm_normalize_kernel, dim3(g2), dim3(kBlmNormThreads), lds, s, np);
+#ifdef MELSPEC_LAB
+            if (norm_dbg && ++dbg_calls == 20) {
+                uint64_t h[64 * 8];
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost));
+                double sum[8] = {0};
+                for (int b = 0; b < 64; ++b) for (int k = 0; k < 8; ++k) sum[k] += static_cast<double>(h[b * 8 + k]);
+                std::fprintf(stderr, "norm phases, us per workgroup (mean of 64): load %.1f  mean %.1f  var %.1f  var-sum %.1f  store %.1f\n",
+                             sum[1] / 64 / 100, sum[2] / 64 / 100, sum[3] / 64 / 100, sum[4] / 64 / 100, sum[5] / 64 / 100);
+            }
+#endif
         }
         HIP_TRY(hipGetLastError());
     }

@@ -1246,11 +1246,19 @@ struct BlmNormParams {
     int fold_sel;           // the wave that folds = (blockIdx.x >> fold_sel) & 3; < 0: wave 0
     int lab_skip;           // lab builds, timing ablations (wrong results): 1 no folds, 2 no stores, 4 no loads
     int stagger;            // 1: first round of a different length per workgroup (0 in lab builds: all workgroups in step)
+    uint64_t *dbg;          // lab builds: [64][8] phase times, see MS_NORM_STAMP
     // ragged batches (rows_per_group == 0 form only): per clip the first output float, the row width and the valid frames
     const uint64_t *d_out_off, *d_cols, *d_valid;
 };
 
 constexpr int kBlmNormThreads = 256;
+
+// lab builds: thread 0 of the first 64 workgroups adds up the time (100 MHz ticks) between the barriers of a round
+#ifdef MELSPEC_LAB
+#define MS_NORM_STAMP(k) do { if (p.dbg && tid == 0 && blockIdx.x < 64) { const uint64_t now = wall_clock64(); if ((k) > 0) p.dbg[blockIdx.x * 8 + (k)] += now - stamp; stamp = now; } } while (0)
+#else
+#define MS_NORM_STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ float *blm_row(const BlmNormParams &p, uint64_t row) {
     const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
@@ -1360,6 +1368,8 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
     const uint64_t row_begin = (uint64_t)blockIdx.x * per_wg;
     const uint64_t row_end = row_begin + per_wg < rows ? row_begin + per_wg : rows;
     float *part = stat + 2 * R;              // [R][PP] partial sums of squares
+    uint64_t stamp = 0;
+    (void)stamp;
     const int PP = kBlmNormThreads / R;      // threads per row in the variance pass
     int first = p.stagger == 1 ? 1 + static_cast<int>((blockIdx.x * 5u + (blockIdx.x >> 8) * 3u) % static_cast<unsigned>(R)) : R;
     if (p.stagger >= 2) {
@@ -1368,6 +1378,7 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
         for (unsigned i = 0; i < 2 * d; ++i) __builtin_amdgcn_s_sleep(127);
     }
     for (uint64_t row0 = row_begin; row0 < row_end;) {
+        MS_NORM_STAMP(0);
         const int want = first;
         first = R;
         const int nr = row_end - row0 < (uint64_t)want ? (int)(row_end - row0) : want;
@@ -1392,13 +1403,17 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
             }
         }
         __syncthreads();
+        MS_NORM_STAMP(1);
         // the means: a few lanes of ONE wave (fold_sel: which one; measured without effect)
         const int ft = tid - 64 * fold_wave;
         if (ft >= 0 && ft < nr) {
             const uint32_t a = (out_f + static_cast<uint32_t>(e00 + (uint64_t)ft * p.row_w)) & 3u;
+            MS_PRIO(3);                          // a chain of dependent adds: every issue slot it is ready for
             stat[2 * ft] = (p.lab_skip & 1) ? 0.0f : blm_row_mean_lds(tile + (size_t)ft * S, a, valid);
+            MS_PRIO(0);
         }
         __syncthreads();
+        MS_NORM_STAMP(2);
         // the unbiased variance: sum of (v - mean)^2 as a fixed tree over all threads, PP strided partial sums per row added in
         // order.  The reference folds this sum left to right as well; unlike the mean, the order is immaterial here -- either
         // sum is within ~1e-6 (relative) of the exact one, 5e-7 of the standard deviation, and the output moves by |out| * 5e-7.
@@ -1408,34 +1423,50 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
                 const uint32_t a = (out_f + static_cast<uint32_t>(e00 + (uint64_t)r * p.row_w)) & 3u;
                 const float *row = tile + (size_t)r * S + a;
                 const float mean = stat[2 * r];
-                float acc = 0.0f;
-                for (uint32_t k = pt; k < valid; k += PP) {
-                    const float c = row[k] - mean;
-                    acc += c * c;
+                // four sums in turn: the strided loop has a run-time step, and with one accumulator every LDS read waited for
+                // the add before it (2.1 us per round, measured with MS_NORM_STAMP; 36 values per thread at 1001 frames)
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                uint32_t k = pt;
+                for (; k + 3 * PP < valid; k += 4 * PP) {
+                    const float c0 = row[k] - mean, c1 = row[k + PP] - mean, c2 = row[k + 2 * PP] - mean, c3 = row[k + 3 * PP] - mean;
+                    a0 += c0 * c0; a1 += c1 * c1; a2 += c2 * c2; a3 += c3 * c3;
                 }
-                part[r * PP + pt] = acc;
+                for (; k < valid; k += PP) {
+                    const float c = row[k] - mean;
+                    a0 += c * c;
+                }
+                part[r * PP + pt] = (a0 + a1) + (a2 + a3);
             }
         }
         __syncthreads();
+        MS_NORM_STAMP(3);
         if (tid < nr) {
-            float q = 0.0f;
-            for (int i = 0; i < PP; ++i) q += part[tid * PP + i];
+            const float *pp = part + tid * PP;
+            float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+            int i = 0;
+            for (; i + 3 < PP; i += 4) { q0 += pp[i]; q1 += pp[i + 1]; q2 += pp[i + 2]; q3 += pp[i + 3]; }
+            for (; i < PP; ++i) q0 += pp[i];
+            const float q = (q0 + q1) + (q2 + q3);
             float denom = static_cast<float>(valid) - 1.0f;
             denom = denom < 1.0f ? 1.0f : denom;
-            stat[2 * tid + 1] = (p.lab_skip & 1) ? 1.0f : __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
+            // the row's values are multiplied by 1 / (std + 1e-5) below: within one ulp of the reference's division, 9 divisions
+            // per round instead of 36 per thread (the divisions were 4.7 us of a 16 us round)
+            const float sd = __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
+            stat[2 * tid + 1] = (p.lab_skip & 1) ? 1.0f : f32_div_rn(1.0f, sd);
         }
         __syncthreads();
+        MS_NORM_STAMP(4);
         const uint32_t row_w = static_cast<uint32_t>(p.row_w);
         for (int rr0 = 0; rr0 < ((p.lab_skip & 2) ? 0 : nr); rr0 += kRowsAtOnce) {
             for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
                 f4 v[kRowsAtOnce];
-                float mean[kRowsAtOnce], sd[kRowsAtOnce];
+                float mean[kRowsAtOnce], rsd[kRowsAtOnce];
                 uint32_t t = static_cast<uint32_t>(rr0) * S + 4 * q;
                 const float *st = stat + 2 * rr0;
 #pragma unroll
                 for (int i = 0; i < kRowsAtOnce; ++i) {           // every LDS read first (rows past the group: its last row again)
                     v[i] = *reinterpret_cast<const f4 *>(tile + t);
-                    mean[i] = st[0]; sd[i] = st[1];
+                    mean[i] = st[0]; rsd[i] = st[1];
                     if (rr0 + i + 1 < nr) { t += S; st += 2; }
                 }
                 uint64_t e0 = e00 + (uint64_t)rr0 * p.row_w;
@@ -1445,8 +1476,10 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
                     const int c0 = static_cast<int>(4 * q) - static_cast<int>(a);       // column of the granule's first float
                     float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)                   // columns past the valid frames keep their zeros
-                        o[e] = (c0 + e >= 0 && static_cast<uint32_t>(c0 + e) < valid) ? f32_div_rn(o[e] - mean[i], sd[i]) : 0.0f;
+                    for (int e = 0; e < 4; ++e) {                 // columns past the valid frames keep their zeros
+                        const float nv = (o[e] - mean[i]) * rsd[i];
+                        o[e] = (c0 + e >= 0 && static_cast<uint32_t>(c0 + e) < valid) ? nv : 0.0f;
+                    }
                     float *g = p.out + e0 + c0;
                     const bool mine = rr0 + i < nr && 4 * q < a + valid;                 // granules that hold valid frames of a row of the group
                     if (mine) {
@@ -1464,6 +1497,7 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
             }
         }
         __syncthreads();
+        MS_NORM_STAMP(5);
         row0 += nr;
     }
 }
