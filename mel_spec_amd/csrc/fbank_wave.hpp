@@ -320,10 +320,8 @@ using LensSlaney128 = LensFbStatic<1, 1, 1, 2, 2, 3, 4, 5, 7>;   // 128 mels, bo
 template <class T, int NSLOTS = kFbSlots, class Lens = LensRuntime>
 MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *mel /* mel section base */,
                            const T *slice, const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
-#pragma unroll
-    for (int i = 0; i < NSLOTS; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
-    if (!active) return;
-    const float *p = reinterpret_cast<const float *>(slice) + fl * FbankLayout<T>::kPStride;
+    // every lane computes (see six_phase3_sums): a lane without a frame reads frame 0's row
+    const float *p = reinterpret_cast<const float *>(slice) + (active ? fl : 0) * FbankLayout<T>::kPStride;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         float ar = 0.0f, af = 0.0f;
@@ -335,8 +333,8 @@ MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const
                 for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
                     const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kFbLanes * r);
                     const float pv = pp[r];
-                    ar += wv.x * pv;
-                    af += wv.y * pv;
+                    if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
+                    else { ar += wv.x * pv; af += wv.y * pv; }
                 }
             }
         } else if (i < ms.n_slots) {

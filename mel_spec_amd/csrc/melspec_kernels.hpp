@@ -140,8 +140,9 @@ struct FastParams {
 
 // One-lane-down shift across the whole wave (lane l receives lane l+1's value).
 __device__ __forceinline__ float wave_shift_down1(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */,
-                                                                 0xf, 0xf, false));
+    // bound_ctrl on (lane 63, which has no source lane, reads 0): no `old` operand, so no v_mov in front of every shift
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 
 __device__ __forceinline__ uint64_t scalar64(uint64_t v) {

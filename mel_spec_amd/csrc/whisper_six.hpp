@@ -166,10 +166,9 @@ MS_DEV void six_phase2(int fl, int j, bool active, const float *blob, float *sli
 template <int NSLOTS, class Lens>
 MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const float *blob, const float *slice,
                             const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
-#pragma unroll
-    for (int i = 0; i < NSLOTS; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
-    if (!active) return;
-    const float *p = slice + fl * SixLayout::kPStride;
+    // Every lane computes (a lane without a frame reads frame 0's row: in bounds, and nobody uses its sums): zeroing the 2 x NSLOTS
+    // results for the sake of the idle lanes, and starting every sum from a zero register, were 27 v_mov per unit (ISA histogram).
+    const float *p = slice + (active ? fl : 0) * SixLayout::kPStride;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         float ar = 0.0f, af = 0.0f;
@@ -181,8 +180,8 @@ MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, cons
                 for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
                     const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kSixLanes * r);
                     const float pv = pp[r];
-                    ar += wv.x * pv;
-                    af += wv.y * pv;
+                    if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
+                    else { ar += wv.x * pv; af += wv.y * pv; }
                 }
             }
         } else if (i < ms.n_slots) {

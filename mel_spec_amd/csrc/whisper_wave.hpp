@@ -189,10 +189,8 @@ MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *sl
 template <int NSLOTS, class Lens>
 MS_DEV void wave_phase3i_sums(int fl, int j12, bool active, const MelSlots &ms, const float *blob, const float *slice,
                               const int (&st)[NSLOTS], float (&rise)[NSLOTS], float (&fprev)[NSLOTS]) {
-#pragma unroll
-    for (int i = 0; i < NSLOTS; ++i) { rise[i] = 0.0f; fprev[i] = 0.0f; }
-    if (!active) return;
-    const float *p = slice + fl * WaveLayout::kPStride;
+    // every lane computes (see six_phase3_sums): a lane without a frame reads frame 0's row
+    const float *p = slice + (active ? fl : 0) * WaveLayout::kPStride;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         float ar = 0.0f, af = 0.0f;
@@ -204,8 +202,8 @@ MS_DEV void wave_phase3i_sums(int fl, int j12, bool active, const MelSlots &ms, 
                 for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
                     const f2 wv = *reinterpret_cast<const f2 *>(w + 24 * r);
                     const float pv = pp[r];
-                    ar += wv.x * pv;
-                    af += wv.y * pv;
+                    if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
+                    else { ar += wv.x * pv; af += wv.y * pv; }
                 }
             }
         } else if (i < ms.n_slots) {
