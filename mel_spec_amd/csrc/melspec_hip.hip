@@ -2260,8 +2260,6 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
         np.fold_sel = fold_sel;
         static const int norm_skip = lab_int("MELSPEC_NORM_SKIP", 0, 0, 7);
         np.lab_skip = norm_skip;
-        static const int norm_stagger = lab_int("MELSPEC_NORM_STAGGER", 1, 0, 3);
-        np.stagger = norm_stagger;
         const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
         // four workgroups of <= 38 KB per CU measured best (1024 x 10 s x 128 mels, ms per call incl. the 0.72 ms mel kernel: 150 KB x 1: 1.72,
         // 76 x 2: 1.45, 50 x 3: 1.34, 38 x 4: 1.28, 25 x 6: 1.68); MELSPEC_NORM_KB / MELSPEC_NORM_PER_CU override
@@ -2328,7 +2326,7 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
     if (n_clips == 0) return MELSPEC_OK;
     if (!h_offsets || !h_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
     if (!b->fast) return fail(MELSPEC_ERR_UNSUPPORTED, "ragged batches need the fused kernel (n_fft = 512, win_length = 400)");
-    std::vector<uint64_t> cols(n_clips), aux(2 * static_cast<size_t>(n_clips));
+    std::vector<uint64_t> cols(n_clips), aux(2 * static_cast<size_t>(n_clips) + 1);        // lengths, valid frames, the normaliser's group counter (0)
     uint64_t total = 0, longest = 0;
     for (uint32_t i = 0; i < n_clips; ++i) {
         const uint64_t valid = blm_valid_frames(b, h_lengths[i]);
@@ -2371,13 +2369,41 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
         else rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
                                                   : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
         if (!rc && b->cfg.normalize_per_feature && longest > 0) {
-            BlmNormParams np{};
-            np.fold_sel = -1;
-            np.out = d_out; np.n_clips = n_clips; np.n_mels = nm; np.rows_per_group = 0;
-            np.d_out_off = pl.desc.d_out_off; np.d_cols = pl.desc.d_frames; np.d_valid = fp.d_valid;
             const uint64_t rows = static_cast<uint64_t>(n_clips) * nm;
-            hipLaunchKernelGGL(blm_normalize_kernel, dim3(grid_for((rows + kBlmNormThreads - 1) / kBlmNormThreads, b->dev.cus, 4)), dim3(kBlmNormThreads), 0, s, np);
-            if (hipGetLastError() != hipSuccess) rc = fail(MELSPEC_ERR_INTERNAL, "blm_normalize_kernel launch failed");
+            // rows staged whole in LDS like the uniform pass (sized for the longest clip), groups of rows from a counter
+            size_t stride = (static_cast<size_t>(longest) + 3 + 31) & ~static_cast<size_t>(31);
+            if ((stride / 4) % 2 == 0) stride += 4;
+            const size_t fixed = (2 * 64 + kBlmNormThreads + 4 * 64 + 4) * sizeof(float);
+            size_t per = (static_cast<size_t>(38) * 1024 - fixed) / (stride * sizeof(float));
+            int per_cu = 4;
+            if (per < 4) { per = (static_cast<size_t>(150) * 1024 - fixed) / (stride * sizeof(float)); per_cu = 1; }
+            if (per > 64) per = 64;
+            if (per >= 1 && longest < (1ull << 31)) {
+                static std::atomic<uint64_t> attr_done{0};
+                if (!device_done(attr_done)) {
+                    rc = allow_big_lds(&blm_normalize_ragged_kernel, "hipFuncSetAttribute(blm_normalize_ragged_kernel)");
+                    if (!rc) mark_device_done(attr_done);
+                }
+                if (!rc) {
+                    BlmNormRaggedParams rp{};
+                    rp.out = d_out; rp.d_out_off = pl.desc.d_out_off; rp.d_cols = pl.desc.d_frames; rp.d_valid = fp.d_valid;
+                    rp.n_clips = n_clips; rp.n_mels = nm; rp.rows_per_group = static_cast<int>(per); rp.lds_stride = static_cast<int>(stride);
+                    rp.longest = static_cast<uint32_t>(longest);
+                    rp.ctr = reinterpret_cast<unsigned *>(static_cast<uint64_t *>(b->aux.p) + 2 * static_cast<size_t>(n_clips));
+                    const size_t lds = (per * stride + 2 * per + kBlmNormThreads + 4 * per + 4) * sizeof(float);
+                    const unsigned g2 = grid_for((rows + per - 1) / per, b->dev.cus, per_cu);
+                    hipLaunchKernelGGL(blm_normalize_ragged_kernel, dim3(g2), dim3(kBlmNormThreads), lds, s, rp);
+                    if (hipGetLastError() != hipSuccess) rc = fail(MELSPEC_ERR_INTERNAL, "blm_normalize_ragged_kernel launch failed");
+                }
+            } else {
+                // rows too long for LDS: one thread per row from HBM
+                BlmNormParams np{};
+                np.fold_sel = -1;
+                np.out = d_out; np.n_clips = n_clips; np.n_mels = nm; np.rows_per_group = 0;
+                np.d_out_off = pl.desc.d_out_off; np.d_cols = pl.desc.d_frames; np.d_valid = fp.d_valid;
+                hipLaunchKernelGGL(blm_normalize_kernel, dim3(grid_for((rows + kBlmNormThreads - 1) / kBlmNormThreads, b->dev.cus, 4)), dim3(kBlmNormThreads), 0, s, np);
+                if (hipGetLastError() != hipSuccess) rc = fail(MELSPEC_ERR_INTERNAL, "blm_normalize_kernel launch failed");
+            }
         }
     }
     plan_ragged_done(slot, s);

@@ -1246,7 +1246,6 @@ struct BlmNormParams {
     int lds_stride;         // floats between staged rows: 4 * odd (16-byte aligned rows whose per-lane walks spread over the banks)
     int fold_sel;           // the wave that folds = (blockIdx.x >> fold_sel) & 3; < 0: wave 0
     int lab_skip;           // lab builds, timing ablations (wrong results): 1 no folds, 2 no stores, 4 no loads
-    int stagger;            // 1: first round of a different length per workgroup (0 in lab builds: all workgroups in step)
     uint64_t *dbg;          // lab builds: [64][8] phase times, see MS_NORM_STAMP
     // ragged batches (rows_per_group == 0 form only): per clip the first output float, the row width and the valid frames
     const uint64_t *d_out_off, *d_cols, *d_valid;
@@ -1362,9 +1361,8 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
     const uint32_t valid = static_cast<uint32_t>(p.valid);
     const uint32_t out_f = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p.out) >> 2) & 3u;
     const uint32_t nq_max = (valid + 6) / 4;            // granules of a row at the worst alignment
-    // A workgroup owns a contiguous range of rows and walks it in rounds of R.  All workgroups marching through "load, fold,
-    // store" in step would leave HBM idle during the folds (measured: the three phases added up, 0.10 + 0.19 + 0.13 ms), so the
-    // first round is short by a different amount in every workgroup and the rounds of the workgroups sharing a CU overlap.
+    // A workgroup owns a contiguous range of rows and walks it in rounds of R.  (Starting the workgroups out of step -- a short
+    // first round, a sleep per workgroup -- was measured: no effect; once its phases are cheap the pass is bandwidth-bound.)
     const uint64_t per_wg = (rows + gridDim.x - 1) / gridDim.x;
     const uint64_t row_begin = (uint64_t)blockIdx.x * per_wg;
     const uint64_t row_end = row_begin + per_wg < rows ? row_begin + per_wg : rows;
@@ -1372,17 +1370,9 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
     uint64_t stamp = 0;
     (void)stamp;
     const int PP = kBlmNormThreads / R;      // threads per row in the variance pass
-    int first = p.stagger == 1 ? 1 + static_cast<int>((blockIdx.x * 5u + (blockIdx.x >> 8) * 3u) % static_cast<unsigned>(R)) : R;
-    if (p.stagger >= 2) {
-        // start the workgroups that share a CU a quarter of a round (~6 us) apart
-        const unsigned d = p.stagger == 2 ? (blockIdx.x >> 8) & 3u : (blockIdx.x * 2654435761u) >> 30;
-        for (unsigned i = 0; i < 2 * d; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     for (uint64_t row0 = row_begin; row0 < row_end;) {
         MS_NORM_STAMP(0);
-        const int want = first;
-        first = R;
-        const int nr = row_end - row0 < (uint64_t)want ? (int)(row_end - row0) : want;
+        const int nr = row_end - row0 < (uint64_t)R ? (int)(row_end - row0) : R;
         const uint64_t e00 = row0 * p.row_w;
         for (int rr0 = 0; rr0 < ((p.lab_skip & 4) ? 0 : nr); rr0 += kRowsAtOnce) {
             for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
@@ -1500,6 +1490,149 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
         __syncthreads();
         MS_NORM_STAMP(5);
         row0 += nr;
+    }
+}
+
+// The same pass for ragged batches (clips of different lengths in one launch): rows are described per clip (first output float, row
+// width, valid frames), a group of R rows is taken from a device counter (rows of long and short clips cost differently, so a static
+// split would leave workgroups idle), its rows' descriptions are put in LDS once per round, and every row is staged at ITS alignment.
+// Rows without valid frames are left alone.  LDS rows are sized for the longest clip of the batch.
+struct BlmNormRaggedParams {
+    float *out;
+    const uint64_t *d_out_off, *d_cols, *d_valid;   // per clip
+    uint32_t n_clips;
+    int n_mels;
+    int rows_per_group, lds_stride;
+    uint32_t longest;       // valid frames of the longest clip
+    unsigned *ctr;          // zero at launch
+};
+
+__global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(const BlmNormRaggedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
+    const int tid = threadIdx.x;
+    const int R = p.rows_per_group, S = p.lds_stride;
+    float *stat = tile + (size_t)R * S;      // [R][2]
+    float *part = stat + 2 * R;              // [R][PP]
+    uint32_t *info = reinterpret_cast<uint32_t *>(part + kBlmNormThreads);     // [R][4]: first float (lo, hi), valid frames, row width
+    uint32_t *next = info + 4 * R;
+    const int PP = kBlmNormThreads / R;
+    constexpr int kRowsAtOnce = 9;
+    const uint32_t out_f = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p.out) >> 2) & 3u;
+    const uint32_t nq_max = (p.longest + 6) / 4;
+    const f4 *out_base = reinterpret_cast<const f4 *>(p.out - out_f);        // the 16-byte granule `out` starts in
+    for (;;) {
+        if (tid == 0) next[0] = atomicAdd(p.ctr, 1u);
+        __syncthreads();
+        const uint64_t row0 = (uint64_t)next[0] * R;
+        if (row0 >= rows) break;
+        const int nr = rows - row0 < (uint64_t)R ? (int)(rows - row0) : R;
+        if (tid < nr) {
+            const uint64_t row = row0 + tid, clip = row / p.n_mels, m = row - clip * p.n_mels;
+            const uint64_t cols = p.d_cols[clip], e0 = p.d_out_off[clip] + m * cols;
+            info[4 * tid] = static_cast<uint32_t>(e0);
+            info[4 * tid + 1] = static_cast<uint32_t>(e0 >> 32);
+            info[4 * tid + 2] = static_cast<uint32_t>(p.d_valid[clip]);
+            info[4 * tid + 3] = static_cast<uint32_t>(cols);
+        }
+        __syncthreads();
+        for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
+            for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
+                f4 v[kRowsAtOnce];
+                uint32_t to[kRowsAtOnce];
+                uint64_t from[kRowsAtOnce];          // float index of the granule (from the 16-byte aligned base of `out`)
+#pragma unroll
+                for (int i = 0; i < kRowsAtOnce; ++i) {
+                    const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
+                    const uint64_t e0 = ((uint64_t)info[4 * rr + 1] << 32) | info[4 * rr];
+                    const uint32_t valid = info[4 * rr + 2];
+                    const uint32_t a = (out_f + static_cast<uint32_t>(e0)) & 3u;
+                    const uint32_t nq = (a + valid + 3) >> 2;
+                    const uint32_t qq = q < nq ? q : (nq ? nq - 1 : 0);
+                    from[i] = valid ? out_f + e0 - a + 4 * qq : 0;       // a row without frames may own no memory at all: the first granule instead
+                    to[i] = static_cast<uint32_t>(rr) * S + 4 * qq;
+                }
+#pragma unroll
+                for (int i = 0; i < kRowsAtOnce; ++i) v[i] = out_base[from[i] >> 2];
+#pragma unroll
+                for (int i = 0; i < kRowsAtOnce; ++i) *reinterpret_cast<f4 *>(tile + to[i]) = v[i];
+            }
+        }
+        __syncthreads();
+        if (tid < nr) {
+            const uint32_t valid = info[4 * tid + 2];
+            const uint32_t a = (out_f + info[4 * tid]) & 3u;
+            MS_PRIO(3);
+            stat[2 * tid] = valid ? blm_row_mean_lds(tile + (size_t)tid * S, a, valid) : 0.0f;
+            MS_PRIO(0);
+        }
+        __syncthreads();
+        {
+            const int r = tid / PP, pt = tid - r * PP;
+            if (r < nr) {
+                const uint32_t valid = info[4 * r + 2];
+                const uint32_t a = (out_f + info[4 * r]) & 3u;
+                const float *row = tile + (size_t)r * S + a;
+                const float mean = stat[2 * r];
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                uint32_t k = pt;
+                for (; k + 3 * PP < valid; k += 4 * PP) {
+                    const float c0 = row[k] - mean, c1 = row[k + PP] - mean, c2 = row[k + 2 * PP] - mean, c3 = row[k + 3 * PP] - mean;
+                    a0 += c0 * c0; a1 += c1 * c1; a2 += c2 * c2; a3 += c3 * c3;
+                }
+                for (; k < valid; k += PP) {
+                    const float c = row[k] - mean;
+                    a0 += c * c;
+                }
+                part[r * PP + pt] = (a0 + a1) + (a2 + a3);
+            }
+        }
+        __syncthreads();
+        if (tid < nr) {
+            const float *pp = part + tid * PP;
+            float q0 = 0.0f, q1 = 0.0f, q2 = 0.0f, q3 = 0.0f;
+            int i = 0;
+            for (; i + 3 < PP; i += 4) { q0 += pp[i]; q1 += pp[i + 1]; q2 += pp[i + 2]; q3 += pp[i + 3]; }
+            for (; i < PP; ++i) q0 += pp[i];
+            float denom = static_cast<float>(info[4 * tid + 2]) - 1.0f;
+            denom = denom < 1.0f ? 1.0f : denom;
+            const float sd = __builtin_sqrtf(f32_div_rn((q0 + q1) + (q2 + q3), denom)) + 1e-5f;
+            stat[2 * tid + 1] = f32_div_rn(1.0f, sd);
+        }
+        __syncthreads();
+        for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
+            for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
+#pragma unroll
+                for (int i = 0; i < kRowsAtOnce; ++i) {
+                    const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
+                    const uint64_t e0 = ((uint64_t)info[4 * rr + 1] << 32) | info[4 * rr];
+                    const uint32_t valid = info[4 * rr + 2], row_w = info[4 * rr + 3];
+                    const uint32_t a = (out_f + static_cast<uint32_t>(e0)) & 3u;
+                    const bool mine = rr0 + i < nr && valid != 0 && 4 * q < a + valid;
+                    const f4 v = *reinterpret_cast<const f4 *>(tile + static_cast<uint32_t>(rr) * S + 4 * q);
+                    const float mean = stat[2 * rr], rsd = stat[2 * rr + 1];
+                    const int c0 = static_cast<int>(4 * q) - static_cast<int>(a);
+                    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float nv = (o[e] - mean) * rsd;
+                        o[e] = (c0 + e >= 0 && static_cast<uint32_t>(c0 + e) < valid) ? nv : 0.0f;
+                    }
+                    float *g = p.out + e0 + c0;
+                    if (mine) {
+                        if (c0 >= 0 && static_cast<uint32_t>(c0 + 3) < row_w) {
+                            f4 w = {o[0], o[1], o[2], o[3]};
+                            *reinterpret_cast<f4 *>(g) = w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c0 + e >= 0 && static_cast<uint32_t>(c0 + e) < row_w) g[e] = o[e];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
