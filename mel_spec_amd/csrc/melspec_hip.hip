@@ -235,9 +235,11 @@ __global__ void plan_upload_kernel(const uint4 *src, uint4 *dst, size_t n16) {
 }
 
 // Fills the next slot and queues its upload on `stream`.  The caller launches on `stream` and then calls plan_ragged_done.
+// want_order: also upload the clips sorted longest first and a zeroed ticket counter (BatchDesc::d_order / d_ticket) for the kernels that
+// hand out whole clips.
 int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float *d_out, const uint64_t *h_off,
                 const std::vector<uint64_t> &frames, const uint64_t *h_out_off, uint32_t n_clips, int n_mels,
-                int frames_per_unit, BatchPlan &pl, RaggedSlot *&used) {
+                int frames_per_unit, BatchPlan &pl, RaggedSlot *&used, bool want_order = false) {
     RaggedSlot &sl = rs.slot[rs.next++ % RaggedScratch::kSlots];
     used = &sl;
     if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -246,7 +248,8 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
     for (uint32_t c = 0; c < n_clips; ++c) units += (frames[c] + frames_per_unit - 1) / frames_per_unit;
     const uint64_t n_blocks = (units + kUnitBlock - 1) / kUnitBlock;
     const size_t words64 = static_cast<size_t>(n_clips) * 4 + 1;
-    const size_t bytes = words64 * sizeof(uint64_t) + static_cast<size_t>(n_blocks ? n_blocks : 1) * sizeof(uint32_t);
+    const size_t blk_words = static_cast<size_t>(n_blocks ? n_blocks : 1);
+    const size_t bytes = words64 * sizeof(uint64_t) + (blk_words + (want_order ? static_cast<size_t>(n_clips) + 1 : 0)) * sizeof(uint32_t);
     int rc = sl.ensure_host((bytes + 15) & ~static_cast<size_t>(15));
     if (rc) return rc;
     if ((rc = sl.dev.ensure((bytes + 15) & ~static_cast<size_t>(15)))) return rc;
@@ -271,6 +274,12 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
             blk[k] = c;
         }
     }
+    if (want_order) {
+        uint32_t *ord = blk + blk_words;
+        for (uint32_t c = 0; c < n_clips; ++c) ord[c] = c;
+        std::stable_sort(ord, ord + n_clips, [&](uint32_t a, uint32_t b2) { return frames[a] > frames[b2]; });
+        ord[n_clips] = 0;       // the ticket counter
+    }
     // the upload is a kernel on the launch stream that reads the pinned slot over the bus: an SDMA copy sits in another
     // hardware queue and the hand-over between the queues costs more than the copy
     {
@@ -286,6 +295,10 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
     b.pcm = d_pcm; b.out = d_out; b.n_clips = n_clips; b.n_units = units; b.frames_per_unit = frames_per_unit;
     b.d_off = d; b.d_frames = d + n_clips; b.d_out_off = d + 2 * n_clips; b.d_unit_prefix = d + 3 * n_clips;
     b.d_unit_block = reinterpret_cast<const uint32_t *>(d + words64);
+    if (want_order) {
+        b.d_order = b.d_unit_block + blk_words;
+        b.d_ticket = const_cast<uint32_t *>(b.d_order) + n_clips;
+    }
     pl.total_frames = total;
     return MELSPEC_OK;
 }
@@ -1431,13 +1444,17 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         static const bool clip_on = lab_int("MELSPEC_FB_CLIP", 1, 0, 1) != 0;
         const uint32_t cus = static_cast<uint32_t>(fb->dev.cus);
         const uint32_t passes = (n_clips + cus - 1) / cus;
-        if (clip_on && fb->cfg.apply_cmn && fb->waves == 8 && pl.desc.d_unit_prefix == nullptr && nm % 4 == 0 && nm <= 89 &&
-            (reinterpret_cast<uintptr_t>(pl.desc.out) & 15) == 0 && pl.desc.out_stride % 4 == 0 &&
-            n_clips >= cus && static_cast<uint64_t>(n_clips) * 100 >= static_cast<uint64_t>(passes) * cus * 85) {
+        const bool ragged_by_clip = pl.desc.d_order != nullptr;       // melspec_fbank_compute_ragged_device decided (and checked the alignment)
+        if (clip_on && (ragged_by_clip ||
+            (fb->cfg.apply_cmn && fb->waves == 8 && pl.desc.d_unit_prefix == nullptr && nm % 4 == 0 && nm <= 89 &&
+             (reinterpret_cast<uintptr_t>(pl.desc.out) & 15) == 0 && pl.desc.out_stride % 4 == 0 &&
+             n_clips >= cus && static_cast<uint64_t>(n_clips) * 100 >= static_cast<uint64_t>(passes) * cus * 85))) {
             static std::atomic<uint64_t> attr_done{0};
             if (!device_done(attr_done)) {
                 rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi80>, "hipFuncSetAttribute(fbank512_clip_kernel)");
                 if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensRuntime>, "hipFuncSetAttribute(fbank512_clip_kernel)");
+                if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi80, true>, "hipFuncSetAttribute(fbank512_clip_kernel)");
+                if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensRuntime, true>, "hipFuncSetAttribute(fbank512_clip_kernel)");
                 if (rc) return rc;
                 mark_device_done(attr_done);
             }
@@ -1448,7 +1465,11 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
             q.lab_skip = clip_skip;
             const size_t lds = fb->fast_lds + sizeof(ClipCmnShared<8>);
             if (lds <= kLdsLimit) {
-                if (fb_lens_match<LensKaldi80>(fb->ft.slots)) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(cus), dim3(512), lds, s, q);
+                const bool k80 = fb_lens_match<LensKaldi80>(fb->ft.slots);
+                if (ragged_by_clip) {
+                    if (k80) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80, true>), dim3(cus), dim3(512), lds, s, q);
+                    else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime, true>), dim3(cus), dim3(512), lds, s, q);
+                } else if (k80) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(cus), dim3(512), lds, s, q);
                 else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime>), dim3(cus), dim3(512), lds, s, q);
                 HIP_TRY(hipGetLastError());
                 return MELSPEC_OK;
@@ -1506,7 +1527,14 @@ int melspec_fbank_compute_ragged_device(melspec_fbank *fb, const float *d_pcm, c
     const bool fused = fb->fast && !fb->use_generic;
     BatchPlan pl;
     RaggedSlot *slot = nullptr;
-    int rc = plan_ragged(fb->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, fb->cfg.num_mel_bins, fused ? kFbFPW : 1, pl, slot);
+    // whole clips per workgroup (fbank512_clip_kernel) when the batch can keep every CU busy: at least two clips per CU and no clip
+    // longer than half a CU's share; outputs at 16-byte offsets (packed outputs of n_mels % 4 == 0 are)
+    const int nm = fb->cfg.num_mel_bins;
+    bool by_clip = fused && fb->cfg.apply_cmn && fb->waves == 8 && nm % 4 == 0 && nm <= 89 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
+                   n_clips >= 2u * static_cast<uint32_t>(fb->dev.cus) && longest * 2 * static_cast<uint64_t>(fb->dev.cus) <= total && longest < (1ull << 31);
+    if (by_clip && h_out_offsets)
+        for (uint32_t i = 0; i < n_clips && by_clip; ++i) by_clip = h_out_offsets[i] % 4 == 0;
+    int rc = plan_ragged(fb->ragged, s, d_pcm, d_out, h_offsets, frames, h_out_offsets, n_clips, nm, fused ? kFbFPW : 1, pl, slot, by_clip);
     if (!rc) rc = fbank_launch(fb, pl, n_clips, longest, s);
     plan_ragged_done(slot, s);
     return rc;

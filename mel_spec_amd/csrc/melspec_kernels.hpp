@@ -52,6 +52,8 @@ struct BatchDesc {
     const uint32_t *d_unit_block;   // ragged: clip that holds unit k * kUnitBlock
     const uint64_t *d_n_units;      // ragged batches planned on the device (plan_ragged_device_kernel): the unit count lives here and
                                     // n_units above is the host's upper bound (grid and scratch sizes)
+    const uint32_t *d_order;        // ragged, host-planned, optional: the clips longest first (whole-clip kernels take them in this order)
+    uint32_t *d_ticket;             //   and the counter they take them from (zero when the launch starts)
 };
 
 __device__ __forceinline__ uint64_t batch_n_units(const BatchDesc &b) { return b.d_n_units ? *b.d_n_units : b.n_units; }
@@ -1029,7 +1031,32 @@ struct ClipCmnShared {
     float part[2][WAVES][96];
     float mean[2][96];
     unsigned arrived[2], ready[2];
+    unsigned published, claimed, ids[8];     // ragged batches: the workgroup's clips, in the order it took them from the ticket counter
 };
+
+// The workgroup's n-th clip of a ragged batch (0xffffffff: the batch is used up).  Whichever wave asks first takes a ticket from the
+// device counter and publishes the clip in LDS; the others read it there.  No wave is ever more than two clips ahead of another (the
+// subtraction of clip c waits for every wave's run of clip c), so a ring of eight cannot wrap.
+template <int WAVES>
+MS_DEV uint32_t clip_queue_get(ClipCmnShared<WAVES> *sh, unsigned n, int lane, const BatchDesc &b) {
+    unsigned id = 0xffffffffu;
+    if (lane == 0) {
+        // bounded: a slot that is never published would be a bug; the parity tests catch a wrong result, nothing recovers a hung GPU
+        for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+            if (__hip_atomic_load(&sh->published, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) > n) { id = sh->ids[n & 7u]; break; }
+            unsigned expect = n;
+            if (__hip_atomic_compare_exchange_strong(&sh->claimed, &expect, n + 1, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                const unsigned t = atomicAdd(b.d_ticket, 1u);
+                id = t < b.n_clips ? b.d_order[t] : 0xffffffffu;
+                sh->ids[n & 7u] = id;
+                __hip_atomic_store(&sh->published, n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(id)));
+}
 
 // The subtraction of a finished clip, one wave's share: groups of R = 64 / (n_mels / 4) rows (one 16-byte piece per lane), group
 // g belongs to wave g % WAVES, the wave's groups are numbered by `slot` (g = wave + WAVES * slot).
@@ -1106,7 +1133,7 @@ struct ClipCmnSub {
     }
 };
 
-template <int NSLOTS, class Lens>
+template <int NSLOTS, class Lens, bool RAGGED = false>
 __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankClipParams q) {
     using T = double;
     using L = FbankLayout<T>;
@@ -1117,6 +1144,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
     for (int i = tid; i < p.blob_words; i += NT) ldsw[i] = p.d_blob[i];
     auto *sh = reinterpret_cast<ClipCmnShared<WAVES> *>(ldsw + p.blob_words + WAVES * L::slice_elems() * 2);
     if (tid < 2) { sh->arrived[tid] = 0; sh->ready[tid] = 0; }
+    if (tid == 2) { sh->published = 0; sh->claimed = 0; }
     __syncthreads();
     const T *tblob = reinterpret_cast<const T *>(ldsw);
     const float *mel = reinterpret_cast<const float *>(ldsw + p.mel_off_words);
@@ -1133,17 +1161,33 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
     const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
     const T preemph = static_cast<T>(p.preemph);
     const int nm = p.n_mels;
-    const uint64_t frames = q.frames;
-    const uint32_t units = static_cast<uint32_t>((frames + kFbFPW - 1) / kFbFPW);
-    const uint32_t u0 = static_cast<uint32_t>((uint64_t)units * wave / WAVES), u1 = static_cast<uint32_t>((uint64_t)units * (wave + 1) / WAVES);
     unsigned gen = 0;                      // clips this workgroup has finished
     ClipCmnSub<WAVES> sub;                 // the previous clip's subtraction
     sub.lab = q.lab_skip & 6;
-    for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x, ++gen) {
+    // uniform batches: clips blockIdx.x, + gridDim.x, ... of one length; ragged: the next clip of the batch's longest-first order
+    for (unsigned seq = 0;; ++seq) {
+        uint32_t clip;
+        uint64_t frames;
+        const float *pcm;
+        float *out;
+        if (RAGGED) {
+            clip = clip_queue_get<WAVES>(sh, seq, lane, p.b);
+            if (clip == 0xffffffffu) break;
+            frames = scalar64(p.b.d_frames[clip]);
+            if (frames == 0) continue;         // zeros((0, num_mel_bins)), src/fbank.rs:147-149: nothing to write
+            pcm = p.b.pcm + scalar64(p.b.d_off[clip]);
+            out = p.b.out + scalar64(p.b.d_out_off[clip]);
+        } else {
+            clip = blockIdx.x + seq * gridDim.x;
+            if (clip >= p.b.n_clips) break;
+            frames = q.frames;
+            pcm = p.b.pcm + (uint64_t)clip * p.b.clip_stride;
+            out = p.b.out + (uint64_t)clip * p.b.out_stride;
+        }
+        const uint32_t units = static_cast<uint32_t>((frames + kFbFPW - 1) / kFbFPW);
+        const uint32_t u0 = static_cast<uint32_t>((uint64_t)units * wave / WAVES), u1 = static_cast<uint32_t>((uint64_t)units * (wave + 1) / WAVES);
         const int par = gen & 1;
         const unsigned prev_turn = (gen + 1) / 2;      // == (gen - 1) / 2 + 1 for gen > 0
-        const float *pcm = p.b.pcm + (uint64_t)clip * p.b.clip_stride;
-        float *out = p.b.out + (uint64_t)clip * p.b.out_stride;
         float acc[NSLOTS];
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) acc[i] = 0.0f;
@@ -1221,6 +1265,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             if (lane == 0) __hip_atomic_store(&sh->ready[par], turn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         sub.begin(out, frames, nm, wave, lane);        // this clip is the next one to subtract
+        ++gen;
     }
     if (gen > 0 && !(q.lab_skip & 1)) {
         sub.wait(sh, (gen - 1) & 1, (gen - 1) / 2 + 1, lane);

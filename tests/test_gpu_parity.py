@@ -888,6 +888,32 @@ def test_fbank_ragged_batches(gpu, oracle, jfk, kw):
     fb.close()
 
 
+def test_fbank_ragged_batch_by_clip(gpu, oracle, jfk):
+    """A ragged batch big and even enough to keep every CU busy takes the workgroup-per-clip kernel (clips handed out longest first
+    from a ticket counter, CMN inside); the same clips in small batches take the fused kernel + cmn_kernel.  Both within the tolerance
+    of the oracle, the two within the rounding of the mean, clips without a frame untouched, same bits on every run."""
+    fb = gpu.Fbank()
+    rng = np.random.default_rng(11)
+    n = 640
+    lens = [int(v) for v in rng.integers(2000, 24000, n)]
+    lens[5] = 0; lens[17] = 399; lens[101] = 400; lens[n - 1] = 23999
+    src = np.concatenate([jfk, jfk])
+    clips = [(src[(i * 977) % 150000:][:m] if i % 3 else oracle.synth_pcm(i, m)).astype(np.float32) for i, m in enumerate(lens)]
+    big = fb.compute_ragged(clips)
+    assert [g.shape[0] for g in big] == [fb.num_frames(m) for m in lens]
+    pick = [0, 5, 17, 101, 200, 333, n - 1]
+    small = fb.compute_ragged([clips[i] for i in pick])
+    for g2, i in zip(small, pick):
+        assert big[i].shape == g2.shape
+        if g2.size:
+            assert np.abs(big[i] - g2).max() <= 5e-5
+            assert np.abs(big[i] - oracle.fbank_compute(clips[i])).max() <= TOL
+            assert np.abs(big[i].mean(axis=0)).max() < 1e-4
+    again = fb.compute_ragged(clips)
+    assert all(np.array_equal(a, b) for a, b in zip(big, again))
+    fb.close()
+
+
 @pytest.mark.parametrize("kw", [dict(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), dict(center=False, n_mels=64, pad_to=16),
                                 dict(preemphasis=0.5, normalize_per_feature=True)])
 def test_nemo_frontend_ragged_batches(gpu, oracle, jfk, kw):
