@@ -252,6 +252,11 @@ int melspec_fbank_compute_ragged_device(melspec_fbank *fb, const float *d_pcm, c
 int melspec_fbank_compute_ragged_device_desc(melspec_fbank *fb, const float *d_pcm, const uint64_t *d_offsets, const uint64_t *d_lengths,
                                              uint32_t n_clips, float *d_out, const uint64_t *d_out_offsets, uint64_t max_total_frames,
                                              void *stream);
+/* Many host clips in one call (the reference calls Fbank::compute once per clip, src/fbank.rs:141): clip i = samples[offsets[i] ..
+ * + lengths[i]) -> its [frames_i][num_mel_bins] rows at out + out_offsets[i] floats (NULL: packed in clip order).  Whole clips in
+ * chunks through the pinned, double-buffered host pipeline (as melspec_compute_batch_host); pinned samples / out are used in place. */
+int melspec_fbank_compute_batch_host(melspec_fbank *fb, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
+                                     float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_frames);
 int melspec_fbank_synchronize(melspec_fbank *fb, void *stream);
 
 /* ---- NeMo/Parakeet log-mel frontend: replaces BatchLogMelSpectrogram (src/mel.rs:171-418) ------- */
@@ -295,6 +300,10 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
  * floats (NULL: packed in clip order), cols_c = melspec_blm_padded_frames(b, h_lengths[c]).  Fused kernel (n_fft 512 / win_length 400). */
 int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
                                       uint32_t n_clips, float *d_out, const uint64_t *h_out_offsets, void *stream);
+/* The same from host memory, many clips per call (BatchLogMelSpectrogram::compute is per clip, src/mel.rs:299): clip i ->
+ * [n_mels][cols_i] at out + out_offsets[i] floats (NULL: packed); *total_columns = sum of cols_i.  Host pipeline as above. */
+int melspec_blm_compute_batch_host(melspec_blm *b, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
+                                   float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_columns);
 int melspec_blm_synchronize(melspec_blm *b, void *stream);
 
 /* ---- streaming: Spectrogram::add + RingBuffer::maybe_mel (src/stft.rs:48-86, src/rb.rs:60-121) ---- */

@@ -149,6 +149,32 @@ public:
         return a;
     }
 
+    // additive: compute() for many clips in one call (melspec_fbank_compute_batch_host)
+    std::vector<Array2f> compute_batch(const std::vector<std::vector<float>> &clips) {
+        std::vector<std::uint64_t> offs, lens;
+        std::vector<float> flat;
+        std::size_t total = 0;
+        const std::size_t nm = static_cast<std::size_t>(melspec_fbank_num_mel_bins(fb_));
+        for (const auto &c : clips) {
+            offs.push_back(flat.size()); lens.push_back(c.size());
+            flat.insert(flat.end(), c.begin(), c.end());
+            total += melspec_fbank_num_frames(fb_, c.size());
+        }
+        std::vector<float> out(total * nm + 1);
+        std::uint64_t frames = 0;
+        detail::check(melspec_fbank_compute_batch_host(fb_, flat.data(), offs.data(), lens.data(), static_cast<std::uint32_t>(clips.size()),
+                                                       out.data(), nullptr, out.size(), &frames), false);
+        std::vector<Array2f> res(clips.size());
+        std::size_t cur = 0;
+        for (std::size_t i = 0; i < clips.size(); ++i) {
+            res[i].rows = melspec_fbank_num_frames(fb_, clips[i].size());
+            res[i].cols = nm;
+            res[i].data.assign(out.begin() + cur, out.begin() + cur + res[i].rows * nm);
+            cur += res[i].rows * nm;
+        }
+        return res;
+    }
+
 private:
     melspec_fbank *fb_ = nullptr;
 };

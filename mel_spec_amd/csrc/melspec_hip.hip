@@ -1317,6 +1317,7 @@ struct melspec_fbank {
     bool use_generic = false;   // melspec_fbank_use_generic: the direct-DFT kernel as the on-device cross-check
     RaggedScratch ragged;
     DevicePlan dplan;
+    HostPipe pipe;              // melspec_fbank_compute_batch_host
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -1388,7 +1389,7 @@ void melspec_fbank_destroy(melspec_fbank *fb) {
     if (!fb) return;
     if (fb->dev.device >= 0) (void)hipSetDevice(fb->dev.device);
     if (fb->stream) { (void)hipStreamSynchronize(fb->stream); (void)hipStreamDestroy(fb->stream); }
-    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->ragged.release(); fb->dplan.release();
+    fb->gt.release(); fb->d_blob.release(); fb->h2d.release(); fb->d2h.release(); fb->ragged.release(); fb->dplan.release(); fb->pipe.release();
     delete fb;
 }
 
@@ -1586,6 +1587,39 @@ int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n
     HIP_TRY(hipStreamSynchronize(fb->stream));
     if (n_frames) *n_frames = static_cast<size_t>(frames);
     return MELSPEC_OK;
+}
+
+// Fbank::compute on many host clips in one call: whole clips (the CMN is per clip) in chunks of ~16 MiB of PCM through the pinned,
+// double-buffered pipeline of host_pipe.hpp, one ragged launch per chunk.
+int melspec_fbank_compute_batch_host(melspec_fbank *fb, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
+                                     float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_frames) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    if (total_frames) *total_frames = 0;
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!offsets || !lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    const uint64_t nm = static_cast<uint64_t>(fb->cfg.num_mel_bins);
+    std::vector<HostSeg> segs;
+    segs.reserve(n_clips);
+    uint64_t total = 0, cursor = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        const uint64_t f = fbank_frames(fb, lengths[i]);
+        const uint64_t oo = out_offsets ? out_offsets[i] : cursor;
+        if (f && oo + f * nm > out_capacity_floats) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+        if (f && (!samples || !out)) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+        if (f) segs.push_back(HostSeg{samples + offsets[i], lengths[i], out + oo, f});
+        cursor += f * nm; total += f;
+    }
+    if (total_frames) *total_frames = total;
+    if (total == 0) return MELSPEC_OK;
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    const char *where = "";
+    const int rc = fb->pipe.run(segs, fb->cfg.num_mel_bins, kPipeChunkSamples, fb->stream,
+                                [fb](const float *d_in, const uint64_t *offs, const uint64_t *lens, uint32_t n, float *d_out,
+                                     const uint64_t *ooffs, hipStream_t s) {
+                                    return melspec_fbank_compute_ragged_device(fb, d_in, offs, lens, n, d_out, ooffs, s);
+                                }, &where);
+    if (rc > 0 && where[0] && std::strcmp(where, "kernel launch") != 0) return fail_hip(static_cast<hipError_t>(rc), where);
+    return rc;
 }
 
 }  // extern "C"
@@ -2145,6 +2179,7 @@ struct melspec_blm {
     size_t fast_lds = 0;
     int waves = 4;
     DevBuf h2d, d2h;
+    HostPipe pipe;              // melspec_blm_compute_batch_host
 };
 
 namespace {
@@ -2234,7 +2269,7 @@ void melspec_blm_destroy(melspec_blm *b) {
     if (!b) return;
     if (b->dev.device >= 0) (void)hipSetDevice(b->dev.device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    b->d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release(); b->ragged.release(); b->aux.release();
+    b->d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release(); b->ragged.release(); b->aux.release(); b->pipe.release();
     delete b;
 }
 
@@ -2467,6 +2502,47 @@ int melspec_blm_compute_host(melspec_blm *b, const float *samples, size_t n_samp
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (cols) *cols = static_cast<size_t>(c);
     return MELSPEC_OK;
+}
+
+// BatchLogMelSpectrogram::compute on many host clips in one call: clip i -> [n_mels][cols_i] floats at out + out_offsets[i] (NULL:
+// packed), cols_i = melspec_blm_padded_frames(lengths[i]).  Whole clips in chunks through the host pipeline, one ragged launch per
+// chunk (configurations on the generic kernel: one clip at a time).
+int melspec_blm_compute_batch_host(melspec_blm *b, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
+                                   float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_columns) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    if (total_columns) *total_columns = 0;
+    if (n_clips == 0) return MELSPEC_OK;
+    if (!offsets || !lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+    const uint64_t nm = static_cast<uint64_t>(b->cfg.n_mels);
+    std::vector<HostSeg> segs;
+    segs.reserve(n_clips);
+    uint64_t total = 0, cursor = 0;
+    for (uint32_t i = 0; i < n_clips; ++i) {
+        const uint64_t c = blm_padded(b, blm_valid_frames(b, lengths[i]));
+        const uint64_t oo = out_offsets ? out_offsets[i] : cursor;
+        if (c && oo + c * nm > out_capacity_floats) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+        if (c && (!samples || !out)) return fail(MELSPEC_ERR_INVALID_ARG, "samples/out is NULL");
+        if (c) segs.push_back(HostSeg{samples + offsets[i], lengths[i], out + oo, c});
+        cursor += c * nm; total += c;
+    }
+    if (total_columns) *total_columns = total;
+    if (total == 0) return MELSPEC_OK;
+    HIP_TRY(hipSetDevice(b->dev.device));
+    if (!b->fast) {
+        for (const HostSeg &sg : segs) {
+            const int rc = melspec_blm_compute_host(b, sg.src, static_cast<size_t>(sg.n), sg.dst, static_cast<size_t>(sg.frames * nm), nullptr, nullptr);
+            if (rc) return rc;
+        }
+        return MELSPEC_OK;
+    }
+    const char *where = "";
+    const int rc = b->pipe.run(segs, b->cfg.n_mels, kPipeChunkSamples, b->stream,
+                               [b](const float *d_in, const uint64_t *offs, const uint64_t *lens, uint32_t n, float *d_out,
+                                   const uint64_t *ooffs, hipStream_t s) {
+                                   return melspec_blm_compute_ragged_device(b, d_in, offs, lens, n, d_out, ooffs, s);
+                               }, &where);
+    if (rc > 0 && where[0] && std::strcmp(where, "kernel launch") != 0) return fail_hip(static_cast<hipError_t>(rc), where);
+    return rc;
 }
 
 // ---- device memory helpers --------------------------------------------------------------

@@ -431,6 +431,35 @@ class Fbank:
             cur += f * self.num_mel_bins
         return res
 
+    def compute_batch_host(self, flat: np.ndarray, offsets, lengths, out: np.ndarray | None = None, out_offsets=None):
+        """melspec_fbank_compute_batch_host: clip i = flat[offsets[i] : + lengths[i]] -> its [frames_i, num_mel_bins] rows at
+        out[out_offsets[i]:] (floats; None = packed), whole clips through the chunked host pipeline.  Returns (out, total_frames)."""
+        x = flat if isinstance(flat, np.ndarray) and flat.dtype == np.float32 and flat.flags.c_contiguous else _f32(flat).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        if out is None:
+            out = np.empty(max(sum(self.num_frames(int(n)) for n in ln) * self.num_mel_bins, 1), np.float32)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        total = C.c_uint64(0)
+        _check(lib().melspec_fbank_compute_batch_host(self._h, _fp(x.reshape(-1)), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
+                                                      _fp(out.reshape(-1)), None if oo is None else oo.ctypes.data_as(u64p), out.size, C.byref(total)))
+        return out, int(total.value)
+
+    def compute_many(self, clips) -> list:
+        """list of 1-D host arrays -> list of [frames_i, num_mel_bins] arrays (Fbank::compute per clip) through the host pipeline"""
+        arrs = [_f32(c).reshape(-1) for c in clips]
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
+        flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
+        out, _ = self.compute_batch_host(flat, offs, lens)
+        res, cur = [], 0
+        for n in lens:
+            f = self.num_frames(int(n))
+            res.append(out[cur:cur + f * self.num_mel_bins].reshape(f, self.num_mel_bins))
+            cur += f * self.num_mel_bins
+        return res
+
     def use_generic(self, on: bool = True) -> None:
         """run on the generic f64 direct-DFT kernel (the on-device cross-check of the fused kernel)"""
         _check(lib().melspec_fbank_use_generic(self._h, int(on)))
@@ -546,6 +575,36 @@ class BatchLogMelSpectrogram:
 
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_blm_synchronize(self._h, C.c_void_p(stream)))
+
+    def compute_batch_host(self, flat: np.ndarray, offsets, lengths, out: np.ndarray | None = None, out_offsets=None):
+        """melspec_blm_compute_batch_host: clip i -> [n_mels, cols_i] floats at out[out_offsets[i]:] (None = packed), whole clips
+        through the chunked host pipeline.  Returns (out, total_columns)."""
+        x = flat if isinstance(flat, np.ndarray) and flat.dtype == np.float32 and flat.flags.c_contiguous else _f32(flat).reshape(-1)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        if out is None:
+            out = np.empty(max(sum(self.padded_frames(int(n)) for n in ln) * self.config.n_mels, 1), np.float32)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        total = C.c_uint64(0)
+        _check(lib().melspec_blm_compute_batch_host(self._h, _fp(x.reshape(-1)), off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), off.shape[0],
+                                                    _fp(out.reshape(-1)), None if oo is None else oo.ctypes.data_as(u64p), out.size, C.byref(total)))
+        return out, int(total.value)
+
+    def compute_many(self, clips) -> list:
+        """list of 1-D host arrays -> list of [n_mels, cols_i] arrays (BatchLogMelSpectrogram::compute per clip) through the host pipeline"""
+        arrs = [_f32(c).reshape(-1) for c in clips]
+        lens = np.array([a.shape[0] for a in arrs], dtype=np.uint64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64) if len(arrs) else np.zeros(0, np.uint64)
+        flat = np.concatenate(arrs) if arrs and int(lens.sum()) else np.zeros(1, np.float32)
+        out, _ = self.compute_batch_host(flat, offs, lens)
+        nm = self.config.n_mels
+        res, cur = [], 0
+        for n in lens:
+            c = self.padded_frames(int(n))
+            res.append(out[cur:cur + c * nm].reshape(nm, c))
+            cur += c * nm
+        return res
 
     def compute_ragged(self, clips) -> list:
         """list of 1-D host arrays of any lengths -> list of [n_mels, cols_i] arrays (BatchLogMelSpectrogram::compute per clip), one launch"""

@@ -62,12 +62,16 @@ unsafe extern "C" {
     fn melspec_fbank_destroy(fb: *mut FbankHandle);
     fn melspec_fbank_num_frames(fb: *const FbankHandle, n: usize) -> usize;
     fn melspec_fbank_compute_host(fb: *mut FbankHandle, samples: *const f32, n: usize, out: *mut f32, cap: usize, frames: *mut usize) -> c_int;
+    fn melspec_fbank_compute_batch_host(fb: *mut FbankHandle, samples: *const f32, offsets: *const u64, lengths: *const u64, n_clips: u32,
+                                        out: *mut f32, out_offsets: *const u64, cap: usize, total_frames: *mut u64) -> c_int;
     // BatchLogMelSpectrogram (src/mel.rs:171-418)
     fn melspec_blm_create(out: *mut *mut BlmHandle, device: c_int, cfg: *const BlmConfigC) -> c_int;
     fn melspec_blm_destroy(b: *mut BlmHandle);
     fn melspec_blm_padded_frames(b: *const BlmHandle, n: usize) -> usize;
     fn melspec_blm_num_frames(b: *const BlmHandle, n: usize) -> usize;
     fn melspec_blm_compute_host(b: *mut BlmHandle, samples: *const f32, n: usize, out: *mut f32, cap: usize, rows: *mut usize, cols: *mut usize) -> c_int;
+    fn melspec_blm_compute_batch_host(b: *mut BlmHandle, samples: *const f32, offsets: *const u64, lengths: *const u64, n_clips: u32,
+                                      out: *mut f32, out_offsets: *const u64, cap: usize, total_columns: *mut u64) -> c_int;
     // vad_boundaries (src/vad.rs:251-340)
     fn melspec_vad_mask_len(n_mels: c_int, width: usize) -> usize;
     fn melspec_vad_boundaries_host(device: c_int, image: *const f32, n_mels: c_int, width: usize, settings: *const VadSettingsC,
@@ -415,6 +419,34 @@ impl HipFbank {
         }
         Ok(ndarray::Array2::from_shape_vec((got, self.num_mel_bins), flat).expect("shape"))
     }
+    /// Additive: `Fbank::compute` for many clips in one call (one ragged launch per ~16 MiB of PCM through the pinned host pipeline).
+    pub fn compute_batch(&mut self, clips: &[&[f32]]) -> Result<Vec<ndarray::Array2<f32>>, HipError> {
+        let lengths: Vec<u64> = clips.iter().map(|c| c.len() as u64).collect();
+        let mut offsets = Vec::with_capacity(clips.len());
+        let mut flat_in = Vec::with_capacity(lengths.iter().sum::<u64>() as usize);
+        for c in clips {
+            offsets.push(flat_in.len() as u64);
+            flat_in.extend_from_slice(c);
+        }
+        let frames: Vec<usize> = clips.iter().map(|c| unsafe { melspec_fbank_num_frames(self.fb, c.len()) }).collect();
+        let mut flat = vec![0.0f32; frames.iter().sum::<usize>() * self.num_mel_bins];
+        let mut total = 0u64;
+        let rc = unsafe {
+            melspec_fbank_compute_batch_host(self.fb, flat_in.as_ptr(), offsets.as_ptr(), lengths.as_ptr(), clips.len() as u32,
+                                             flat.as_mut_ptr(), std::ptr::null(), flat.len(), &mut total)
+        };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        let mut out = Vec::with_capacity(clips.len());
+        let mut cur = 0usize;
+        for f in frames {
+            let n = f * self.num_mel_bins;
+            out.push(ndarray::Array2::from_shape_vec((f, self.num_mel_bins), flat[cur..cur + n].to_vec()).expect("shape"));
+            cur += n;
+        }
+        Ok(out)
+    }
 }
 impl Drop for HipFbank {
     fn drop(&mut self) {
@@ -464,6 +496,35 @@ impl HipBatchLogMel {
             return Err(HipError::Runtime(last_error()));
         }
         Ok((ndarray::Array2::from_shape_vec((self.n_mels, got_cols), flat).expect("shape"), valid))
+    }
+    /// Additive: `compute` for many clips in one call; every clip comes back as its `(n_mels, cols)` array and valid frame count.
+    pub fn compute_batch(&mut self, clips: &[&[f32]]) -> Result<Vec<(ndarray::Array2<f32>, usize)>, HipError> {
+        let lengths: Vec<u64> = clips.iter().map(|c| c.len() as u64).collect();
+        let mut offsets = Vec::with_capacity(clips.len());
+        let mut flat_in = Vec::with_capacity(lengths.iter().sum::<u64>() as usize);
+        for c in clips {
+            offsets.push(flat_in.len() as u64);
+            flat_in.extend_from_slice(c);
+        }
+        let cols: Vec<usize> = clips.iter().map(|c| unsafe { melspec_blm_padded_frames(self.b, c.len()) }).collect();
+        let mut flat = vec![0.0f32; cols.iter().sum::<usize>() * self.n_mels];
+        let mut total = 0u64;
+        let rc = unsafe {
+            melspec_blm_compute_batch_host(self.b, flat_in.as_ptr(), offsets.as_ptr(), lengths.as_ptr(), clips.len() as u32,
+                                           flat.as_mut_ptr(), std::ptr::null(), flat.len(), &mut total)
+        };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        let mut out = Vec::with_capacity(clips.len());
+        let mut cur = 0usize;
+        for (c, clip) in cols.into_iter().zip(clips) {
+            let n = c * self.n_mels;
+            let valid = unsafe { melspec_blm_num_frames(self.b, clip.len()) };
+            out.push((ndarray::Array2::from_shape_vec((self.n_mels, c), flat[cur..cur + n].to_vec()).expect("shape"), valid));
+            cur += n;
+        }
+        Ok(out)
     }
 }
 impl Drop for HipBatchLogMel {

@@ -55,6 +55,17 @@ int main() {
     melspec::Fbank fb;
     const melspec::Array2f feats = fb.compute(std::vector<float>(16000, 0.0f));
     if (feats.cols != 80 || feats.rows != 98) { std::puts("FAIL: fbank shape"); return 1; }
+    {
+        // many clips in one call == one call per clip
+        std::vector<std::vector<float>> clips = {std::vector<float>(samples.begin(), samples.begin() + 9000), std::vector<float>(399, 0.5f),
+                                                 std::vector<float>(samples.begin() + 100, samples.begin() + 4100)};
+        const auto many = fb.compute_batch(clips);
+        if (many.size() != 3 || many[1].rows != 0) { std::puts("FAIL: fbank batch shape"); return 1; }
+        for (size_t i = 0; i < 3; ++i) {
+            const melspec::Array2f one = fb.compute(clips[i]);
+            if (one.rows != many[i].rows || one.data != many[i].data) { std::puts("FAIL: fbank batch values"); return 1; }
+        }
+    }
     const std::vector<double> w = melspec::mel(sr, 400, 80);
     if (w.size() != 80 * 201) { std::puts("FAIL: mel shape"); return 1; }
     // precise build, streaming mirror and the quantiser through the same header

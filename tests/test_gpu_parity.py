@@ -888,6 +888,42 @@ def test_fbank_ragged_batches(gpu, oracle, jfk, kw):
     fb.close()
 
 
+def test_fbank_and_nemo_batch_host(gpu, oracle, jfk):
+    """melspec_fbank_compute_batch_host / melspec_blm_compute_batch_host: many host clips of different lengths in one call through the
+    chunked host pipeline, equal to the one-clip host calls; explicit output offsets; clips without a frame; capacity errors."""
+    rng = np.random.default_rng(21)
+    lens = [int(v) for v in rng.integers(300, 30000, 37)] + [0, 399, 400]
+    clips = [(jfk[(i * 1777) % 100000:][:m] if i % 2 else oracle.synth_pcm(i, m)).astype(np.float32) for i, m in enumerate(lens)]
+    fb = gpu.Fbank()
+    got = fb.compute_many(clips)
+    for g, x in zip(got, clips):
+        one = fb.compute(x)
+        assert g.shape == one.shape and np.array_equal(g, one)
+    flat = np.concatenate(clips)
+    ln = np.array(lens, np.uint64)
+    offs = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.uint64)
+    frames = np.array([fb.num_frames(m) for m in lens], np.uint64)
+    oo = (np.concatenate([[0], np.cumsum(frames * 80)[:-1]]) + 8 * np.arange(len(lens))).astype(np.uint64)      # gaps between the outputs
+    out = np.full(int(oo[-1] + frames[-1] * 80) + 8, 7.0, np.float32)
+    _, total = fb.compute_batch_host(flat, offs, ln, out, oo)
+    assert total == int(frames.sum())
+    for i, g in enumerate(got):
+        assert np.array_equal(out[int(oo[i]):int(oo[i]) + g.size].reshape(g.shape), g)
+        assert np.all(out[int(oo[i]) + g.size:int(oo[i]) + g.size + 8] == 7.0)
+    with pytest.raises(gpu.HipError):
+        fb.compute_batch_host(flat, offs, ln, np.empty(100, np.float32))
+    fb.close()
+    for kw in (dict(n_mels=80), dict(n_mels=128, preemphasis=0.97, normalize_per_feature=True, pad_to=16)):
+        fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+        got = fe.compute_many(clips)
+        for g, x in zip(got, clips):
+            one = fe.compute(x)
+            assert g.shape == one.shape
+            if g.size:
+                assert np.abs(g - one).max() <= (2e-5 if kw.get("normalize_per_feature") else 0.0)
+        fe.close()
+
+
 def test_fbank_ragged_batch_by_clip(gpu, oracle, jfk):
     """A ragged batch big and even enough to keep every CU busy takes the workgroup-per-clip kernel (clips handed out longest first
     from a ticket counter, CMN inside); the same clips in small batches take the fused kernel + cmn_kernel.  Both within the tolerance
