@@ -158,15 +158,17 @@ static_assert(kSixFixOff >= SixLayout::kPmaxOff + kSixFrames * SixLayout::kPmaxS
 static_assert(kWaveFixOff >= WaveLayout::kPmaxOff + kFPW * WaveLayout::kPmaxStride && kWaveFixOff + 2 * FixTables::kScratchDoubles <= WaveLayout::slice_floats(), "five-frame slice");
 
 // f64 power row of frame `f` of the unit (whisper_fix64.hpp): every lane of the wave takes part
-__device__ __forceinline__ void fix_power_row(int lane, const float *frame, const double *tab, float *slice, int scratch_off, float *prow) {
+// `next`: the frame recomputed after this one (nullptr: none); its samples are loaded while steps 2-4 run
+__device__ __forceinline__ void fix_power_row(int lane, FixSamples &smp, const float *next, const double *tab, const FixTw &tw, float *slice, int scratch_off, float *prow) {
     double *z = reinterpret_cast<double *>(slice + scratch_off);
-    fix_step1(lane, frame, tab, z);
+    fix_step1(lane, smp, tab, z);
+    if (next) fix_load_samples(lane, next, smp);
     __builtin_amdgcn_wave_barrier();
-    fix_step2(lane, tab, z);
+    fix_step2(lane, tw, z);
     __builtin_amdgcn_wave_barrier();
     fix_step3(lane, z);
     __builtin_amdgcn_wave_barrier();
-    fix_step4(lane, tab, z, prow);
+    fix_step4(lane, tw, z, prow);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -179,20 +181,28 @@ __device__ __forceinline__ unsigned frame_mask(uint64_t any) {
     return m;
 }
 
-// The frames `mask` of a unit, one after the other: f64 power row, then the kernel's own phases 3-4 for that frame alone.
+// The frames `mask` of a unit: their f64 power rows one after the other, then the kernel's own phases 3-4 once for all of them.
 // The f32 kernels do not call this inside their unit loop -- with the f64 code in the loop body the register allocator gives the
 // hot path 5 % (a call) to 40 % (inlined) away -- but note the unit (FixSink::list) and come back to it when their run is done.
 // Six frames x ten lanes.
 template <int NSLOTS, class Lens, bool LAYOUT>
 __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
-                                          const FixSink &fix, const float *src, float *out_tile, long long row_w) {
+                                          const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w) {
     const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
     const bool in = lane < kSixFrames * kSixLanes;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    for (int f = 0; f < kSixFrames; ++f) {
-        if (!((mask >> f) & 1u)) continue;                                                         // wave-uniform
-        fix_power_row(lane, src + f * hop, fix.tab, slice, kSixFixOff, slice + f * SixLayout::kPStride);
-        const bool act = in && fl == f;
+    {
+        FixSamples smp;
+        fix_load_samples(lane, src + (__builtin_ctz(mask)) * hop, smp);
+        for (unsigned rest = mask; rest;) {                                                       // wave-uniform
+            const int f = __builtin_ctz(rest);
+            rest &= rest - 1;
+            fix_power_row(lane, smp, rest ? src + __builtin_ctz(rest) * hop : nullptr, fix.tab, tw, slice, kSixFixOff, slice + f * SixLayout::kPStride);
+        }
+    }
+    // one pass of phases 3-4 over all the recomputed frames of the unit (each has its own power row)
+    {
+        const bool act = in && ((mask >> fl) & 1u);
         int st[NSLOTS];
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
@@ -212,14 +222,21 @@ __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int ho
 // The same for the five-frame kernels (12 lanes per frame in phases 3-4).
 template <int NSLOTS, class Lens, bool LAYOUT>
 __device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
-                                           const FixSink &fix, const float *src, float *out_tile, long long row_w) {
+                                           const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w) {
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
-    for (int f = 0; f < kFPW; ++f) {
-        if (!((mask >> f) & 1u)) continue;                                                         // wave-uniform
-        fix_power_row(lane, src + f * hop, fix.tab, slice, kWaveFixOff, slice + f * WaveLayout::kPStride);
-        const bool act3 = in3 && fl3 == f;
+    {
+        FixSamples smp;
+        fix_load_samples(lane, src + (__builtin_ctz(mask)) * hop, smp);
+        for (unsigned rest = mask; rest;) {                                                       // wave-uniform
+            const int f = __builtin_ctz(rest);
+            rest &= rest - 1;
+            fix_power_row(lane, smp, rest ? src + __builtin_ctz(rest) * hop : nullptr, fix.tab, tw, slice, kWaveFixOff, slice + f * WaveLayout::kPStride);
+        }
+    }
+    {
+        const bool act3 = in3 && ((mask >> fl3) & 1u);
         int st[NSLOTS];
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
@@ -358,6 +375,8 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
     }
     // the units whose frames tripped the precision guard, again, in f64 (no barrier of the rounds involved any more)
     unsigned redone = 0;
+    FixTw tw;
+    if (noted) fix_load_tw(lane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
@@ -367,7 +386,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
@@ -450,6 +469,8 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         rs.after_round();
     }
     unsigned redone = 0;
+    FixTw tw;
+    if (noted) fix_load_tw(lane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
@@ -459,7 +480,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         const uint64_t f0 = loc.unit * kSixFrames;
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
@@ -588,13 +609,15 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     }
     // the units whose frames tripped the precision guard, again, in f64
     unsigned redone = 0;
+    FixTw tw;
+    if (noted) fix_load_tw(lane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
         e = scalar64(e);
         const UnitLoc loc = locate_unit(p.b, e >> 8);
         const uint64_t f0 = loc.unit * kSixFrames;
-        redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
@@ -664,13 +687,15 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
         }
     }
     unsigned redone = 0;
+    FixTw tw;
+    if (noted) fix_load_tw(lane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
         e = scalar64(e);
         const UnitLoc loc = locate_unit(p.b, e >> 8);
         const uint64_t f0 = loc.unit * kFPW;
-        redone += wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix,
+        redone += wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
                                            loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);

@@ -3,12 +3,14 @@
 // The f32 kernels check every frame against an error bound in phase 4 (wave_phase4: a mel band within kGuardBand decades of the
 // per-frame clamp).  A wave notes the units that have such frames and, when its run of units is done, recomputes those frames
 // itself: window, 400-point real FFT, Hermitian split and |X|^2 in f64 (the reference's arithmetic, src/stft.rs:98-111), then the
-// kernel's own f32 mel / log10 / clamp phases on the new power row.  No second launch (two dependent launches cost the 0.3 ms
-// bench step 9.5 us), no cross-wave queue: noise-like input notes nothing (the bench workload pays one ballot per unit and runs
-// at the f32 rate), a recomputed frame costs its wave ~6 us (three dependent trips to the global tables; keeping the tables in
-// 60 VGPRs per lane was tried and spills both the tail and the hot loop).  Measured (tools/guard_bench.py, 1024 x 10 s, 80 mels):
-// noise 0.307 ms; speech, 66 % of the frames recomputed: 1.57 ms; a tone over a -70 dB floor, 100 %: 1.87 ms -- against 0.50 ms
-// for MELSPEC_PRECISION_F64, the dedicated f64 kernel (whisper_wave_f64.hpp) on everything, which is the mode for such input.
+// kernel's own f32 mel / log10 / clamp phases on the new power rows (once per unit).  No second launch (two dependent launches cost the
+// 0.3 ms bench step 9.5 us), no cross-wave queue: noise-like input notes nothing (the bench workload pays one ballot per unit and runs
+// at the f32 rate), a recomputed frame costs its wave ~4.5 us.  What that is made of was taken apart in round 2 (tools/guard_bench.py,
+// 1024 x 10 s, 80 mels, speech = jfk tiled, 66 % of the frames recomputed): phases 3-4 per frame 1.57 ms -> once per unit 1.35 ms;
+// the twiddles of steps 2 and 4 (lane constants) loaded once per wave instead of per frame 1.31 ms; the next frame's samples in
+// flight during steps 2-4 1.21-1.24 ms; the window taps in registers as well: 47 spilled VGPRs and 1.58 ms, so they stay a table read
+// per frame.  A tone over a -70 dB floor (100 % recomputed): 1.87 -> 1.45 ms.  MELSPEC_PRECISION_F64, the dedicated f64 kernel
+// (whisper_wave_f64.hpp) on everything, takes 0.50 ms: that is the mode for such input.
 //
 // Register budget is what shapes it: the f32 kernels live at <= 128 VGPRs (four waves per SIMD), so no lane may hold a 20-point
 // f64 DFT (80 VGPRs of data).  The complex-200 transform is spread over the lanes instead, 200 = 8 x 25 by Good-Thomas (no
@@ -122,6 +124,73 @@ MS_DEV void fix_step4(int lane, const double *MS_RESTRICT tab, const double *MS_
         const cd S = {zk.re + zm.re, zk.im - zm.im};
         const cd D = {zk.re - zm.re, zk.im + zm.im};
         const cd wd = cmul(ldc(tab + FixTables::kW400 + 2 * k), D);
+        const double ar = S.re + wd.im, ai = S.im - wd.re;
+        const double br = S.re - wd.im, bi = S.im + wd.re;
+        prow[k] = static_cast<float>(ar * ar + ai * ai);
+        prow[200 - k] = static_cast<float>(br * br + bi * bi);
+    }
+}
+
+// step 1 in two halves, so that the samples of the NEXT frame to recompute can be in flight during steps 2-4 of this one (they come
+// from HBM or the Infinity Cache: the hot loop read them long ago)
+struct FixSamples {
+    float a[8], b[8];
+};
+MS_DEV void fix_load_samples(int lane, const float *MS_RESTRICT frame, FixSamples &s) {
+    const int l = lane < 25 ? lane : 0;          // every lane loads (no divergent branch around the loads); lanes >= 25 are not used
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) fix_load2(frame + 2 * ((25 * n1 + 8 * l) % 200), s.a[n1], s.b[n1]);
+}
+// (The window taps of a lane are the same for every frame too; keeping those 16 doubles in registers next to the twiddles below
+// was measured: 47 spilled VGPRs in the tail and 1.58 ms instead of 1.21 ms on speech -- they stay a table read per frame.)
+MS_DEV void fix_step1(int lane, const FixSamples &s, const double *MS_RESTRICT tab, double *MS_RESTRICT z) {
+    if (lane >= 25) return;
+    cd u[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+        const int n = (25 * n1 + 8 * lane) % 200;
+        u[n1] = {static_cast<double>(s.a[n1]) * tab[FixTables::kWin + 2 * n], static_cast<double>(s.b[n1]) * tab[FixTables::kWin + 2 * n + 1]};
+    }
+    fft8(u);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; ++k1) stc(z + 2 * (25 * k1 + lane), u[k1]);
+}
+
+// The twiddles of steps 2 and 4 depend on the lane only, not on the frame: a wave with frames to recompute loads them once
+// (14 doubles) instead of paying two more dependent trips to the global table per frame.
+struct FixTw {
+    cd w25[5];      // W_25^{a c}, a = lane % 5
+    cd w400[2];     // W_400^k, k = lane, lane + 64
+};
+MS_DEV void fix_load_tw(int lane, const double *MS_RESTRICT tab, FixTw &tw) {
+    const int a = lane % 5;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) tw.w25[c] = ldc(tab + FixTables::kW25 + 2 * (5 * a + c));
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int k = lane + 64 * r;
+        tw.w400[r] = ldc(tab + FixTables::kW400 + 2 * (k <= 100 ? k : 100));
+    }
+}
+MS_DEV void fix_step2(int lane, const FixTw &tw, double *z) {
+    if (lane >= 40) return;
+    const int k1 = lane / 5, a = lane - 5 * k1;
+    cd v[5];
+#pragma unroll
+    for (int b = 0; b < 5; ++b) v[b] = ldc(z + 2 * (25 * k1 + 5 * b + a));
+    bf5(v[0], v[1], v[2], v[3], v[4]);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) stc(z + 2 * (25 * k1 + 5 * c + a), c == 0 ? v[0] : cmul(v[c], tw.w25[c]));
+}
+MS_DEV void fix_step4(int lane, const FixTw &tw, const double *MS_RESTRICT z, float *MS_RESTRICT prow) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int k = lane + 64 * r;
+        if (k > 100) continue;
+        const cd zk = ldc(z + 2 * k), zm = ldc(z + 2 * ((200 - k) % 200));
+        const cd S = {zk.re + zm.re, zk.im - zm.im};
+        const cd D = {zk.re - zm.re, zk.im + zm.im};
+        const cd wd = cmul(tw.w400[r], D);
         const double ar = S.re + wd.im, ai = S.im - wd.re;
         const double br = S.re - wd.im, bi = S.im + wd.re;
         prow[k] = static_cast<float>(ar * ar + ai * ai);

@@ -53,14 +53,14 @@ def run_fbank(tag, n_clips, clip_len, iters):
     print(tag, res[tag], flush=True)
     pcm.free(); out.free(); fb.close()
 
-def run_nemo(tag, n_clips, clip_len, n_mels, iters):
-    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=n_mels, preemphasis=0.97, log_zero_guard=2.0 ** -24))
+def run_nemo(tag, n_clips, clip_len, n_mels, iters, norm=False):
+    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=n_mels, preemphasis=0.97, log_zero_guard=2.0 ** -24, normalize_per_feature=norm))
     cols = fe.padded_frames(clip_len)
     pcm = M.DeviceBuffer(n_clips * clip_len * 4); out = M.DeviceBuffer(n_clips * cols * n_mels * 4)
     M.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips); M.device_synchronize()
     dt = timed(lambda: fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), fe.synchronize, iters)
     frames = n_clips * cols
-    cfg = O.blm_default_config(n_mels=n_mels, preemphasis=0.97, log_zero_guard=2.0 ** -24)
+    cfg = O.blm_default_config(n_mels=n_mels, preemphasis=0.97, log_zero_guard=2.0 ** -24, normalize_per_feature=norm)
     worst = 0.0
     for c in (0, n_clips - 1):
         got = out.download((n_mels, cols), offset_bytes=c * cols * n_mels * 4)
@@ -75,6 +75,7 @@ if "cfg3" in which: run_fbank("cfg3_fbank_1024x10s", 1024, 160000, 50)
 if "cfg4" in which: run_mel("cfg4_w128_8192x30s", 8192, 480000, 128, 10)
 if "cfg5" in which: run_mel("cfg5_w80_8192x30s_per_gpu_share", 8192, 480000, 80, 10)
 if "nemo" in which: run_nemo("nemo_parakeet_128_1024x10s", 1024, 160000, 128, 50)
+if "nemo" in which: run_nemo("nemo_parakeet_128_1024x10s_normalised", 1024, 160000, 128, 50, True)
 if "host" in which:
     m = M.HipMelSpectrogram(400, 160, 16000.0, 80)
     x = np.concatenate([O.synth_pcm(c, 160000) for c in range(64)])
