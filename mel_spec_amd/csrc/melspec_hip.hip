@@ -2173,7 +2173,9 @@ struct melspec_blm {
     bool fast = false;          // fused 512-point kernel (n_fft 512 / win_length 400) vs the generic f64 kernel (any validated config)
     GenericTables gt;
     RaggedScratch ragged;
-    DevBuf aux;                 // ragged batches: per-clip sample counts and valid frames
+    DevBuf aux;                 // ragged batches: per-clip sample counts and valid frames, the normaliser's group counter; used in
+    hipStream_t aux_stream = nullptr;   //   stream order (a call on another stream first waits for the stream that used it last)
+    bool aux_used = false;
     FbankFastTables ft;
     DevBuf d_blob;
     size_t fast_lds = 0;
@@ -2404,6 +2406,8 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
     HIP_TRY(hipSetDevice(b->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
     const int nm = b->cfg.n_mels;
+    if (b->aux_used && b->aux_stream != s) HIP_TRY(hipStreamSynchronize(b->aux_stream));
+    b->aux_used = true; b->aux_stream = s;
     int rc = b->aux.ensure(aux.size() * sizeof(uint64_t));
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(b->aux.p, aux.data(), aux.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));    // pageable source: staged before the call returns

@@ -376,7 +376,13 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
     // the units whose frames tripped the precision guard, again, in f64 (no barrier of the rounds involved any more)
     unsigned redone = 0;
     FixTw tw;
-    if (noted) fix_load_tw(lane, p.fix.tab, tw);
+    // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
+    // SAME values as the hot loop's they stayed live across the tail's register-hungry f64 code, and the allocator spilled them for
+    // the loop as well (the mel-major kernel reloaded one from scratch eight times per unit: 0.37 -> 0.45 ms).
+    int tlane = lane;
+    float *tslice = slice;
+    asm volatile("" : "+v"(tlane));
+    if (noted) fix_load_tw(tlane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
+        redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
@@ -470,7 +476,13 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     }
     unsigned redone = 0;
     FixTw tw;
-    if (noted) fix_load_tw(lane, p.fix.tab, tw);
+    // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
+    // SAME values as the hot loop's they stayed live across the tail's register-hungry f64 code, and the allocator spilled them for
+    // the loop as well (the mel-major kernel reloaded one from scratch eight times per unit: 0.37 -> 0.45 ms).
+    int tlane = lane;
+    float *tslice = slice;
+    asm volatile("" : "+v"(tlane));
+    if (noted) fix_load_tw(tlane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         const uint64_t f0 = loc.unit * kSixFrames;
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
+        redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
@@ -610,14 +622,20 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     // the units whose frames tripped the precision guard, again, in f64
     unsigned redone = 0;
     FixTw tw;
-    if (noted) fix_load_tw(lane, p.fix.tab, tw);
+    // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
+    // SAME values as the hot loop's they stayed live across the tail's register-hungry f64 code, and the allocator spilled them for
+    // the loop as well (the mel-major kernel reloaded one from scratch eight times per unit: 0.37 -> 0.45 ms).
+    int tlane = lane;
+    float *tslice = slice;
+    asm volatile("" : "+v"(tlane));
+    if (noted) fix_load_tw(tlane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
         e = scalar64(e);
         const UnitLoc loc = locate_unit(p.b, e >> 8);
         const uint64_t f0 = loc.unit * kSixFrames;
-        redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
+        redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
@@ -688,14 +706,20 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     }
     unsigned redone = 0;
     FixTw tw;
-    if (noted) fix_load_tw(lane, p.fix.tab, tw);
+    // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
+    // SAME values as the hot loop's they stayed live across the tail's register-hungry f64 code, and the allocator spilled them for
+    // the loop as well (the mel-major kernel reloaded one from scratch eight times per unit: 0.37 -> 0.45 ms).
+    int tlane = lane;
+    float *tslice = slice;
+    asm volatile("" : "+v"(tlane));
+    if (noted) fix_load_tw(tlane, p.fix.tab, tw);
     for (unsigned k = 0; k < noted; ++k) {
         uint64_t e = 0;
         if (lane == 0) e = notes[k];
         e = scalar64(e);
         const UnitLoc loc = locate_unit(p.b, e >> 8);
         const uint64_t f0 = loc.unit * kFPW;
-        redone += wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), lane, p.hop, n_mels, p.slots, blob, slice, p.fix, tw,
+        redone += wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                            loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
     if (redone && lane == 0) atomicAdd(p.fix.count, redone);
