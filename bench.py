@@ -307,10 +307,13 @@ def main() -> None:
 
         def host_rate(src, dst):
             mel.compute_batch_host(src, offs, lens, dst)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                mel.compute_batch_host(src, offs, lens, dst)
-            return reps * frames_host / (time.perf_counter() - t1)
+            best = 0.0
+            for _ in range(3):                      # the staging memcpy threads share the host with whatever else runs: best of three
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    mel.compute_batch_host(src, offs, lens, dst)
+                best = max(best, reps * frames_host / (time.perf_counter() - t1))
+            return best
 
         host_io = host_rate(x, out_h)
         pin_in, pin_out = M.HostBuffer(x.size), M.HostBuffer(out_h.size)

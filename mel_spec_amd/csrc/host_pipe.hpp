@@ -13,6 +13,7 @@
 
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -144,7 +145,11 @@ struct HostPipe {
             if ((e = hipEventCreateWithFlags(&ev_cmp[b], hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&ev_out[b], hipEventDisableTiming)) != hipSuccess) return e;
         }
-        pool = new CopyPool(3);
+        int workers = 3;
+#ifdef MELSPEC_LAB
+        if (const char *e = std::getenv("MELSPEC_COPY_THREADS")) workers = std::atoi(e) > 0 && std::atoi(e) <= 63 ? std::atoi(e) : workers;
+#endif
+        pool = new CopyPool(workers);
         ready = true;
         return hipSuccess;
     }
