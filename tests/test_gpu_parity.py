@@ -456,7 +456,7 @@ def test_fbank_batch_config3_sampled(gpu, oracle):
     pcm.free(); out.free()
 
 
-@pytest.mark.parametrize("n_mels,clip_len", [(80, 11357), (40, 4000), (64, 400), (80, 399 + 160 * 3), (80, 160000)])
+@pytest.mark.parametrize("n_mels,clip_len", [(80, 11357), (40, 4000), (64, 400), (80, 399 + 160 * 3), (80, 160000), (24, 5000), (88, 7001), (4, 3000)])
 def test_fbank_clip_kernel_against_the_two_kernel_path(gpu, oracle, jfk, n_mels, clip_len):
     """Uniform batches that fill the CUs evenly take fbank512_clip_kernel (a workgroup per clip, CMN inside, the column sums as
     a fixed tree instead of the left fold of src/fbank.rs:224-233); smaller ones the fused kernel + cmn_kernel (the reference's
@@ -886,6 +886,24 @@ def test_fbank_ragged_batches(gpu, oracle, jfk, kw):
     for b in (din, dout, d_off, d_len):
         b.free()
     fb.close()
+
+
+def test_nemo_ragged_normaliser_long_rows(gpu, oracle, jfk):
+    """The ragged normaliser stages whole rows in LDS, sized for the longest clip of the batch: a batch whose longest clip leaves room
+    for only a few rows per workgroup, next to short clips and clips without a frame."""
+    kw = dict(n_mels=80, preemphasis=0.97, normalize_per_feature=True)
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
+    cfg = oracle.blm_default_config(**kw)
+    src = np.concatenate([jfk] * 5)
+    lens = [700000, 1200, 0, 160, 40000, 3333]
+    clips = [(src[(i * 911):][:m] if i % 2 == 0 else oracle.synth_pcm(i, m)).astype(np.float32) for i, m in enumerate(lens)]
+    got = fe.compute_ragged(clips)
+    for g, x in zip(got, clips):
+        want, _ = oracle.blm_compute(x, cfg, True)
+        assert g.shape == want.shape
+        if want.size:
+            assert np.abs(g - want).max() <= 2e-3, (len(x), float(np.abs(g - want).max()))
+    fe.close()
 
 
 def test_fbank_and_nemo_batch_host(gpu, oracle, jfk):
