@@ -156,9 +156,50 @@ def case_nemo():
     note("nemo", d)
     fe.close()
 
+def case_fbank_batch():
+    """many clips per call through the host pipeline: the workgroup-per-clip kernel (uniform and ragged batches that fill the CUs) and
+    the two-kernel path behind the same entry point"""
+    nm = int(rng.choice([80, 80, 40, 64, 23]))
+    fb = M.Fbank(M.FbankConfig(num_mel_bins=nm))
+    oc = O.fbank_default_config(); oc.num_mel_bins = nm
+    n_clips = int(rng.choice([7, 300, 512, 530, 700]))
+    if rng.random() < 0.5:
+        lens = [int(rng.integers(400, 6000))] * n_clips
+    else:
+        lens = [int(v) for v in rng.integers(0, 6000, n_clips)]
+    clips = [signal(m) if m else np.zeros(0, np.float32) for m in lens]
+    got = fb.compute_many(clips)
+    for i in rng.choice(n_clips, min(n_clips, 12), replace=False):
+        want = O.fbank_compute(clips[i], oc)
+        assert got[i].shape == want.shape, ("fbank_batch", nm, n_clips, lens[i], got[i].shape, want.shape)
+        if want.size:
+            d = float(np.abs(got[i] - want).max())
+            assert d <= 1e-4, ("fbank_batch", nm, n_clips, lens[i], d)
+            note("fbank_batch", d)
+    fb.close()
+
+def case_nemo_batch():
+    kw = dict(n_mels=int(rng.choice([80, 128])), preemphasis=float(rng.choice([0.97, 0.0])), log_zero_guard=2.0 ** -24,
+              normalize_per_feature=bool(rng.integers(0, 2)), pad_to=int(rng.choice([0, 16])))
+    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(**kw))
+    cfg = O.blm_default_config(**kw)
+    n_clips = int(rng.choice([5, 40, 200]))
+    lens = [int(v) for v in rng.integers(0, 30000, n_clips)]
+    clips = [signal(m) if m else np.zeros(0, np.float32) for m in lens]
+    got = fe.compute_many(clips)
+    for i in rng.choice(n_clips, min(n_clips, 6), replace=False):
+        want = O.blm_compute(clips[i], cfg, True)[0]
+        assert got[i].shape == want.shape, ("nemo_batch", kw, lens[i], got[i].shape, want.shape)
+        if want.size:
+            one = fe.compute(clips[i])                 # the one-clip call is judged against the oracle by case_nemo: here, the batch against it
+            d = float(np.abs(got[i] - one).max())
+            assert d <= (2e-5 if kw["normalize_per_feature"] else 0.0), ("nemo_batch", kw, lens[i], d)
+            note("nemo_batch", d)
+    fe.close()
+
 n = 0
 while time.time() < t_end:
     r = rng.random()
-    (case_whisper if r < 0.7 else case_fbank if r < 0.85 else case_nemo)()
+    (case_whisper if r < 0.66 else case_fbank if r < 0.78 else case_fbank_batch if r < 0.84 else case_nemo if r < 0.95 else case_nemo_batch)()
     n += 1
 print("cases", n, {k: (v[0], float(f"{v[1]:.3g}")) for k, v in stats.items()})
