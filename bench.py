@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-host-io", action="store_true", help="skip the PCIe-inclusive host API figure (never `value`)")
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the consolidation of the outputs on rank 0")
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 (two short PMC passes of this "
+                    "script, ~1 min); the committed profiles/traffic.json is reported instead")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn the ranks (gloo), plan every rank's shard, run the timing protocol on a "
                                                             "sleep and print the JSON line -- the CPU test of the launch path")
     return ap.parse_args()
@@ -69,6 +71,40 @@ def respawn_under_torchrun(args) -> None:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     os.execv(sys.executable, cmd)
+
+
+def measure_traffic(config: int, timeout_s: float = 150.0):
+    """HBM bytes per launch of the dominant kernel, measured now: one rocprofv3 --pmc pass per counter (FETCH_SIZE, WRITE_SIZE; separate
+    passes, with --kernel-trace only, as the guide prescribes) over a few steps of this script, 2 x FETCH_SIZE + WRITE_SIZE (KiB; the x 2 is
+    the gfx950 correction calibrated in profiles/r01_calibration.txt).  Returns (bytes, note) or (None, why)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="melspec_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--config", str(config), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-io", "--no-traffic"]
+            subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "whisper400" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                        got.append(float(r["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows in the rocprofv3 output"
+            vals[counter] = sum(got) / len(got) * 1024.0
+        except Exception as e:          # a profiler that cannot run must not cost the bench line
+            return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"], (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over 7 launches "
+                                                            f"of this command, 2 x {vals['FETCH_SIZE'] / 1e6:.1f} MB + {vals['WRITE_SIZE'] / 1e6:.1f} MB per launch")
 
 
 def cpu_baseline(clip_len: int, n_mels: int, target_s: float, pool: int) -> dict:
@@ -328,6 +364,7 @@ def main() -> None:
         algo_bytes_per_launch = frames_per_step * bytes_per_frame
         achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
+        traffic_kernel_ok = args.clips is None and args.clip_seconds is None and args.n_mels is None     # the child run repeats the default workload
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.config == 2:
             try:
@@ -338,6 +375,12 @@ def main() -> None:
                                       "2 x FETCH_SIZE + WRITE_SIZE per launch; not re-measured in this run")
             except Exception:
                 traffic = None
+        if not args.no_traffic and world == 1 and args.config == 2 and traffic_kernel_ok:
+            live, note = measure_traffic(args.config)
+            if live is not None:
+                traffic, traffic_source = live, note
+            elif traffic_source is not None:
+                traffic_source += f" ({note})"
         res = {
             "metric": "mel frames/sec/GPU (Whisper 400/160/80 @16 kHz); realtime x vs CPU ref",
             "value": value, "unit": "mel frames/s",

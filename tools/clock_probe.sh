@@ -7,7 +7,7 @@ for LIB in "$@"; do
   OUT=/tmp/clk_$(basename $LIB .so)
   rm -rf $OUT
   if [ "$LIB" != "default" ]; then export MELSPEC_LIB=$GRAFT_REPO_ROOT/mel_spec_amd/$LIB; else unset MELSPEC_LIB; fi
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python bench.py --steps 200 --warmup 50 --no-cpu-baseline --no-host-io --no-traffic > $OUT.log 2>&1
   python - "$OUT" "$LIB" <<'PY'
 import csv, glob, sys
 out, lib = sys.argv[1], sys.argv[2]

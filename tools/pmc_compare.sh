@@ -16,7 +16,7 @@ for SPEC in "$@"; do
   i=0
   for P in "${PASSES[@]}"; do
     i=$((i+1)); OUT=/tmp/pmc_${TAG}_$i; rm -rf $OUT
-    timeout 100 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT -- python bench.py --steps 20 --warmup 10 --no-cpu-baseline > $OUT.log 2>&1; echo "pass $i rc=$? $(date +%T)"
+    timeout 100 rocprofv3 --pmc $P --kernel-trace --output-format csv -d $OUT -- python bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-host-io --no-traffic > $OUT.log 2>&1; echo "pass $i rc=$? $(date +%T)"
   done
   python - "$TAG" <<'PY'
 import csv, glob, sys, collections
