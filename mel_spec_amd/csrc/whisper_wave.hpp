@@ -239,8 +239,8 @@ MS_DEV void wave_phase3i_finish(int fl, int j12, bool active, int n_mels, const 
 // f32 FFT leaves the strongest line's rounding noise in every bin, so a band within kGuardBand decades of the clamp can be
 // off by more than 1e-4 after log10 (measured with tools/flag_calib.py on tones / chirps / speech over noise floors and five
 // filterbanks: bands >= 2 decades above the clamp stay under 3.9e-5, bands at the clamp reach 4.9e-4).  The function
-// returns true on lanes that hold such a band; the kernel then queues the frame for the f64 recompute
-// (whisper400_fixup_kernel).  Bands exactly at the clamp count too: whether a band is clamped is decided by the same noisy
+// returns true on lanes that hold such a band; the kernel then notes the unit and recomputes the frame in f64 after its run
+// (whisper_fix64.hpp).  Bands exactly at the clamp count too: whether a band is clamped is decided by the same noisy
 // value.  A silent frame (every band at the 1e-10 floor, nothing within 8 decades below) is never queued.
 constexpr float kGuardBand = 2.0f;
 

@@ -6,8 +6,9 @@
 // per-frame clamp at max-8 lets mel bands 80 dB under the frame maximum through, and for a strong
 // line over broadband content ~70 dB down the f32 FFT's rounding noise puts the bands next to the clamp
 // up to 4.9e-4 off (tools/flag_calib.py).  This build holds ~1e-6 on everything at about 60 % of the
-// throughput.  It runs in two roles: on every frame of a context in MELSPEC_PRECISION_F64, and -- the
-// default, MELSPEC_PRECISION_AUTO -- on just the frames the f32 kernels queue (whisper400_fixup_kernel).
+// throughput.  It runs on every frame of a context in MELSPEC_PRECISION_F64 (and its phases 1-2 are the STFT export,
+// whisper400_stft_kernel); the default, MELSPEC_PRECISION_AUTO, recomputes just the frames the f32 kernels' guard trips with the
+// wave-cooperative form of whisper_fix64.hpp, inside those kernels.
 #pragma once
 #include "whisper_wave.hpp"
 
