@@ -395,7 +395,7 @@ def main() -> None:
                        "clips_per_gpu": n_clips, "frames_per_step_per_gpu": frames_per_step,
                        "sub_shards_per_step": sub,
                        "precision": f"melspec_set_precision({args.precision}): " + (
-                           "f32 FFT, frames failing the error bound recomputed in f64 by a second launch inside the step" if args.precision == "auto" else
+                           "f32 FFT, frames failing the error bound recomputed in f64 inside the same launch" if args.precision == "auto" else
                            ("f64 FFT on every frame" if args.precision == "f64" else "f32 FFT, no guard")),
                        "frames_recomputed_in_f64_per_step": queued,
                        "parallelism": f"per-clip split x{world}, no data-path collective"},
