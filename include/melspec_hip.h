@@ -128,6 +128,15 @@ int melspec_stft_ragged_device(melspec_ctx *ctx, const float *d_pcm, const uint6
 int melspec_stft_host(melspec_ctx *ctx, const float *samples, size_t n_samples, void *out, size_t out_capacity_complex,
                       int dtype, int full, size_t *n_frames);
 
+/* ---- the mel stage on its own: MelSpectrogram::add(&fft) (src/mel.rs:13-32) ---------------------------------------------
+ * For callers that hold complex STFT frames -- melspec_stft_*'s, or their own (the reference's split API: Spectrogram::add then
+ * MelSpectrogram::add): per frame project_stft_log10 (src/mel.rs:148-168: |X[bin]|^2 through the sparse Slaney bank, bins >= n_fft/2
+ * contribute nothing, log10(max(E, 1e-10))) and norm_mel_slice_f64 (src/mel.rs:645-654), in f64 like the reference; [frame][n_mels]
+ * f32 out.  spec = [frame][bins] interleaved (re, im), dtype / full as in the STFT export (full: n_fft complex per frame, else
+ * n_fft/2 + 1). */
+int melspec_mel_from_stft_device(melspec_ctx *ctx, const void *d_spec, int dtype, int full, uint64_t n_frames, float *d_out, void *stream);
+int melspec_mel_from_stft_host(melspec_ctx *ctx, const void *spec, int dtype, int full, size_t n_frames, float *out, size_t out_capacity_floats);
+
 /* The context's scratch only grows (pipeline buffers sized by the largest chunk, the precision guard's queue of 4 B per frame of
  * the largest batch, ragged plans): this waits for the context's queued work and gives all of it back.  The next call re-allocates. */
 int melspec_release_scratch(melspec_ctx *ctx);

@@ -114,6 +114,18 @@ public:
         for (std::size_t f = 0; f < got; ++f) out[f].assign(flat.begin() + f * bins * 2, flat.begin() + (f + 1) * bins * 2);
         return out;
     }
+    // MelSpectrogram::add(&fft) (src/mel.rs:13-32) for every frame of compute_all's output (or any [frame][fft_size] (re, im) doubles)
+    std::vector<std::vector<float>> mel_from_stft(const std::vector<std::vector<double>> &frames) {
+        const std::size_t nm = static_cast<std::size_t>(melspec_n_mels(ctx_)), bins = melspec_stft_bins(ctx_, 1);
+        std::vector<double> flat;
+        flat.reserve(frames.size() * bins * 2);
+        for (const auto &f : frames) flat.insert(flat.end(), f.begin(), f.end());
+        std::vector<float> out(frames.size() * nm + 1);
+        detail::check(melspec_mel_from_stft_host(ctx_, flat.data(), MELSPEC_STFT_F64, 1, frames.size(), out.data(), out.size()), false);
+        std::vector<std::vector<float>> res(frames.size());
+        for (std::size_t f = 0; f < frames.size(); ++f) res[f].assign(out.begin() + f * nm, out.begin() + (f + 1) * nm);
+        return res;
+    }
     melspec_ctx *raw() { return ctx_; }
 
 private:

@@ -63,6 +63,8 @@ SIGNATURES = {
     "melspec_is_precise": (C.c_int, [_vp]),
     "melspec_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_compute_batch_host": (C.c_int, [_vp, _f32p, _u64p, _u64p, C.c_uint32, _f32p, _u64p, C.c_size_t, _u64p]),
+    "melspec_mel_from_stft_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),
+    "melspec_mel_from_stft_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _f32p, C.c_size_t]),
     "melspec_release_scratch": (C.c_int, [_vp]),
     "melspec_stft_bins": (C.c_size_t, [_vp, C.c_int]),
     "melspec_stft_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _vp]),

@@ -475,6 +475,9 @@ struct melspec_ctx {
     FixState fix;
     // generic path
     GenericTables gt;
+    // the mel stage on its own (melspec_mel_from_stft_*): the banded filterbank in f64, built on first use
+    DevBuf st_start, st_len, st_off, st_w;
+    bool stage_built = false;
     // scratch
     RaggedScratch ragged;
     DevicePlan dplan;
@@ -761,6 +764,7 @@ void melspec_destroy(melspec_ctx *c) {
     c->fix.release();
     c->dplan.release();
     c->pipe.release();
+    c->st_start.release(); c->st_len.release(); c->st_off.release(); c->st_w.release();
     delete c;
 }
 
@@ -999,6 +1003,70 @@ int melspec_compute_batch_host(melspec_ctx *c, const float *samples, const uint6
     if (total == 0) return MELSPEC_OK;
     HIP_TRY(hipSetDevice(c->dev.device));
     return run_host_pipe(c, segs);
+}
+
+// ---- the mel stage on its own: MelSpectrogram::add(&fft) (src/mel.rs:13-32) over complex STFT frames --------------------------
+namespace {
+int stage_tables(melspec_ctx *c) {
+    if (c->stage_built) return MELSPEC_OK;
+    const int bins = c->fft_size / 2 + 1;
+    const std::vector<double> dense = mel_filterbank(c->sr, c->fft_size, c->n_mels, -1.0, -1.0, false, true);
+    const BandedFilterbank fb = band_filterbank(dense, c->n_mels, bins, c->fft_size / 2);      // bins >= n_fft/2 contribute nothing (src/mel.rs:155-163)
+    int rc;
+    if ((rc = upload(c->st_start, fb.start))) return rc;
+    if ((rc = upload(c->st_len, fb.len))) return rc;
+    if ((rc = upload(c->st_off, fb.offset))) return rc;
+    if ((rc = upload(c->st_w, fb.w))) return rc;
+    c->stage_built = true;
+    return MELSPEC_OK;
+}
+}  // namespace
+
+int melspec_mel_from_stft_device(melspec_ctx *c, const void *d_spec, int dtype, int full, uint64_t n_frames, float *d_out, void *stream) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_frames == 0) return MELSPEC_OK;
+    if (!d_spec || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    int rc = stage_tables(c);
+    if (rc) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    MelStageParams p{};
+    p.spec = d_spec; p.out = d_out; p.n_frames = n_frames;
+    p.stride = static_cast<uint32_t>(full ? c->fft_size : c->fft_size / 2 + 1);
+    p.bin_limit = c->fft_size / 2; p.n_mels = c->n_mels;
+    p.d_mstart = static_cast<const int *>(c->st_start.p); p.d_mlen = static_cast<const int *>(c->st_len.p);
+    p.d_moff = static_cast<const int *>(c->st_off.p); p.d_mw = static_cast<const double *>(c->st_w.p);
+    constexpr int kWaves = 4;
+    const size_t lds = static_cast<size_t>(kWaves) * (p.bin_limit + p.n_mels) * sizeof(double);
+    if (lds > 64 * 1024) return fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than the mel stage kernel has");
+    const unsigned grid = grid_for((n_frames + kWaves - 1) / kWaves, c->dev.cus, 16);
+    if (dtype == MELSPEC_STFT_F64) hipLaunchKernelGGL((mel_stage_kernel<double, kWaves>), dim3(grid), dim3(kWaves * 64), lds, s, p);
+    else hipLaunchKernelGGL((mel_stage_kernel<float, kWaves>), dim3(grid), dim3(kWaves * 64), lds, s, p);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int melspec_mel_from_stft_host(melspec_ctx *c, const void *spec, int dtype, int full, size_t n_frames, float *out, size_t out_capacity_floats) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_frames == 0) return MELSPEC_OK;
+    if (!spec || !out) return fail(MELSPEC_ERR_INVALID_ARG, "spec/out is NULL");
+    const size_t need = n_frames * static_cast<size_t>(c->n_mels);
+    if (out_capacity_floats < need) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    const size_t in_bytes = n_frames * static_cast<size_t>(full ? c->fft_size : c->fft_size / 2 + 1) * 2 * (dtype == MELSPEC_STFT_F64 ? sizeof(double) : sizeof(float));
+    void *d_in = nullptr, *d_o = nullptr;
+    HIP_TRY(hipMalloc(&d_in, in_bytes));
+    hipError_t e = hipMalloc(&d_o, need * sizeof(float));
+    if (e != hipSuccess) { (void)hipFree(d_in); return fail_hip(e, "hipMalloc"); }
+    int rc = MELSPEC_OK;
+    if ((e = hipMemcpyAsync(d_in, spec, in_bytes, hipMemcpyHostToDevice, c->stream)) != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync");
+    if (!rc) rc = melspec_mel_from_stft_device(c, d_in, dtype, full, n_frames, static_cast<float *>(d_o), c->stream);
+    if (!rc && (e = hipMemcpyAsync(out, d_o, need * sizeof(float), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) rc = fail_hip(e, "hipMemcpyAsync");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess && !rc) rc = fail_hip(e, "hipStreamSynchronize");
+    (void)hipFree(d_in); (void)hipFree(d_o);
+    return rc;
 }
 
 // ---- STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) / Spectrogram::add (src/stft.rs:48-86) -----------------

@@ -1732,6 +1732,63 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(c
 }
 
 // ------------------------------------------------------------------------------------
+// The mel stage on its own: MelSpectrogram::add(&fft) (src/mel.rs:13-32) = SparseMelFilterbank::project_stft_log10
+// (src/mel.rs:148-168) + norm_mel_slice_f64 (src/mel.rs:645-654) for callers that hold complex STFT frames (their own, or
+// melspec_stft_*'s): E[m] = sum over the row's contiguous bins of w * |X[bin]|^2 in ascending bin order (bins >= n_fft/2
+// contribute nothing), log10(max(E, 1e-10)), max - 8 clamp, (x + 4) / 4 -- the reference's f64 arithmetic step by step.
+// One frame per 64-thread wave of a workgroup; spectra as interleaved (re, im) of float or double, `stride` complex per frame.
+// ------------------------------------------------------------------------------------
+struct MelStageParams {
+    const void *spec;
+    float *out;
+    uint64_t n_frames;
+    uint32_t stride;        // complex elements per frame (n_fft/2 + 1 or n_fft)
+    int bin_limit;          // n_fft / 2
+    int n_mels;
+    const int *d_mstart, *d_mlen, *d_moff;
+    const double *d_mw;
+};
+
+template <class T, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void mel_stage_kernel(const MelStageParams p) {
+    extern __shared__ __attribute__((aligned(16))) double stage_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double *pw = stage_lds + (size_t)wave * (p.bin_limit + p.n_mels);      // [bin_limit] powers, [n_mels] log values
+    double *lv = pw + p.bin_limit;
+    for (uint64_t f = (uint64_t)blockIdx.x * WAVES + wave; f < p.n_frames; f += (uint64_t)gridDim.x * WAVES) {
+        const T *x = static_cast<const T *>(p.spec) + 2 * f * p.stride;
+        for (int k = lane; k < p.bin_limit; k += 64) {
+            const double re = static_cast<double>(x[2 * k]), im = static_cast<double>(x[2 * k + 1]);
+            pw[k] = re * re + im * im;                                   // norm_sqr, src/mel.rs:159
+        }
+        __builtin_amdgcn_wave_barrier();
+        double mx = -1.0e300;
+        for (int m = lane; m < p.n_mels; m += 64) {
+            const int st = p.d_mstart[m], len = p.d_mlen[m];
+            const double *w = p.d_mw + p.d_moff[m];
+            double e = 0.0;
+            for (int i = 0; i < len; ++i) e += w[i] * pw[st + i];        // ascending bins, src/mel.rs:155-163
+            const double v = log10(e > 1e-10 ? e : 1e-10);               // src/mel.rs:166
+            lv[m] = v;
+            mx = v > mx ? v : mx;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double other = __shfl_xor(mx, o);
+            mx = other > mx ? other : mx;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double lo = mx - 8.0;                                      // src/mel.rs:645-654
+        float *o = p.out + f * (uint64_t)p.n_mels;
+        for (int m = lane; m < p.n_mels; m += 64) {
+            const double v = lv[m];
+            o[m] = static_cast<float>(((v > lo ? v : lo) + 4.0) / 4.0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Generic kernel: any n_fft / hop / n_mels, Whisper or Kaldi-fbank flavour, one frame per
 // workgroup iteration, direct DFT in f64 from an LDS twiddle table.  It follows the
 // reference's f64 arithmetic step by step (src/stft.rs:119-138, src/fbank.rs:160-222) and

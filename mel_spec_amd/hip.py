@@ -198,6 +198,22 @@ class HipMelSpectrogram:
         assert got.value == nf
         return out
 
+    def mel_from_stft(self, spec) -> np.ndarray:
+        """MelSpectrogram::add(&fft) for every frame of `spec` ([frames][n_fft] or [frames][n_fft/2 + 1] complex64 / complex128, e.g. what
+        compute_all returns): project_stft_log10 + norm_mel in f64 on the GPU (melspec_mel_from_stft_host) -> [frames][n_mels] f32."""
+        a = np.ascontiguousarray(spec)
+        if a.dtype not in (np.dtype(np.complex64), np.dtype(np.complex128)):
+            a = a.astype(np.complex128)
+        assert a.ndim == 2 and a.shape[1] in (self.stft_bins(True), self.stft_bins(False)), a.shape
+        full = a.shape[1] == self.stft_bins(True)
+        out = np.empty((a.shape[0], self.n_mels), np.float32)
+        _check(lib().melspec_mel_from_stft_host(self._h, a.ctypes.data_as(C.c_void_p), int(a.dtype == np.dtype(np.complex128)), int(full), a.shape[0],
+                                                _fp(out.reshape(-1)), out.size))
+        return out
+
+    def mel_from_stft_device(self, d_spec: int, n_frames: int, d_out: int, f64: bool = False, full: bool = False, stream: int = 0) -> None:
+        _check(lib().melspec_mel_from_stft_device(self._h, C.c_void_p(d_spec), int(f64), int(full), n_frames, C.c_void_p(d_out), C.c_void_p(stream)))
+
     def stft_uniform_device(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int, f64: bool = False, full: bool = False,
                             stream: int = 0) -> None:
         _check(lib().melspec_stft_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips, C.c_void_p(d_out), int(f64), int(full),

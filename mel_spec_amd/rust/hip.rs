@@ -55,6 +55,7 @@ unsafe extern "C" {
     fn melspec_compute_batch_host(ctx: *mut Ctx, samples: *const f32, offsets: *const u64, lengths: *const u64, n_clips: u32,
                                   out: *mut f32, out_offsets: *const u64, cap: usize, total_frames: *mut u64) -> c_int;
     fn melspec_stft_bins(ctx: *const Ctx, full: c_int) -> usize;
+    fn melspec_mel_from_stft_host(ctx: *mut Ctx, spec: *const c_void, dtype: c_int, full: c_int, n_frames: usize, out: *mut f32, cap: usize) -> c_int;
     fn melspec_stft_host(ctx: *mut Ctx, samples: *const f32, n: usize, out: *mut c_void, cap: usize, dtype: c_int, full: c_int,
                          frames: *mut usize) -> c_int;
     // Fbank (src/fbank.rs:85-247)
@@ -224,6 +225,30 @@ impl HipMelSpectrogram {
     }
 
     /// f64 window/FFT/power like `Spectrogram::compute_mel_spectrogram_cpu` and the CUDA backend's Z2Z FFT.
+    /// `MelSpectrogram::add(&fft)` (src/mel.rs:13-32) for every frame of `frames` -- the reference's split API: the complex frames of
+    /// `compute_all` / `Spectrogram::add` (n_fft bins each) -> `[frame][n_mels]`.
+    pub fn mel_from_stft(&mut self, frames: &[Vec<num::Complex<f64>>]) -> Result<Vec<Vec<f32>>, HipError> {
+        if frames.is_empty() {
+            return Ok(Vec::new());
+        }
+        let bins = frames[0].len();
+        let full = unsafe { melspec_stft_bins(self.ctx, 1) } == bins;
+        let mut flat = Vec::with_capacity(frames.len() * bins * 2);
+        for f in frames {
+            for c in f {
+                flat.push(c.re);
+                flat.push(c.im);
+            }
+        }
+        let mut out = vec![0.0f32; frames.len() * self.n_mels];
+        let rc = unsafe {
+            melspec_mel_from_stft_host(self.ctx, flat.as_ptr() as *const c_void, 1, full as c_int, frames.len(), out.as_mut_ptr(), out.len())
+        };
+        if rc != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        Ok(out.chunks(self.n_mels).map(|r| r.to_vec()).collect())
+    }
     pub fn set_precise(&mut self, on: bool) -> Result<(), HipError> {
         match unsafe { melspec_set_precise(self.ctx, on as c_int) } {
             0 => Ok(()),

@@ -52,6 +52,17 @@ int main() {
         }
     std::printf("max delta %.3g mean delta %.3g\n", max_delta, sum / (98 * 80));
     if (!(max_delta <= 1e-4f)) { std::puts("FAIL: tolerance"); return 1; }
+    {
+        // the reference's split API: compute_all's frames through MelSpectrogram::add == the fused pipeline
+        melspec::HipMelSpectrogram hip2(400, 160, sr, 80);
+        const auto spec = hip2.compute_all(samples);
+        const auto staged = hip2.mel_from_stft(spec);
+        float md = 0.0f;
+        for (size_t f = 0; f < 98; ++f)
+            for (size_t m = 0; m < 80; ++m) md = std::fmax(md, std::fabs(staged[f][m] - cpu[f * 80 + m]));
+        std::printf("mel stage on STFT frames: max delta %.3g\n", md);
+        if (staged.size() != 98 || !(md <= 2e-6f)) { std::puts("FAIL: mel_from_stft"); return 1; }
+    }
     melspec::Fbank fb;
     const melspec::Array2f feats = fb.compute(std::vector<float>(16000, 0.0f));
     if (feats.cols != 80 || feats.rows != 98) { std::puts("FAIL: fbank shape"); return 1; }

@@ -906,6 +906,34 @@ def test_nemo_ragged_normaliser_long_rows(gpu, oracle, jfk):
     fe.close()
 
 
+@pytest.mark.parametrize("geom", [(400, 160, 80), (400, 160, 128), (512, 160, 80), (256, 64, 40)])
+def test_mel_stage_on_stft_frames(gpu, oracle, jfk, geom):
+    """The reference's split API: Spectrogram::add gives complex frames, MelSpectrogram::add(&fft) (src/mel.rs:13-32) turns each into a
+    mel column.  melspec_mel_from_stft_* on the frames of the STFT export (both layouts, f64 and f32 spectra, host and device) against
+    the oracle's fused pipeline."""
+    n_fft, hop, n_mels = geom
+    m = gpu.HipMelSpectrogram(n_fft, hop, 16000.0, n_mels)
+    for x in (jfk[3000:40000], oracle.synth_pcm(5, 9000), np.zeros(2000, np.float32)):
+        want = oracle.compute_mel_spectrogram_cpu(x, n_fft, hop, n_mels)
+        for full in (True, False):
+            spec = m.compute_all(x, np.complex128, full)
+            assert np.abs(m.mel_from_stft(spec) - want).max() <= 2e-6
+            assert np.abs(m.mel_from_stft(spec.astype(np.complex64)) - want).max() <= TOL
+    # device resident: STFT export straight into the mel stage
+    x = oracle.synth_pcm(2, 16000)
+    nf, bins = m.num_frames(len(x)), m.stft_bins(False)
+    din, dspec, dout = gpu.DeviceBuffer(len(x) * 4), gpu.DeviceBuffer(nf * bins * 16), gpu.DeviceBuffer(nf * n_mels * 4)
+    din.upload(x)
+    m.stft_uniform_device(din.ptr, len(x), len(x), 1, dspec.ptr, f64=True, full=False)
+    m.mel_from_stft_device(dspec.ptr, nf, dout.ptr, f64=True, full=False)
+    m.synchronize()
+    assert np.abs(dout.download((nf, n_mels)) - oracle.compute_mel_spectrogram_cpu(x, n_fft, hop, n_mels)).max() <= 2e-6
+    assert m.mel_from_stft(np.zeros((0, bins), np.complex128)).shape == (0, n_mels)
+    for b in (din, dspec, dout):
+        b.free()
+    m.close()
+
+
 def test_fbank_and_nemo_batch_host(gpu, oracle, jfk):
     """melspec_fbank_compute_batch_host / melspec_blm_compute_batch_host: many host clips of different lengths in one call through the
     chunked host pipeline, equal to the one-clip host calls; explicit output offsets; clips without a frame; capacity errors."""
