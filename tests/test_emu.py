@@ -371,3 +371,36 @@ def test_in_kernel_f64_recompute_is_f64_accurate(emu, oracle, jfk, n_mels, six):
         assert emu.lib.emu_fix_frame(x.ctypes.data_as(f32p), n_mels, 16000.0, six, out.ctypes.data_as(f32p)) == 0
         want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, n_mels)[0]
         assert np.abs(out - want).max() <= 2e-6
+
+
+def _clip_kernel_cmn(x_no_cmn: np.ndarray, waves: int = 8, fpw: int = 4) -> np.ndarray:
+    """The column means of fbank512_clip_kernel, in its order, in f32: a wave owns a contiguous eighth of the clip's units of four
+    frames and keeps one running sum per frame position; positions (0+1)+(2+3); waves ((0+1)+(2+3))+((4+5)+(6+7)); one division."""
+    frames, nm = x_no_cmn.shape
+    units = (frames + fpw - 1) // fpw
+    part = np.zeros((waves, nm), np.float32)
+    for w in range(waves):
+        acc = np.zeros((fpw, nm), np.float32)
+        for u in range(units * w // waves, units * (w + 1) // waves):
+            for fl in range(fpw):
+                f = u * fpw + fl
+                if f < frames:
+                    acc[fl] = acc[fl] + x_no_cmn[f]
+        part[w] = (acc[0] + acc[1]) + (acc[2] + acc[3])
+    s = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]))
+    return x_no_cmn - (s / np.float32(frames)).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [160000, 11357, 400, 4000])
+def test_clip_kernel_column_sums_stay_inside_the_tolerance(oracle, jfk, n):
+    """fbank512_clip_kernel does not fold the CMN's column sums in the reference's order (src/fbank.rs:224-233: ndarray's mean() of a
+    strided column, an f32 left fold over the frames) but as a fixed tree.  The tree in f32 on the oracle's un-normalised features
+    against the oracle's own CMN: far inside 1e-4 (the reference's fold itself carries ~1e-5 of rounding at 1000 frames)."""
+    oc = oracle.fbank_default_config(); oc.apply_cmn = 0
+    for x in (jfk[:n], oracle.synth_pcm(3, n)):
+        raw = oracle.fbank_compute(x, oc)
+        want = oracle.fbank_compute(x)
+        got = _clip_kernel_cmn(raw)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 5e-5
+        assert np.abs(got.mean(axis=0)).max() < 1e-4
