@@ -404,3 +404,53 @@ def test_clip_kernel_column_sums_stay_inside_the_tolerance(oracle, jfk, n):
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 5e-5
         assert np.abs(got.mean(axis=0)).max() < 1e-4
+
+
+def _blm_normalise_like_the_kernel(rows: np.ndarray, valid: int, pp: int = 28) -> np.ndarray:
+    """blm_normalize_kernel's arithmetic in f32: the mean as a left fold (the reference's order), the variance as `pp` strided partial
+    sums per row with four accumulators each, added in order, one reciprocal per row."""
+    out = rows.copy()
+    for r in range(rows.shape[0]):
+        v = rows[r, :valid].astype(np.float32)
+        s = np.float32(0.0)
+        for x in v:
+            s = np.float32(s + x)
+        mean = np.float32(s / np.float32(valid))
+        parts = np.zeros(pp, np.float32)
+        for pt in range(pp):
+            a = [np.float32(0.0)] * 4
+            idx = list(range(pt, valid, pp))
+            full = (len(idx) // 4) * 4
+            for i in range(0, full, 4):
+                for k in range(4):
+                    c = np.float32(v[idx[i + k]] - mean)
+                    a[k] = np.float32(a[k] + np.float32(c * c))
+            for i in range(full, len(idx)):
+                c = np.float32(v[idx[i]] - mean)
+                a[0] = np.float32(a[0] + np.float32(c * c))
+            parts[pt] = np.float32(np.float32(a[0] + a[1]) + np.float32(a[2] + a[3]))
+        q = [np.float32(0.0)] * 4
+        full = (pp // 4) * 4
+        for i in range(0, full, 4):
+            for k in range(4):
+                q[k] = np.float32(q[k] + parts[i + k])
+        for i in range(full, pp):
+            q[0] = np.float32(q[0] + parts[i])
+        qq = np.float32(np.float32(q[0] + q[1]) + np.float32(q[2] + q[3]))
+        denom = np.float32(max(valid - 1, 1))
+        rsd = np.float32(1.0) / np.float32(np.sqrt(np.float32(qq / denom)) + np.float32(1e-5))
+        out[r, :valid] = ((v - mean) * rsd).astype(np.float32)
+    return out
+
+
+def test_nemo_normaliser_order_stays_inside_the_tolerance(oracle, jfk):
+    """The per-feature normaliser keeps the reference's left fold for the mean (src/mel.rs:721-749) and takes the variance as a fixed tree
+    and the division as a multiplication by the reciprocal: restated in f32 on the oracle's un-normalised features against the oracle's
+    literal normaliser."""
+    kw = dict(n_mels=80, preemphasis=0.97)
+    x = jfk[5000:5000 + 48000]
+    raw, valid = oracle.blm_compute(x, oracle.blm_default_config(**kw), False)
+    want, _ = oracle.blm_compute(x, oracle.blm_default_config(normalize_per_feature=True, **kw), False)
+    got = _blm_normalise_like_the_kernel(np.asarray(raw, np.float32), int(valid))
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 2e-5
