@@ -142,7 +142,7 @@ int upload(DevBuf &buf, const std::vector<T> &v) {
 // Tables of the generic (f64 DFT) kernel.
 struct GenericTables {
     DevBuf win, tw, mstart, mlen, moff, mw;
-    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0;
+    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0;
     size_t lds_bytes = 0;
     int build(int n_fft_, int frame_len_, int n_bins_, const std::vector<double> &window,
               const std::vector<double> &dense, int n_mels_, int dense_bins) {
@@ -161,7 +161,12 @@ struct GenericTables {
         if ((rc = upload(mlen, fb.len))) return rc;
         if ((rc = upload(moff, fb.offset))) return rc;
         if ((rc = upload(mw, fb.w))) return rc;
-        lds_bytes = sizeof(double) * (2 * static_cast<size_t>(n_fft) + frame_len + n_bins + n_mels + kGenericNT);
+        // power-of-two transforms run as an in-LDS FFT over n_fft/2 complex points (the frame slot then holds n_fft doubles)
+        fft_log2 = 0;
+        if (n_fft >= 8 && (n_fft & (n_fft - 1)) == 0 && frame_len <= n_fft) {
+            while ((1 << fft_log2) < n_fft) ++fft_log2;
+        }
+        lds_bytes = sizeof(double) * (2 * static_cast<size_t>(n_fft) + (fft_log2 ? n_fft : frame_len) + n_bins + n_mels + kGenericNT);
         return MELSPEC_OK;
     }
     void release() { win.release(); tw.release(); mstart.release(); mlen.release(); moff.release(); mw.release(); }
@@ -370,6 +375,8 @@ int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int 
     gp.n_fft = gt.n_fft; gp.frame_len = gt.frame_len; gp.hop = hop; gp.n_bins = gt.n_bins; gp.n_mels = gt.n_mels;
     gp.fbank = flavour; gp.use_log = use_log; gp.use_power = use_power; gp.preemph = preemph; gp.floor_v = floor_v;
     gp.clip_len = clip_len; gp.pad = pad;
+    static const bool generic_fft = lab_int("MELSPEC_GENERIC_FFT", 1, 0, 1) != 0;
+    gp.fft_log2 = generic_fft ? gt.fft_log2 : 0;
     gp.d_win = static_cast<const double *>(gt.win.p);
     gp.d_tw = static_cast<const double *>(gt.tw.p);
     gp.d_mstart = static_cast<const int *>(gt.mstart.p);

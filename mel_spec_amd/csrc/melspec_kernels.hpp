@@ -1807,6 +1807,7 @@ struct GenericParams {
     double preemph, floor_v;   // NeMo: preemph = the f32 coefficient, floor_v = log_zero_guard
     long long clip_len;    // NeMo (uniform batches): samples per clip
     int pad;               // NeMo: n_fft / 2 when centred (zero padding either side, src/mel.rs:685-694), else 0
+    int fft_log2;          // log2(n_fft) when n_fft is a power of two >= 8: the transform is an in-LDS radix-2 FFT; 0: direct DFT
     const double *d_win;   // [frame_len]
     const double *d_tw;    // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
     const int *d_mstart;   // [n_mels]
@@ -1836,8 +1837,16 @@ template <int NT>
 __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p) {
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     double *tw = ldsd;                       // 2*n_fft
-    double *xw = tw + 2 * p.n_fft;           // frame_len
-    double *pw = xw + p.frame_len;           // n_bins
+    double *xw = tw + 2 * p.n_fft;           // frame_len (direct DFT) or n_fft (FFT: n_fft/2 complex points, bit-reversed)
+    double *pw = xw + (p.fft_log2 ? p.n_fft : p.frame_len);           // n_bins
+    // FFT form (power-of-two n_fft): the real frame as n_fft/2 complex points z[n] = x[2n] + i x[2n+1], stored at the bit-reversed
+    // index for the in-place decimation-in-time passes below; sample i goes to slot(i)
+    const int mbits = p.fft_log2 - 1;
+    auto slot = [&](int i) -> int {
+        if (!p.fft_log2) return i;
+        const unsigned r = mbits > 0 ? (__brev(static_cast<unsigned>(i >> 1)) >> (32 - mbits)) : 0u;
+        return static_cast<int>(2 * r) + (i & 1);
+    };
     double *mv = pw + p.n_bins;              // n_mels
     double *red = mv + p.n_mels;             // NT
     const int tid = threadIdx.x;
@@ -1857,7 +1866,7 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
         __syncthreads();
         if (!p.fbank) {
             // frame_windows: x[start+i] as f64 * window[i]   (src/stft.rs:160-165)
-            for (int i = tid; i < p.frame_len; i += NT) xw[i] = (double)x[i] * p.d_win[i];
+            for (int i = tid; i < p.frame_len; i += NT) xw[slot(i)] = (double)x[i] * p.d_win[i];
         } else if (p.fbank == 2) {
             // whole-clip pre-emphasis in f32 with the reference's two roundings (src/mel.rs:696-706), zero centre padding, window
             const float coeff = (float)p.preemph;
@@ -1868,7 +1877,7 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
                     v = loc.pcm[sidx];
                     if (coeff != 0.0f && sidx > 0) v = v - f32_mul_rn(coeff, loc.pcm[sidx - 1]);
                 }
-                xw[i] = (double)v * p.d_win[i];
+                xw[slot(i)] = (double)v * p.d_win[i];
             }
         } else {
             // DC removal, pre-emphasis, Povey window   (src/fbank.rs:164-190)
@@ -1881,22 +1890,56 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
                     if (i > 0) v -= p.preemph * ((double)x[i - 1] - mean);
                     else if (start > 0) v -= p.preemph * ((double)*(x - 1) - mean);
                 }
-                xw[i] = v * p.d_win[i];
+                xw[slot(i)] = v * p.d_win[i];
             }
         }
-        __syncthreads();
-        for (int k = tid; k < p.n_bins; k += NT) {
-            double re = 0.0, im = 0.0;
-            int idx = 0;
-            for (int n = 0; n < p.frame_len; ++n) {
-                const double c = tw[2 * idx], s = tw[2 * idx + 1];
-                re += xw[n] * c;
-                im += xw[n] * s;
-                idx += k;
-                if (idx >= p.n_fft) idx -= p.n_fft;
+        if (p.fft_log2) {
+            // zero padding up to n_fft (frame_len < n_fft: Kaldi's 400 of 512), then log2(n_fft/2) radix-2 passes over the n_fft/2
+            // complex points and the real-FFT split X[k] = E[k] + W_N^k O[k] -- O(N log N) instead of the O(N^2) direct form below
+            for (int i = p.frame_len + tid; i < p.n_fft; i += NT) xw[slot(i)] = 0.0;
+            const int M = p.n_fft >> 1;
+            for (int len = 2; len <= M; len <<= 1) {
+                __syncthreads();
+                const int half = len >> 1, tstep = p.n_fft / len;
+                for (int b = tid; b < (M >> 1); b += NT) {
+                    const int g = b / half, j = b - g * half;
+                    const int i0 = g * len + j, i1 = i0 + half;
+                    const double c = tw[2 * (j * tstep)], sn = tw[2 * (j * tstep) + 1];     // W_len^j = W_N^{j N / len}
+                    const double ur = xw[2 * i0], ui = xw[2 * i0 + 1];
+                    const double xr = xw[2 * i1], xi = xw[2 * i1 + 1];
+                    const double vr = xr * c - xi * sn, vi = xr * sn + xi * c;
+                    xw[2 * i0] = ur + vr; xw[2 * i0 + 1] = ui + vi;
+                    xw[2 * i1] = ur - vr; xw[2 * i1 + 1] = ui - vi;
+                }
             }
-            const double ns = re * re + im * im;
-            pw[k] = (p.fbank && !p.use_power) ? sqrt(ns) : ns;
+            __syncthreads();
+            for (int k = tid; k < p.n_bins; k += NT) {
+                const int ka = k == M ? 0 : k, kb = (M - k) & (M - 1);        // Z[M] = Z[0]; partner Z[M - k]
+                const double ar = xw[2 * ka], ai = xw[2 * ka + 1];
+                const double br = xw[2 * kb], bi = -xw[2 * kb + 1];           // conj
+                const double er = 0.5 * (ar + br), ei = 0.5 * (ai + bi);     // E = (A + B) / 2
+                const double dr = 0.5 * (ar - br), di = 0.5 * (ai - bi);     // O = -i (A - B) / 2 = (di, -dr)
+                const double c = tw[2 * k], sn = tw[2 * k + 1];
+                const double orr = di, oi = -dr;
+                const double re = er + (orr * c - oi * sn), im = ei + (orr * sn + oi * c);
+                const double ns = re * re + im * im;
+                pw[k] = (p.fbank && !p.use_power) ? sqrt(ns) : ns;
+            }
+        } else {
+            __syncthreads();
+            for (int k = tid; k < p.n_bins; k += NT) {
+                double re = 0.0, im = 0.0;
+                int idx = 0;
+                for (int n = 0; n < p.frame_len; ++n) {
+                    const double c = tw[2 * idx], s = tw[2 * idx + 1];
+                    re += xw[n] * c;
+                    im += xw[n] * s;
+                    idx += k;
+                    if (idx >= p.n_fft) idx -= p.n_fft;
+                }
+                const double ns = re * re + im * im;
+                pw[k] = (p.fbank && !p.use_power) ? sqrt(ns) : ns;
+            }
         }
         __syncthreads();
         double mx = -1.0e300;

@@ -203,7 +203,8 @@ def test_other_geometries_fast_path(gpu, oracle, jfk, hop, n_mels):
     assert np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels, SR)).max() <= TOL
 
 
-@pytest.mark.parametrize("fft,hop,n_mels", [(256, 64, 40), (1024, 256, 80), (400, 160, 200), (100, 50, 20), (400, 160, 1), (400, 160, 5), (400, 160, 132)])
+@pytest.mark.parametrize("fft,hop,n_mels", [(256, 64, 40), (1024, 256, 80), (400, 160, 200), (100, 50, 20), (400, 160, 1), (400, 160, 5), (400, 160, 132),
+                                            (2048, 512, 128), (4096, 1024, 128), (8, 4, 2), (64, 16, 10), (320, 160, 80)])
 def test_other_geometries_generic_path(gpu, oracle, jfk, fft, hop, n_mels):
     m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
     assert not m.uses_fast_path
@@ -397,6 +398,19 @@ def test_fbank_jfk(gpu, oracle, jfk, golden):
     raw = gpu.Fbank(gpu.FbankConfig(apply_cmn=False)).compute(jfk)
     assert np.abs(raw - golden["jfk_fbank_nocmn"]).max() <= TOL
     assert abs(float(raw[0, 0]) - float(np.log(np.float64(np.finfo(np.float32).eps)))) < 1e-4
+
+
+@pytest.mark.parametrize("sr,bins", [(8000.0, 23), (8000.0, 40), (32000.0, 80), (44100.0, 80)])
+def test_fbank_other_sample_rates(gpu, oracle, jfk, sr, bins):
+    """Kaldi fbank off the default geometry (25 ms / 10 ms at 8, 32 and 44.1 kHz: 256-, 1024- and 2048-point transforms) runs on the
+    generic kernel, whose power-of-two transforms are an in-LDS FFT."""
+    fb = gpu.Fbank(gpu.FbankConfig(sample_rate=sr, num_mel_bins=bins))
+    oc = oracle.fbank_default_config()
+    oc.sample_rate = sr; oc.num_mel_bins = bins
+    for x in (jfk[1000:30000], oracle.synth_pcm(4, 12345)):
+        got, want = fb.compute(x), oracle.fbank_compute(x, oc)
+        assert got.shape == want.shape and np.abs(got - want).max() <= TOL
+    fb.close()
 
 
 def test_fbank_generic_kernel_agrees(gpu, oracle, jfk):
