@@ -1111,6 +1111,7 @@ int launch_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipS
     g.n_fft = c->fft_size; g.hop = c->hop_size; g.bins = bins; g.words_per_frame = words; g.f64 = dtype == MELSPEC_STFT_F64;
     g.d_win = static_cast<const double *>(c->gt.win.p);
     g.d_tw = static_cast<const double *>(c->gt.tw.p);
+    g.fft_log2 = c->gt.fft_log2;
     const size_t lds = sizeof(double) * 3 * static_cast<size_t>(c->fft_size);
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {

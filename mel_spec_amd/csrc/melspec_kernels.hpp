@@ -866,6 +866,7 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_stft_kernel(con
 struct GenericStftParams {
     BatchDesc b;             // units == frames
     int n_fft, hop, bins, words_per_frame, f64;
+    int fft_log2;            // log2(n_fft) for a power-of-two n_fft >= 8 (in-LDS FFT as in generic_frame_kernel), else 0 (direct DFT)
     const double *d_win;     // [n_fft]
     const double *d_tw;      // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
 };
@@ -882,17 +883,50 @@ __global__ __launch_bounds__(NT) void generic_stft_kernel(const GenericStftParam
         const UnitLoc loc = locate_unit(p.b, unit);
         const float *x = loc.pcm + loc.unit * (uint64_t)p.hop;
         __syncthreads();
-        for (int i = tid; i < p.n_fft; i += NT) xw[i] = (double)x[i] * p.d_win[i];     // src/stft.rs:160-165
+        const int mbits = p.fft_log2 - 1;
+        for (int i = tid; i < p.n_fft; i += NT) {
+            // FFT form: sample i of the real frame is component (i & 1) of complex point i >> 1, stored bit-reversed
+            const int at = p.fft_log2 ? static_cast<int>(2 * (mbits > 0 ? (__brev(static_cast<unsigned>(i >> 1)) >> (32 - mbits)) : 0u)) + (i & 1) : i;
+            xw[at] = (double)x[i] * p.d_win[i];                                        // src/stft.rs:160-165
+        }
+        const int M = p.n_fft >> 1;
+        if (p.fft_log2) {
+            for (int len = 2; len <= M; len <<= 1) {
+                __syncthreads();
+                const int half = len >> 1, tstep = p.n_fft / len;
+                for (int b = tid; b < (M >> 1); b += NT) {
+                    const int g = b / half, j = b - g * half;
+                    const int i0 = g * len + j, i1 = i0 + half;
+                    const double c = tw[2 * (j * tstep)], sn = tw[2 * (j * tstep) + 1];
+                    const double ur = xw[2 * i0], ui = xw[2 * i0 + 1];
+                    const double xr = xw[2 * i1], xi = xw[2 * i1 + 1];
+                    const double vr = xr * c - xi * sn, vi = xr * sn + xi * c;
+                    xw[2 * i0] = ur + vr; xw[2 * i0 + 1] = ui + vi;
+                    xw[2 * i1] = ur - vr; xw[2 * i1 + 1] = ui - vi;
+                }
+            }
+        }
         __syncthreads();
         float *o = loc.out + loc.unit * (uint64_t)p.words_per_frame;
         for (int k = tid; k <= p.n_fft / 2; k += NT) {
             double re = 0.0, im = 0.0;
-            int idx = 0;
-            for (int n = 0; n < p.n_fft; ++n) {
-                re += xw[n] * tw[2 * idx];
-                im += xw[n] * tw[2 * idx + 1];
-                idx += k;
-                if (idx >= p.n_fft) idx -= p.n_fft;
+            if (p.fft_log2) {
+                const int ka = k == M ? 0 : k, kb = (M - k) & (M - 1);
+                const double ar = xw[2 * ka], ai = xw[2 * ka + 1];
+                const double br = xw[2 * kb], bi = -xw[2 * kb + 1];
+                const double er = 0.5 * (ar + br), ei = 0.5 * (ai + bi);
+                const double orr = 0.5 * (ai - bi), oi = -0.5 * (ar - br);
+                const double c = tw[2 * k], sn = tw[2 * k + 1];
+                re = er + (orr * c - oi * sn);
+                im = ei + (orr * sn + oi * c);
+            } else {
+                int idx = 0;
+                for (int n = 0; n < p.n_fft; ++n) {
+                    re += xw[n] * tw[2 * idx];
+                    im += xw[n] * tw[2 * idx + 1];
+                    idx += k;
+                    if (idx >= p.n_fft) idx -= p.n_fft;
+                }
             }
             const int mk = p.n_fft - k;
             const bool mirror = p.bins == p.n_fft && k > 0 && mk > k;
