@@ -266,6 +266,9 @@ int melspec_fbank_compute_ragged_device_desc(melspec_fbank *fb, const float *d_p
  * chunks through the pinned, double-buffered host pipeline (as melspec_compute_batch_host); pinned samples / out are used in place. */
 int melspec_fbank_compute_batch_host(melspec_fbank *fb, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
                                      float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_frames);
+/* As melspec_release_scratch: waits for the object's own stream and gives its grow-only scratch back (pipeline and staging buffers,
+ * ragged plans); work queued on caller streams must have been synchronised by the caller. */
+int melspec_fbank_release_scratch(melspec_fbank *fb);
 int melspec_fbank_synchronize(melspec_fbank *fb, void *stream);
 
 /* ---- NeMo/Parakeet log-mel frontend: replaces BatchLogMelSpectrogram (src/mel.rs:171-418) ------- */
@@ -313,6 +316,7 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
  * [n_mels][cols_i] at out + out_offsets[i] floats (NULL: packed); *total_columns = sum of cols_i.  Host pipeline as above. */
 int melspec_blm_compute_batch_host(melspec_blm *b, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
                                    float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_columns);
+int melspec_blm_release_scratch(melspec_blm *b);   /* as melspec_fbank_release_scratch */
 int melspec_blm_synchronize(melspec_blm *b, void *stream);
 
 /* ---- streaming: Spectrogram::add + RingBuffer::maybe_mel (src/stft.rs:48-86, src/rb.rs:60-121) ---- */

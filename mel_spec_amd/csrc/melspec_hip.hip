@@ -1635,6 +1635,14 @@ int melspec_fbank_compute_ragged_device_desc(melspec_fbank *fb, const float *d_p
     return fbank_launch(fb, pl, n_clips, max_total_frames, s);
 }
 
+int melspec_fbank_release_scratch(melspec_fbank *fb) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    HIP_TRY(hipStreamSynchronize(fb->stream));
+    fb->pipe.release(); fb->ragged.release(); fb->dplan.release(); fb->h2d.release(); fb->d2h.release();
+    return MELSPEC_OK;
+}
+
 int melspec_fbank_synchronize(melspec_fbank *fb, void *stream) {
     if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
     HIP_TRY(hipSetDevice(fb->dev.device));
@@ -2551,6 +2559,16 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
     }
     plan_ragged_done(slot, s);
     return rc;
+}
+
+int melspec_blm_release_scratch(melspec_blm *b) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->aux_used && b->aux_stream != b->stream) HIP_TRY(hipStreamSynchronize(b->aux_stream));
+    b->pipe.release(); b->ragged.release(); b->aux.release(); b->h2d.release(); b->d2h.release();
+    b->aux_used = false;
+    return MELSPEC_OK;
 }
 
 int melspec_blm_synchronize(melspec_blm *b, void *stream) {

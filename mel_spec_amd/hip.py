@@ -498,6 +498,10 @@ class Fbank:
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_fbank_synchronize(self._h, C.c_void_p(stream)))
 
+    def release_scratch(self) -> None:
+        """give the object's grow-only scratch back (pipeline / staging buffers, ragged plans); the next call re-allocates"""
+        _check(lib().melspec_fbank_release_scratch(self._h))
+
     def compute_batch(self, clips) -> np.ndarray:
         x = _f32(clips)
         n_clips, clip_len = x.shape
@@ -591,6 +595,9 @@ class BatchLogMelSpectrogram:
 
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_blm_synchronize(self._h, C.c_void_p(stream)))
+
+    def release_scratch(self) -> None:
+        _check(lib().melspec_blm_release_scratch(self._h))
 
     def compute_batch_host(self, flat: np.ndarray, offsets, lengths, out: np.ndarray | None = None, out_offsets=None):
         """melspec_blm_compute_batch_host: clip i -> [n_mels, cols_i] floats at out[out_offsets[i]:] (None = packed), whole clips

@@ -972,6 +972,8 @@ def test_fbank_and_nemo_batch_host(gpu, oracle, jfk):
         assert np.all(out[int(oo[i]) + g.size:int(oo[i]) + g.size + 8] == 7.0)
     with pytest.raises(gpu.HipError):
         fb.compute_batch_host(flat, offs, ln, np.empty(100, np.float32))
+    fb.release_scratch()                                   # scratch is given back and re-allocated on demand
+    assert all(np.array_equal(a, b) for a, b in zip(fb.compute_many(clips), got))
     fb.close()
     for kw in (dict(n_mels=80), dict(n_mels=128, preemphasis=0.97, normalize_per_feature=True, pad_to=16)):
         fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(**kw))
@@ -981,6 +983,8 @@ def test_fbank_and_nemo_batch_host(gpu, oracle, jfk):
             assert g.shape == one.shape
             if g.size:
                 assert np.abs(g - one).max() <= (2e-5 if kw.get("normalize_per_feature") else 0.0)
+        fe.release_scratch()
+        assert all(np.array_equal(a, b) for a, b in zip(fe.compute_many(clips), got))
         fe.close()
 
 
