@@ -709,9 +709,10 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
 
-    // fused kernels: n_fft == 400, even hop (8-byte PCM loads), a two-filters-per-bin bank of <= 131 mels
+    // fused kernels: n_fft == 400, any hop up to 1024 (the 8-byte PCM loads only need 4-byte alignment, as every ragged clip offset
+    // already demands), a two-filters-per-bin bank of <= 131 mels
     const bool runtime_lens = lab_int("MELSPEC_RUNTIME_LENS", 0, 0, 1) != 0;
-    c->fast = (fft_size == 400) && (hop_size % 2 == 0) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft, true) &&
+    c->fast = (fft_size == 400) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft, true) &&
               c->ft.interval;
     if (c->fast) {
         c->lens_kind = lens_match<LensI80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensI128>(c->ft.slots, n_mels) ? 2 : 0);

@@ -168,14 +168,18 @@ def test_precise_mode_batch_and_other_geometry(gpu, oracle):
     m.close(); g.close(); w.close()
 
 
-def test_generic_kernel_agrees_with_fused_kernel(gpu, w80, oracle, jfk):
-    """hop=161 is odd, so that geometry takes the f64 generic kernel; on the same frames the two
-    device paths and the oracle must agree."""
-    g = gpu.HipMelSpectrogram(400, 161, SR, 80)
-    assert not g.uses_fast_path
-    x = jfk[30000:60000]
-    got = g.compute_mel_spectrogram(x)
-    assert np.abs(got - oracle.compute_mel_spectrogram_cpu(x, 400, 161, 80, SR)).max() <= 2e-6
+@pytest.mark.parametrize("hop", [161, 1, 37, 399, 1023])
+def test_odd_hops_run_on_the_fused_kernels(gpu, oracle, jfk, hop):
+    """An odd hop puts frames at odd sample offsets; the fused n_fft = 400 kernels' 8-byte loads need 4-byte alignment only (as any
+    ragged clip offset does), so these geometries stay on the fused kernels -- f32 with the guard, and f64 -- and agree with the oracle."""
+    g = gpu.HipMelSpectrogram(400, hop, SR, 80)
+    assert g.uses_fast_path
+    x = jfk[30001:30001 + (60000 if hop > 30 else 3000)]
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, hop, 80, SR)
+    assert np.abs(g.compute_mel_spectrogram(x) - want).max() <= TOL
+    g.set_precision("f64")
+    assert np.abs(g.compute_mel_spectrogram(x) - want).max() <= 2e-6
+    g.close()
 
 
 @pytest.mark.parametrize("n", [0, 1, 399, 400, 559, 560, 400 + 22 * 160, 400 + 23 * 160, 400 + 45 * 160 + 7])

@@ -153,7 +153,7 @@ def test_push_errors_on_the_host():
 @pytest.mark.parametrize("fft,hop,n_mels,max_chunk,seed", [(400, 160, 80, 1000, 1), (400, 160, 128, 160, 2), (400, 128, 40, 517, 3),
                                                            (512, 160, 80, 700, 4), (400, 161, 80, 333, 5)])
 def test_gpu_bank_random_chunks(gpu, oracle, jfk, fft, hop, n_mels, max_chunk, seed):
-    """fused f32 kernel (400/even hop), and the generic f64 kernel (512, odd hop) behind the same bank"""
+    """the fused f32 kernels (n_fft 400, even and odd hop) and the fused f64 kernel (512) behind the same bank"""
     m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
     bank = gpu.StreamBank(m, 7, max_chunk)
     assert _drive(bank, oracle, jfk, hop, n_mels, 7, max_chunk, seed, fft=fft) <= TOL
