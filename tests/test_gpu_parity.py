@@ -657,7 +657,8 @@ def test_seeded_sweep_of_geometries_and_lengths(gpu, oracle, jfk):
             worst[kind] = max(worst.get(kind, 0.0), d)
             assert d <= (TOL if kind == "f32" else 3e-6), (fft, hop, n_mels, sr, n, kind, d)
         m.close()
-    assert set(worst) == {"f32", "f64"}
+    # (MELSPEC_PRECISE=1, how the suite is run a second time with f64 as the initial mode, leaves no f32 context)
+    assert set(worst) == ({"f64"} if os.environ.get("MELSPEC_PRECISE", "")[:1] == "1" else {"f32", "f64"})
 
 
 def test_one_context_per_thread_runs_concurrently(gpu, oracle, jfk):
