@@ -143,6 +143,7 @@ int upload(DevBuf &buf, const std::vector<T> &v) {
 struct GenericTables {
     DevBuf win, tw, mstart, mlen, moff, mw;
     int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0;
+    FftPlan plan{};
     size_t lds_bytes = 0;
     int build(int n_fft_, int frame_len_, int n_bins_, const std::vector<double> &window,
               const std::vector<double> &dense, int n_mels_, int dense_bins) {
@@ -166,7 +167,21 @@ struct GenericTables {
         if (n_fft >= 8 && (n_fft & (n_fft - 1)) == 0 && frame_len <= n_fft) {
             while ((1 << fft_log2) < n_fft) ++fft_log2;
         }
-        lds_bytes = sizeof(double) * (2 * static_cast<size_t>(n_fft) + (fft_log2 ? n_fft : frame_len) + n_bins + n_mels + kGenericNT);
+        // other 2-3-5-smooth sizes (320, 480, 800, 1200 ...; 400 when a geometry is off the fused kernels): mixed-radix passes over
+        // n_fft complex points, two LDS buffers; anything else (a prime factor > 5, or no room) keeps the direct DFT
+        plan = FftPlan{};
+        if (!fft_log2 && n_fft >= 6 && frame_len <= n_fft) {
+            int rest = n_fft, nr = 0, rad[14];
+            for (int f : {4, 2, 3, 5})
+                while (rest % f == 0 && nr < 14) { rad[nr++] = f; rest /= f; }
+            const size_t need = sizeof(double) * (2 * static_cast<size_t>(n_fft) + 4 * static_cast<size_t>(n_fft) + n_bins + n_mels + kGenericNT);
+            if (rest == 1 && need <= kLdsLimit) {
+                plan.n_rad = nr;
+                for (int i = 0; i < nr; ++i) plan.packed |= static_cast<unsigned long long>(rad[i]) << (4 * i);
+            }
+        }
+        lds_bytes = sizeof(double) * (2 * static_cast<size_t>(n_fft) + (plan.n_rad ? 4 * static_cast<size_t>(n_fft) : static_cast<size_t>(fft_log2 ? n_fft : frame_len)) +
+                                      n_bins + n_mels + kGenericNT);
         return MELSPEC_OK;
     }
     void release() { win.release(); tw.release(); mstart.release(); mlen.release(); moff.release(); mw.release(); }
@@ -377,6 +392,7 @@ int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int 
     gp.clip_len = clip_len; gp.pad = pad;
     static const bool generic_fft = lab_int("MELSPEC_GENERIC_FFT", 1, 0, 1) != 0;
     gp.fft_log2 = generic_fft ? gt.fft_log2 : 0;
+    if (generic_fft) gp.plan = gt.plan;
     gp.d_win = static_cast<const double *>(gt.win.p);
     gp.d_tw = static_cast<const double *>(gt.tw.p);
     gp.d_mstart = static_cast<const int *>(gt.mstart.p);
@@ -1113,7 +1129,9 @@ int launch_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipS
     g.d_win = static_cast<const double *>(c->gt.win.p);
     g.d_tw = static_cast<const double *>(c->gt.tw.p);
     g.fft_log2 = c->gt.fft_log2;
-    const size_t lds = sizeof(double) * 3 * static_cast<size_t>(c->fft_size);
+    g.plan = c->gt.plan;
+    const size_t lds = sizeof(double) * (c->gt.plan.n_rad ? 6 : 3) * static_cast<size_t>(c->fft_size);
+    if (lds > kLdsLimit) return fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has");
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&generic_stft_kernel<kGenericNT>, "hipFuncSetAttribute(generic_stft_kernel)");

@@ -863,10 +863,69 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_stft_kernel(con
 
 // The same for any n_fft: one frame per workgroup, direct f64 DFT of bins 0..n_fft/2 from an LDS twiddle table (the
 // arithmetic of generic_frame_kernel below), the upper half mirrored for the full layout.
+// Mixed-radix FFT of n complex points in LDS for the generic kernels (n_fft = 2^a 3^b 5^c that is not a power of two: 320, 400, 480,
+// 800, 1200 ...): Stockham auto-sort passes, one per factor (4, 2, 3 or 5), ping-pong between x and y (2n doubles each), the twiddle
+// table tw[2j] = cos, tw[2j+1] = -sin of 2 pi j / n.  Pass for radix P, current length len, stride st:
+//   y[q + st (P j + r)] = W_len^{j r} * sum_k x[q + st (j + m k)] W_P^{k r},   m = len / P, q < st, j < m.
+// Every thread of the workgroup calls it; returns the buffer that holds the result in natural order.
+struct FftPlan {
+    int n_rad;
+    unsigned long long packed;      // four bits per pass, first pass lowest (an array in the kernel arguments, indexed by the pass, would be
+                                    // copied to scratch)
+};
+template <int NT, int P>
+__device__ __forceinline__ void lds_fft_pass(int n, int len, int st, const double *tw, const double *x, double *y, int tid) {
+    const int m = len / P, wstep = n / len, pstep = n / P;
+    for (int b = tid; b < m * st; b += NT) {
+        const int j = b / st, q = b - j * st;
+        double ar[P], ai[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const int at = q + st * (j + m * k);
+            ar[k] = x[2 * at]; ai[k] = x[2 * at + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            double vr = ar[0], vi = ai[0];
+#pragma unroll
+            for (int k = 1; k < P; ++k) {
+                const int t = ((k * r) % P) * pstep;           // W_P^{k r}
+                const double c = tw[2 * t], sn = tw[2 * t + 1];
+                vr += ar[k] * c - ai[k] * sn;
+                vi += ar[k] * sn + ai[k] * c;
+            }
+            const int t = static_cast<int>((static_cast<long long>(j) * r * wstep) % n);      // W_len^{j r}
+            const double c = tw[2 * t], sn = tw[2 * t + 1];
+            const int to = q + st * (P * j + r);
+            y[2 * to] = vr * c - vi * sn;
+            y[2 * to + 1] = vr * sn + vi * c;
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ double *lds_fft_mixed(const FftPlan &plan, int n, const double *tw, double *x, double *y, int tid) {
+    int len = n, st = 1;
+    for (int pass = 0; pass < plan.n_rad; ++pass) {
+        const int P = static_cast<int>((plan.packed >> (4 * pass)) & 15ull);
+        __syncthreads();
+        switch (P) {
+            case 2: lds_fft_pass<NT, 2>(n, len, st, tw, x, y, tid); break;
+            case 3: lds_fft_pass<NT, 3>(n, len, st, tw, x, y, tid); break;
+            case 4: lds_fft_pass<NT, 4>(n, len, st, tw, x, y, tid); break;
+            default: lds_fft_pass<NT, 5>(n, len, st, tw, x, y, tid); break;
+        }
+        len /= P; st *= P;
+        double *tmp = x; x = y; y = tmp;
+    }
+    __syncthreads();
+    return x;
+}
+
 struct GenericStftParams {
     BatchDesc b;             // units == frames
     int n_fft, hop, bins, words_per_frame, f64;
-    int fft_log2;            // log2(n_fft) for a power-of-two n_fft >= 8 (in-LDS FFT as in generic_frame_kernel), else 0 (direct DFT)
+    int fft_log2;            // log2(n_fft) for a power-of-two n_fft >= 8 (in-LDS FFT as in generic_frame_kernel), else 0
+    FftPlan plan;            // n_rad > 0: mixed-radix FFT (lds_fft_mixed) for 2-3-5-smooth n_fft; both zero: direct DFT
     const double *d_win;     // [n_fft]
     const double *d_tw;      // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
 };
@@ -884,12 +943,17 @@ __global__ __launch_bounds__(NT) void generic_stft_kernel(const GenericStftParam
         const float *x = loc.pcm + loc.unit * (uint64_t)p.hop;
         __syncthreads();
         const int mbits = p.fft_log2 - 1;
+        const bool mixed = p.plan.n_rad > 0;
         for (int i = tid; i < p.n_fft; i += NT) {
-            // FFT form: sample i of the real frame is component (i & 1) of complex point i >> 1, stored bit-reversed
-            const int at = p.fft_log2 ? static_cast<int>(2 * (mbits > 0 ? (__brev(static_cast<unsigned>(i >> 1)) >> (32 - mbits)) : 0u)) + (i & 1) : i;
+            // FFT form: sample i of the real frame is component (i & 1) of complex point i >> 1, stored bit-reversed; mixed-radix
+            // form: complex point i with a zero imaginary part
+            const int at = p.fft_log2 ? static_cast<int>(2 * (mbits > 0 ? (__brev(static_cast<unsigned>(i >> 1)) >> (32 - mbits)) : 0u)) + (i & 1) : (mixed ? 2 * i : i);
             xw[at] = (double)x[i] * p.d_win[i];                                        // src/stft.rs:160-165
+            if (mixed) xw[at + 1] = 0.0;
         }
         const int M = p.n_fft >> 1;
+        const double *res = xw;
+        if (mixed) res = lds_fft_mixed<NT>(p.plan, p.n_fft, tw, xw, xw + 2 * p.n_fft, tid);
         if (p.fft_log2) {
             for (int len = 2; len <= M; len <<= 1) {
                 __syncthreads();
@@ -910,7 +974,9 @@ __global__ __launch_bounds__(NT) void generic_stft_kernel(const GenericStftParam
         float *o = loc.out + loc.unit * (uint64_t)p.words_per_frame;
         for (int k = tid; k <= p.n_fft / 2; k += NT) {
             double re = 0.0, im = 0.0;
-            if (p.fft_log2) {
+            if (mixed) {
+                re = res[2 * k]; im = res[2 * k + 1];
+            } else if (p.fft_log2) {
                 const int ka = k == M ? 0 : k, kb = (M - k) & (M - 1);
                 const double ar = xw[2 * ka], ai = xw[2 * ka + 1];
                 const double br = xw[2 * kb], bi = -xw[2 * kb + 1];
@@ -1841,7 +1907,8 @@ struct GenericParams {
     double preemph, floor_v;   // NeMo: preemph = the f32 coefficient, floor_v = log_zero_guard
     long long clip_len;    // NeMo (uniform batches): samples per clip
     int pad;               // NeMo: n_fft / 2 when centred (zero padding either side, src/mel.rs:685-694), else 0
-    int fft_log2;          // log2(n_fft) when n_fft is a power of two >= 8: the transform is an in-LDS radix-2 FFT; 0: direct DFT
+    int fft_log2;          // log2(n_fft) when n_fft is a power of two >= 8: the transform is an in-LDS radix-2 FFT; 0: not
+    FftPlan plan;          // n_rad > 0: mixed-radix in-LDS FFT (2-3-5-smooth n_fft that is not a power of two); both zero: direct DFT
     const double *d_win;   // [frame_len]
     const double *d_tw;    // [n_fft] interleaved (cos, -sin) of 2*pi*j/n_fft
     const int *d_mstart;   // [n_mels]
@@ -1872,11 +1939,13 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     double *tw = ldsd;                       // 2*n_fft
     double *xw = tw + 2 * p.n_fft;           // frame_len (direct DFT) or n_fft (FFT: n_fft/2 complex points, bit-reversed)
-    double *pw = xw + (p.fft_log2 ? p.n_fft : p.frame_len);           // n_bins
+    const bool mixed = p.plan.n_rad > 0;                              // mixed-radix FFT: xw = two buffers of n_fft complex points
+    double *pw = xw + (mixed ? 4 * p.n_fft : (p.fft_log2 ? p.n_fft : p.frame_len));           // n_bins
     // FFT form (power-of-two n_fft): the real frame as n_fft/2 complex points z[n] = x[2n] + i x[2n+1], stored at the bit-reversed
     // index for the in-place decimation-in-time passes below; sample i goes to slot(i)
     const int mbits = p.fft_log2 - 1;
     auto slot = [&](int i) -> int {
+        if (mixed) return 2 * i;
         if (!p.fft_log2) return i;
         const unsigned r = mbits > 0 ? (__brev(static_cast<unsigned>(i >> 1)) >> (32 - mbits)) : 0u;
         return static_cast<int>(2 * r) + (i & 1);
@@ -1927,7 +1996,19 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
                 xw[slot(i)] = v * p.d_win[i];
             }
         }
-        if (p.fft_log2) {
+        if (mixed) {
+            // imaginary parts and the zero padding, then one Stockham pass per factor of n_fft (lds_fft_mixed)
+            for (int i = tid; i < p.n_fft; i += NT) {
+                xw[2 * i + 1] = 0.0;
+                if (i >= p.frame_len) xw[2 * i] = 0.0;
+            }
+            const double *res = lds_fft_mixed<NT>(p.plan, p.n_fft, tw, xw, xw + 2 * p.n_fft, tid);
+            for (int k = tid; k < p.n_bins; k += NT) {
+                const double re = res[2 * k], im = res[2 * k + 1];
+                const double ns = re * re + im * im;
+                pw[k] = (p.fbank && !p.use_power) ? sqrt(ns) : ns;
+            }
+        } else if (p.fft_log2) {
             // zero padding up to n_fft (frame_len < n_fft: Kaldi's 400 of 512), then log2(n_fft/2) radix-2 passes over the n_fft/2
             // complex points and the real-FFT split X[k] = E[k] + W_N^k O[k] -- O(N log N) instead of the O(N^2) direct form below
             for (int i = p.frame_len + tid; i < p.n_fft; i += NT) xw[slot(i)] = 0.0;

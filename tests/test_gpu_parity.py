@@ -208,7 +208,8 @@ def test_other_geometries_fast_path(gpu, oracle, jfk, hop, n_mels):
 
 
 @pytest.mark.parametrize("fft,hop,n_mels", [(256, 64, 40), (1024, 256, 80), (400, 160, 200), (100, 50, 20), (400, 160, 1), (400, 160, 5), (400, 160, 132),
-                                            (2048, 512, 128), (4096, 1024, 128), (8, 4, 2), (64, 16, 10), (320, 160, 80)])
+                                            (2048, 512, 128), (4096, 1024, 128), (8, 4, 2), (64, 16, 10), (320, 160, 80), (800, 200, 80), (1200, 300, 128),
+                                            (1000, 250, 40), (6, 3, 2), (30, 7, 5), (441, 160, 64), (3000, 750, 80)])
 def test_other_geometries_generic_path(gpu, oracle, jfk, fft, hop, n_mels):
     m = gpu.HipMelSpectrogram(fft, hop, SR, n_mels)
     assert not m.uses_fast_path

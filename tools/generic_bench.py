@@ -11,7 +11,8 @@ from oracle import oracle as O
 n_clips, clip_len = 256, 160000
 pcm = M.DeviceBuffer(n_clips * clip_len * 4)
 M.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips); M.device_synchronize()
-for n_fft, hop, n_mels in ((256, 64, 40), (1024, 256, 80), (2048, 512, 128), (4096, 1024, 128), (320, 160, 80)):
+for n_fft, hop, n_mels in ((256, 64, 40), (1024, 256, 80), (2048, 512, 128), (4096, 1024, 128), (320, 160, 80), (800, 200, 80), (1200, 300, 128), (1000, 250, 80),
+                           (400, 160, 160), (441, 160, 80)):
     m = M.HipMelSpectrogram(n_fft, hop, 16000.0, n_mels)
     nf = m.num_frames(clip_len)
     out = M.DeviceBuffer(n_clips * nf * n_mels * 4)
