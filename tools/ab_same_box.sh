@@ -1,5 +1,9 @@
 #!/bin/bash
-# same-box A/B: previous commit's library (libmelspec_hip_prev.so) against the current one
+# same-box A/B (boxes differ by up to 10 %): a previous commit's library against the current one.  Build the former first:
+#   rm -rf /tmp/prev && mkdir /tmp/prev && git archive <commit> mel_spec_amd/csrc include | tar -x -C /tmp/prev &&
+#   (cd /tmp/prev && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -DMELSPEC_LAB \
+#      -o $REPO/mel_spec_amd/libmelspec_hip_prev.so mel_spec_amd/csrc/melspec_hip.hip)
+# then: gpurun -- tools/ab_same_box.sh
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/probe_g.txt
 : > $O
