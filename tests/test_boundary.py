@@ -77,3 +77,28 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmelspec_hip.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.lib()
+
+
+def test_null_handles_are_rejected_without_a_device():
+    """Every per-object entry point answers a NULL handle with MELSPEC_ERR_INVALID_ARG and a message (no HIP call is made first, so
+    this holds on a box without a GPU): never a crash across the ABI, like the integer status convention of src/cuda.rs:164."""
+    L = _lib.lib()
+    u64 = (C.c_uint64 * 1)(0)
+    f32 = (C.c_float * 4)()
+    tot = C.c_uint64(0)
+    calls = [
+        lambda: L.melspec_compute_batch_host(None, f32, u64, u64, 1, f32, None, 4, C.byref(tot)),
+        lambda: L.melspec_fbank_compute_batch_host(None, f32, u64, u64, 1, f32, None, 4, C.byref(tot)),
+        lambda: L.melspec_blm_compute_batch_host(None, f32, u64, u64, 1, f32, None, 4, C.byref(tot)),
+        lambda: L.melspec_mel_from_stft_host(None, f32, 0, 0, 1, f32, 4),
+        lambda: L.melspec_mel_from_stft_device(None, None, 0, 0, 1, None, None),
+        lambda: L.melspec_fbank_compute_ragged_device(None, None, u64, u64, 1, None, None, None),
+        lambda: L.melspec_blm_compute_ragged_device(None, None, u64, u64, 1, None, None, None),
+        lambda: L.melspec_fbank_release_scratch(None),
+        lambda: L.melspec_blm_release_scratch(None),
+        lambda: L.melspec_release_scratch(None),
+        lambda: L.melspec_set_precision(None, 0),
+    ]
+    for call in calls:
+        assert call() == _lib.ERR_INVALID_ARG
+        assert "NULL" in _lib.last_error()
