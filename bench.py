@@ -329,7 +329,7 @@ def main() -> None:
             gather = {"seconds": gdt, "gigabytes_into_rank0": gb, "GB_per_s": gb / gdt, "note": "RCCL send/recv, not part of `value`"}
 
     host_io = None
-    if not args.no_host_io and rank == 0:
+    if not args.no_host_io and rank == 0 and world == 1:          # like cpu_baseline: at N = 1 only
         from oracle import oracle as O
         # 64 host clips per call through melspec_compute_batch_host, caller-owned buffers reused from call to call (a fresh numpy
         # output per call measures the page faults of its first touch instead): pageable, then pinned (melspec_host_alloc)
