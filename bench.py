@@ -47,7 +47,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS),
+                    help="default 2; with --gpus N > 1 and no --config the line also carries config 5's per-clip split (`config.cfg5`)")
+    ap.add_argument("--no-speech", action="store_true", help="skip the real-input leg (`config.speech`: jfk_f32le.wav tiled to the config-2 batch)")
+    ap.add_argument("--no-cfg5", action="store_true", help="N > 1 without --config: skip the extra config-5 leg")
     ap.add_argument("--clips", type=int, default=None, help="override the clip count (per GPU for weak, total for strong)")
     ap.add_argument("--clip-seconds", type=int, default=None)
     ap.add_argument("--n-mels", type=int, default=None)
@@ -89,7 +92,7 @@ def measure_traffic(config: int, timeout_s: float = 150.0):
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--config", str(config), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-io", "--no-traffic"]
+                   "--config", str(config), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech"]
             subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             got = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -172,53 +175,37 @@ def dry_run(args) -> None:
     else:
         allr = [mine]
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "scaling": scaling, "config": args.config,
-                          "shards": [[int(t[0]), int(t[1])] for t in allr], "max_over_ranks_s": elapsed}), flush=True)
+        line = {"dry_run": True, "n_gpus": world, "scaling": scaling, "config": args.config,
+                "shards": [[int(t[0]), int(t[1])] for t in allr], "max_over_ranks_s": elapsed}
+        if world > 1 and not args.explicit_config and not args.no_cfg5:        # the extra leg of a plain `bench.py --gpus N`
+            fpc5 = (CONFIGS[5][1] * int(SR) - N_FFT) // HOP + 1
+            sh5 = [list(shard_range(CONFIGS[5][0], r, world)) for r in range(world)]
+            line["cfg5"] = {"scaling": "strong", "shards": sh5, "per_rank_frames": [(b - a) * fpc5 for a, b in sh5]}
+        if world == 1 and args.config == 2 and not args.no_speech:
+            line["speech"] = {"input": "tests/golden/jfk_f32le.wav tiled to the config-2 batch"}
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main() -> None:
-    args = parse_args()
-    launched = "WORLD_SIZE" in os.environ
-    if args.gpus > 1 and not launched:
-        respawn_under_torchrun(args)          # does not return
-    if args.dry_run:
-        return dry_run(args)
+def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, torch, dist, dev, rank: int, world: int, local_rank: int) -> dict:
+    """One config of BASELINE.json through the bench protocol: the rank's share resident in HBM, parity spot check, spin-up,
+    `warmup` untimed + exactly `steps` timed steps between barrier + synchronize, MAX over ranks; HIP events around the same
+    launches.  primary: the workload `value` is quoted on (the command line's overrides apply to it only)."""
     import numpy as np
-    import torch
-    import mel_spec_amd as M
     from mel_spec_amd.parallel import shard_range, timed_steps
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     distributed = world > 1
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    cfg_clips, cfg_seconds, cfg_mels, scaling = CONFIGS[args.config]
-    n_mels = args.n_mels or cfg_mels
-    clip_seconds = args.clip_seconds or cfg_seconds
+    cfg_clips, cfg_seconds, cfg_mels, scaling = CONFIGS[config]
+    n_mels = (args.n_mels if primary else None) or cfg_mels
+    clip_seconds = (args.clip_seconds if primary else None) or cfg_seconds
     clip_len = int(clip_seconds * SR)
-    total_or_per = args.clips or cfg_clips
+    total_or_per = (args.clips if primary else None) or cfg_clips
     if scaling == "weak":
         n_clips, first_clip = total_or_per, rank * total_or_per          # rank r owns clips [r*n, (r+1)*n)
     else:
         lo, hi = shard_range(total_or_per, rank, world)                  # contiguous per-clip split of the fixed set
         n_clips, first_clip = hi - lo, lo
-    steps = args.steps if args.steps is not None else (1000 if args.config == 2 else 20)
-    warmup = args.warmup if args.warmup is not None else (100 if args.config == 2 else 3)
 
     mel = M.HipMelSpectrogram(N_FFT, HOP, SR, n_mels, device=local_rank)
     mel.set_precision(args.precision)
@@ -277,10 +264,10 @@ def main() -> None:
     # steps, then straight into the timed region.  Nothing here is timed.
     spin_t0, spinup_steps = time.perf_counter(), 0
     while time.perf_counter() - spin_t0 < 0.3:
-        for _ in range(20 if args.config == 2 else 1):
+        for _ in range(20 if config == 2 else 1):
             step()
         torch.cuda.synchronize()
-        spinup_steps += 20 if args.config == 2 else 1
+        spinup_steps += 20 if config == 2 else 1
     for _ in range(warmup):
         step()
 
@@ -307,6 +294,104 @@ def main() -> None:
         dist.all_gather(allr, mine)                   # per-rank {frames, ms}: tiny, the only collective of the run
         per_rank = [[float(t[0].item()), float(t[1].item())] for t in allr]
         kernel_ms = max(p[1] for p in per_rank)
+
+    mel_name = mel.plain_kernel_name()
+    res = dict(elapsed=elapsed, per_rank=per_rank, kernel_ms=kernel_ms, frames_per_step=frames_per_step, n_clips=n_clips, sub=sub,
+               parity=parity, queued=queued, spinup_steps=spinup_steps, scaling=scaling, n_mels=n_mels, clip_seconds=clip_seconds,
+               clip_len=clip_len, total_or_per=total_or_per, fpc=fpc, kernel=mel_name, mel=mel, out=out, pcm=pcm, stream=stream)
+    return res
+
+
+def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) -> dict:
+    """The real-input figure next to `value` (never instead of it): the reference's own fixture, tests/golden/jfk_f32le.wav
+    (/root/reference/testdata/jfk_f32le.wav, the signal its README numbers are quoted on), tiled with per-clip offsets to the
+    config-2 batch, resident in HBM, default precision mode, same event-timed protocol.  Speech trips AUTO's guard on most
+    frames, so after its first batch the context runs the f64 kernel on whole batches."""
+    import numpy as np
+    from oracle import oracle as O
+    jfk = O.load_wav_f32(os.path.join(ROOT, "tests", "golden", "jfk_f32le.wav"))
+    uniq = 64
+    x = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(uniq)])
+    pcm = torch.from_numpy(np.tile(x, (n_clips // uniq + 1, 1))[:n_clips].reshape(-1)).to(dev)
+    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, n_mels, device=dev.index)
+    fpc = mel.num_frames(clip_len)
+    out = torch.empty(n_clips * fpc * n_mels, dtype=torch.float32, device=dev)
+    run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    regimes = []
+    for _ in range(3):                      # the statistics of a finished batch decide the regime of the next one
+        mel.guard_last_count()
+        run(); torch.cuda.synchronize()
+        tripped = mel.guard_last_count()
+        regimes.append(mel.auto_state()[0])
+    o3 = out.view(n_clips, fpc, n_mels)
+    worst = 0.0
+    for c in (0, uniq - 1, n_clips - 1):
+        want = O.compute_mel_spectrogram_cpu(x[c % uniq], N_FFT, HOP, n_mels, SR)
+        worst = max(worst, float(np.abs(o3[c].cpu().numpy() - want).max()))
+    if worst > 1e-4:
+        raise SystemExit(f"speech leg: parity check failed, max|diff| = {worst}")
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:
+        for _ in range(20):
+            run()
+        torch.cuda.synchronize()
+    k = 200
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(k):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / k
+    frames = n_clips * fpc
+    gbs = frames * (HOP * 4 + n_mels * 4) / (ms * 1e-3) / 1e9
+    res = {"input": f"tests/golden/jfk_f32le.wav tiled (per-clip offsets) to {n_clips} x {clip_len / SR:.0f} s, resident in HBM, precision mode auto",
+           "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+           "frames_tripping_the_guard_per_step": tripped, "fraction_tripping": tripped / frames,
+           "regime_after_each_of_the_first_batches": ["f64 kernel on whole batches" if h else "f32 kernel + f64 recompute of tripped frames" for h in regimes],
+           "kernel": mel.plain_kernel_name(), "parity_max_abs_diff": worst, "steps": k}
+    mel.close()
+    del pcm, out
+    return res
+
+
+def main() -> None:
+    args = parse_args()
+    explicit_config = args.explicit_config = args.config is not None
+    if args.config is None:
+        args.config = 2
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        respawn_under_torchrun(args)          # does not return
+    if args.dry_run:
+        return dry_run(args)
+    import numpy as np
+    import torch
+    import mel_spec_amd as M
+    from mel_spec_amd.parallel import shard_range, timed_steps
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    steps = args.steps if args.steps is not None else (1000 if args.config == 2 else 20)
+    warmup = args.warmup if args.warmup is not None else (100 if args.config == 2 else 3)
+    w = run_workload(args, args.config, True, steps, warmup, M, torch, dist, dev, rank, world, local_rank)
+    elapsed, per_rank, kernel_ms, frames_per_step = w["elapsed"], w["per_rank"], w["kernel_ms"], w["frames_per_step"]
+    n_clips, sub, parity, queued, spinup_steps, scaling = w["n_clips"], w["sub"], w["parity"], w["queued"], w["spinup_steps"], w["scaling"]
+    n_mels, clip_seconds, clip_len, total_or_per, fpc = w["n_mels"], w["clip_seconds"], w["clip_len"], w["total_or_per"], w["fpc"]
+    mel, out, stream = w["mel"], w["out"], w["stream"]
 
     gather = None
     if distributed and args.gather and sub == 1:
@@ -357,6 +442,31 @@ def main() -> None:
         host_io_pinned = host_rate(pin_in.array, pin_out.array)
         pin_in.free(); pin_out.free()
 
+    # the real-input leg (N = 1, the default workload) and, for N > 1 without --config, north_star's 65 536 x 30 s per-clip split
+    speech = None
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_speech and args.precision == "auto" and args.n_mels is None:
+        speech = speech_leg(M, torch, dev, stream, n_clips, clip_len, n_mels)
+    cfg5 = None
+    if distributed and not explicit_config and not args.no_cfg5:
+        kernel_name = mel.plain_kernel_name()
+        mel.close()
+        del w, out
+        torch.cuda.empty_cache()
+        steps5, warmup5 = 10, 2
+        w5 = run_workload(args, 5, False, steps5, warmup5, M, torch, dist, dev, rank, world, local_rank)
+        frames5 = sum(p[0] for p in w5["per_rank"])
+        cfg5 = {"workload": f"configs[4]: {CONFIGS[5][0]} synthetic {CONFIGS[5][1]} s f32 clips @16 kHz split per clip over {world} GPU(s) "
+                            f"(mel_spec_amd.parallel.shard_range), Whisper n_fft={N_FFT} hop={HOP} n_mels={CONFIGS[5][2]}, resident in HBM",
+                "scaling": "strong", "value": frames5 * steps5 / w5["elapsed"], "unit": "mel frames/s", "steps": steps5, "warmup": warmup5,
+                "ms_per_step": w5["elapsed"] / steps5 * 1e3, "frames_per_step_all_ranks": frames5,
+                "sub_shards_per_step": w5["sub"], "parity_max_abs_diff": w5["parity"],
+                "per_rank": [{"frames_per_step": p[0], "kernel_ms": p[1]} for p in w5["per_rank"]],
+                "roofline_frac": frames5 * (HOP * 4 + CONFIGS[5][2] * 4) / world / (w5["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        w5["mel"].close()
+        mel = None
+    else:
+        kernel_name = mel.plain_kernel_name()
+
     if rank == 0:
         total_frames = sum(p[0] for p in per_rank) * steps
         value = total_frames / elapsed
@@ -404,7 +514,7 @@ def main() -> None:
             "realtime_x": value * (HOP / SR),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": mel.plain_kernel_name(),
+                         "kernel": kernel_name,
                          "kernel_ms": kernel_ms,
                          "kernel_ms_note": "HIP events on the launch stream around the K timed steps / K (one launch per step: the f64 recompute of guarded frames happens inside it)",
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch},
@@ -415,6 +525,10 @@ def main() -> None:
             res["host_api_pinned_frames_per_s_pcie_inclusive"] = host_io_pinned
             res["host_api_note"] = ("64 host clips per call through melspec_compute_batch_host (H2D + kernels + D2H, chunked and overlapped), caller's buffers "
                                     "reused: pageable memory, and memory from melspec_host_alloc (pinned); never `value`")
+        if speech is not None:
+            res["config"]["speech"] = speech
+        if cfg5 is not None:
+            res["config"]["cfg5"] = cfg5
         if gather is not None:
             res["gather_to_rank0"] = gather
         if world == 1 and not args.no_cpu_baseline:
@@ -423,7 +537,8 @@ def main() -> None:
             res["realtime_x_vs_cpu"] = value / cb["value"]
         print(json.dumps(res), flush=True)
 
-    mel.close()
+    if mel is not None:
+        mel.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

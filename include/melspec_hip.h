@@ -73,12 +73,17 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
 
 /* Arithmetic of the fused n_fft = 400 kernels (the reference computes in f64, src/stft.rs:98-111, and its CUDA plugin runs
  * an f64 FFT too, cufftExecZ2Z src/cuda.rs:204-219).  Every mode but F32 is within 1e-4 of the f64 reference on every input.
- *   AUTO (default)  f32 FFT; in the same pass every frame is checked against an error bound -- a mel band within two
+ *   AUTO (default)  f32 FFT; in the same pass every frame is checked against an empirical error bound -- a mel band within two
  *                   decades of the per-frame clamp (max - 8, src/mel.rs:645-654) is where the f32 FFT's rounding noise can
- *                   exceed 1e-4 -- and a frame that fails it is recomputed in f64 on the spot by the wavefront that owns it
- *                   (same launch).  Noise-like input never takes that branch (the bench workload runs at the f32 rate); a
- *                   line over a quiet floor or speech with > 60 dB of in-frame dynamic range takes it on most frames
- *                   (~2 us per frame and wavefront), and F64 -- the dedicated f64 kernel on everything -- is then faster.
+ *                   exceed 1e-4 (calibrated with tools/flag_calib.py / flag_calib2.py, soaked by tools/fuzz_gpu.py) -- and a
+ *                   frame that fails it is recomputed in f64 by the wavefront that owns it (same launch).  Noise-like input
+ *                   never takes that branch (the bench workload runs at the f32 rate).  Speech and tonal material trip the
+ *                   guard on 40-100 % of their frames; the context notices (the kernels publish the tripped fraction of every
+ *                   launch into host-mapped memory, nothing is added to the stream) and, while the last finished batch tripped
+ *                   it on more than 12.5 % of its frames, runs the f64 kernel on whole batches (the F64 rate) until the
+ *                   fraction falls under 6.25 % again.  Results are within 1e-4 in either regime; a frame the guard does not
+ *                   trip carries f32 bits in one regime and f64 bits in the other, so AUTO is not bit-stable across a change of
+ *                   regime -- F32 and F64 are, and melspec_set_auto_adaptive(ctx, 0) pins AUTO to the f32 regime.
  *   F64             window, FFT and |X|^2 in f64 for every frame: ~4e-7 from the reference, about 60 % of the f32 rate.
  *   F32             the f32 kernel alone: ~3e-5 on speech and noise, up to ~5e-4 on a line over a floor 70..90 dB down.
  * Geometries on the generic kernel and the fused n_fft = 512 kernel always compute in f64. */
@@ -92,8 +97,13 @@ int melspec_set_precise(melspec_ctx *ctx, int on);
 int melspec_is_precise(const melspec_ctx *ctx);
 /* Name of the kernel(s) a plain [clip][frame][mel] batch of this context runs on (for profiles and bench lines). */
 const char *melspec_plain_kernel_name(const melspec_ctx *ctx);
-/* Frames the AUTO mode of this context has recomputed in f64 since it was created (synchronises the device). */
+/* Frames that tripped AUTO's guard since the context was created (f32 regime: recomputed in f64; f64 regime: counted only).
+ * Synchronises the device. */
 int melspec_guard_count(melspec_ctx *ctx, uint64_t *frames);
+/* AUTO's adaptive dispatch (default on).  melspec_auto_state: *heavy = 1 while whole batches go to the f64 kernel, *fraction =
+ * the tripped fraction of the last finished window of launches (>= 256 frames); does not synchronise. */
+int melspec_set_auto_adaptive(melspec_ctx *ctx, int on);
+int melspec_auto_state(melspec_ctx *ctx, int *heavy, double *fraction);
 
 /* compute_mel_spectrogram(&mut self, samples: &[f32]) -> Vec<Vec<f32>> (src/cuda.rs:88-101)
  * == Spectrogram::compute_mel_spectrogram_cpu (src/stft.rs:119-138) on the GPU.

@@ -58,6 +58,8 @@ SIGNATURES = {
     "melspec_set_precision": (C.c_int, [_vp, C.c_int]),
     "melspec_precision": (C.c_int, [_vp]),
     "melspec_guard_count": (C.c_int, [_vp, _u64p]),
+    "melspec_set_auto_adaptive": (C.c_int, [_vp, C.c_int]),
+    "melspec_auto_state": (C.c_int, [_vp, C.POINTER(C.c_int), _f64p]),
     "melspec_plain_kernel_name": (C.c_char_p, [_vp]),
     "melspec_set_precise": (C.c_int, [_vp, C.c_int]),
     "melspec_is_precise": (C.c_int, [_vp]),

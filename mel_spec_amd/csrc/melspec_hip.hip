@@ -59,7 +59,7 @@ constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the 
 constexpr uint64_t kPipeChunkSamples = 4u << 20;      // host pipeline: 16 MiB of PCM per chunk (host_pipe.hpp)
 
 // Tuning switches exist only in -DMELSPEC_LAB builds (mel_spec_amd.build.build(lab=True), used by tools/): the product
-// library runs the measured defaults below and reads no environment variable except MELSPEC_PRECISE (melspec_create).
+// library runs the measured defaults below and reads no environment variable.
 #ifdef MELSPEC_LAB
 int lab_int(const char *name, int dflt, int lo, int hi) {
     const char *e = std::getenv(name);
@@ -460,11 +460,28 @@ bool fb_lens_match(const MelSlots &ms) {
 // ------------------------------------------------------------------------------------
 // MELSPEC_PRECISION_AUTO state (FixSink in melspec_kernels.hpp): the f64 tables of the in-kernel recompute and its counter.
 struct FixState {
-    DevBuf tab, count, list;
+    DevBuf tab, count, list;              // count: {u64 frames that tripped the guard, u32 workgroup tickets}
     hipStream_t last_stream = nullptr;    // the note list is used in stream order: a call on another stream first waits for this one
     bool used = false;
-    void release() { tab.release(); count.release(); list.release(); used = false; last_stream = nullptr; }
+    // Statistics of the guarded launches, published by the kernels into host-mapped memory (FixSink::host) and read here without
+    // touching the stream.  They drive the adaptive dispatch of MELSPEC_PRECISION_AUTO: a context whose recent batches tripped the
+    // guard on more than kAutoUp of their frames (speech, tonal material: DESIGN.md section 5) runs the f64 kernel on whole batches --
+    // 0.50 ms instead of 1.2 ms at config 2 -- until the fraction falls under kAutoDown again.  The f64 kernel counts the frames that
+    // WOULD trip the guard with the same test, so the fraction is known in either state and nothing has to be re-probed.
+    unsigned long long *host = nullptr;   // {seq, frames_cum, flagged_cum}
+    uint64_t frames_cum = 0;              // frames handed to guarded launches so far
+    uint32_t tickets = 0, seq = 0;
+    uint64_t seen_frames = 0, seen_flagged = 0;
+    bool adaptive = true, heavy = false;
+    double fraction = 0.0;                // of the last window of >= kAutoMinFrames frames
+    void release() {
+        tab.release(); count.release(); list.release(); used = false; last_stream = nullptr;
+        if (host) (void)hipHostFree(host);
+        host = nullptr;
+    }
 };
+constexpr double kAutoUp = 0.125, kAutoDown = 0.0625;     // crossover of (f32 + recompute tail) and the f64 kernel: 14 % at 80 mels, 10 % at 128
+constexpr uint64_t kAutoMinFrames = 256;
 
 struct melspec_ctx {
     DeviceInfo dev;
@@ -509,9 +526,32 @@ struct melspec_ctx {
 
 namespace {
 
-// frames per work unit of the kernel a batch will run on
-int ctx_frames_per_unit(const melspec_ctx *c) {
-    if (c->fast) return (c->six && c->precision != MELSPEC_PRECISION_F64) ? kSixFrames : kFPW;
+// MELSPEC_PRECISION_AUTO: take in what the finished launches published and move between the two regimes
+void auto_poll(melspec_ctx *c) {
+    FixState &fx = c->fix;
+    if (!fx.host) return;
+    volatile unsigned long long *h = fx.host;
+    const unsigned long long s0 = h[0];
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const unsigned long long fr = h[1], fl = h[2];
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (h[0] != s0) return;                                       // a launch is publishing right now: next time
+    if (fr < fx.seen_frames + kAutoMinFrames || fl < fx.seen_flagged) return;
+    fx.fraction = static_cast<double>(fl - fx.seen_flagged) / static_cast<double>(fr - fx.seen_frames);
+    fx.seen_frames = fr; fx.seen_flagged = fl;
+    if (!fx.heavy && fx.fraction > kAutoUp) fx.heavy = true;
+    else if (fx.heavy && fx.fraction < kAutoDown) fx.heavy = false;
+}
+
+// AUTO in its heavy regime: whole batches on the f64 kernel
+bool ctx_auto_heavy(const melspec_ctx *c) { return c->precision == MELSPEC_PRECISION_AUTO && c->fix.adaptive && c->fix.heavy; }
+
+// frames per work unit of the kernel a batch will run on (called once per batch, before it is planned)
+int ctx_frames_per_unit(melspec_ctx *c) {
+    if (c->fast) {
+        if (c->precision == MELSPEC_PRECISION_AUTO) auto_poll(c);
+        return (c->six && c->precision != MELSPEC_PRECISION_F64 && !ctx_auto_heavy(c)) ? kSixFrames : kFPW;
+    }
     return c->fast512 ? kFbFPW : 1;
 }
 
@@ -520,9 +560,24 @@ int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
     return MELSPEC_OK;
 }
 
-PreciseParams precise_params(melspec_ctx *c, const BatchDesc &desc) {
+// the launch-specific part of a guarded launch's statistics sink (the grid is only known where the launch is made)
+FixSink sink_armed(melspec_ctx *c, FixSink sink, const BatchDesc &desc, unsigned grid) {
+    if (!sink.ticket) return sink;
+    FixState &fx = c->fix;
+    const uint64_t frames = desc.d_unit_prefix == nullptr ? static_cast<uint64_t>(desc.n_clips) * desc.frames_per_clip
+                                                          : desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);   // ragged: upper bound
+    fx.tickets += grid;
+    fx.frames_cum += frames;
+    sink.ticket_end = fx.tickets;
+    sink.seq = ++fx.seq;
+    sink.frames_cum = fx.frames_cum;
+    return sink;
+}
+
+PreciseParams precise_params(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat) {
     PreciseParams pp{};
     pp.b = desc;
+    pp.stat = stat;
     pp.d_blob = static_cast<const uint32_t *>(c->d_blob64.p);
     pp.blob_words = static_cast<int>(c->pt.blob.size());
     pp.mel_off_words = c->pt.mel_off_words;
@@ -534,7 +589,7 @@ PreciseParams precise_params(melspec_ctx *c, const BatchDesc &desc) {
 
 // the f64 kernel on the whole batch (MELSPEC_PRECISION_F64)
 template <int NSLOTS, class Lens>
-int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, false>, "hipFuncSetAttribute(whisper400_precise_kernel)");
@@ -542,10 +597,10 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const PreciseParams pp = precise_params(c, desc);
     const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
     static const int per_cu = lab_int("MELSPEC_PRECISE_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
+    const PreciseParams pp = precise_params(c, desc, sink_armed(c, stat, desc, grid));
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     if (layout)
         hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, false>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
@@ -555,10 +610,10 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) 
     return MELSPEC_OK;
 }
 
-int launch_precise(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
+int launch_precise(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream) {
     if (c->ft.slots.n_slots <= 8)
-        return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stream) : launch_precise_t<8, LensRuntime>(c, desc, stream);
-    return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stream) : launch_precise_t<12, LensRuntime>(c, desc, stream);
+        return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stat, stream) : launch_precise_t<8, LensRuntime>(c, desc, stat, stream);
+    return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stat, stream) : launch_precise_t<12, LensRuntime>(c, desc, stat, stream);
 }
 
 FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf &blob, melspec_ctx *c, const FixSink &sink) {
@@ -584,11 +639,11 @@ int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hi
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const FastParams fp = fast_params(desc, c->ft, c->d_blob, c, sink);
     const uint64_t blocks = (desc.n_units + kWaveWaves - 1) / kWaveWaves;
     // two workgroups are resident per CU; 4 per CU measured best (8192 x 15..45 s x 128 mels: 9.17 vs 9.50 ms)
     static const int per_cu = lab_int("MELSPEC_GRID_PER_CU", 4, 1, 64);
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
+    const FastParams fp = fast_params(desc, c->ft, c->d_blob, c, sink_armed(c, sink, desc, grid));
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     if (layout)
         hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, Lens>), dim3(grid), dim3(kWaveWaves * 64), c->fast_lds, stream, fp);
@@ -613,10 +668,10 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const FastParams fp = fast_params(desc, c->ft6, c->d_blob6, c, sink);
     const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
     static const int per_cu = lab_int("MELSPEC_SIX_GRID_PER_CU", 1, 1, 4096);     // one 16-wave workgroup per CU
     const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
+    const FastParams fp = fast_params(desc, c->ft6, c->d_blob6, c, sink_armed(c, sink, desc, grid.x));
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     // plain batches, uniform and ragged, take the run-per-wave kernel (no division per unit, the clip record in scalar registers, a
     // wave re-reads its own frame-tail halo): cfg2 0.3105 -> 0.3055 ms, 8192 x 30 s 7.55 -> 7.42 ms against the round-robin deal
@@ -629,11 +684,15 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (desc_in.n_units == 0) return MELSPEC_OK;
     BatchDesc desc = desc_in;
+    // AUTO's regime for this batch: a six-frame context planned it for the kernel it meant (ctx_frames_per_unit); the others have
+    // one unit size and decide here
+    const bool heavy = c->fast && c->precision == MELSPEC_PRECISION_AUTO &&
+                       (c->six ? desc.frames_per_unit != kSixFrames : ctx_auto_heavy(c));
     if (desc.sync_rounds < 0) {
         // measured (profiles/r01_variants.txt): six-frame kernel, 16 waves: four waves 4 apart; precise kernel, 8 waves:
         // consecutive pairs; 5-frame kernel, two 8-wave workgroups per CU: pairs 4 apart
         if (c->fast && desc.frames_per_unit == kSixFrames) desc.sync_rounds = 20;
-        else if (c->fast && c->precision == MELSPEC_PRECISION_F64) desc.sync_rounds = 2;
+        else if (c->fast && (c->precision == MELSPEC_PRECISION_F64 || heavy)) desc.sync_rounds = 2;
         else if (c->fast) desc.sync_rounds = 18;
         else desc.sync_rounds = 1;
     }
@@ -653,21 +712,30 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
                                                   : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, 0, 1, 1, 0.0, 0.0, c->dev.cus, stream);
-    if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, stream);
+    if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, FixSink{}, stream);
     FixSink sink{};
     if (c->precision == MELSPEC_PRECISION_AUTO) {
         FixState &fx = c->fix;
         if (fx.used && fx.last_stream != stream) HIP_TRY(hipStreamSynchronize(fx.last_stream));
-        const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
-        if (need > fx.list.cap) {
-            if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
-            int rc = fx.list.ensure(need);
-            if (rc) return rc;
+        if (!heavy) {
+            const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
+            if (need > fx.list.cap) {
+                if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
+                int rc = fx.list.ensure(need);
+                if (rc) return rc;
+            }
+            sink.tab = static_cast<const double *>(fx.tab.p);
+            sink.list = static_cast<uint64_t *>(fx.list.p);
+        }
+        if (!fx.host) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&fx.host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(fx.host, 0, 64);
         }
         fx.used = true; fx.last_stream = stream;
-        sink.tab = static_cast<const double *>(fx.tab.p);
-        sink.count = static_cast<unsigned *>(fx.count.p);
-        sink.list = static_cast<uint64_t *>(fx.list.p);
+        sink.count = static_cast<unsigned long long *>(fx.count.p);
+        sink.ticket = reinterpret_cast<unsigned *>(static_cast<char *>(fx.count.p) + 8);
+        sink.host = fx.host;
+        if (heavy) return launch_precise(c, desc, sink, stream);
     }
     if (c->six && desc.frames_per_unit == kSixFrames)
         return c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
@@ -761,7 +829,7 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
         if ((rc = upload(c->d_blob64, c->pt.blob))) return bail(rc);
         if ((rc = upload(c->fix.tab, build_fix_tables()))) return bail(rc);
-        if ((rc = upload(c->fix.count, std::vector<uint32_t>(16, 0u)))) return bail(rc);
+        if ((rc = upload(c->fix.count, std::vector<uint64_t>(8, 0ull)))) return bail(rc);
     }
     if (!c->fast) {          // the generic kernel also serves the layouts the fused 512 build does not store
         const int bins = fft_size / 2 + 1;
@@ -770,11 +838,6 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if ((rc = c->gt.build(fft_size, fft_size, fft_size / 2, hann_window(fft_size), dense, n_mels, bins))) return bail(rc);
         if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
         if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
-    }
-    // MELSPEC_PRECISE=1 / =f32: the initial melspec_set_precision of every context (how the GPU suite is run a second time in f64 mode)
-    if (const char *ep = std::getenv("MELSPEC_PRECISE")) {
-        if (ep[0] == '1') c->precision = MELSPEC_PRECISION_F64;
-        else if (ep[0] == 'f') c->precision = MELSPEC_PRECISION_F32;
     }
     *out = c;
     return MELSPEC_OK;
@@ -825,7 +888,7 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
         if (c->fast512) return "melspec::fbank512_wave_kernel<double, 8, 1, kFlavorWhisper, RUNS> (n_fft = 512, f64)";
         return "melspec::generic_frame_kernel<256> (f64 direct DFT)";
     }
-    if (c->precision == MELSPEC_PRECISION_F64)
+    if (c->precision == MELSPEC_PRECISION_F64 || ctx_auto_heavy(c))
         return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";
     const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
     if (c->six)
@@ -841,9 +904,24 @@ int melspec_guard_count(melspec_ctx *c, uint64_t *frames) {
     if (!c->fix.count.p) return MELSPEC_OK;
     HIP_TRY(hipSetDevice(c->dev.device));
     HIP_TRY(hipDeviceSynchronize());
-    uint32_t n = 0;
+    uint64_t n = 0;
     HIP_TRY(hipMemcpy(&n, c->fix.count.p, sizeof(n), hipMemcpyDeviceToHost));
     *frames = n;
+    return MELSPEC_OK;
+}
+
+int melspec_set_auto_adaptive(melspec_ctx *c, int on) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    c->fix.adaptive = on != 0;
+    if (!on) c->fix.heavy = false;
+    return MELSPEC_OK;
+}
+
+int melspec_auto_state(melspec_ctx *c, int *heavy, double *fraction) {
+    if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
+    if (c->fast && c->precision == MELSPEC_PRECISION_AUTO) auto_poll(c);
+    if (heavy) *heavy = ctx_auto_heavy(c) ? 1 : 0;
+    if (fraction) *fraction = c->fix.fraction;
     return MELSPEC_OK;
 }
 

@@ -123,11 +123,36 @@ __device__ __forceinline__ unsigned xcd_logical_block() {
 // spot (whisper_fix64.hpp).  tab == nullptr: guard off (MELSPEC_PRECISION_F32).  count: frames recomputed since the context was
 // created (statistics; one atomic per recomputed frame).
 struct FixSink {
-    const double *tab;      // FixTables in global memory
-    unsigned *count;
+    const double *tab;      // FixTables in global memory (nullptr: no guard, or -- the f64 kernel -- statistics only)
+    unsigned long long *count;   // frames that tripped the guard since the context was created
     uint64_t *list;         // one entry per unit of the launch (+ a round of slack): every wave notes the units it has to revisit in
                             // the part of it that its own units index, so no two waves share an entry
+    // Publication of the launch's statistics (guard_wave_done): the last workgroup to finish writes {frames_cum, count} and then `seq`
+    // into host-mapped memory, which the host polls before its next call -- no copy, no event, nothing on the stream.
+    unsigned *ticket;       // workgroups finished since the context was created (nullptr: no publication)
+    unsigned ticket_end;    // its value once this launch's last workgroup is through
+    unsigned seq;           // number of this launch
+    unsigned long long frames_cum;      // frames handed to guarded launches up to and including this one
+    unsigned long long *host;           // host-mapped {seq, frames_cum, count}
 };
+
+// A wave of a guarded launch is through (every wave calls this, also one without units).  wg: two zeroed LDS words of the
+// workgroup {flagged frames, waves through}.  One global atomic pair per WORKGROUP; the workgroup that takes the launch's last
+// ticket publishes the totals.
+__device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg, int waves, int lane, unsigned flagged) {
+    if (fx.ticket == nullptr || lane != 0) return;
+    if (flagged) __hip_atomic_fetch_add(wg, flagged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned through = __hip_atomic_fetch_add(wg + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (through + 1 != static_cast<unsigned>(waves)) return;
+    const unsigned total = __hip_atomic_load(wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (total) __hip_atomic_fetch_add(fx.count, static_cast<unsigned long long>(total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned t = __hip_atomic_fetch_add(fx.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1 != fx.ticket_end) return;
+    const unsigned long long c = __hip_atomic_load(fx.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(fx.host + 1, fx.frames_cum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fx.host + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(fx.host, static_cast<unsigned long long>(fx.seq), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct FastParams {
     BatchDesc b;
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
-    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
+    guard_wave_done(p.fix, arrive + WAVES - 2, WAVES, lane, redone);
 }
 
 // ------------------------------------------------------------------------------------
@@ -495,7 +520,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
     }
-    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
+    guard_wave_done(p.fix, arrive + kSixWaves - 2, kSixWaves, lane, redone);
 }
 
 // Plain [frame][mel] output, uniform and ragged batches, on the six-frame build -- the default kernel of the bench workload.
@@ -566,6 +591,8 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
+    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());   // guard_wave_done's two words
+    if (tid < 2) wg_done[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -580,7 +607,10 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     const bool guard = p.fix.tab != nullptr;
 
     ClipRun cr;
-    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) return;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) {
+        guard_wave_done(p.fix, wg_done, kSixWaves, lane, 0);
+        return;
+    }
     uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;        // this wave's notes: the entries its own run indexes
     unsigned noted = 0;
     for (; cr.unit < cr.end; ++cr.unit) {
@@ -639,7 +669,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
-    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
+    guard_wave_done(p.fix, wg_done, kSixWaves, lane, redone);
 }
 
 // The same for the 5-frame kernel (81..131 mels): interval mel scheme, direct PCM reads, 8-wave workgroups.
@@ -650,6 +680,8 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
+    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // guard_wave_done's two words
+    if (tid < 2) wg_done[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -665,7 +697,10 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
     const bool guard = p.fix.tab != nullptr;
     ClipRun cr;
-    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) {
+        guard_wave_done(p.fix, wg_done, WAVES, lane, 0);
+        return;
+    }
     uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;
     unsigned noted = 0;
     for (; cr.unit < cr.end; ++cr.unit) {
@@ -723,7 +758,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
         redone += wave_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                            loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
-    if (redone && lane == 0) atomicAdd(p.fix.count, redone);
+    guard_wave_done(p.fix, wg_done, WAVES, lane, redone);
 }
 
 // ------------------------------------------------------------------------------------
@@ -738,6 +773,8 @@ struct PreciseParams {
     int hop;
     int n_mels;
     MelSlots slots;       // woff[] as in the f32 blob (float offsets from FastBlob's base)
+    FixSink stat;         // MELSPEC_PRECISION_AUTO running this kernel on a whole batch (most of whose frames trip the guard): the frames
+                          // that would have tripped it are counted and published like the f32 kernels do (tab and list unused)
 };
 
 constexpr int kPreciseWaves = 8;    // one workgroup per CU
@@ -752,7 +789,7 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
     unsigned *arrive = ldsw + p.blob_words + WAVES * PreciseLayout::slice_doubles() * 2;   // RoundSync counters
-    if (LAYOUT && tid < WAVES) arrive[tid] = 0;
+    if (tid < WAVES) arrive[tid] = 0;
     __syncthreads();
     const double *tb = reinterpret_cast<const double *>(ldsw);
     // the shared phase-3 code addresses the mel tables as offsets from the base of the f32 blob
@@ -775,7 +812,12 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
     }
     RoundSync<WAVES> rs(LAYOUT ? p.b.sync_rounds : 0, wave, arrive);
     ClipRun cr;
-    if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
+    const bool stats = p.stat.ticket != nullptr;
+    unsigned flagged = 0;
+    if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) {
+        guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, 0);
+        return;
+    }
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES;; first += (uint64_t)gridDim.x * WAVES) {
         if (RUNS) {
             if (cr.unit >= cr.end) break;
@@ -809,14 +851,17 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT) rs.template before_stores<2>(lane);
+        bool flag;
         if (LAYOUT && p.b.mel_major)
-            wave_phase4<NSLOTS, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
+            flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
         else
-            wave_phase4<NSLOTS, LAYOUT>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
+            flag = wave_phase4<NSLOTS, LAYOUT, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
+        if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(__builtin_amdgcn_ballot_w64(flag))));
         if (LAYOUT) rs.after_round();
         if (RUNS) ++cr.unit;
     }
+    guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, flagged);
 }
 
 // STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) -- the complex spectrum itself, f64 phases 1-2 of the

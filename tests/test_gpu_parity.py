@@ -109,6 +109,60 @@ def test_precision_modes(gpu, oracle, jfk, n_mels):
     m.close()
 
 
+def test_auto_moves_speech_batches_to_the_f64_kernel(gpu, oracle, jfk):
+    """MELSPEC_PRECISION_AUTO's adaptive dispatch: speech trips the guard on most frames, so from the second batch on the context runs
+    the f64 kernel on whole batches and costs what F64 costs (round 2: 2.4 x F64); noise moves it back; results stay inside the
+    tolerance in both regimes; melspec_set_auto_adaptive(0) pins the f32 regime (round 2's behaviour, bit-stable)."""
+    if _ENV_MODE != "auto":
+        pytest.skip("the suite is being run with a fixed precision mode")
+    n_clips, clip_len, n_mels = 256, 160000, 80
+    speech = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(32)])
+    noise = np.stack([oracle.synth_pcm(c, clip_len) for c in range(32)])
+    m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+    nf = m.num_frames(clip_len)
+    pcm, out = gpu.DeviceBuffer(n_clips * clip_len * 4), gpu.DeviceBuffer(n_clips * nf * n_mels * 4)
+
+    def load(x):
+        for r in range(n_clips // 32):
+            pcm.upload(x, offset_bytes=r * x.nbytes)
+
+    def run():
+        m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+        m.synchronize()
+        return out.download((2, nf, n_mels))       # clips 0 and 1
+
+    load(speech)
+    want = np.stack([oracle.compute_mel_spectrogram_cpu(speech[c], 400, 160, n_mels, SR) for c in range(2)])
+    assert m.auto_state() == (False, 0.0)
+    first = run()                                   # f32 regime: tripped frames recomputed in the launch
+    heavy, frac = m.auto_state()
+    assert heavy and 0.3 < frac < 0.9, (heavy, frac)
+    assert "precise" in m.plain_kernel_name()
+    second = run()                                  # f64 kernel on the whole batch
+    assert np.abs(first - want).max() <= TOL and np.abs(second - want).max() <= 2e-6
+    assert m.auto_state()[0]                        # the f64 kernel keeps counting: still heavy
+    ms_auto = m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=5, iters=30)
+    m.set_precision("f64")
+    ms_f64 = m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=5, iters=30)
+    m.set_precision("auto")
+    assert ms_auto <= 1.15 * ms_f64, (ms_auto, ms_f64)
+    # noise: one batch in the f64 regime reports a low fraction, the next one is back on the f32 kernel
+    load(noise)
+    wantn = np.stack([oracle.compute_mel_spectrogram_cpu(noise[c], 400, 160, n_mels, SR) for c in range(2)])
+    a = run()
+    heavy, frac = m.auto_state()
+    assert not heavy and frac < 0.01
+    b = run()
+    assert "six_runs" in m.plain_kernel_name()
+    assert np.abs(a - wantn).max() <= 2e-6 and np.abs(b - wantn).max() <= TOL
+    # pinned: speech stays on the f32 kernel + recompute tail, bit-identical from call to call
+    m.set_auto_adaptive(False)
+    load(speech)
+    p1 = run(); p2 = run()
+    assert not m.auto_state()[0] and np.array_equal(p1, p2) and np.array_equal(p1, first) and np.abs(p1 - want).max() <= TOL
+    pcm.free(); out.free(); m.close()
+
+
 def _hard_signals(n, sr, seed=42):
     rng = np.random.default_rng(seed)
     t = np.arange(n) / sr

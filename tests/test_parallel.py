@@ -150,3 +150,25 @@ def test_bench_spawns_its_ranks(gpus, config):
     else:
         assert line["scaling"] == "weak" and sh == [[1024 * r, 1024 * (r + 1)] for r in range(gpus)]
     assert line["max_over_ranks_s"] >= 0.002 * gpus * 3 * 0.9
+
+
+def test_plain_bench_line_carries_the_speech_leg_and_config5():
+    """What the driver runs: `bench.py` (N = 1) carries the real-input leg next to `value`; `bench.py --gpus N` without --config
+    also times north_star's 65 536 x 30 s per-clip split (configs[4]) whose per-rank frames sum to 196 476 928.  --dry-run: the
+    plan of both records without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+
+    def run(*extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", *extra], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run()
+    assert one["n_gpus"] == 1 and one["config"] == 2 and "speech" in one and "cfg5" not in one
+    two = run("--gpus", "2")
+    assert two["n_gpus"] == 2 and two["config"] == 2 and two["scaling"] == "weak" and two["shards"] == [[0, 1024], [1024, 2048]]
+    c5 = two["cfg5"]
+    assert c5["scaling"] == "strong" and c5["shards"][0][0] == 0 and c5["shards"][-1][1] == 65536
+    assert sum(c5["per_rank_frames"]) == 196476928
+    assert "cfg5" not in run("--gpus", "2", "--config", "2")

@@ -24,11 +24,15 @@ for n_mels in (80, 128):
     for name, x in sets.items():
         for r in range(n_clips // 64):
             pcm.upload(x, offset_bytes=r * x.nbytes)
-        for mode in ("f32", "auto", "f64"):
-            m.set_precision(mode)
+        for mode in ("f32", "auto", "auto-pinned", "f64"):
+            m.set_precision(mode.split("-")[0])
+            m.set_auto_adaptive(mode != "auto-pinned")      # "auto-pinned": the f32 regime whatever the input (round 2's AUTO)
             m.guard_last_count()
-            m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); m.synchronize()
-            flagged = m.guard_last_count()
+            for _ in range(2):      # the first call's statistics decide the regime of the second
+                m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); m.synchronize()
+            flagged = m.guard_last_count() / 2
             ms = m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=20, iters=100)
-            print(f"{n_mels:3d} mels  {name:24s} {mode:4s}  {ms:7.4f} ms  {n_clips * nf / ms / 1e6:7.2f} G frames/s   recomputed {flagged / (n_clips * nf) * 100:5.1f} % of the frames", flush=True)
+            heavy, frac = m.auto_state()
+            print(f"{n_mels:3d} mels  {name:24s} {mode:11s}  {ms:7.4f} ms  {n_clips * nf / ms / 1e6:7.2f} G frames/s   guard tripped on {flagged / (n_clips * nf) * 100:5.1f} % of the frames"
+                  f"   regime {'f64 kernel' if heavy and mode == 'auto' else '-'}  ({m.plain_kernel_name()})", flush=True)
     pcm.free(); out.free(); m.close()
