@@ -193,6 +193,21 @@ struct HostPipe {
     // Returns 0, a positive hipError_t, or the launch's status; *where names the failing call.
     template <class Launch>
     int run(const std::vector<HostSeg> &segs, int n_mels, uint64_t chunk_samples, hipStream_t compute, Launch &&launch, const char **where) {
+        const int rc = run_impl(segs, n_mels, chunk_samples, compute, launch, where);
+        if (rc != 0) {
+            // A call that fails half-way must not return while copies are still reading `samples` or writing `out`, and the next call
+            // reuses the buffers and events from chunk 0: drain all three streams (their own errors do not matter any more).
+            if (s_in) (void)hipStreamSynchronize(s_in);
+            (void)hipStreamSynchronize(compute);
+            if (s_out) (void)hipStreamSynchronize(s_out);
+            (void)hipGetLastError();
+            if (!ready) release();          // init() failed part-way: give back what it had created
+        }
+        return rc;
+    }
+
+    template <class Launch>
+    int run_impl(const std::vector<HostSeg> &segs, int n_mels, uint64_t chunk_samples, hipStream_t compute, Launch &&launch, const char **where) {
 #define MS_PIPE_TRY(expr)                                        \
     do {                                                         \
         const hipError_t e_ = (expr);                            \
@@ -201,6 +216,7 @@ struct HostPipe {
         *where = "";
         if (segs.empty()) return 0;
         MS_PIPE_TRY(init());
+        // cheap screen on the ends of the batch; every merged piece of a chunk is then checked on its own (clips may live anywhere)
         const bool in_pinned = host_ptr_is_pinned(segs.front().src) && host_ptr_is_pinned(segs.back().src + segs.back().n - 1);
         const bool out_pinned = host_ptr_is_pinned(segs.front().dst) &&
                                 host_ptr_is_pinned(segs.back().dst + segs.back().frames * static_cast<uint64_t>(n_mels) - 1);
@@ -240,6 +256,11 @@ struct HostPipe {
             }
             return v;
         };
+        auto all_pinned = [&](const std::vector<Piece> &v) {
+            for (const Piece &p : v)
+                if (!host_ptr_is_pinned(p.host) || !host_ptr_is_pinned(p.host + p.bytes - 1)) return false;
+            return true;
+        };
         auto retire_out = [&](size_t k) -> int {          // staged output of chunk k: wait for its D2H, scatter to the caller
             const int b = static_cast<int>(k % kBuf);
             MS_PIPE_TRY(hipEventSynchronize(ev_out[b]));
@@ -264,7 +285,7 @@ struct HostPipe {
             }
             const int rc = launch(static_cast<const float *>(d_in[0]), offs.data(), lens.data(), static_cast<uint32_t>(c.count),
                                   static_cast<float *>(d_out[0]), ooffs.data(), compute);
-            if (rc) { *where = "kernel launch"; (void)hipStreamSynchronize(compute); return rc; }
+            if (rc) { *where = "kernel launch"; return rc; }
             for (const Piece &p : pieces_of(c, true))
                 MS_PIPE_TRY(hipMemcpyAsync(const_cast<char *>(p.host), static_cast<const char *>(d_out[0]) + p.dev_off, p.bytes, hipMemcpyDeviceToHost, compute));
             MS_PIPE_TRY(hipStreamSynchronize(compute));
@@ -283,7 +304,7 @@ struct HostPipe {
             // ---- upload
             const std::vector<Piece> pin = pieces_of(c, false);
             if (k >= kBuf) MS_PIPE_TRY(hipStreamWaitEvent(s_in, ev_cmp[b], 0));                // d_in[b] consumed by chunk k-2's kernels
-            if (in_pinned && pin.size() <= kDirectPieces) {
+            if (in_pinned && pin.size() <= kDirectPieces && all_pinned(pin)) {
                 for (const Piece &p : pin)
                     MS_PIPE_TRY(hipMemcpyAsync(static_cast<char *>(d_in[b]) + p.dev_off, p.host, p.bytes, hipMemcpyHostToDevice, s_in));
             } else {
@@ -307,12 +328,12 @@ struct HostPipe {
             }
             const int rc = launch(static_cast<const float *>(d_in[b]), offs.data(), lens.data(), static_cast<uint32_t>(c.count),
                                   static_cast<float *>(d_out[b]), ooffs.data(), compute);
-            if (rc) { *where = "kernel launch"; (void)hipStreamSynchronize(s_in); (void)hipStreamSynchronize(compute); (void)hipStreamSynchronize(s_out); return rc; }
+            if (rc) { *where = "kernel launch"; return rc; }
             MS_PIPE_TRY(hipEventRecord(ev_cmp[b], compute));
             // ---- download
             MS_PIPE_TRY(hipStreamWaitEvent(s_out, ev_cmp[b], 0));
             const std::vector<Piece> pout = pieces_of(c, true);
-            c.staged_out = !(out_pinned && pout.size() <= kDirectPieces);
+            c.staged_out = !(out_pinned && pout.size() <= kDirectPieces && all_pinned(pout));
             if (!c.staged_out) {
                 for (const Piece &p : pout)
                     MS_PIPE_TRY(hipMemcpyAsync(const_cast<char *>(p.host), static_cast<const char *>(d_out[b]) + p.dev_off, p.bytes, hipMemcpyDeviceToHost, s_out));

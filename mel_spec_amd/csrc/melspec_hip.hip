@@ -460,7 +460,7 @@ bool fb_lens_match(const MelSlots &ms) {
 // ------------------------------------------------------------------------------------
 // MELSPEC_PRECISION_AUTO state (FixSink in melspec_kernels.hpp): the f64 tables of the in-kernel recompute and its counter.
 struct FixState {
-    DevBuf tab, count, list;              // count: {u64 frames that tripped the guard, u32 workgroup tickets}
+    DevBuf tab, count, list;              // count: {u64 frames that tripped the guard, u64 accumulator of the launch in flight}
     hipStream_t last_stream = nullptr;    // the note list is used in stream order: a call on another stream first waits for this one
     bool used = false;
     // Statistics of the guarded launches, published by the kernels into host-mapped memory (FixSink::host) and read here without
@@ -468,12 +468,10 @@ struct FixState {
     // guard on more than kAutoUp of their frames (speech, tonal material: DESIGN.md section 5) runs the f64 kernel on whole batches --
     // 0.50 ms instead of 1.2 ms at config 2 -- until the fraction falls under kAutoDown again.  The f64 kernel counts the frames that
     // WOULD trip the guard with the same test, so the fraction is known in either state and nothing has to be re-probed.
-    unsigned long long *host = nullptr;   // {seq, frames_cum, flagged_cum}
-    uint64_t frames_cum = 0;              // frames handed to guarded launches so far
-    uint32_t tickets = 0, seq = 0;
-    uint64_t seen_frames = 0, seen_flagged = 0;
+    unsigned long long *host = nullptr;   // {seq << 40 | tripped, seq << 40 | frames} of the last finished launch
+    uint32_t seq = 0, seen_seq = 0;
     bool adaptive = true, heavy = false;
-    double fraction = 0.0;                // of the last window of >= kAutoMinFrames frames
+    double fraction = 0.0;                // of the last finished launch of >= kAutoMinFrames frames
     void release() {
         tab.release(); count.release(); list.release(); used = false; last_stream = nullptr;
         if (host) (void)hipHostFree(host);
@@ -481,7 +479,7 @@ struct FixState {
     }
 };
 constexpr double kAutoUp = 0.125, kAutoDown = 0.0625;     // crossover of (f32 + recompute tail) and the f64 kernel: 14 % at 80 mels, 10 % at 128
-constexpr uint64_t kAutoMinFrames = 256;
+constexpr unsigned long long kAutoMinFrames = 256;
 
 struct melspec_ctx {
     DeviceInfo dev;
@@ -530,15 +528,14 @@ namespace {
 void auto_poll(melspec_ctx *c) {
     FixState &fx = c->fix;
     if (!fx.host) return;
-    volatile unsigned long long *h = fx.host;
-    const unsigned long long s0 = h[0];
-    std::atomic_thread_fence(std::memory_order_acquire);
-    const unsigned long long fr = h[1], fl = h[2];
-    std::atomic_thread_fence(std::memory_order_acquire);
-    if (h[0] != s0) return;                                       // a launch is publishing right now: next time
-    if (fr < fx.seen_frames + kAutoMinFrames || fl < fx.seen_flagged) return;
-    fx.fraction = static_cast<double>(fl - fx.seen_flagged) / static_cast<double>(fr - fx.seen_frames);
-    fx.seen_frames = fr; fx.seen_flagged = fl;
+    const volatile unsigned long long *h = fx.host;
+    const unsigned long long a = h[0], b = h[1];
+    const uint32_t seq = static_cast<uint32_t>(a >> kStatShift);
+    if (seq != static_cast<uint32_t>(b >> kStatShift) || seq == fx.seen_seq) return;     // a launch is publishing right now, or nothing new
+    fx.seen_seq = seq;
+    const unsigned long long tripped = a & kStatMask, frames = b & kStatMask;
+    if (frames < kAutoMinFrames) return;
+    fx.fraction = static_cast<double>(tripped) / static_cast<double>(frames);
     if (!fx.heavy && fx.fraction > kAutoUp) fx.heavy = true;
     else if (fx.heavy && fx.fraction < kAutoDown) fx.heavy = false;
 }
@@ -562,15 +559,11 @@ int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
 
 // the launch-specific part of a guarded launch's statistics sink (the grid is only known where the launch is made)
 FixSink sink_armed(melspec_ctx *c, FixSink sink, const BatchDesc &desc, unsigned grid) {
-    if (!sink.ticket) return sink;
-    FixState &fx = c->fix;
-    const uint64_t frames = desc.d_unit_prefix == nullptr ? static_cast<uint64_t>(desc.n_clips) * desc.frames_per_clip
-                                                          : desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);   // ragged: upper bound
-    fx.tickets += grid;
-    fx.frames_cum += frames;
-    sink.ticket_end = fx.tickets;
-    sink.seq = ++fx.seq;
-    sink.frames_cum = fx.frames_cum;
+    if (!sink.acc) return sink;
+    sink.frames = desc.d_unit_prefix == nullptr ? static_cast<uint64_t>(desc.n_clips) * desc.frames_per_clip
+                                                : desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);   // ragged: upper bound
+    sink.n_groups = grid;
+    sink.seq = (c->fix.seq = (c->fix.seq + 1) & 0xffffffu) ? c->fix.seq : (c->fix.seq = 1);      // never 0: the host's "nothing seen yet"
     return sink;
 }
 
@@ -733,7 +726,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         }
         fx.used = true; fx.last_stream = stream;
         sink.count = static_cast<unsigned long long *>(fx.count.p);
-        sink.ticket = reinterpret_cast<unsigned *>(static_cast<char *>(fx.count.p) + 8);
+        sink.acc = sink.count + 1;
         sink.host = fx.host;
         if (heavy) return launch_precise(c, desc, sink, stream);
     }
@@ -1351,9 +1344,14 @@ int melspec_sharded_create(melspec_sharded **out, const int *devices, int n_devi
         if (n_devices < 1) return fail(MELSPEC_ERR_INVALID_ARG, "n_devices must be >= 1");
         devs.assign(devices, devices + n_devices);
     } else {
-        const int n = melspec_device_count();
-        if (n < 1) return n;
-        for (int d = 0; d < n; ++d) devs.push_back(d);
+        // the ordinals of the gfx950 devices themselves: on a node with another GPU in front of them they are not 0 .. n-1
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+        for (int d = 0; d < count; ++d) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d) == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) devs.push_back(d);
+        }
+        if (devs.empty()) return fail(MELSPEC_ERR_UNAVAILABLE, "no gfx950 device visible");
     }
     melspec_sharded *s = new (std::nothrow) melspec_sharded();
     if (!s) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
