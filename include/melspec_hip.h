@@ -44,6 +44,9 @@ typedef struct melspec_fbank melspec_fbank;  /* Kaldi-style fbank (Fbank)       
 
 /* ABI version of this header (bumped on incompatible change). */
 int melspec_abi_version(void);
+/* Hash of the sources this library was built from (mel_spec_amd/build.py: csrc/*.hip, csrc/*.hpp, include/*.h), "unknown" for a
+ * build made by hand.  The test harness rebuilds when it differs from the hash of the checkout, so a stale prebuilt library cannot pass. */
+const char *melspec_source_hash(void);
 /* Number of usable gfx950 devices, or MELSPEC_ERR_UNAVAILABLE. */
 int melspec_device_count(void);
 /* Message for the last failure on this thread (valid until the next failing call).

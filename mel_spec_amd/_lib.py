@@ -45,6 +45,7 @@ _vp, _f32p, _f64p, _u64p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_doubl
 _u32p = C.POINTER(C.c_uint32)
 SIGNATURES = {
     "melspec_abi_version": (C.c_int, []),
+    "melspec_source_hash": (C.c_char_p, []),
     "melspec_device_count": (C.c_int, []),
     "melspec_last_error": (C.c_char_p, []),
     "melspec_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),

@@ -26,11 +26,41 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def source_hash() -> str:
+    """sha256 over the sources the library is built from (csrc/*.hip, csrc/*.hpp, include/*.h); baked into the library at build time
+    (-DMELSPEC_SOURCE_HASH) and returned by melspec_source_hash(), so a stale prebuilt library is detected whatever its mtime."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _inputs():
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:32]
+
+
+HASH_MARKER = b"@melspec-source-hash:"
+
+
+def built_hash(path: str = LIB_PATH):
+    """The source hash a built library carries (what its melspec_source_hash() returns), read from the file without loading it -- the
+    caller may be about to overwrite it; None if the file has none."""
+    try:
+        with open(path, "rb") as fh:
+            blob = fh.read()
+    except OSError:
+        return None
+    i = blob.find(HASH_MARKER)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(HASH_MARKER):j].decode(errors="replace")
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(f) > t for f in _inputs())
+    return not os.path.exists(LIB_PATH) or built_hash() != source_hash()
+
+
+INFO_PATH = os.path.join(PKG_DIR, "build_info.json")
 
 
 def build(force: bool = False, verbose: bool = False, lab: bool = False, defines=()) -> str:
@@ -39,7 +69,9 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False, defines
     out = LAB_LIB_PATH if lab else LIB_PATH
     if not lab and not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + (["-DMELSPEC_LAB"] if lab else []) + [f"-D{d}" for d in defines] + [
+    import json, time
+    src_hash = source_hash()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f'-DMELSPEC_SOURCE_HASH="{src_hash}"'] + (["-DMELSPEC_LAB"] if lab else []) + [f"-D{d}" for d in defines] + [
            # no SLP packing: v_pk_*_f32 issues at half the rate of the plain op on gfx950 (measured,
            # tools/valu_rate.hip) and pairing registers costs ~250 v_mov per kernel
            "-fno-slp-vectorize",
@@ -47,7 +79,21 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False, defines
            "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
+    t0 = time.time()
     subprocess.check_call(cmd)
+    if not lab:
+        # what was compiled, by what, where: printed by __graft_entry__.smoke() so that the record of a run shows which build it used
+        import hashlib, platform
+        try:
+            ver = subprocess.run([cmd[0], "--version"], capture_output=True, text=True).stdout.strip().splitlines()[0]
+        except Exception:
+            ver = "?"
+        with open(out, "rb") as fh:
+            so_hash = hashlib.sha256(fh.read()).hexdigest()[:32]
+        with open(INFO_PATH, "w") as fh:
+            json.dump({"library": os.path.basename(out), "source_hash": src_hash, "library_sha256_32": so_hash, "hipcc": ver,
+                       "seconds": round(time.time() - t0, 1), "host": platform.node(), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                       "gpu_visible_at_build": os.path.exists("/dev/kfd"), "command": " ".join(cmd)}, fh, indent=1)
     return out
 
 

@@ -749,6 +749,12 @@ extern "C" {
 
 int melspec_abi_version(void) { return 1; }
 
+#ifndef MELSPEC_SOURCE_HASH
+#define MELSPEC_SOURCE_HASH "unknown"
+#endif
+static const char kSourceHash[] = "@melspec-source-hash:" MELSPEC_SOURCE_HASH;      // the marker lets build.py read it from the file
+const char *melspec_source_hash(void) { return kSourceHash + sizeof("@melspec-source-hash:") - 1; }
+
 int melspec_device_count(void) {
     int count = 0;
     const hipError_t e = hipGetDeviceCount(&count);
@@ -1662,19 +1668,22 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         CmnParams cp{};
         cp.b = pl.desc;
         cp.n_mels = nm;
-        // rows staged per chunk: what fits one workgroup's LDS next to the means; two workgroups per CU when a whole clip fits half of it
-        const size_t head = static_cast<size_t>((nm + 3) & ~3) * sizeof(float);
+        // rows staged per chunk (a multiple of 4: the fold works on units of 4 frames): what fits one workgroup's LDS next to the means and
+        // the run sums; two workgroups per CU when a whole clip fits half of it
+        const size_t head = static_cast<size_t>((nm + 3) & ~3) * 9 * sizeof(float);
+        const bool staged = nm <= 512;
         size_t budget = kLdsLimit - head - 256;
         if (fpc * static_cast<uint64_t>(nm) * sizeof(float) + head <= kLdsLimit / 2 - 256) budget = kLdsLimit / 2 - head - 256;
-        uint64_t rows = budget / (static_cast<size_t>(nm) * sizeof(float));
-        if (rows > fpc) rows = fpc;
-        cp.rows_per_chunk = nm <= 512 ? static_cast<int>(rows) : 0;
+        uint64_t rows = (budget / (static_cast<size_t>(nm) * sizeof(float))) & ~3ull;
+        if (rows > ((fpc + 3) & ~3ull)) rows = (fpc + 3) & ~3ull;
+        cp.rows_per_chunk = staged ? static_cast<int>(rows) : 0;
         static std::atomic<uint64_t> cmn_attr{0};
         if (!device_done(cmn_attr)) {
             if ((rc = allow_big_lds(&cmn_kernel<512>, "hipFuncSetAttribute(cmn_kernel)"))) return rc;
             mark_device_done(cmn_attr);
         }
-        const size_t lds = head + (cp.rows_per_chunk ? static_cast<size_t>(cp.rows_per_chunk) * nm : 512) * sizeof(float);
+        const size_t lds = staged ? head + static_cast<size_t>(cp.rows_per_chunk) * nm * sizeof(float)
+                                  : (static_cast<size_t>((nm + 3) & ~3) + 8 * 512 + 512) * sizeof(float);
         const unsigned grid = grid_for(n_clips, fb->dev.cus, 8);
         hipLaunchKernelGGL(cmn_kernel<512>, dim3(grid), dim3(512), lds, s, cp);
         HIP_TRY(hipGetLastError());

@@ -2146,14 +2146,45 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
 }
 
 // CMN (src/fbank.rs:224-233): per clip and mel column subtract the f32 mean over the clip's frames.  The reference's
-// `column(m).mean()` (ndarray on a strided view) is a left fold in f32 followed by one division, and its rounding error
-// (~1e-5 of a feature value at 1000 frames, more on longer clips) is part of its output, so the sum runs in that order.
-// One workgroup per clip.  The fold is a chain of `frames` dependent adds per column and must not wait on memory: all 512
-// threads stage the clip's rows in LDS, a chunk of up to rows_per_chunk at a time (coalesced 16-byte loads, every load of a
-// chunk in flight together), lanes m < n_mels fold the chunk in frame order from LDS, and when the whole clip has been
-// folded every thread subtracts -- the last chunk straight from its LDS copy, the earlier ones re-read (L2 / Infinity
-// Cache).  (r01: 80 threads folded from global memory with 16 rows in flight and everything was read twice: 0.2 ms of
-// config 3's 0.92.)  rows_per_chunk == 0 (no LDS given): the r01 form, for banks wider than the staging allows.
+// `column(m).mean()` (ndarray on a strided view) is a left fold in f32 followed by one division; its rounding error is ~1e-5 of a
+// feature value at 1000 frames.  The column sum here is the FIXED TREE of fbank512_clip_kernel (which cannot afford a serial fold
+// inside the producing kernel) -- so that a clip's output bits do not depend on which of the two kernels its batch was given to,
+// i.e. on the batch it is in (round 2: the two orders differed by up to 1.6e-5):
+//   units of 4 frames; eight contiguous runs of units, run w = [units*w/8, units*(w+1)/8);
+//   S[w][p] = left fold, from +0, of the values of frame position p = frame & 3 over the run's units (frames past the clip's end add +0);
+//   run sum = (S[w][0] + S[w][1]) + (S[w][2] + S[w][3]);   sum = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));   mean = sum / frames.
+// It depends on the clip's frame count only, sits within ~2e-5 of the left fold (tests gate both at 1e-4 against the oracle) and gives
+// the fold four independent chains instead of one.
+// One workgroup per clip: all 512 threads stage the clip's rows in LDS, a chunk of up to rows_per_chunk (a multiple of 4) at a time
+// (coalesced 16-byte loads, every load of a chunk in flight together), lanes m < n_mels fold the chunk from LDS, and when the whole
+// clip has been folded every thread subtracts -- the last chunk straight from its LDS copy, the earlier ones re-read (L2 / Infinity
+// Cache).  rows_per_chunk == 0 (no staging): the columns are folded from global memory, for banks wider than the staging allows.
+struct CmnTree {
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    uint32_t w = 0;
+    uint64_t units, bound;          // bound: first unit of run w + 1
+    float *part;                    // this column's eight run sums, stride `pstride`
+    int pstride;
+    __device__ __forceinline__ CmnTree(uint64_t frames, float *part_, int pstride_) : units((frames + 3) / 4), part(part_), pstride(pstride_) { bound = units / 8; }
+    __device__ __forceinline__ void close() {
+        part[w * pstride] = (s0 + s1) + (s2 + s3);
+        s0 = s1 = s2 = s3 = 0.0f;
+        ++w;
+        bound = units * (w + 1) / 8;
+    }
+    // the four frames of unit u (values past the clip's end: +0)
+    __device__ __forceinline__ void unit(uint64_t u, float v0, float v1, float v2, float v3) {
+        while (u >= bound) close();                 // runs may be empty (fewer than eight units)
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    __device__ __forceinline__ float finish() {
+        while (w < 8) close();
+        const float *q = part;
+        const int t = pstride;
+        return ((q[0] + q[t]) + (q[2 * t] + q[3 * t])) + ((q[4 * t] + q[5 * t]) + (q[6 * t] + q[7 * t]));
+    }
+};
+
 struct CmnParams {
     BatchDesc b;   // only the clip geometry is used
     int n_mels;
@@ -2163,11 +2194,13 @@ struct CmnParams {
 template <int NT>
 __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
     extern __shared__ __attribute__((aligned(16))) float cmn_lds[];
-    float *mean_s = cmn_lds;                 // [n_mels rounded up to 4]
     const int nm = p.n_mels;
-    float *rows = cmn_lds + ((nm + 3) & ~3);
     const int tid = threadIdx.x;
     const int R = p.rows_per_chunk;
+    const int nmp = (nm + 3) & ~3;
+    float *mean_s = cmn_lds;                 // [nmp]
+    float *part_s = cmn_lds + nmp;           // the eight run sums of every column: [8][nmp] (staged form) / [8][NT]
+    float *rows = part_s + 8 * (R > 0 ? nmp : NT);
     for (uint32_t clip = blockIdx.x; clip < p.b.n_clips; clip += gridDim.x) {
         float *o;
         uint64_t frames;
@@ -2180,7 +2213,7 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
         }
         if (frames == 0) continue;
         if (R > 0) {
-            float s = 0.0f;
+            CmnTree tree(frames, part_s + tid, nmp);
             uint64_t f0 = 0;
             const bool vec = ((reinterpret_cast<uintptr_t>(o) & 15) == 0) && (nm % 4 == 0);
             for (;; f0 += R) {
@@ -2210,20 +2243,24 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
                 }
                 __syncthreads();
                 if (tid < nm) {
+                    // chunks start at multiples of 4 frames (rows_per_chunk is one): whole units, then the clip's last, partial unit
                     const float *col = rows + tid;
+                    const uint64_t ub = f0 / 4;
                     int r = 0;
                     for (; r + 16 <= nr; r += 16) {
                         float v[16];
 #pragma unroll
                         for (int i = 0; i < 16; ++i) v[i] = col[(r + i) * nm];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) s += v[i];
+                        for (int i = 0; i < 4; ++i) tree.unit(ub + (r >> 2) + i, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
                     }
-                    for (; r < nr; ++r) s += col[r * nm];
+                    for (; r + 4 <= nr; r += 4) tree.unit(ub + (r >> 2), col[r * nm], col[(r + 1) * nm], col[(r + 2) * nm], col[(r + 3) * nm]);
+                    if (r < nr)
+                        tree.unit(ub + (r >> 2), col[r * nm], r + 1 < nr ? col[(r + 1) * nm] : 0.0f, r + 2 < nr ? col[(r + 2) * nm] : 0.0f, 0.0f);
                 }
                 if (f0 + nr >= frames) break;
             }
-            if (tid < nm) mean_s[tid] = f32_div_rn(s, (float)frames);
+            if (tid < nm) mean_s[tid] = f32_div_rn(tree.finish(), (float)frames);
             __syncthreads();
             // the last chunk from LDS, the earlier ones from memory
             const int nr = (int)(frames - f0);
@@ -2253,17 +2290,19 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
             if (tid < cols) {
                 constexpr int kB = 16;
                 const float *col = o + m0 + tid;
-                float s = 0.0f;
+                CmnTree tree(frames, part_s + tid, NT);
                 uint64_t f = 0;
                 for (; f + kB <= frames; f += kB) {
                     float v[kB];
 #pragma unroll
                     for (int i = 0; i < kB; ++i) v[i] = col[(f + i) * nm];
 #pragma unroll
-                    for (int i = 0; i < kB; ++i) s += v[i];
+                    for (int i = 0; i < kB / 4; ++i) tree.unit(f / 4 + i, v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
                 }
-                for (; f < frames; ++f) s += col[f * nm];
-                rows[tid] = f32_div_rn(s, (float)frames);
+                for (; f + 4 <= frames; f += 4) tree.unit(f / 4, col[f * nm], col[(f + 1) * nm], col[(f + 2) * nm], col[(f + 3) * nm]);
+                if (f < frames)
+                    tree.unit(f / 4, col[f * nm], f + 1 < frames ? col[(f + 1) * nm] : 0.0f, f + 2 < frames ? col[(f + 2) * nm] : 0.0f, 0.0f);
+                rows[tid] = f32_div_rn(tree.finish(), (float)frames);
             }
             __syncthreads();
             if (g < G) {

@@ -730,6 +730,10 @@ static void blm_normalize(float *features, int n_mels, int64_t valid, int64_t pa
     }
 }
 
+/* normalize_per_feature (src/mel.rs:721-749) on its own: the reference's f32 left folds applied in place to a [n_mels][padded] image --
+ * how the tests check the device normaliser on the device's own un-normalised rows, ill-conditioned ones included. */
+void oracle_blm_normalize(float *features, int n_mels, int64_t valid, int64_t padded) { blm_normalize(features, n_mels, valid, padded); }
+
 /* out: [n_mels][padded_frames] f32.  Returns padded_frames (cols); *valid_out = valid frames. */
 int64_t oracle_blm_compute_f32(const oracle_blm_config *c, const float *samples, int64_t len, float *out, int64_t *valid_out) {
     const int64_t valid = oracle_blm_num_frames(c, len), padded = oracle_blm_padded_frames(c, valid);

@@ -355,6 +355,17 @@ def blm_compute(samples, cfg: BlmConfig | None = None, f64: bool = True):
     return out, int(valid.value)
 
 
+def blm_normalize(features, valid: int) -> np.ndarray:
+    """normalize_per_feature (src/mel.rs:721-749): the reference's f32 left folds on a [n_mels, cols] f32 image (a copy is returned)."""
+    a = np.array(features, dtype=np.float32, order="C", copy=True)
+    fn = lib().oracle_blm_normalize
+    fn.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int64]
+    fn.restype = None
+    if a.size:
+        fn(_p(a, C.c_float), a.shape[0], int(valid), a.shape[1])
+    return a
+
+
 SYNTH_SEED = 0x4D454C53
 
 

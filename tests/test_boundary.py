@@ -102,3 +102,17 @@ def test_null_handles_are_rejected_without_a_device():
     for call in calls:
         assert call() == _lib.ERR_INVALID_ARG
         assert "NULL" in _lib.last_error()
+
+
+def test_library_is_built_from_these_sources(tmp_path):
+    """melspec_source_hash(): the hash of csrc/ + include/ baked into the library at build time equals the hash of this checkout (conftest
+    rebuilds when it does not), and a library without / with another hash is reported as stale -- a prebuilt library that travelled with
+    the snapshot cannot silently be an old one."""
+    from mel_spec_amd import build as B, _lib
+    assert _lib.lib().melspec_source_hash().decode() == B.source_hash() == B.built_hash()
+    assert not B.needs_build()
+    stale = tmp_path / "libstale.so"
+    blob = open(B.LIB_PATH, "rb").read()
+    stale.write_bytes(blob.replace(B.HASH_MARKER + B.source_hash().encode(), B.HASH_MARKER + b"0" * 32))
+    assert B.built_hash(str(stale)) == "0" * 32 != B.source_hash()
+    assert B.built_hash(str(tmp_path / "missing.so")) is None
