@@ -44,7 +44,7 @@ typedef struct melspec_fbank melspec_fbank;  /* Kaldi-style fbank (Fbank)       
 
 /* ABI version of this header (bumped on incompatible change). */
 int melspec_abi_version(void);
-/* Hash of the sources this library was built from (mel_spec_amd/build.py: csrc/*.hip, csrc/*.hpp, include/*.h), "unknown" for a
+/* Hash of the sources this library was built from (mel_spec_amd/build.py: the .hip / .hpp files of csrc/ and the headers of include/), "unknown" for a
  * build made by hand.  The test harness rebuilds when it differs from the hash of the checkout, so a stale prebuilt library cannot pass. */
 const char *melspec_source_hash(void);
 /* Number of usable gfx950 devices, or MELSPEC_ERR_UNAVAILABLE. */
@@ -61,6 +61,15 @@ const char *melspec_last_error(void);
  * twiddles in f64 on the host, uploads them as f32 tables.  device < 0 -> current device. */
 int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size,
                    double sampling_rate, int n_mels);
+/* MelSpectrogram with a caller-chosen filterbank instead of new()'s mel(sr, fft, n_mels, None, None, false, true) (src/mel.rs:19-24):
+ * SparseMelFilterbank::from_mel(sr, n_fft, n_mels, f_min, f_max, htk, norm) (src/mel.rs:73-87; f_min < 0 == None, f_max <= 0 == None)
+ * or from_dense(filters) (src/mel.rs:48-71; row-major [n_mels][fft_size / 2 + 1] f64) -- what log_mel_spectrogram(stft, mel_filters)
+ * (src/mel.rs:436-441) takes.  Everything else as melspec_create; a two-filters-per-bin bank (every triangular one) of <= 131 rows
+ * runs on the fused n_fft = 400 / 512 kernels, any other matrix on the generic kernel. */
+int melspec_create_with_filterbank(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels,
+                                   double f_min, double f_max, int htk, int norm);
+int melspec_create_with_dense_filterbank(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels,
+                                         const double *filters, int fft_bins);
 void melspec_destroy(melspec_ctx *ctx);   /* Drop (src/cuda.rs:142-148,366-375) */
 
 /* frame_windows' count: len < fft ? 0 : (len - fft)/hop + 1 (src/stft.rs:153-157). */
@@ -172,6 +181,16 @@ melspec_ctx *melspec_sharded_ctx(melspec_sharded *s, int shard);   /* for device
 int melspec_sharded_compute_batch_host(melspec_sharded *s, const float *samples, const uint64_t *offsets, const uint64_t *lengths,
                                        uint32_t n_clips, float *out, const uint64_t *out_offsets, size_t out_capacity_floats,
                                        uint64_t *total_frames);
+/* Device-resident shards: shard k's clips are on device k (d_pcm[k]), its frames stay there (d_out[k]); n_clips[k] clips per shard.
+ * uniform: clip c of shard k = d_pcm[k] + c * clip_stride.  ragged: the clip tables of the shards one after the other (n_clips[0]
+ * entries, then n_clips[1], ...), offsets relative to the shard's own d_pcm[k] / d_out[k]; h_out_offsets NULL = packed per shard.
+ * Stream-ordered on every shard's context stream; melspec_sharded_synchronize waits for all shards.  No data crosses a device
+ * boundary (per-clip split, no collective). */
+int melspec_sharded_compute_uniform_device(melspec_sharded *s, const float *const *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                           const uint32_t *n_clips, float *const *d_out);
+int melspec_sharded_compute_ragged_device(melspec_sharded *s, const float *const *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                                          const uint32_t *n_clips, float *const *d_out, const uint64_t *h_out_offsets);
+int melspec_sharded_synchronize(melspec_sharded *s);
 /* Optional consolidation of device-resident results on one device: bytes[i] bytes at srcs[i] (device src_devices[i]) ->
  * dst + dst_offsets[i] bytes on dst_device, each piece on a stream of its source device (hipMemcpyPeerAsync: the pieces
  * cross their own xGMI links concurrently).  Synchronous; time it separately from the frames/s figure. */
@@ -219,6 +238,32 @@ int melspec_time_uniform_device(melspec_ctx *ctx, const float *d_pcm, uint64_t c
 
 /* Wait for everything this context has queued on `stream` (cudaStreamSynchronize, src/cuda.rs:129). */
 int melspec_synchronize(melspec_ctx *ctx, void *stream);
+
+/* ---- the stand-alone mel helpers: SparseMelFilterbank, log_mel_spectrogram, norm_mel (src/mel.rs:40-168, 436-469) ----------
+ * For callers that keep the reference's split API (examples/vad_ten_eval/src/main.rs:232-256: compute_all_cpu -> their own bank).
+ * dtype: MELSPEC_STFT_F32 / MELSPEC_STFT_F64 (element type of the arrays).  The sums are the reference's left folds over its sparse
+ * rows with a separate multiply and add: project_power is bit-exact against the f32 / f64 reference arithmetic. */
+typedef struct melspec_bank melspec_bank;
+/* SparseMelFilterbank::from_dense (src/mel.rs:48-71) / from_mel (:73-87) */
+int melspec_bank_from_dense(melspec_bank **out, int device, const double *filters, int n_mels, int fft_bins);
+int melspec_bank_from_mel(melspec_bank **out, int device, double sample_rate, int n_fft, int n_mels, double f_min, double f_max,
+                          int htk, int norm);
+void melspec_bank_destroy(melspec_bank *bank);
+int melspec_bank_n_mels(const melspec_bank *bank);              /* n_mels()            src/mel.rs:89-91  */
+int melspec_bank_fft_bins(const melspec_bank *bank);            /* fft_bins()          src/mel.rs:93-95  */
+int melspec_bank_non_zero_weights(const melspec_bank *bank);    /* non_zero_weights()  src/mel.rs:97-99  */
+/* project_power_f64 / project_power_f32 (src/mel.rs:106-146) for n_frames rows: power [n_frames][fft_bins] -> [n_frames][n_mels] */
+int melspec_bank_project_power_device(melspec_bank *bank, const void *d_power, int dtype, uint64_t n_frames, void *d_out, void *stream);
+int melspec_bank_project_power_host(melspec_bank *bank, const void *power, int dtype, size_t n_frames, void *out);
+/* log_mel_spectrogram(stft, mel_filters) (src/mel.rs:436-441 -> project_stft_log10 :148-168) for n_frames frames: complex frames
+ * [n_frames][n_fft] (interleaved re, im; what compute_all_cpu / melspec_stft_* with full = 1 return) -> log10(max(E, 1e-10)),
+ * [n_frames][n_mels] f64, NOT normalised (norm_mel below). */
+int melspec_bank_log_mel_device(melspec_bank *bank, const void *d_stft, int dtype, int n_fft, uint64_t n_frames, double *d_out, void *stream);
+int melspec_bank_log_mel_host(melspec_bank *bank, const void *stft, int dtype, int n_fft, size_t n_frames, double *out);
+/* norm_mel (f64, src/mel.rs:448-454) / norm_mel_vec (f32, :457-469): ONE maximum over the n_values given (a frame, a window of
+ * frames, a whole clip: "flexibility in the sample size that's normalised over"), then (max(x, mmax - 8) + 4) / 4. */
+int melspec_bank_norm_mel_device(melspec_bank *bank, const void *d_in, int dtype, uint64_t n_values, void *d_out, void *stream);
+int melspec_bank_norm_mel_host(melspec_bank *bank, const void *in, int dtype, size_t n_values, void *out);
 
 /* ---- host-side table builders (pure CPU, usable without a GPU) --------------------- */
 

@@ -1,14 +1,14 @@
 """mel_spec_amd -- MI355X (gfx950) log-mel spectrogram frontend behind the API of
 wavey-ai/mel-spec's GPU plugin slot.  All compute runs in hand-written HIP kernels
 (csrc/) reached through the C ABI of libmelspec_hip.so (include/melspec_hip.h)."""
-from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, DeviceBuffer, HostBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable,
+from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, DeviceBuffer, HostBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable, SparseMelFilterbank,
                   device_count, device_synchronize, hann_window, kaldi_mel_filterbank, mel, synth_pcm_device, synth_pcm_window)
 from .parallel import ShardedMelSpectrogram, gather_peer, shard_by_samples, shard_range
 from .quant import QuantizationRange, TgaCodec, to_array2
 from .stream import RingBuffer, StreamBank
 from .vad import DetectionSettings, EdgeInfo, VoiceActivity, VoiceActivityDetector, vad_boundaries, vad_on
 
-__all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "HostBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError",
+__all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "HostBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError", "SparseMelFilterbank",
            "HipUnavailable", "device_count", "device_synchronize", "hann_window", "kaldi_mel_filterbank", "mel",
            "synth_pcm_device", "synth_pcm_window", "shard_range", "shard_by_samples", "ShardedMelSpectrogram", "gather_peer", "QuantizationRange", "TgaCodec", "to_array2", "RingBuffer", "StreamBank", "DetectionSettings", "EdgeInfo", "VoiceActivity", "VoiceActivityDetector",
            "vad_boundaries", "vad_on"]

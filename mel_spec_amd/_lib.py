@@ -49,7 +49,21 @@ SIGNATURES = {
     "melspec_device_count": (C.c_int, []),
     "melspec_last_error": (C.c_char_p, []),
     "melspec_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "melspec_create_with_filterbank": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "melspec_create_with_dense_filterbank": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, _f64p, C.c_int]),
     "melspec_destroy": (None, [_vp]),
+    "melspec_bank_from_dense": (C.c_int, [C.POINTER(_vp), C.c_int, _f64p, C.c_int, C.c_int]),
+    "melspec_bank_from_mel": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]),
+    "melspec_bank_destroy": (None, [_vp]),
+    "melspec_bank_n_mels": (C.c_int, [_vp]),
+    "melspec_bank_fft_bins": (C.c_int, [_vp]),
+    "melspec_bank_non_zero_weights": (C.c_int, [_vp]),
+    "melspec_bank_project_power_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, _vp, _vp]),
+    "melspec_bank_project_power_host": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
+    "melspec_bank_log_mel_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),
+    "melspec_bank_log_mel_host": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_size_t, _f64p]),
+    "melspec_bank_norm_mel_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, _vp, _vp]),
+    "melspec_bank_norm_mel_host": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
     "melspec_num_frames": (C.c_size_t, [_vp, C.c_size_t]),
     "melspec_max_frames_per_batch": (C.c_size_t, [_vp]),
     "melspec_fft_size": (C.c_int, [_vp]),
@@ -83,6 +97,9 @@ SIGNATURES = {
     "melspec_sharded_n_shards": (C.c_int, [_vp]),
     "melspec_sharded_ctx": (_vp, [_vp, C.c_int]),
     "melspec_sharded_compute_batch_host": (C.c_int, [_vp, _f32p, _u64p, _u64p, C.c_uint32, _f32p, _u64p, C.c_size_t, _u64p]),
+    "melspec_sharded_compute_uniform_device": (C.c_int, [_vp, C.POINTER(_vp), C.c_uint64, C.c_uint64, _u32p, C.POINTER(_vp)]),
+    "melspec_sharded_compute_ragged_device": (C.c_int, [_vp, C.POINTER(_vp), _u64p, _u64p, _u32p, C.POINTER(_vp), _u64p]),
+    "melspec_sharded_synchronize": (C.c_int, [_vp]),
     "melspec_gather_peer": (C.c_int, [C.c_int, _vp, C.POINTER(C.c_int), C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]),
     "melspec_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "melspec_interleaved_width": (C.c_size_t, [_vp, C.c_size_t, C.c_size_t]),

@@ -96,7 +96,8 @@ inline bool build_interval_mel(const std::vector<double> &dense, int n_mels, int
 }
 
 // Returns false if the geometry is outside the fused kernel's coverage.
-inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_interval = false) {
+// dense: the filterbank, [n_mels][201] (MelSpectrogram::new's default, or a caller's bank: melspec_create_with_filterbank)
+inline bool build_fast_tables(const std::vector<double> &dense, int n_mels, FastTables &out, bool want_interval = false) {
     constexpr int N = 400, M = 200;
     const int n_slots = (n_mels + kMelJobs - 1) / kMelJobs;
     if (n_mels < 1 || n_slots > kMaxSlots) return false;
@@ -124,7 +125,6 @@ inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_
     // MelSpectrogram::new: mel(sr, fft, n_mels, None, None, false, true)  (src/mel.rs:19-24);
     // bins >= n_fft/2 are zeroed by project_stft_log10 (src/mel.rs:155-163).
     const int bins = N / 2 + 1;
-    const std::vector<double> dense = mel_filterbank(sr, N, n_mels, -1.0, -1.0, false, true);
     const BandedFilterbank fb = band_filterbank(dense, n_mels, bins, M);
     out.nnz = fb.nnz;
     out.n_mels = n_mels;
@@ -163,6 +163,10 @@ inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_
     return true;
 }
 
+inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_interval = false) {
+    return build_fast_tables(mel_filterbank(sr, 400, n_mels, -1.0, -1.0, false, true), n_mels, out, want_interval);
+}
+
 }  // namespace melspec
 
 #include "whisper_wave_f64.hpp"
@@ -172,7 +176,7 @@ namespace melspec {
 
 // Tables of the six-frames-per-wave kernel (SixBlob in whisper_six.hpp).  false: filterbank outside its coverage
 // (more than 9 slots of 9 intervals, or not a two-filters-per-bin bank).
-inline bool build_six_tables(double sr, int n_mels, FastTables &out) {
+inline bool build_six_tables(const std::vector<double> &dense, int n_mels, FastTables &out) {
     constexpr int N = 400, M = 200;
     if (n_mels < 1 || n_mels > kSixOwn * kSixMaxSlots - 1) return false;
     std::vector<float> &b = out.blob;
@@ -194,12 +198,15 @@ inline bool build_six_tables(double sr, int n_mels, FastTables &out) {
             b[SixBlob::kTw2 + j * SixBlob::kTw2Stride + 2 * s + 1] = static_cast<float>(std::sin(a));
         }
     const int bins = N / 2 + 1;
-    const std::vector<double> dense = mel_filterbank(sr, N, n_mels, -1.0, -1.0, false, true);
     out.n_mels = n_mels;
     out.nnz = 0;
     out.interval = build_interval_mel(dense, n_mels, bins, M, b, out.slots, kSixLanes, 0.25, SixBlob::kMelStart, kSixMaxSlots);
     while (b.size() % 4) b.push_back(0.0f);
     return out.interval;
+}
+
+inline bool build_six_tables(double sr, int n_mels, FastTables &out) {
+    return build_six_tables(mel_filterbank(sr, 400, n_mels, -1.0, -1.0, false, true), n_mels, out);
 }
 
 // Blob of the precise kernel: [PreciseBlob tables in f64][the mel section of an interval-scheme f32 blob].

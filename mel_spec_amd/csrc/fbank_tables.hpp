@@ -82,9 +82,12 @@ inline bool build_blm_fast_tables(int sample_rate, int n_mels, double f_min, dou
 // Whisper flavour at n_fft = 512: periodic Hann(512) (src/stft.rs:141-145), Slaney mel() over 257 bins of which
 // project_stft_log10 uses those below n_fft/2 = 256 (src/mel.rs:155-163).
 template <class T>
-inline bool build_whisper512_tables(double sample_rate, int n_mels, FbankFastTables &out) {
-    const std::vector<double> dense = mel_filterbank(sample_rate, 512, n_mels, -1.0, -1.0, false, true);
+inline bool build_whisper512_tables(const std::vector<double> &dense /* [n_mels][257] */, int n_mels, FbankFastTables &out) {
     return build_fused512_tables<T>(hann_window(512), dense, n_mels, 0.25, kBlmSlots, out, 256);
+}
+template <class T>
+inline bool build_whisper512_tables(double sample_rate, int n_mels, FbankFastTables &out) {
+    return build_whisper512_tables<T>(mel_filterbank(sample_rate, 512, n_mels, -1.0, -1.0, false, true), n_mels, out);
 }
 
 }  // namespace melspec

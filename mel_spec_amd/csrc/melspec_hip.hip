@@ -23,6 +23,7 @@
 #include "fast_tables.hpp"
 #include "fbank_tables.hpp"
 #include "melspec_kernels.hpp"
+#include "mel_bank.hpp"
 #include "host_pipe.hpp"
 #include "stream_plan.hpp"
 #include "tga_quant.hpp"
@@ -485,6 +486,8 @@ struct melspec_ctx {
     DeviceInfo dev;
     int fft_size = 0, hop_size = 0, n_mels = 0;
     double sr = 0.0;
+    std::vector<double> dense;      // the filterbank, [n_mels][fft_size / 2 + 1]: MelSpectrogram::new's mel(sr, fft, n_mels, None, None, false, true)
+                                    // (src/mel.rs:19-24) or the caller's (melspec_create_with_filterbank / _with_dense_filterbank)
     hipStream_t stream = nullptr;
     // fused n_fft = 400 build, five frames per wave (whisper400_wave_*): every bank of <= 131 mels; serves 81..131 mels and
     // carries the tables the f64 kernels share
@@ -773,7 +776,11 @@ int melspec_device_count(void) {
 
 const char *melspec_last_error(void) { return g_last_error.c_str(); }
 
-int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels) {
+}  // extern "C"
+
+namespace {
+// dense: [n_mels][fft_size / 2 + 1], empty = the default bank of MelSpectrogram::new
+int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels, std::vector<double> dense) {
     if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
     *out = nullptr;
     // src/cuda.rs:45-49
@@ -788,6 +795,8 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     melspec_ctx *c = new (std::nothrow) melspec_ctx();
     if (!c) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
     c->dev = info; c->fft_size = fft_size; c->hop_size = hop_size; c->n_mels = n_mels; c->sr = sampling_rate;
+    if (dense.empty()) dense = mel_filterbank(sampling_rate, fft_size, n_mels, -1.0, -1.0, false, true);
+    c->dense = std::move(dense);
     auto bail = [&](int code) { melspec_destroy(c); return code; };
     if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
     if (hipStreamCreate(&c->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
@@ -795,7 +804,7 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     // fused kernels: n_fft == 400, any hop up to 1024 (the 8-byte PCM loads only need 4-byte alignment, as every ragged clip offset
     // already demands), a two-filters-per-bin bank of <= 131 mels
     const bool runtime_lens = lab_int("MELSPEC_RUNTIME_LENS", 0, 0, 1) != 0;
-    c->fast = (fft_size == 400) && (hop_size <= 1024) && build_fast_tables(sampling_rate, n_mels, c->ft, true) &&
+    c->fast = (fft_size == 400) && (hop_size <= 1024) && build_fast_tables(c->dense, n_mels, c->ft, true) &&
               c->ft.interval;
     if (c->fast) {
         c->lens_kind = lens_match<LensI80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensI128>(c->ft.slots, n_mels) ? 2 : 0);
@@ -808,14 +817,14 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
         if (c->fast_lds > kLdsLimit || !pt_ok || c->precise_lds > kLdsLimit) c->fast = false;
         else c->pt = std::move(pt);
     }
-    if (!c->fast && fft_size == 512 && lab_int("MELSPEC_W512", 1, 0, 1) != 0 && build_whisper512_tables<double>(sampling_rate, n_mels, c->ft512)) {
+    if (!c->fast && fft_size == 512 && lab_int("MELSPEC_W512", 1, 0, 1) != 0 && build_whisper512_tables<double>(c->dense, n_mels, c->ft512)) {
         const size_t slice_bytes = FbankLayout<double>::slice_elems() * sizeof(double) + 512;      // + the frame maxima
         c->waves512 = fused512_waves(c->ft512.blob.size() * 4, slice_bytes);
         c->lds512 = c->ft512.blob.size() * 4 + static_cast<size_t>(c->waves512) * slice_bytes;
         c->fast512 = c->lds512 <= kLdsLimit;
         if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
     }
-    if (c->fast && build_six_tables(sampling_rate, n_mels, c->ft6)) {
+    if (c->fast && build_six_tables(c->dense, n_mels, c->ft6)) {
         c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves);   // + arrival counters
         c->six = c->lds6 <= kLdsLimit;
         bool st = c->ft6.slots.n_slots == LensSix80::kSlots && n_mels == LensSix80::kMels;
@@ -832,14 +841,42 @@ int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, do
     }
     if (!c->fast) {          // the generic kernel also serves the layouts the fused 512 build does not store
         const int bins = fft_size / 2 + 1;
-        const std::vector<double> dense = mel_filterbank(sampling_rate, fft_size, n_mels, -1.0, -1.0, false, true);
         // bins >= n_fft/2 contribute nothing (src/mel.rs:155-163)
-        if ((rc = c->gt.build(fft_size, fft_size, fft_size / 2, hann_window(fft_size), dense, n_mels, bins))) return bail(rc);
+        if ((rc = c->gt.build(fft_size, fft_size, fft_size / 2, hann_window(fft_size), c->dense, n_mels, bins))) return bail(rc);
         if (c->gt.lds_bytes > kLdsLimit) return bail(fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than one workgroup has"));
         if ((rc = allow_big_lds(&generic_frame_kernel<kGenericNT>, "hipFuncSetAttribute(generic_frame_kernel)"))) return bail(rc);
     }
     *out = c;
     return MELSPEC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int melspec_create(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels) {
+    return create_ctx(out, device, fft_size, hop_size, sampling_rate, n_mels, {});
+}
+
+int melspec_create_with_filterbank(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels,
+                                   double f_min, double f_max, int htk, int norm) {
+    if (out) *out = nullptr;
+    if (fft_size < 2 || n_mels <= 0 || !(sampling_rate > 0.0) || fft_size > kMaxGenericFft || n_mels > kMaxGenericMels)
+        return create_ctx(out, device, fft_size, hop_size, sampling_rate, n_mels, {});       // the common argument checks and messages
+    return create_ctx(out, device, fft_size, hop_size, sampling_rate, n_mels,
+                      mel_filterbank(sampling_rate, fft_size, n_mels, f_min, f_max, htk != 0, norm != 0));
+}
+
+int melspec_create_with_dense_filterbank(melspec_ctx **out, int device, int fft_size, int hop_size, double sampling_rate, int n_mels,
+                                         const double *filters, int fft_bins) {
+    if (out) *out = nullptr;
+    if (!filters) return fail(MELSPEC_ERR_INVALID_ARG, "filters is NULL");
+    if (fft_size < 2 || n_mels <= 0 || fft_size > kMaxGenericFft || n_mels > kMaxGenericMels)
+        return create_ctx(out, device, fft_size, hop_size, sampling_rate, n_mels, {});
+    if (fft_bins != fft_size / 2 + 1) return fail(MELSPEC_ERR_INVALID_ARG, "filters must have fft_size / 2 + 1 columns");
+    std::vector<double> dense(filters, filters + static_cast<size_t>(n_mels) * fft_bins);
+    for (double w : dense)
+        if (!std::isfinite(w)) return fail(MELSPEC_ERR_INVALID_ARG, "filters must be finite");
+    return create_ctx(out, device, fft_size, hop_size, sampling_rate, n_mels, std::move(dense));
 }
 
 void melspec_destroy(melspec_ctx *c) {
@@ -1111,8 +1148,7 @@ namespace {
 int stage_tables(melspec_ctx *c) {
     if (c->stage_built) return MELSPEC_OK;
     const int bins = c->fft_size / 2 + 1;
-    const std::vector<double> dense = mel_filterbank(c->sr, c->fft_size, c->n_mels, -1.0, -1.0, false, true);
-    const BandedFilterbank fb = band_filterbank(dense, c->n_mels, bins, c->fft_size / 2);      // bins >= n_fft/2 contribute nothing (src/mel.rs:155-163)
+    const BandedFilterbank fb = band_filterbank(c->dense, c->n_mels, bins, c->fft_size / 2);      // bins >= n_fft/2 contribute nothing (src/mel.rs:155-163)
     int rc;
     if ((rc = upload(c->st_start, fb.start))) return rc;
     if ((rc = upload(c->st_len, fb.len))) return rc;
@@ -1424,6 +1460,48 @@ int melspec_sharded_compute_batch_host(melspec_sharded *s, const float *samples,
     return MELSPEC_OK;
 }
 
+// Device-resident shards ("one ctx + stream per device" with the data already where it is computed): shard k's
+// clips are on device k, its frames stay there.  The launches are stream-ordered on every shard's own context stream and issued
+// from the calling thread (a launch costs microseconds; the host pipeline of the host form is what needs a thread per device);
+// melspec_sharded_synchronize waits for all of them.  Nothing crosses a device boundary.
+int melspec_sharded_compute_uniform_device(melspec_sharded *s, const float *const *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                           const uint32_t *n_clips, float *const *d_out) {
+    if (!s || s->ctx.empty()) return fail(MELSPEC_ERR_INVALID_ARG, "sharded object is NULL");
+    if (!d_pcm || !n_clips || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "per-shard array is NULL");
+    for (size_t k = 0; k < s->ctx.size(); ++k) {
+        if (n_clips[k] == 0) continue;
+        const int rc = melspec_compute_uniform_device(s->ctx[k], d_pcm[k], clip_stride, clip_len, n_clips[k], d_out[k], nullptr);
+        if (rc) { g_last_error = "shard " + std::to_string(k) + ": " + g_last_error; return rc; }
+    }
+    return MELSPEC_OK;
+}
+
+int melspec_sharded_compute_ragged_device(melspec_sharded *s, const float *const *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,
+                                          const uint32_t *n_clips, float *const *d_out, const uint64_t *h_out_offsets) {
+    if (!s || s->ctx.empty()) return fail(MELSPEC_ERR_INVALID_ARG, "sharded object is NULL");
+    if (!d_pcm || !n_clips || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "per-shard array is NULL");
+    uint64_t first = 0;
+    for (size_t k = 0; k < s->ctx.size(); ++k) {
+        if (n_clips[k] != 0) {
+            if (!h_offsets || !h_lengths) return fail(MELSPEC_ERR_INVALID_ARG, "offset/length array is NULL");
+            const int rc = melspec_compute_ragged_device(s->ctx[k], d_pcm[k], h_offsets + first, h_lengths + first, n_clips[k], d_out[k],
+                                                         h_out_offsets ? h_out_offsets + first : nullptr, nullptr);
+            if (rc) { g_last_error = "shard " + std::to_string(k) + ": " + g_last_error; return rc; }
+        }
+        first += n_clips[k];
+    }
+    return MELSPEC_OK;
+}
+
+int melspec_sharded_synchronize(melspec_sharded *s) {
+    if (!s) return fail(MELSPEC_ERR_INVALID_ARG, "sharded object is NULL");
+    for (melspec_ctx *c : s->ctx) {
+        const int rc = melspec_synchronize(c, nullptr);
+        if (rc) return rc;
+    }
+    return MELSPEC_OK;
+}
+
 // Consolidation of per-device results on one device (optional, not part of the frames/s figure): piece i =
 // bytes[i] bytes at srcs[i] on src_devices[i] -> dst + dst_offsets[i] on dst_device, every piece on a stream of its source
 // device so that the pieces travel over their own xGMI links at the same time.  Synchronous.
@@ -1454,6 +1532,187 @@ int melspec_gather_peer(int dst_device, void *dst, const int *src_devices, const
     }
     return rc;
 }
+
+}  // extern "C"
+
+// ---- stand-alone mel helpers (mel_bank.hpp): SparseMelFilterbank, project_power, log_mel_spectrogram, norm_mel -------------------
+struct melspec_bank {
+    DeviceInfo dev;
+    hipStream_t stream = nullptr;
+    int n_mels = 0, fft_bins = 0, nnz = 0;
+    DevBuf row_ptr, bin, w, wf, key, tmp_in, tmp_out;
+    BankDesc desc() const {
+        return BankDesc{static_cast<const int *>(row_ptr.p), static_cast<const int *>(bin.p), static_cast<const double *>(w.p),
+                        static_cast<const float *>(wf.p), n_mels, fft_bins};
+    }
+};
+
+namespace {
+int bank_create(melspec_bank **out, int device, const std::vector<double> &dense, int n_mels, int fft_bins) {
+    DeviceInfo info;
+    int rc = pick_device(device, info);
+    if (rc) return rc;
+    melspec_bank *b = new (std::nothrow) melspec_bank();
+    if (!b) return fail(MELSPEC_ERR_INTERNAL, "out of host memory");
+    b->dev = info; b->n_mels = n_mels; b->fft_bins = fft_bins;
+    auto bail = [&](int code) { melspec_bank_destroy(b); return code; };
+    if (hipSetDevice(info.device) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipSetDevice failed"));
+    if (hipStreamCreate(&b->stream) != hipSuccess) return bail(fail(MELSPEC_ERR_UNAVAILABLE, "hipStreamCreate failed"));
+    // from_dense (src/mel.rs:48-71): per row the non-zero entries in ascending bin order
+    std::vector<int> row_ptr(static_cast<size_t>(n_mels) + 1, 0), bins;
+    std::vector<double> w;
+    std::vector<float> wf;
+    for (int m = 0; m < n_mels; ++m) {
+        for (int k = 0; k < fft_bins; ++k) {
+            const double v = dense[static_cast<size_t>(m) * fft_bins + k];
+            if (v != 0.0) { bins.push_back(k); w.push_back(v); wf.push_back(static_cast<float>(v)); }
+        }
+        row_ptr[m + 1] = static_cast<int>(bins.size());
+    }
+    b->nnz = static_cast<int>(bins.size());
+    if ((rc = upload(b->row_ptr, row_ptr)) || (rc = upload(b->bin, bins)) || (rc = upload(b->w, w)) || (rc = upload(b->wf, wf))) return bail(rc);
+    if ((rc = b->key.ensure(16))) return bail(rc);
+    *out = b;
+    return MELSPEC_OK;
+}
+
+template <class T>
+int norm_launch(const T *d_in, uint64_t n, T *d_out, unsigned long long *key, int cus, hipStream_t s) {
+    const unsigned grid = static_cast<unsigned>(std::min<uint64_t>((n + 255) / 256, static_cast<uint64_t>(cus) * 16));
+    hipLaunchKernelGGL(norm_init_kernel, dim3(1), dim3(1), 0, s, key);
+    hipLaunchKernelGGL(norm_max_kernel<T>, dim3(grid), dim3(256), 0, s, d_in, n, key);
+    hipLaunchKernelGGL(norm_map_kernel<T>, dim3(grid), dim3(256), 0, s, d_in, n, key, d_out);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int melspec_bank_from_dense(melspec_bank **out, int device, const double *filters, int n_mels, int fft_bins) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!filters || n_mels <= 0 || fft_bins <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "filters is NULL or a dimension is not positive");
+    return bank_create(out, device, std::vector<double>(filters, filters + static_cast<size_t>(n_mels) * fft_bins), n_mels, fft_bins);
+}
+
+int melspec_bank_from_mel(melspec_bank **out, int device, double sample_rate, int n_fft, int n_mels, double f_min, double f_max, int htk, int norm) {
+    if (!out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!(sample_rate > 0.0) || n_fft < 2 || n_mels <= 0) return fail(MELSPEC_ERR_INVALID_ARG, "sample_rate, n_fft and n_mels must be positive");
+    return bank_create(out, device, mel_filterbank(sample_rate, n_fft, n_mels, f_min, f_max, htk != 0, norm != 0), n_mels, n_fft / 2 + 1);
+}
+
+void melspec_bank_destroy(melspec_bank *b) {
+    if (!b) return;
+    if (b->dev.device >= 0) (void)hipSetDevice(b->dev.device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    b->row_ptr.release(); b->bin.release(); b->w.release(); b->wf.release(); b->key.release(); b->tmp_in.release(); b->tmp_out.release();
+    delete b;
+}
+
+int melspec_bank_n_mels(const melspec_bank *b) { return b ? b->n_mels : 0; }
+int melspec_bank_fft_bins(const melspec_bank *b) { return b ? b->fft_bins : 0; }
+int melspec_bank_non_zero_weights(const melspec_bank *b) { return b ? b->nnz : 0; }
+
+int melspec_bank_project_power_device(melspec_bank *b, const void *d_power, int dtype, uint64_t n_frames, void *d_out, void *stream) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_frames == 0) return MELSPEC_OK;
+    if (!d_power || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
+    const uint64_t items = n_frames * static_cast<uint64_t>(b->n_mels);
+    if ((items + 255) / 256 > 0x7fffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "too many frames for one call");
+    const dim3 grid(static_cast<unsigned>((items + 255) / 256));
+    if (dtype == MELSPEC_STFT_F64)
+        hipLaunchKernelGGL(bank_project_power_kernel<double>, grid, dim3(256), 0, s, b->desc(), static_cast<const double *>(d_power), static_cast<double *>(d_out), n_frames);
+    else
+        hipLaunchKernelGGL(bank_project_power_kernel<float>, grid, dim3(256), 0, s, b->desc(), static_cast<const float *>(d_power), static_cast<float *>(d_out), n_frames);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int melspec_bank_log_mel_device(melspec_bank *b, const void *d_stft, int dtype, int n_fft, uint64_t n_frames, double *d_out, void *stream) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_fft < 2 || n_fft < b->fft_bins) return fail(MELSPEC_ERR_INVALID_ARG, "n_fft must be at least the bank's fft_bins");
+    if (n_frames == 0) return MELSPEC_OK;
+    if (!d_stft || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
+    const uint64_t items = n_frames * static_cast<uint64_t>(b->n_mels);
+    if ((items + 255) / 256 > 0x7fffffffull) return fail(MELSPEC_ERR_UNSUPPORTED, "too many frames for one call");
+    const dim3 grid(static_cast<unsigned>((items + 255) / 256));
+    if (dtype == MELSPEC_STFT_F64)
+        hipLaunchKernelGGL(bank_log_mel_kernel<double>, grid, dim3(256), 0, s, b->desc(), static_cast<const double *>(d_stft), n_fft, d_out, n_frames);
+    else
+        hipLaunchKernelGGL(bank_log_mel_kernel<float>, grid, dim3(256), 0, s, b->desc(), static_cast<const float *>(d_stft), n_fft, d_out, n_frames);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int melspec_bank_norm_mel_device(melspec_bank *b, const void *d_in, int dtype, uint64_t n_values, void *d_out, void *stream) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_values == 0) return MELSPEC_OK;
+    if (!d_in || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(b->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
+    unsigned long long *key = static_cast<unsigned long long *>(b->key.p);
+    return dtype == MELSPEC_STFT_F64 ? norm_launch<double>(static_cast<const double *>(d_in), n_values, static_cast<double *>(d_out), key, b->dev.cus, s)
+                                     : norm_launch<float>(static_cast<const float *>(d_in), n_values, static_cast<float *>(d_out), key, b->dev.cus, s);
+}
+
+// host forms: staged through the bank's own buffers, synchronous
+static int bank_host_call(melspec_bank *b, const void *in, size_t in_bytes, void *out, size_t out_bytes, int (*run)(melspec_bank *, const void *, void *, void *), void *ctx) {
+    HIP_TRY(hipSetDevice(b->dev.device));
+    int rc;
+    if ((rc = b->tmp_in.ensure(in_bytes + 16)) || (rc = b->tmp_out.ensure(out_bytes + 16))) return rc;
+    HIP_TRY(hipMemcpyAsync(b->tmp_in.p, in, in_bytes, hipMemcpyHostToDevice, b->stream));
+    if ((rc = run(b, b->tmp_in.p, b->tmp_out.p, ctx))) { (void)hipStreamSynchronize(b->stream); return rc; }
+    HIP_TRY(hipMemcpyAsync(out, b->tmp_out.p, out_bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return MELSPEC_OK;
+}
+
+int melspec_bank_project_power_host(melspec_bank *b, const void *power, int dtype, size_t n_frames, void *out) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_frames == 0) return MELSPEC_OK;
+    if (!power || !out) return fail(MELSPEC_ERR_INVALID_ARG, "pointer is NULL");
+    const size_t el = dtype == MELSPEC_STFT_F64 ? 8 : 4;
+    struct A { int dtype; uint64_t n; } a{dtype, n_frames};
+    return bank_host_call(b, power, n_frames * b->fft_bins * el, out, n_frames * b->n_mels * el,
+                          [](melspec_bank *bb, const void *i, void *o, void *c) { auto *x = static_cast<A *>(c); return melspec_bank_project_power_device(bb, i, x->dtype, x->n, o, bb->stream); }, &a);
+}
+
+int melspec_bank_log_mel_host(melspec_bank *b, const void *stft, int dtype, int n_fft, size_t n_frames, double *out) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_fft < 2) return fail(MELSPEC_ERR_INVALID_ARG, "n_fft must be >= 2");
+    if (n_frames == 0) return MELSPEC_OK;
+    if (!stft || !out) return fail(MELSPEC_ERR_INVALID_ARG, "pointer is NULL");
+    const size_t el = dtype == MELSPEC_STFT_F64 ? 8 : 4;
+    struct A { int dtype, n_fft; uint64_t n; } a{dtype, n_fft, n_frames};
+    return bank_host_call(b, stft, n_frames * n_fft * 2 * el, out, n_frames * b->n_mels * 8,
+                          [](melspec_bank *bb, const void *i, void *o, void *c) { auto *x = static_cast<A *>(c); return melspec_bank_log_mel_device(bb, i, x->dtype, x->n_fft, x->n, static_cast<double *>(o), bb->stream); }, &a);
+}
+
+int melspec_bank_norm_mel_host(melspec_bank *b, const void *in, int dtype, size_t n_values, void *out) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");
+    if (dtype != MELSPEC_STFT_F32 && dtype != MELSPEC_STFT_F64) return fail(MELSPEC_ERR_INVALID_ARG, "dtype must be MELSPEC_STFT_F32 or MELSPEC_STFT_F64");
+    if (n_values == 0) return MELSPEC_OK;
+    if (!in || !out) return fail(MELSPEC_ERR_INVALID_ARG, "pointer is NULL");
+    const size_t el = dtype == MELSPEC_STFT_F64 ? 8 : 4;
+    struct A { int dtype; uint64_t n; } a{dtype, n_values};
+    return bank_host_call(b, in, n_values * el, out, n_values * el,
+                          [](melspec_bank *bb, const void *i, void *o, void *c) { auto *x = static_cast<A *>(c); return melspec_bank_norm_mel_device(bb, i, x->dtype, x->n, o, bb->stream); }, &a);
+}
+
+}  // extern "C"
+
+extern "C" {
 
 // ---- host-side table builders ------------------------------------------------------------
 

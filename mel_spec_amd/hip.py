@@ -134,10 +134,23 @@ def device_synchronize() -> None:
 class HipMelSpectrogram:
     """MI355X twin of CudaMelSpectrogram (src/cuda.rs:27-140)."""
 
-    def __init__(self, fft_size: int, hop_size: int, sampling_rate: float, n_mels: int, device: int = -1):
+    def __init__(self, fft_size: int, hop_size: int, sampling_rate: float, n_mels: int, device: int = -1, filterbank=None):
+        """filterbank: None = MelSpectrogram::new's mel(sr, fft, n_mels, None, None, false, true); a dict(f_min=, f_max=, htk=, norm=)
+        = SparseMelFilterbank::from_mel (src/mel.rs:73-87); a [n_mels, fft_size // 2 + 1] array = from_dense (src/mel.rs:48-71)."""
         self._h = None
         h = C.c_void_p()
-        rc = lib().melspec_create(C.byref(h), device, int(fft_size), int(hop_size), float(sampling_rate), int(n_mels))
+        if filterbank is None:
+            rc = lib().melspec_create(C.byref(h), device, int(fft_size), int(hop_size), float(sampling_rate), int(n_mels))
+        elif isinstance(filterbank, dict):
+            fmin, fmax = filterbank.get("f_min"), filterbank.get("f_max")
+            rc = lib().melspec_create_with_filterbank(C.byref(h), device, int(fft_size), int(hop_size), float(sampling_rate), int(n_mels),
+                                                      -1.0 if fmin is None else float(fmin), -1.0 if fmax is None else float(fmax),
+                                                      int(filterbank.get("htk", False)), int(filterbank.get("norm", True)))
+        else:
+            fb = np.ascontiguousarray(filterbank, dtype=np.float64)
+            assert fb.ndim == 2 and fb.shape[0] == n_mels, fb.shape
+            rc = lib().melspec_create_with_dense_filterbank(C.byref(h), device, int(fft_size), int(hop_size), float(sampling_rate), int(n_mels),
+                                                            fb.ctypes.data_as(C.POINTER(C.c_double)), fb.shape[1])
         _check(rc, construct=True)
         self._h = h
         self.fft_size, self.hop_size, self.n_mels = int(fft_size), int(hop_size), int(n_mels)
@@ -689,6 +702,79 @@ class BatchLogMelSpectrogram:
     def close(self) -> None:
         if self._h is not None:
             lib().melspec_blm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SparseMelFilterbank:
+    """SparseMelFilterbank (src/mel.rs:40-168) + log_mel_spectrogram / norm_mel / norm_mel_vec (:436-469) on the GPU (melspec_bank_*)."""
+
+    def __init__(self, h):
+        self._h = h
+
+    @classmethod
+    def from_dense(cls, filters, device: int = -1):
+        fb = np.ascontiguousarray(filters, dtype=np.float64)
+        assert fb.ndim == 2
+        h = C.c_void_p()
+        _check(lib().melspec_bank_from_dense(C.byref(h), device, fb.ctypes.data_as(C.POINTER(C.c_double)), fb.shape[0], fb.shape[1]), construct=True)
+        return cls(h)
+
+    @classmethod
+    def from_mel(cls, sample_rate: float, n_fft: int, n_mels: int, f_min=None, f_max=None, htk: bool = False, norm: bool = True, device: int = -1):
+        h = C.c_void_p()
+        _check(lib().melspec_bank_from_mel(C.byref(h), device, float(sample_rate), int(n_fft), int(n_mels), -1.0 if f_min is None else float(f_min),
+                                           -1.0 if f_max is None else float(f_max), int(htk), int(norm)), construct=True)
+        return cls(h)
+
+    n_mels = property(lambda self: int(lib().melspec_bank_n_mels(self._h)))
+    fft_bins = property(lambda self: int(lib().melspec_bank_fft_bins(self._h)))
+    non_zero_weights = property(lambda self: int(lib().melspec_bank_non_zero_weights(self._h)))
+
+    def dense_weights(self) -> int:
+        return self.n_mels * self.fft_bins
+
+    @staticmethod
+    def _dt(a):
+        if a.dtype not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.complex64), np.dtype(np.complex128)):
+            a = a.astype(np.float64)
+        return np.ascontiguousarray(a), int(a.dtype in (np.dtype(np.float64), np.dtype(np.complex128)))
+
+    def project_power(self, power) -> np.ndarray:
+        """project_power_f64 / project_power_f32 by the dtype of `power` ([fft_bins] or [frames, fft_bins])"""
+        a, f64 = self._dt(np.asarray(power))
+        one = a.ndim == 1
+        a2 = a.reshape(-1, self.fft_bins)
+        out = np.empty((a2.shape[0], self.n_mels), a.dtype)
+        _check(lib().melspec_bank_project_power_host(self._h, a2.ctypes.data_as(C.c_void_p), f64, a2.shape[0], out.ctypes.data_as(C.c_void_p)))
+        return out[0] if one else out
+
+    def log_mel_spectrogram(self, stft) -> np.ndarray:
+        """log_mel_spectrogram(stft, mel_filters) for [n_fft] or [frames, n_fft] complex frames -> [frames, n_mels] f64 (the reference
+        returns the [n_mels, 1] column of one frame)"""
+        a, f64 = self._dt(np.asarray(stft))
+        assert a.dtype in (np.dtype(np.complex64), np.dtype(np.complex128))
+        one = a.ndim == 1
+        a2 = a.reshape(-1, a.shape[-1])
+        out = np.empty((a2.shape[0], self.n_mels), np.float64)
+        _check(lib().melspec_bank_log_mel_host(self._h, a2.ctypes.data_as(C.c_void_p), f64, a2.shape[1], a2.shape[0], out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out[0] if one else out
+
+    def norm_mel(self, mel_spec) -> np.ndarray:
+        """norm_mel (f64 input) / norm_mel_vec (f32 input): one maximum over everything given"""
+        a, f64 = self._dt(np.asarray(mel_spec))
+        out = np.empty_like(a)
+        _check(lib().melspec_bank_norm_mel_host(self._h, a.ctypes.data_as(C.c_void_p), f64, a.size, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self) -> None:
+        if self._h is not None:
+            lib().melspec_bank_destroy(self._h)
             self._h = None
 
     def __del__(self):

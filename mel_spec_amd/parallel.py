@@ -82,6 +82,39 @@ class ShardedMelSpectrogram:
             cur += f * self.n_mels
         return res
 
+    def compute_uniform_device(self, d_pcm, clip_stride: int, clip_len: int, n_clips, d_out) -> None:
+        """melspec_sharded_compute_uniform_device: per-shard device pointers (shard k's clips on device k), asynchronous"""
+        import ctypes as C
+        import numpy as np
+        from ._lib import lib
+        from .hip import _check
+        n = self.n_shards
+        assert len(d_pcm) == len(d_out) == len(n_clips) == n
+        pin, pout = (C.c_void_p * n)(*d_pcm), (C.c_void_p * n)(*d_out)
+        nc = np.ascontiguousarray(n_clips, dtype=np.uint32)
+        _check(lib().melspec_sharded_compute_uniform_device(self._h, pin, clip_stride, clip_len, nc.ctypes.data_as(C.POINTER(C.c_uint32)), pout))
+
+    def compute_ragged_device(self, d_pcm, offsets, lengths, n_clips, d_out, out_offsets=None) -> None:
+        """melspec_sharded_compute_ragged_device: the shards' clip tables concatenated, offsets relative to each shard's own buffers"""
+        import ctypes as C
+        import numpy as np
+        from ._lib import lib
+        from .hip import _check
+        n = self.n_shards
+        pin, pout = (C.c_void_p * n)(*d_pcm), (C.c_void_p * n)(*d_out)
+        nc = np.ascontiguousarray(n_clips, dtype=np.uint32)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        _check(lib().melspec_sharded_compute_ragged_device(self._h, pin, off.ctypes.data_as(u64p), ln.ctypes.data_as(u64p), nc.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                           pout, None if oo is None else oo.ctypes.data_as(u64p)))
+
+    def synchronize(self) -> None:
+        from ._lib import lib
+        from .hip import _check
+        _check(lib().melspec_sharded_synchronize(self._h))
+
     def close(self) -> None:
         if self._h is not None:
             from ._lib import lib

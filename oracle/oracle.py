@@ -355,6 +355,58 @@ def blm_compute(samples, cfg: BlmConfig | None = None, f64: bool = True):
     return out, int(valid.value)
 
 
+def project_power(filters, power) -> np.ndarray:
+    """SparseMelFilterbank::from_dense(filters).project_power_f64 / _f32 (src/mel.rs:48-71, 106-146) for [frames, fft_bins] power in
+    f64 or f32: per mel row the non-zero weights in ascending bin order, `energy += weight * power[bin]` (f32: `weight as f32`),
+    a separate multiply and add -- numpy's elementwise ops are exactly that."""
+    p2 = np.asarray(power)
+    T = p2.dtype.type
+    assert T in (np.float32, np.float64)
+    fb = np.asarray(filters, dtype=np.float64)
+    p2 = p2.reshape(-1, fb.shape[1])
+    out = np.zeros((p2.shape[0], fb.shape[0]), T)
+    for m in range(fb.shape[0]):
+        e = np.zeros(p2.shape[0], T)
+        for k in np.nonzero(fb[m])[0]:
+            e = e + T(fb[m, k]) * p2[:, k]
+        out[:, m] = e
+    return out
+
+
+def log_mel_spectrogram(stft, filters) -> np.ndarray:
+    """log_mel_spectrogram(stft, mel_filters) (src/mel.rs:436-441) = project_stft_log10 (:148-168) for [frames, n_fft] complex128
+    frames: norm_sqr of the bins below n_fft / 2, the sparse rows in ascending bin order, log10(max(E, 1e-10)); f64, not normalised."""
+    z = np.asarray(stft, dtype=np.complex128)
+    z = z.reshape(-1, z.shape[-1])
+    fb = np.asarray(filters, dtype=np.float64)
+    half = z.shape[1] // 2
+    pw = z.real * z.real + z.imag * z.imag
+    out = np.zeros((z.shape[0], fb.shape[0]))
+    for m in range(fb.shape[0]):
+        e = np.zeros(z.shape[0])
+        for k in np.nonzero(fb[m])[0]:
+            e = e + fb[m, k] * (pw[:, k] if k < half else 0.0)
+        out[:, m] = np.log10(np.maximum(e, 1e-10))
+    return out
+
+
+def norm_mel(mel_spec) -> np.ndarray:
+    """norm_mel (f64, src/mel.rs:448-454) / norm_mel_vec (f32, :457-469): one maximum over everything given, max(x, mmax - 8), (+ 4) / 4"""
+    a = np.asarray(mel_spec)
+    T = a.dtype.type
+    mmax = T(np.nanmax(a) if a.size and not np.all(np.isnan(a)) else -np.inf) - T(8)
+    c = np.where(a > mmax, a, mmax).astype(T)          # x.max(mmax): NaN x -> mmax
+    return ((c + T(4)) / T(4)).astype(T)
+
+
+def compute_mel_spectrogram_with_filters(samples, fft_size, hop_size, filters) -> np.ndarray:
+    """compute_all_cpu + MelSpectrogram::add with `filters` in place of new()'s bank (src/stft.rs:119-138, src/mel.rs:13-32): log_mel of every
+    frame, norm_mel per frame (norm_mel_slice_f64, :645-654), f32 out."""
+    lm = log_mel_spectrogram(compute_all_cpu(samples, fft_size, hop_size), filters)
+    mmax = lm.max(axis=1, keepdims=True) - 8.0
+    return ((np.maximum(lm, mmax) + 4.0) / 4.0).astype(np.float32)
+
+
 def blm_normalize(features, valid: int) -> np.ndarray:
     """normalize_per_feature (src/mel.rs:721-749): the reference's f32 left folds on a [n_mels, cols] f32 image (a copy is returned)."""
     a = np.array(features, dtype=np.float32, order="C", copy=True)

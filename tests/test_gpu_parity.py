@@ -1149,3 +1149,101 @@ def test_nemo_frontend_ragged_batches(gpu, oracle, jfk, kw):
         if want.size:
             assert np.abs(g - want).max() <= tol, (kw, len(x), float(np.abs(g - want).max()))
     fe.close()
+
+
+# ---- caller-supplied filterbanks and the stand-alone mel helpers (src/mel.rs:40-168, 436-469) -------------------------------------
+
+@pytest.mark.parametrize("fft,n_mels,fbkw,fused", [(400, 80, dict(htk=True), True), (400, 64, dict(f_min=300.0, f_max=3400.0), True),
+                                                  (400, 40, dict(norm=False, f_max=7000.0), True), (512, 80, dict(htk=True, f_min=50.0), True),
+                                                  (400, 128, dict(htk=True, norm=False), True), (256, 32, dict(f_min=100.0), False)])
+def test_caller_supplied_filterbank(gpu, oracle, jfk, fft, n_mels, fbkw, fused):
+    """melspec_create_with_filterbank == MelSpectrogram with SparseMelFilterbank::from_mel(sr, n_fft, n_mels, f_min, f_max, htk, norm)
+    (src/mel.rs:73-87) in place of new()'s default bank: HTK, band-limited and un-normalised banks on the fused kernels (run-time slot
+    lengths), every precision mode, uniform / ragged batches and the mel-major layout."""
+    filters = oracle.mel_filterbank(SR, fft, n_mels, fbkw.get("f_min"), fbkw.get("f_max"), fbkw.get("htk", False), fbkw.get("norm", True))
+    assert np.abs(gpu.mel(SR, fft, n_mels, fbkw.get("f_min"), fbkw.get("f_max"), fbkw.get("htk", False), fbkw.get("norm", True)) - filters).max() <= 1e-12
+    m = gpu.HipMelSpectrogram(fft, 160, SR, n_mels, filterbank=fbkw)
+    assert m.uses_fast_path == fused
+    sigs = [jfk[:48000], oracle.synth_pcm(3, 16000), _tone_over_noise_floor(16000)]
+    for mode in (("auto", "f64", "f32") if fft == 400 else ("auto",)):
+        if fft == 400:
+            m.set_precision(mode)
+        for i, x in enumerate(sigs):
+            want = oracle.compute_mel_spectrogram_with_filters(x, fft, 160, filters)
+            got = m.compute_mel_spectrogram(x)
+            assert got.shape == want.shape
+            if not (mode == "f32" and i == 2):          # the bare f32 FFT misses the tolerance on the tone over a floor, whatever the bank
+                assert np.abs(got - want).max() <= (2e-6 if mode == "f64" or fft != 400 else TOL), (mode, i)
+    if fft == 400:
+        m.set_precision("auto")
+    clips = [jfk[1000:9000], oracle.synth_pcm(1, 400), oracle.synth_pcm(2, 12345), np.zeros(100, np.float32)]
+    for g, x in zip(m.compute_ragged(clips), clips):
+        want = oracle.compute_mel_spectrogram_with_filters(x, fft, 160, filters) if len(x) >= fft else np.zeros((0, n_mels), np.float32)
+        assert g.shape == want.shape and (g.size == 0 or np.abs(g - want).max() <= TOL)
+    img = m.compute_batch_interleaved(oracle.synth_pcm(5, 16000)[None, :], False, 0)[0]
+    want = oracle.compute_mel_spectrogram_with_filters(oracle.synth_pcm(5, 16000), fft, 160, filters)
+    assert img.shape == want.T.shape and np.abs(img - want.T).max() <= TOL
+    m.close()
+
+
+def test_dense_filterbank_of_any_shape(gpu, oracle, jfk):
+    """melspec_create_with_dense_filterbank: what log_mel_spectrogram(stft, mel_filters) accepts is any matrix (src/mel.rs:436-441);
+    one that is not two-filters-per-bin (rectangular bands that overlap three deep, a negative weight) runs on the generic kernel, the
+    default matrix handed over as a dense array runs on the fused kernel with the default context's bits."""
+    x = jfk[20000:52000]
+    bins = 201
+    rng = np.random.default_rng(3)
+    filters = np.zeros((24, bins))
+    for r in range(24):
+        lo = r * 8
+        filters[r, lo:lo + 24] = rng.uniform(0.01, 0.05, min(24, bins - lo))[:bins - lo]      # three rows deep on every bin
+    filters[5, 44] = -0.004
+    m = gpu.HipMelSpectrogram(400, 160, SR, 24, filterbank=filters)
+    assert not m.uses_fast_path
+    want = oracle.compute_mel_spectrogram_with_filters(x, 400, 160, filters)
+    assert np.abs(m.compute_mel_spectrogram(x) - want).max() <= 2e-6
+    m.close()
+    d = gpu.HipMelSpectrogram(400, 160, SR, 80, filterbank=oracle.mel_filterbank(SR, 400, 80))
+    w = gpu.HipMelSpectrogram(400, 160, SR, 80)
+    d.set_auto_adaptive(False); w.set_auto_adaptive(False)
+    assert d.uses_fast_path and np.array_equal(d.compute_mel_spectrogram(x), w.compute_mel_spectrogram(x))
+    with pytest.raises(gpu.HipError):
+        gpu.HipMelSpectrogram(400, 160, SR, 80, filterbank=np.zeros((80, 200)))          # fft_bins must be fft_size / 2 + 1
+    d.close(); w.close()
+
+
+@pytest.mark.parametrize("kw", [dict(sample_rate=16000.0, n_fft=400, n_mels=80), dict(sample_rate=16000.0, n_fft=512, n_mels=128, htk=True, f_min=20.0),
+                                dict(sample_rate=8000.0, n_fft=256, n_mels=23, norm=False, f_max=3800.0)])
+def test_sparse_filterbank_helpers(gpu, oracle, jfk, kw):
+    """SparseMelFilterbank::{from_mel, project_power_f64, project_power_f32} (src/mel.rs:73-146): bit-exact against the reference's fold;
+    log_mel_spectrogram (:436-441) on the frames of compute_all_cpu; norm_mel / norm_mel_vec (:448-469) over a frame, a window, a clip."""
+    fb = gpu.SparseMelFilterbank.from_mel(**kw)
+    filters = oracle.mel_filterbank(kw["sample_rate"], kw["n_fft"], kw["n_mels"], kw.get("f_min"), kw.get("f_max"), kw.get("htk", False), kw.get("norm", True))
+    assert (fb.n_mels, fb.fft_bins, fb.non_zero_weights) == (kw["n_mels"], kw["n_fft"] // 2 + 1, int(np.count_nonzero(filters)))
+    spec = oracle.compute_all_cpu(jfk[:30000], kw["n_fft"], kw["n_fft"] // 2)
+    power = (spec.real ** 2 + spec.imag ** 2)[:, :fb.fft_bins]
+    for T in (np.float64, np.float32):
+        p = np.ascontiguousarray(power.astype(T))
+        got = fb.project_power(p)
+        assert got.dtype == T and np.array_equal(got, oracle.project_power(filters, p))
+        assert np.array_equal(fb.project_power(p[7]), got[7])
+    lm = fb.log_mel_spectrogram(spec)
+    want = oracle.log_mel_spectrogram(spec, filters)
+    assert lm.shape == want.shape and np.abs(lm - want).max() <= 1e-12
+    assert np.abs(fb.log_mel_spectrogram(spec.astype(np.complex64)) - want).max() <= 1e-5
+    for piece in (lm[3], lm[10:20], lm):
+        assert np.array_equal(fb.norm_mel(piece), oracle.norm_mel(piece))
+        p32 = piece.astype(np.float32)
+        got = fb.norm_mel(p32)
+        assert got.dtype == np.float32 and np.array_equal(got, oracle.norm_mel(p32))
+    # the split pipeline == the fused one: frames -> log_mel -> per-frame norm_mel
+    if kw["n_fft"] == 400 and "htk" not in kw:
+        m = gpu.HipMelSpectrogram(400, 200, 16000.0, kw["n_mels"])
+        m.set_precision("f64")
+        fused = m.compute_mel_spectrogram(jfk[:30000])
+        split = np.stack([fb.norm_mel(r) for r in lm]).astype(np.float32)
+        assert np.abs(fused - split).max() <= 2e-6
+        m.close()
+    dense = gpu.SparseMelFilterbank.from_dense(filters)
+    assert dense.non_zero_weights == fb.non_zero_weights and np.array_equal(dense.project_power(power), fb.project_power(power))
+    dense.close(); fb.close()

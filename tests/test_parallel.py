@@ -76,6 +76,51 @@ def test_sharded_mel_spectrogram_on_the_devices_of_this_box(gpu, oracle, jfk, de
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0], None])
+def test_sharded_device_resident_calls(gpu, oracle, jfk, devices):
+    """melspec_sharded_compute_uniform_device / _ragged_device: every shard's clips already on its device, its frames left there, one
+    launch per shard on the shard's own stream; the same bits as one context computing the shard's clips (a device listed several
+    times gives the 1-GPU box several shards)."""
+    sh = gpu.ShardedMelSpectrogram(400, 160, 16000.0, 80, devices=devices)
+    n = sh.n_shards
+    single = gpu.HipMelSpectrogram(400, 160, 16000.0, 80)
+    single.set_auto_adaptive(False)
+    for k in range(n):
+        gpu._lib.lib().melspec_set_auto_adaptive(gpu._lib.lib().melspec_sharded_ctx(sh._h, k), 0)      # bits are compared below
+    clip_len, fpc = 24000, single.num_frames(24000)
+    counts = [5 + 3 * k for k in range(n)]
+    pcm, out, want = [], [], []
+    for k in range(n):
+        x = np.stack([oracle.synth_pcm(100 * k + c, clip_len) if c % 2 else np.resize(jfk[977 * (k + c):], clip_len) for c in range(counts[k])]).astype(np.float32)
+        b = gpu.DeviceBuffer(x.nbytes); b.upload(x)
+        pcm.append(b); out.append(gpu.DeviceBuffer(counts[k] * fpc * 80 * 4))
+        want.append(single.compute_batch(x))
+        assert np.abs(want[-1][0] - oracle.compute_mel_spectrogram_cpu(x[0], 400, 160, 80, 16000.0)).max() <= 1e-4
+    sh.compute_uniform_device([b.ptr for b in pcm], clip_len, clip_len, counts, [b.ptr for b in out])
+    sh.synchronize()
+    for k in range(n):
+        assert np.array_equal(out[k].download((counts[k], fpc, 80)), want[k])
+    # ragged: per shard three clips of different lengths cut from its buffer, packed outputs
+    lens = [24000, 399, 5000]
+    offs, lns = [], []
+    for k in range(n):
+        offs += [0, clip_len, 2 * clip_len]; lns += lens
+    for b in out:
+        b.upload(np.zeros(b.nbytes // 4, np.float32))
+    sh.compute_ragged_device([b.ptr for b in pcm], offs, lns, [3] * n, [b.ptr for b in out])
+    sh.synchronize()
+    f2 = single.num_frames(5000)
+    for k in range(n):
+        got = out[k].download(((fpc + f2) * 80,))
+        assert np.array_equal(got[:fpc * 80].reshape(fpc, 80), want[k][0])
+        x2 = pcm[k].download((5000,), offset_bytes=2 * clip_len * 4)
+        assert np.abs(got[fpc * 80:].reshape(f2, 80) - oracle.compute_mel_spectrogram_cpu(x2, 400, 160, 80, 16000.0)).max() <= 1e-4
+    for b in pcm + out:
+        b.free()
+    single.close(); sh.close()
+
+
+@pytest.mark.gpu
 def test_gather_peer_consolidates_device_results(gpu):
     """melspec_gather_peer with every piece on device 0 (the only one of this box): the offsets / sizes / streams path."""
     a = gpu.DeviceBuffer(4096 * 4); b = gpu.DeviceBuffer(1000 * 4); dst = gpu.DeviceBuffer(6000 * 4)
