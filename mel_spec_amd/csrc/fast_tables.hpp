@@ -104,7 +104,9 @@ inline bool build_fast_tables(const std::vector<double> &dense, int n_mels, Fast
     std::vector<float> &b = out.blob;
     b.assign(FastBlob::kMelW, 0.0f);
     const std::vector<double> win = hann_window(N);
-    for (int i = 0; i < N; ++i) b[FastBlob::kWin + i] = static_cast<float>(win[i]);
+    for (int t = 0; t < 10; ++t)
+        for (int n1 = 0; n1 < 20; ++n1)
+            for (int c = 0; c < 2; ++c) b[FastBlob::kWin + t * FastBlob::kWinStride + 2 * n1 + c] = static_cast<float>(win[20 * n1 + 2 * t + c]);
     for (int t = 0; t < 10; ++t)
         for (int k1 = 0; k1 < 20; ++k1) {
             const double a = -2.0 * kPi * ((t * k1) % M) / M;
@@ -182,7 +184,9 @@ inline bool build_six_tables(const std::vector<double> &dense, int n_mels, FastT
     std::vector<float> &b = out.blob;
     b.assign(SixBlob::kMelW, 0.0f);
     const std::vector<double> win = hann_window(N);
-    for (int i = 0; i < N; ++i) b[SixBlob::kWin + i] = static_cast<float>(win[i]);
+    for (int t = 0; t < 10; ++t)
+        for (int n1 = 0; n1 < 20; ++n1)
+            for (int c = 0; c < 2; ++c) b[SixBlob::kWin + t * SixBlob::kWinStride + 2 * n1 + c] = static_cast<float>(win[20 * n1 + 2 * t + c]);
     for (int t = 0; t < 10; ++t)
         for (int k1 = 0; k1 < 20; ++k1) {
             const double a = -2.0 * kPi * ((t * k1) % M) / M;

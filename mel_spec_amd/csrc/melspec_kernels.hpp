@@ -236,7 +236,7 @@ __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int ho
         const bool act = in && ((mask >> fl) & 1u);
         int st[NSLOTS];
 #pragma unroll
-        for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
+        for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];       // lanes 60..63 read valid entries too
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS], vals[NSLOTS];
         six_phase3_sums<NSLOTS, Lens>(fl, j, act, ms, blob, slice, st, rise, fprev);
 #pragma unroll
@@ -270,7 +270,7 @@ __device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int h
         const bool act3 = in3 && ((mask >> fl3) & 1u);
         int st[NSLOTS];
 #pragma unroll
-        for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
+        for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * 12];       // lanes 60..63 (j3 = 0..3 of a sixth frame) read valid entries too
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS], vals[NSLOTS];
         wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, ms, blob, slice, st, rise, fprev);
 #pragma unroll
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
             // per-lane start bins: re-read every unit (NSLOTS LDS words) rather than held in registers across the loop
             int st[NSLOTS];
 #pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
+            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * 12];       // lanes 60..63 (j3 = 0..3 of a sixth frame) read valid entries too
             float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
             wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
 #pragma unroll
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             // per-lane start bins: re-read every unit (9 LDS words) rather than held in registers across the loop
             int st[NSLOTS];
 #pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
+            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];       // lanes 60..63 (j = 0..3 of a seventh frame) read valid entries too
             float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
             six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, blob, slice, st, rise, fprev);
 #pragma unroll
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         {
             int st[NSLOTS];
 #pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kSixLanes] : 0;
+            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];       // lanes 60..63 (j = 0..3 of a seventh frame) read valid entries too
             float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
             six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, blob, slice, st, rise, fprev);
 #pragma unroll
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
         {
             int st[NSLOTS];
 #pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = in3 ? starts[i * 12] : 0;
+            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * 12];       // lanes 60..63 (j3 = 0..3 of a sixth frame) read valid entries too
             float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
             wave_phase3i_sums<NSLOTS, Lens>(fl3, j3, act3, p.slots, blob, slice, st, rise, fprev);
 #pragma unroll

@@ -27,9 +27,12 @@ constexpr int kSlotCap = 17;        // capacity of MelSlots (the NeMo frontend u
 
 // LDS layout of the constant table blob (float offsets).  Built by build_fast_tables().
 struct FastBlob {
-    static constexpr int kWin = 0;                       // [400] Hann
+    // the 40 taps of lane t in the order it uses them, w[20*n1 + 2t + {0, 1}] at [t][2*n1 + {0, 1}]: ten 16-byte reads per unit
+    // (taps in natural order came out as ds_read2_b64 pairs, half the LDS rate); 44 = 40 + 4 pad: ten rows in ten groups of four banks
+    static constexpr int kWinStride = 44;
+    static constexpr int kWin = 0;                       // [10][44] Hann
     static constexpr int kTw1Stride = 44;                // 20 complex + 4 pad (bank spread)
-    static constexpr int kTw1 = 400;                     // [10][44] W_200^{t*k1}
+    static constexpr int kTw1 = 10 * kWinStride;         // [10][44] W_200^{t*k1}
     static constexpr int kMod = kTw1 + 10 * kTw1Stride;  // [10] complex W_10^{n2}
     static constexpr int kTw2 = kMod + 20;               // [11][10] complex W_400^{j+20q}
     static constexpr int kMelStart = kTw2 + kMelJobs * 20;   // [kMaxSlots*12] int bit patterns

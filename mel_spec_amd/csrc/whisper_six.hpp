@@ -29,9 +29,12 @@ constexpr int kSixWaves = MELSPEC_SIX_WAVES;     // waves per workgroup (one wor
 constexpr int kSixMaxSlots = 9;   // ceil(81 / 9): up to 80 mel bins
 
 struct SixBlob {                  // float offsets inside the table blob
-    static constexpr int kWin = 0;                        // [400] Hann
+    // the 40 taps of lane t in the order it uses them, w[20*n1 + 2t + {0, 1}] at [t][2*n1 + {0, 1}]: ten 16-byte reads per unit;
+    // 44 = 40 + 4 pad: the ten rows start in ten different groups of four banks
+    static constexpr int kWinStride = 44;
+    static constexpr int kWin = 0;                        // [10][44] Hann
+    static constexpr int kTw1 = 10 * kWinStride;
     static constexpr int kTw1Stride = 44;                 // 20 complex + 4 pad
-    static constexpr int kTw1 = 400;                      // [10][44] W_200^{t*k1}
     static constexpr int kTw2Stride = 24;                 // 11 complex + 2 pad
     static constexpr int kTw2 = kTw1 + 10 * kTw1Stride;   // [10][24]: lane j >= 1: W_400^{j+20s}, s < 10;
                                                           //   lane 0: W_400^{20s} (s <= 5), W_400^{10+20(s-6)} (s = 6..10)
@@ -83,14 +86,15 @@ using LensSix80 = LensSixStatic<80, 1, 1, 1, 2, 2, 3, 4, 6, 7>;
 MS_DEV void six_phase1(int fl, int t, bool active, int hop, const float *blob, const float *gsrc /* unit's first sample */,
                        float *slice) {
     if (!active) return;
-    const float *w = blob + SixBlob::kWin + 2 * t;
     const float *s = gsrc + fl * hop + 2 * t;
     cf x[20];
+    const float *w = blob + SixBlob::kWin + t * SixBlob::kWinStride;
 #pragma unroll
-    for (int n1 = 0; n1 < 20; ++n1) {
-        const f2 sv = load2_unaligned(s + 20 * n1);
-        const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
-        x[n1] = {sv.x * wv.x, sv.y * wv.y};
+    for (int n1 = 0; n1 < 20; n1 += 2) {
+        const f2 s0 = load2_unaligned(s + 20 * n1), s1 = load2_unaligned(s + 20 * n1 + 20);
+        const f4 wv = ld4(w + 2 * n1);
+        x[n1] = {s0.x * wv.x, s0.y * wv.y};
+        x[n1 + 1] = {s1.x * wv.z, s1.y * wv.w};
     }
     fft20(x);
     const float *tw = blob + SixBlob::kTw1 + t * SixBlob::kTw1Stride;
@@ -178,7 +182,7 @@ MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, cons
                 const float *w = blob + Lens::woff(i < Lens::kSlots ? i : 0) + 2 * j;
 #pragma unroll
                 for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
-                    const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kSixLanes * r);
+                    const f2 wv = ld2_single(w + 2 * kSixLanes * r);
                     const float pv = pp[r];
                     if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
                     else { ar += wv.x * pv; af += wv.y * pv; }
@@ -195,52 +199,65 @@ MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, cons
 }
 
 // mel[m] = rise of interval m (this lane) + fall of interval m+1 (next lane); log10, lane maximum to LDS
+// The log-mel values are carried with a bias of +16: log10(max(e, 1e-10)) + 16 lies in [6, ~30], a POSITIVE float, and positive
+// floats order like their bit patterns.  Every maximum / minimum of phases 3-4 is then an integer one (v_max_i32 / v_max3_i32 /
+// v_min3_i32): a float maximum of a value that comes from memory or from another basic block costs a canonicalising v_max(x, x)
+// first (17 per unit in the ISA of the float form), the floor is one v_max against 6.0 instead of compare + select, and the bias
+// folds into the two FMAs that were multiplies.  (x + 4) / 4 = biased * 0.25 - 3.
+MS_DEV int six_bits(float v) { return __builtin_bit_cast(int, v); }
+MS_DEV float six_float(int v) { return __builtin_bit_cast(float, v); }
+MS_DEV int six_imax(int a, int b) { return a > b ? a : b; }
+MS_DEV int six_imin(int a, int b) { return a < b ? a : b; }
 template <int NSLOTS>
 MS_DEV void six_phase3_finish(int fl, int j, bool active, int n_mels, const float (&rise)[NSLOTS],
                               const float (&fnext)[NSLOTS] /* fprev of lane+1 */, float *slice, float (&vals)[NSLOTS]) {
     if (!active) return;
-    float mx = -3.0e38f;
+    int mx = 0;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const float e = rise[i] + fnext[i];
-        const float v = e > 1e-10f ? fast_log2(e) * 0.30102999566398120f : -10.0f;
+        // below the floor the logarithm is <= -10 (log2(0) = -inf; of a negative sum, which only a caller's bank can produce, NaN)
+        // and the maximum with 6 = -10 + 16 returns exactly 6
+        const float v = __builtin_fmaxf(fast_log2(e) * 0.30102999566398120f + 16.0f, 6.0f);
         vals[i] = v;
-        if (j < kSixOwn && j + kSixOwn * i < n_mels) mx = __builtin_fmaxf(mx, v);
+        if (j < kSixOwn && j + kSixOwn * i < n_mels) mx = six_imax(mx, six_bits(v));
     }
-    slice[SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride + j] = mx;
+    reinterpret_cast<int *>(slice)[SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride + j] = mx;
 }
 
 // ---- phase 4: frame maximum, clamp at max - 8, (x + 4) / 4, store ---------------------------------------------------
 // store: this lane's frame column exists in the output; valid: it is a real frame (otherwise a zero column of a padded
 // layout).  row_w == 0: [frame][mel] rows; row_w > 0: [mel][row_w] rows (interleave_frames, src/mel.rs:480-544).
 // GUARD: returns true on lanes that hold a band within kGuardBand decades of the clamp (see wave_phase4).
+struct alignas(16) SixI4 { int x, y, z, w; };
+struct alignas(8) SixI2 { int x, y; };
 template <int NSLOTS, bool LAYOUT = false, bool GUARD = false>
 MS_DEV bool six_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
                        float *out_tile, long long row_w) {
     if (!LAYOUT) { valid = true; row_w = 0; }
     if (!store || j >= kSixOwn) return false;
-    float lo = 0.0f;
+    int lo = 0;          // bits of (frame maximum - 8), biased
     if (valid) {
-        const float *pm = slice + SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride;
-        const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4);
-        const f2 c = *reinterpret_cast<const f2 *>(pm + 8);
-        const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
-        const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
-        lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(c.x, c.y)) - 8.0f;
+        const int *pm = reinterpret_cast<const int *>(slice) + SixLayout::kPmaxOff + fl * SixLayout::kPmaxStride;
+        const SixI4 a = *reinterpret_cast<const SixI4 *>(pm), b = *reinterpret_cast<const SixI4 *>(pm + 4);
+        const SixI2 c = *reinterpret_cast<const SixI2 *>(pm + 8);
+        const int m0 = six_imax(six_imax(a.x, a.y), six_imax(a.z, a.w));
+        const int m1 = six_imax(six_imax(b.x, b.y), six_imax(b.z, b.w));
+        lo = six_bits(six_float(six_imax(six_imax(m0, m1), six_imax(c.x, c.y))) - 8.0f);      // >= -2: negative only when every band sits on the floor
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kSixOwn * row_w : kSixOwn;
-    float cmin = 3.0e38f;
+    int cmin = 0x7f000000;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kSixOwn * i;
         if (m < n_mels) {
-            const float c = __builtin_fmaxf(vals[i], lo);
-            o[i * step] = valid ? (c + 4.0f) * 0.25f : 0.0f;
-            if (GUARD) cmin = __builtin_fminf(cmin, c);
+            const int c = six_imax(six_bits(vals[i]), lo);       // vals >= 6 > 0: the integer order is the float order, also against a negative lo
+            o[i * step] = valid ? six_float(c) * 0.25f - 3.0f : 0.0f;
+            if (GUARD) cmin = six_imin(cmin, c);
         }
     }
-    return GUARD && valid && cmin < lo + kGuardBand;
+    return GUARD && valid && six_float(cmin) < six_float(lo) + kGuardBand;
 }
 
 }  // namespace melspec

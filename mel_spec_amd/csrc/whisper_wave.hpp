@@ -115,14 +115,15 @@ MS_DEV f2 load2_unaligned(const float *p) {
 MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, const float *gsrc /* tile's first sample */,
                         float *slice) {
     if (!active) return;
-    const float *w = blob + FastBlob::kWin + 2 * t;
+    const float *w = blob + FastBlob::kWin + t * FastBlob::kWinStride;
     const float *s = gsrc + fl * hop + 2 * t;
     cf x[20];
 #pragma unroll
-    for (int n1 = 0; n1 < 20; ++n1) {
-        const f2 sv = load2_unaligned(s + 20 * n1);
-        const f2 wv = *reinterpret_cast<const f2 *>(w + 20 * n1);
-        x[n1] = {sv.x * wv.x, sv.y * wv.y};
+    for (int n1 = 0; n1 < 20; n1 += 2) {
+        const f2 s0 = load2_unaligned(s + 20 * n1), s1 = load2_unaligned(s + 20 * n1 + 20);
+        const f4 wv = ld4(w + 2 * n1);
+        x[n1] = {s0.x * wv.x, s0.y * wv.y};
+        x[n1 + 1] = {s1.x * wv.z, s1.y * wv.w};
     }
     fft20(x);
     const float *tw = blob + FastBlob::kTw1 + t * FastBlob::kTw1Stride;
@@ -200,7 +201,7 @@ MS_DEV void wave_phase3i_sums(int fl, int j12, bool active, const MelSlots &ms, 
                 const float *w = blob + Lens::woff(i < Lens::kSlots ? i : 0) + 2 * j12;
 #pragma unroll
                 for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
-                    const f2 wv = *reinterpret_cast<const f2 *>(w + 24 * r);
+                    const f2 wv = ld2_single(w + 24 * r);
                     const float pv = pp[r];
                     if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
                     else { ar += wv.x * pv; af += wv.y * pv; }
@@ -216,19 +217,25 @@ MS_DEV void wave_phase3i_sums(int fl, int j12, bool active, const MelSlots &ms, 
     }
 }
 
+// The log-mel values are carried with a bias of +16 (whisper_six.hpp, six_phase3_finish: positive floats order like their bit
+// patterns, so every maximum / minimum of phases 3-4 is an integer one and needs no canonicalising v_max(x, x)).
+MS_DEV int wave_bits(float v) { return __builtin_bit_cast(int, v); }
+MS_DEV float wave_float(int v) { return __builtin_bit_cast(float, v); }
+MS_DEV int wave_imax(int a, int b) { return a > b ? a : b; }
+MS_DEV int wave_imin(int a, int b) { return a < b ? a : b; }
 template <int NSLOTS>
 MS_DEV void wave_phase3i_finish(int fl, int j12, bool active, int n_mels, const float (&rise)[NSLOTS],
                                 const float (&fnext)[NSLOTS] /* fprev of lane+1 */, float *slice, float (&vals)[NSLOTS]) {
     if (!active) return;
-    float mx = -3.0e38f;
+    int mx = 0;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const float e = rise[i] + fnext[i];
-        const float v = e > 1e-10f ? fast_log2(e) * 0.30102999566398120f : -10.0f;
+        const float v = __builtin_fmaxf(fast_log2(e) * 0.30102999566398120f + 16.0f, 6.0f);       // log10(max(e, 1e-10)) + 16
         vals[i] = v;
-        if (j12 < kMelJobs && j12 + kMelJobs * i < n_mels) mx = __builtin_fmaxf(mx, v);
+        if (j12 < kMelJobs && j12 + kMelJobs * i < n_mels) mx = wave_imax(mx, wave_bits(v));
     }
-    slice[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j12] = mx;
+    reinterpret_cast<int *>(slice)[WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride + j12] = mx;
 }
 
 // ---- phase 4: frame max, clamp, scale, store ------------------------------------------------
@@ -244,34 +251,34 @@ MS_DEV void wave_phase3i_finish(int fl, int j12, bool active, int n_mels, const 
 // value.  A silent frame (every band at the 1e-10 floor, nothing within 8 decades below) is never queued.
 constexpr float kGuardBand = 2.0f;
 
+struct alignas(16) WaveI4 { int x, y, z, w; };
 template <int NSLOTS, bool LAYOUT = true, bool GUARD = false>
 MS_DEV bool wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
                         float *out_tile, long long row_w) {
     if (!LAYOUT) { valid = true; row_w = 0; }     // plain output: every stored column is a real frame
     if (!store || j >= kMelJobs) return false;
-    float lo = 0.0f;
+    int lo = 0;                                   // bits of (frame maximum - 8), biased by 16
     if (valid) {
-        const float *pm = slice + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
-        const f4 a = *reinterpret_cast<const f4 *>(pm), b = *reinterpret_cast<const f4 *>(pm + 4),
-                 c = *reinterpret_cast<const f4 *>(pm + 8);
-        const float m0 = __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w));
-        const float m1 = __builtin_fmaxf(__builtin_fmaxf(b.x, b.y), __builtin_fmaxf(b.z, b.w));
-        const float m2 = __builtin_fmaxf(__builtin_fmaxf(c.x, c.y), __builtin_fmaxf(c.z, c.w));
-        lo = __builtin_fmaxf(__builtin_fmaxf(m0, m1), m2) - 8.0f;
+        const int *pm = reinterpret_cast<const int *>(slice) + WaveLayout::kPmaxOff + fl * WaveLayout::kPmaxStride;
+        const WaveI4 a = *reinterpret_cast<const WaveI4 *>(pm), b = *reinterpret_cast<const WaveI4 *>(pm + 4), c = *reinterpret_cast<const WaveI4 *>(pm + 8);
+        const int m0 = wave_imax(wave_imax(a.x, a.y), wave_imax(a.z, a.w));
+        const int m1 = wave_imax(wave_imax(b.x, b.y), wave_imax(b.z, b.w));
+        const int m2 = wave_imax(wave_imax(c.x, c.y), c.z);           // 11 maxima (the twelfth word is the ghost lane's)
+        lo = wave_bits(wave_float(wave_imax(wave_imax(m0, m1), m2)) - 8.0f);
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kMelJobs * row_w : kMelJobs;
-    float cmin = 3.0e38f;
+    int cmin = 0x7f000000;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
         if (m < n_mels) {
-            const float c = __builtin_fmaxf(vals[i], lo);
-            o[i * step] = valid ? (c + 4.0f) * 0.25f : 0.0f;
-            if (GUARD) cmin = __builtin_fminf(cmin, c);
+            const int c = wave_imax(wave_bits(vals[i]), lo);
+            o[i * step] = valid ? wave_float(c) * 0.25f - 3.0f : 0.0f;
+            if (GUARD) cmin = wave_imin(cmin, c);
         }
     }
-    return GUARD && valid && cmin < lo + kGuardBand;
+    return GUARD && valid && wave_float(cmin) < wave_float(lo) + kGuardBand;
 }
 
 }  // namespace melspec
