@@ -132,18 +132,19 @@ MS_DEV void six_phase2(int fl, int j, bool active, const float *blob, float *sli
     const int koff = lane0 ? -110 : j;
     const float *tw = blob + SixBlob::kTw2 + j * SixBlob::kTw2Stride;
     float *p = slice + fl * SixLayout::kPStride;
-    auto pair = [&](cf zk, cf zm, cf W, int k) {
+    auto pair = [&](cf zk, cf zm, cf W, float &pk, float &pm) {
         const cf S = {zk.re + zm.re, zk.im - zm.im};
         const cf D = {zk.re - zm.re, zk.im + zm.im};
         const cf wd = cmul(W, D);
         const float ar = S.re + wd.im, ai = S.im - wd.re;
         const float br = S.re - wd.im, bi = S.im + wd.re;
-        p[k] = ar * ar + ai * ai;             // 4*|X[k]|^2 (the mel weights carry the 1/4)
-        p[200 - k] = br * br + bi * bi;
+        pk = ar * ar + ai * ai;               // 4*|X[k]|^2 (the mel weights carry the 1/4)
+        pm = br * br + bi * bi;               // 4*|X[200-k]|^2
     };
 #pragma unroll
     for (int s = 0; s < 10; s += 2) {
         const f4 w2 = *reinterpret_cast<const f4 *>(tw + 2 * s);
+        float pk[2], pm[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ss = s + h;
@@ -157,12 +158,22 @@ MS_DEV void six_phase2(int fl, int j, bool active, const float *blob, float *sli
                 zm = {lane0 ? v[15 - ss].re : v[9 - ss].re, lane0 ? v[15 - ss].im : v[9 - ss].im};
             }
             const cf W = h == 0 ? cf{w2.x, w2.y} : cf{w2.z, w2.w};
-            pair(zk, zm, W, ss < 6 ? j + 20 * ss : koff + 20 * ss);
+            pair(zk, zm, W, pk[h], pm[h]);
         }
+        // the two stores of a side next to each other: same base, offsets 20 words apart -> one ds_write2_b32 (6 LDS cycles for the
+        // two words; four single stores in k, 200-k, k, 200-k order were 4 x 4)
+        const int k = (s < 6 ? j : koff) + 20 * s;
+        p[k] = pk[0];
+        p[k + 20] = pk[1];
+        p[200 - k] = pm[0];
+        p[180 - k] = pm[1];
     }
     if (lane0) {                              // eleventh pair: Z[90] with Z[110]
         const f2 w2 = *reinterpret_cast<const f2 *>(tw + 20);
-        pair(v[4], v[5], cf{w2.x, w2.y}, 90);
+        float pk, pm;
+        pair(v[4], v[5], cf{w2.x, w2.y}, pk, pm);
+        p[90] = pk;
+        p[110] = pm;
     }
 }
 

@@ -52,7 +52,7 @@ MS_DEV void interval_bins_runtime(const float *pp, const float *w, int len, floa
         float pv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            wv[q] = *reinterpret_cast<const f2 *>(w + WSTRIDE * (r + q));
+            wv[q] = ld2_single(w + WSTRIDE * (r + q));
             pv[q] = pp[r + q];
         }
 #pragma unroll
@@ -62,7 +62,7 @@ MS_DEV void interval_bins_runtime(const float *pp, const float *w, int len, floa
         }
     }
     for (; r < len; ++r) {
-        const f2 wv = *reinterpret_cast<const f2 *>(w + WSTRIDE * r);
+        const f2 wv = ld2_single(w + WSTRIDE * r);
         const float pv = pp[r];
         ar += wv.x * pv;
         af += wv.y * pv;
