@@ -331,7 +331,7 @@ MS_DEV void fb_phase3_sums(int fl, int j, bool active, const MelSlots &ms, const
                 const float *w = mel + Lens::woff(i < Lens::kSlots ? i : 0) + 2 * j;
 #pragma unroll
                 for (int r = 0; r < Lens::len(i < Lens::kSlots ? i : 0); ++r) {
-                    const f2 wv = *reinterpret_cast<const f2 *>(w + 2 * kFbLanes * r);
+                    const f2 wv = ld2_single(w + 2 * kFbLanes * r);      // one ds_read_b64 (see device_fft.hpp)
                     const float pv = pp[r];
                     if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
                     else { ar += wv.x * pv; af += wv.y * pv; }
@@ -387,19 +387,20 @@ MS_DEV void nemo_phase3_store(int fl, int j, bool store, bool valid, int n_mels,
 // Whisper epilogue for the 512 flavour.  log10(max(E, 1e-10)) (src/mel.rs:148-168); the frame maximum goes through
 // 16 LDS words per frame (pmax, behind the power rows), then max(x, mx - 8), (x + 4) / 4 (src/mel.rs:645-654).
 constexpr int kW512PmaxOff = kFbFPW * 259 + 4;       // float offset of the maxima inside the slice (16-byte aligned)
+// The values are carried with a bias of +16 and compared as integers (whisper_six.hpp, six_phase3_finish).
 template <int NSLOTS>
 MS_DEV void w512_phase3_log(int fl, int j, bool active, int n_mels, const float (&rise)[NSLOTS], const float (&fnext)[NSLOTS],
                             float *slice_f, float (&vals)[NSLOTS]) {
     if (!active) return;
-    float mx = -3.0e38f;
+    int mx = 0;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const float e = rise[i] + fnext[i];
-        const float v = e > 1e-10f ? fast_log2(e) * 0.30102999566398120f : -10.0f;
+        const float v = __builtin_fmaxf(fast_log2(e) * 0.30102999566398120f + 16.0f, 6.0f);       // log10(max(e, 1e-10)) + 16
         vals[i] = v;
-        if (j < kFbOwn && j + kFbOwn * i < n_mels) mx = __builtin_fmaxf(mx, v);
+        if (j < kFbOwn && j + kFbOwn * i < n_mels) mx = wave_imax(mx, wave_bits(v));
     }
-    slice_f[kW512PmaxOff + fl * kFbLanes + j] = mx;
+    reinterpret_cast<int *>(slice_f)[kW512PmaxOff + fl * kFbLanes + j] = mx;
 }
 // store: this lane's column exists in the output; valid: it is a real frame (otherwise a zero column of a padded
 // layout).  row_w == 0: [frame][mel] rows of n_mels; row_w > 0: [mel][row_w] rows (interleave_frames, src/mel.rs:480-544).
@@ -407,23 +408,23 @@ template <int NSLOTS>
 MS_DEV void w512_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice_f, const float (&vals)[NSLOTS],
                         float *out_tile, long long row_w) {
     if (!store || j >= kFbOwn) return;
-    float lo = 0.0f;
+    int lo = 0;
     if (valid) {
-        const float *pm = slice_f + kW512PmaxOff + fl * kFbLanes;
-        lo = -3.0e38f;
+        const int *pm = reinterpret_cast<const int *>(slice_f) + kW512PmaxOff + fl * kFbLanes;
+        int mx = 0;
 #pragma unroll
         for (int k = 0; k < kFbLanes; k += 4) {
-            const f4 a = *reinterpret_cast<const f4 *>(pm + k);
-            lo = __builtin_fmaxf(lo, __builtin_fmaxf(__builtin_fmaxf(a.x, a.y), __builtin_fmaxf(a.z, a.w)));
+            const WaveI4 a = *reinterpret_cast<const WaveI4 *>(pm + k);
+            mx = wave_imax(mx, wave_imax(wave_imax(a.x, a.y), wave_imax(a.z, a.w)));
         }
-        lo -= 8.0f;
+        lo = wave_bits(wave_float(mx) - 8.0f);
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kFbOwn * row_w : kFbOwn;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kFbOwn * i;
-        if (m < n_mels) o[i * step] = valid ? (__builtin_fmaxf(vals[i], lo) + 4.0f) * 0.25f : 0.0f;
+        if (m < n_mels) o[i * step] = valid ? wave_float(wave_imax(wave_bits(vals[i]), lo)) * 0.25f - 3.0f : 0.0f;
     }
 }
 
