@@ -22,7 +22,9 @@
 // VMEM-, VALU- and LDS-heavy phases.  Measured (profiles/r01_variants.txt): six-frame Whisper kernel -2.3 .. -3.5 %, fused
 // 512-point kernels -8 % (Kaldi) / -11 % (Whisper-512) / 0 (NeMo), precise kernel -3.8 %; the 5-frame kernel with two
 // 8-wave workgroups per CU loses 1-4 % under every table tried in its round-robin form and stays at the default priority
-// there; its run-per-wave form (whisper400_wave_runs_kernel) gains 5 % (cfg4 9.02 -> 8.53 ms).
+// there; its run-per-wave form (whisper400_wave_runs_kernel) gains 5 % (cfg4 9.02 -> 8.53 ms).  Round 3, after the LDS / VALU trims of
+// the six-frame kernel (same box, config 2): 0/1/2 0.2867 ms; 1/2/3 0.2863; 0/1/3 0.2875; 0/2/3 0.2887; 0/1/1 0.2917; 0/0/1 0.2934;
+// 2/1/0 0.2898; none 0.3146 (+9.8 %).  A one-instruction touch of the next unit's 4 KB of PCM (64-byte pieces, a unit ahead): +7 %.
 #ifndef MELSPEC_NO_PRIO
 #define MS_PRIO(n) __builtin_amdgcn_s_setprio(n)
 #else
