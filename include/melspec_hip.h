@@ -443,6 +443,14 @@ int melspec_tga_encode_device(melspec_tga *q, const float *d_images, size_t imag
                               uint32_t n_images, uint8_t *d_blobs, size_t blob_stride, void *stream);
 /* parse_tga_8bit / load_tga_8bit (src/quant.rs:66-98) for the same layout: reads {min,max} from bytes
  * 18..25 of every chunk and dequantises (dequantize, :156-165: u8 * ((max-min)/255) + min, two roundings). */
+/* PCM -> TGA blobs, device resident: tga_8bit_data(interleave_frames(mel(clip), false, min_width)) for n_clips uniform clips
+ * (src/quant.rs:38-64, src/mel.rs:480-544), the images left in d_images ([n_clips][n_mels][W], W = melspec_interleaved_width) and one
+ * blob per clip at d_blobs + i * blob_stride (melspec_tga_layout).  On the fused n_fft = 400 kernels the mel kernel folds each image's
+ * {min, max} while it stores it, so the quantiser reads the image once: same bytes as melspec_compute_uniform_device_interleaved followed
+ * by melspec_tga_encode_device.  `q` and `ctx` must be on one device; asynchronous on `stream` (NULL: the context's). */
+int melspec_tga_encode_pcm_uniform_device(melspec_tga *q, melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                          uint32_t n_clips, uint64_t min_width, float *d_images, uint8_t *d_blobs, size_t blob_stride,
+                                          void *stream);
 int melspec_tga_decode_device(melspec_tga *q, const uint8_t *d_blobs, size_t blob_stride, int n_mels, size_t width,
                               uint32_t n_images, float *d_images, size_t image_stride, void *stream);
 /* tga_8bit(data, n_mels) on host memory; n_chunks blobs laid out as melspec_tga_layout says. */

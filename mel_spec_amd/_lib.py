@@ -159,6 +159,7 @@ SIGNATURES = {
     "melspec_tga_destroy": (None, [_vp]),
     "melspec_tga_layout": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "melspec_tga_encode_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "melspec_tga_encode_pcm_uniform_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, _vp, _vp, C.c_size_t, _vp]),
     "melspec_tga_decode_device": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, _vp, C.c_size_t, _vp]),
     "melspec_tga_encode_host": (C.c_int, [_vp, _f32p, C.c_size_t, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_uint32)]),
     "melspec_tga_decode_host": (C.c_int, [_vp, _vp, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -2416,6 +2416,46 @@ int melspec_tga_encode_device(melspec_tga *q, const float *d_images, size_t imag
                         stream ? static_cast<hipStream_t>(stream) : q->stream);
 }
 
+// PCM -> TGA bytes with the image read once: the mel kernel folds every image's {min, max} into the quantiser's keys while it stores
+// the image (mel-major, BatchDesc::d_keys: one wave-wide reduction and two atomics per work unit), so only the encoding pass reads
+// it again -- 5 B/pixel moved for 5 B/pixel algorithmic, where minmax + encode moved 9 ("4x smaller D2H").  The bytes are
+// those of melspec_compute_uniform_device_interleaved(.., major_column_order = 0, min_width) followed by melspec_tga_encode_device.
+int melspec_tga_encode_pcm_uniform_device(melspec_tga *q, melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                          uint32_t n_clips, uint64_t min_width, float *d_images, uint8_t *d_blobs, size_t blob_stride,
+                                          void *stream) {
+    if (!q || !c) return fail(MELSPEC_ERR_INVALID_ARG, "tga / ctx is NULL");
+    if (q->dev.device != c->dev.device) return fail(MELSPEC_ERR_INVALID_ARG, "the codec and the context are on different devices");
+    if (min_width % 2 != 0) return fail(MELSPEC_ERR_INVALID_ARG, "min_width must be even");   // src/mel.rs:488
+    if (n_clips == 0) return MELSPEC_OK;
+    uint64_t fpc; ctx_num_frames(c, clip_len, fpc);
+    if (fpc == 0) return fail(MELSPEC_ERR_INVALID_ARG, "frames is empty");                      // src/mel.rs:487
+    if (!d_pcm || !d_images || !d_blobs) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const uint64_t width = interleaved_width(fpc, min_width);
+    const size_t image_stride = static_cast<size_t>(c->n_mels) * width;
+    if (!c->fast || width > kTgaMaxWidth) {
+        // geometries on the generic / 512-point kernels, and images wider than one TGA chunk: the two-pass form
+        int rc = melspec_compute_uniform_device_interleaved(c, d_pcm, clip_stride, clip_len, n_clips, d_images, 0, min_width, s);
+        if (rc) return rc;
+        return melspec_tga_encode_device(q, d_images, image_stride, c->n_mels, width, n_clips, d_blobs, blob_stride, s);
+    }
+    QuantDesc d;
+    uint32_t items, bpx, bdw;
+    int rc = quant_plan(q, d, d_images, image_stride, static_cast<uint32_t>(c->n_mels), width, n_clips, d_blobs, blob_stride, true, items, bpx, bdw);
+    if (rc) return rc;
+    d.img = d_images; d.blob = d_blobs; d.ranges = nullptr;
+    if (q->keys_used && q->keys_stream != s) HIP_TRY(hipStreamSynchronize(q->keys_stream));
+    q->keys_used = true; q->keys_stream = s;
+    hipLaunchKernelGGL(quant_init_keys_kernel, dim3((items + 255) / 256), dim3(256), 0, s, d.keys, items);
+    BatchPlan pl = plan_uniform(d_pcm, d_images, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c), width, true);
+    pl.desc.d_keys = d.keys;                          // one chunk per image: item == clip
+    if ((rc = launch_ctx(c, pl.desc, s))) return rc;
+    hipLaunchKernelGGL(quant_encode_kernel, dim3(items * bdw), dim3(kQuantThreads), 0, s, d, bdw);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
 int melspec_tga_decode_device(melspec_tga *q, const uint8_t *d_blobs, size_t blob_stride, int n_mels, size_t width,
                               uint32_t n_images, float *d_images, size_t image_stride, void *stream) {
     if (!q) return fail(MELSPEC_ERR_INVALID_ARG, "tga is NULL");

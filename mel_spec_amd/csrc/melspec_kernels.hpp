@@ -56,6 +56,8 @@ struct BatchDesc {
                                     // n_units above is the host's upper bound (grid and scratch sizes)
     const uint32_t *d_order;        // ragged, host-planned, optional: the clips longest first (whole-clip kernels take them in this order)
     uint32_t *d_ticket;             //   and the counter they take them from (zero when the launch starts)
+    uint32_t *d_keys;               // uniform mel-major layouts, optional: [n_clips][2] ordered keys of {min, max} of every clip's image, folded
+                                    //   with atomics as the image is stored (the TGA quantiser's first pass, tga_quant.hpp); initialised by the caller
 };
 
 __device__ __forceinline__ uint64_t batch_n_units(const BatchDesc &b) { return b.d_n_units ? *b.d_n_units : b.n_units; }
@@ -180,6 +182,38 @@ __device__ __forceinline__ float wave_shift_down1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
 }
 
+
+// ---- min / max keys of the stored images (BatchDesc::d_keys) ------------------------------------------------------------------
+// Wave-wide minimum / maximum of non-negative ints (the biased values of phase 4): an inclusive scan inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8), then row_bcast:15 / :31 carry the row results up; lane 63 holds the result.
+template <bool MAX>
+__device__ __forceinline__ int wave_reduce_int(int v) {
+    constexpr int ident = MAX ? 0 : 0x7fffffff;
+    auto op = [](int a, int b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// order-preserving map f32 -> u32 (ordered_key of tga_quant.hpp)
+__device__ __forceinline__ uint32_t image_key(float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+// kmin / kmax: this lane's extremes of the biased values it stored for the clip (0x7fffffff / 0 when it stored nothing, or when its
+// frame is going to be recomputed and will report then); every lane of the wave calls this.  out(c) = the float that was stored.
+template <class OUT>
+__device__ __forceinline__ void image_keys_commit(uint32_t *keys, int lane, int kmin, int kmax, OUT out) {
+    const int lo = wave_reduce_int<false>(kmin), hi = wave_reduce_int<true>(kmax);
+    if (lane == 0 && hi != 0) {
+        atomicMin(keys, image_key(out(lo)));
+        atomicMax(keys + 1, image_key(out(hi)));
+    }
+}
+
 __device__ __forceinline__ uint64_t scalar64(uint64_t v) {
     // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
@@ -220,7 +254,8 @@ __device__ __forceinline__ unsigned frame_mask(uint64_t any) {
 // Six frames x ten lanes.
 template <int NSLOTS, class Lens, bool LAYOUT>
 __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
-                                          const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w) {
+                                          const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w,
+                                          uint32_t *keys = nullptr /* LAYOUT: the clip's {min, max} keys, or nullptr */) {
     const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
     const bool in = lane < kSixFrames * kSixLanes;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
@@ -245,8 +280,10 @@ __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int ho
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
         six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
         __builtin_amdgcn_wave_barrier();
-        six_phase4<NSLOTS, LAYOUT, false>(fl, j, act, act, n_mels, slice, vals, out_tile, row_w);
+        int kmin = 0x7fffffff, kmax = 0;
+        six_phase4<NSLOTS, LAYOUT, false, LAYOUT>(fl, j, act, act, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT && keys) image_keys_commit(keys, lane, kmin, kmax, [](int c) { return six_out(c); });
     }
     return static_cast<unsigned>(__builtin_popcount(mask));      // frames recomputed (the caller adds them up: one atomic per wave, not per
                                                                   // frame -- a million atomics on one address took 10 ms)
@@ -255,7 +292,8 @@ __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int ho
 // The same for the five-frame kernels (12 lanes per frame in phases 3-4).
 template <int NSLOTS, class Lens, bool LAYOUT>
 __device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
-                                           const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w) {
+                                           const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w,
+                                           uint32_t *keys = nullptr) {
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
@@ -279,8 +317,10 @@ __device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int h
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
         wave_phase3i_finish<NSLOTS>(fl3, j3, act3, n_mels, rise, fnext, slice, vals);
         __builtin_amdgcn_wave_barrier();
-        wave_phase4<NSLOTS, LAYOUT, false>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w);
+        int kmin = 0x7fffffff, kmax = 0;
+        wave_phase4<NSLOTS, LAYOUT, false, LAYOUT>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT && keys) image_keys_commit(keys, lane, kmin, kmax, [](int c) { return wave_out(c); });
     }
     return static_cast<unsigned>(__builtin_popcount(mask));      // frames recomputed (the caller adds them up: one atomic per wave, not per
                                                                   // frame -- a million atomics on one address took 10 ms)
@@ -393,14 +433,21 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         rs.template before_stores<0>(lane);
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
         const long long row_w = p.b.mel_major ? (long long)width : 0;
-        const bool flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, out_tile, row_w);
+        int kmin = 0x7fffffff, kmax = 0;
+        const bool flag = wave_phase4<NSLOTS, true, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
+        unsigned redo = 0;                  // frames of this unit that the tail recomputes
         if (guard) {
             const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
             if (any != 0) {
-                if (lane == 0) notes[noted] = (unit << 8) | frame_mask<12, kFPW>(any);
+                redo = frame_mask<12, kFPW>(any);
+                if (lane == 0) notes[noted] = (unit << 8) | redo;
                 ++noted;
             }
+        }
+        if (p.b.d_keys && have) {           // wave-uniform; a frame that is recomputed reports its extremes then
+            if ((redo >> fl3) & 1u) { kmin = 0x7fffffff; kmax = 0; }
+            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return wave_out(c); });
         }
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
@@ -426,7 +473,8 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
         redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
-                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
+                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0,
+                                          p.b.d_keys ? p.b.d_keys + 2 * (uint64_t)loc.clip : nullptr);
     }
     guard_wave_done(p.fix, arrive + WAVES - 2, WAVES, lane, redone);
 }
@@ -496,14 +544,21 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         rs.template before_stores<3>(lane);
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
         const long long row_w = p.b.mel_major ? (long long)width : 0;
-        const bool flag = six_phase4<NSLOTS, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, out_tile, row_w);
+        int kmin = 0x7fffffff, kmax = 0;
+        const bool flag = six_phase4<NSLOTS, true, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
+        unsigned redo = 0;                  // frames of this unit that the tail recomputes
         if (guard) {
             const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
             if (any != 0) {
-                if (lane == 0) notes[noted] = (unit << 8) | frame_mask<kSixLanes, kSixFrames>(any);
+                redo = frame_mask<kSixLanes, kSixFrames>(any);
+                if (lane == 0) notes[noted] = (unit << 8) | redo;
                 ++noted;
             }
+        }
+        if (p.b.d_keys && have) {           // wave-uniform; a frame that is recomputed reports its extremes then
+            if ((redo >> fl) & 1u) { kmin = 0x7fffffff; kmax = 0; }
+            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return six_out(c); });
         }
         rs.after_round();
     }
@@ -526,7 +581,8 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
         redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
-                                         loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0);
+                                         loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0,
+                                         p.b.d_keys ? p.b.d_keys + 2 * (uint64_t)loc.clip : nullptr);
     }
     guard_wave_done(p.fix, arrive + kSixWaves - 2, kSixWaves, lane, redone);
 }
@@ -860,11 +916,14 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         __builtin_amdgcn_wave_barrier();
         if (LAYOUT) rs.template before_stores<2>(lane);
         bool flag;
+        int kmin = 0x7fffffff, kmax = 0;
         if (LAYOUT && p.b.mel_major)
-            flag = wave_phase4<NSLOTS, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width);
+            flag = wave_phase4<NSLOTS, true, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0, (long long)width, &kmin, &kmax);
         else
             flag = wave_phase4<NSLOTS, LAYOUT, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
+        if (LAYOUT && p.b.mel_major && p.b.d_keys && have)
+            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return wave_out(c); });
         if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(__builtin_amdgcn_ballot_w64(flag))));
         if (LAYOUT) rs.after_round();
         if (RUNS) ++cr.unit;

@@ -242,9 +242,12 @@ MS_DEV void six_phase3_finish(int fl, int j, bool active, int n_mels, const floa
 // GUARD: returns true on lanes that hold a band within kGuardBand decades of the clamp (see wave_phase4).
 struct alignas(16) SixI4 { int x, y, z, w; };
 struct alignas(8) SixI2 { int x, y; };
-template <int NSLOTS, bool LAYOUT = false, bool GUARD = false>
+// KEYS (mel-major stores feeding the TGA quantiser, tga_quant.hpp): *kmin / *kmax = the smallest / largest biased value this lane
+// stored, a zero column counting as 12 (12 * 0.25 - 3 == 0 exactly); lanes that store nothing leave them untouched.
+MS_DEV float six_out(int c) { return six_float(c) * 0.25f - 3.0f; }          // (x + 4) / 4 of the biased value
+template <int NSLOTS, bool LAYOUT = false, bool GUARD = false, bool KEYS = false>
 MS_DEV bool six_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
-                       float *out_tile, long long row_w) {
+                       float *out_tile, long long row_w, int *kmin = nullptr, int *kmax = nullptr) {
     if (!LAYOUT) { valid = true; row_w = 0; }
     if (!store || j >= kSixOwn) return false;
     int lo = 0;          // bits of (frame maximum - 8), biased
@@ -258,16 +261,19 @@ MS_DEV bool six_phase4(int fl, int j, bool store, bool valid, int n_mels, const 
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kSixOwn * row_w : kSixOwn;
-    int cmin = 0x7f000000;
+    int cmin = 0x7f000000, cmax = 0;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kSixOwn * i;
         if (m < n_mels) {
-            const int c = six_imax(six_bits(vals[i]), lo);       // vals >= 6 > 0: the integer order is the float order, also against a negative lo
-            o[i * step] = valid ? six_float(c) * 0.25f - 3.0f : 0.0f;
-            if (GUARD) cmin = six_imin(cmin, c);
+            // vals >= 6 > 0: the integer order is the float order, also against a negative lo; a zero column is the value 12
+            const int c = valid ? six_imax(six_bits(vals[i]), lo) : 0x41400000;
+            o[i * step] = six_out(c);
+            if (GUARD || KEYS) cmin = six_imin(cmin, c);
+            if (KEYS) cmax = six_imax(cmax, c);
         }
     }
+    if (KEYS) { *kmin = cmin; *kmax = cmax; }
     return GUARD && valid && six_float(cmin) < six_float(lo) + kGuardBand;
 }
 

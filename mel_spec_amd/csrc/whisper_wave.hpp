@@ -252,9 +252,11 @@ MS_DEV void wave_phase3i_finish(int fl, int j12, bool active, int n_mels, const 
 constexpr float kGuardBand = 2.0f;
 
 struct alignas(16) WaveI4 { int x, y, z, w; };
-template <int NSLOTS, bool LAYOUT = true, bool GUARD = false>
+MS_DEV float wave_out(int c) { return wave_float(c) * 0.25f - 3.0f; }          // (x + 4) / 4 of the biased value
+// KEYS: see six_phase4 (whisper_six.hpp)
+template <int NSLOTS, bool LAYOUT = true, bool GUARD = false, bool KEYS = false>
 MS_DEV bool wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice, const float (&vals)[NSLOTS],
-                        float *out_tile, long long row_w) {
+                        float *out_tile, long long row_w, int *kmin = nullptr, int *kmax = nullptr) {
     if (!LAYOUT) { valid = true; row_w = 0; }     // plain output: every stored column is a real frame
     if (!store || j >= kMelJobs) return false;
     int lo = 0;                                   // bits of (frame maximum - 8), biased by 16
@@ -268,16 +270,18 @@ MS_DEV bool wave_phase4(int fl, int j, bool store, bool valid, int n_mels, const
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kMelJobs * row_w : kMelJobs;
-    int cmin = 0x7f000000;
+    int cmin = 0x7f000000, cmax = 0;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kMelJobs * i;
         if (m < n_mels) {
-            const int c = wave_imax(wave_bits(vals[i]), lo);
-            o[i * step] = valid ? wave_float(c) * 0.25f - 3.0f : 0.0f;
-            if (GUARD) cmin = wave_imin(cmin, c);
+            const int c = valid ? wave_imax(wave_bits(vals[i]), lo) : 0x41400000;       // a zero column is the biased value 12
+            o[i * step] = wave_out(c);
+            if (GUARD || KEYS) cmin = wave_imin(cmin, c);
+            if (KEYS) cmax = wave_imax(cmax, c);
         }
     }
+    if (KEYS) { *kmin = cmin; *kmax = cmax; }
     return GUARD && valid && wave_float(cmin) < wave_float(lo) + kGuardBand;
 }
 

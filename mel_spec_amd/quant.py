@@ -105,6 +105,13 @@ class TgaCodec:
         _check(lib().melspec_tga_encode_device(self._h, C.c_void_p(d_images), image_stride, n_mels, width, n_images,
                                                C.c_void_p(d_blobs), blob_stride, C.c_void_p(stream)))
 
+    def encode_pcm_uniform_device(self, mel, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, min_width: int, d_images: int,
+                                  d_blobs: int, blob_stride: int, stream: int = 0) -> None:
+        """melspec_tga_encode_pcm_uniform_device: PCM -> mel-major images (left in d_images) -> one TGA blob per clip, the image's
+        {min, max} folded by the mel kernel while it stores (`mel`: a HipMelSpectrogram on the same device)"""
+        _check(lib().melspec_tga_encode_pcm_uniform_device(self._h, mel._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips, min_width,
+                                                           C.c_void_p(d_images), C.c_void_p(d_blobs), blob_stride, C.c_void_p(stream)))
+
     def decode_device(self, d_blobs: int, blob_stride: int, n_mels: int, width: int, n_images: int, d_images: int,
                       image_stride: int, stream: int = 0) -> None:
         _check(lib().melspec_tga_decode_device(self._h, C.c_void_p(d_blobs), blob_stride, n_mels, width, n_images,

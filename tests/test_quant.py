@@ -225,3 +225,51 @@ def test_gpu_batched_device_path_config2_shape(gpu, codec, oracle):
     for b in (pcm, img, blobs, back):
         b.free()
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mels,mode,min_width,kind", [(80, "auto", 2, "noise"), (80, "auto", 3000, "noise"), (80, "auto", 2, "speech"), (80, "f64", 0, "speech"),
+                                                        (80, "f32", 1200, "speech"), (128, "auto", 2, "speech"), (128, "auto", 0, "noise"), (64, "auto", 2, "tone")])
+def test_gpu_pcm_to_tga_with_the_minmax_folded_into_the_mel_store(gpu, codec, oracle, jfk, n_mels, mode, min_width, kind):
+    """melspec_tga_encode_pcm_uniform_device: the mel kernel folds every image's {min, max} while it stores the image (also through
+    the f64 recompute of AUTO's tripped frames, whose f32 values must not leave a trace in the range, and through zero-padded
+    columns), the quantiser reads the image once.  Byte for byte what the two-pass form and the oracle make of the same images."""
+    n_clips, clip_len = 40, 48000
+    if kind == "noise":
+        x = np.stack([oracle.synth_pcm(c, clip_len) for c in range(n_clips)])
+    elif kind == "speech":
+        x = np.stack([np.resize(np.roll(jfk, -2111 * c), clip_len) for c in range(n_clips)])
+    else:
+        t = np.arange(clip_len) / 16000.0
+        rng = np.random.default_rng(4)
+        x = np.stack([(0.9 * np.sin(2 * np.pi * (300 + 170 * c) * t) + 10 ** (-70 / 20) * rng.standard_normal(clip_len)) for c in range(n_clips)])
+    x = x.astype(np.float32)
+    m = gpu.HipMelSpectrogram(400, 160, 16000.0, n_mels)
+    m.set_precision(mode)
+    m.set_auto_adaptive(False)                 # one regime for both forms (bits are compared)
+    W = m.interleaved_width(clip_len, min_width)
+    pcm = gpu.DeviceBuffer(x.nbytes); pcm.upload(x)
+    n, stride, last = codec.layout(n_mels, W)
+    assert n == 1
+    img = gpu.DeviceBuffer(n_clips * n_mels * W * 4); img2 = gpu.DeviceBuffer(n_clips * n_mels * W * 4)
+    blobs = gpu.DeviceBuffer(n_clips * stride); blobs2 = gpu.DeviceBuffer(n_clips * stride)
+    for rep in range(2):                       # twice: the keys are reset per call
+        codec.encode_pcm_uniform_device(m, pcm.ptr, clip_len, clip_len, n_clips, min_width, img.ptr, blobs.ptr, stride)
+        m.synchronize()
+    if mode == "auto" and kind != "noise":
+        assert m.guard_last_count() > 0          # the recompute tail took part
+    m.compute_uniform_device_interleaved(pcm.ptr, clip_len, clip_len, n_clips, img2.ptr, False, min_width)
+    m.synchronize()
+    codec.encode_device(img2.ptr, n_mels * W, n_mels, W, n_clips, blobs2.ptr, stride)
+    codec.synchronize()
+    a, b = blobs.download((n_clips, stride), np.uint8), blobs2.download((n_clips, stride), np.uint8)
+    imgs = img.download((n_clips, n_mels * W))
+    assert np.array_equal(imgs, img2.download((n_clips, n_mels * W)))
+    assert np.array_equal(a[:, :last], b[:, :last])
+    for c in (0, 7, n_clips - 1):
+        assert a[c, :last].tobytes() == oracle.tga_8bit_data(imgs[c], n_mels)
+        want = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(x[c], 400, 160, n_mels, 16000.0), False, min_width)
+        assert np.abs(imgs[c].reshape(n_mels, W) - want).max() <= (1e-4 if not (mode == "f32" and kind == "tone") else 1e-3)
+    for buf in (pcm, img, img2, blobs, blobs2):
+        buf.free()
+    m.close()
