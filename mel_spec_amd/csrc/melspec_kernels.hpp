@@ -396,18 +396,10 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
 
     RoundSync<WAVES> rs(p.b.sync_rounds, wave, arrive);
     // this wave's notes: one slot per round, rounds * (its rank among all waves) onwards
-    // A workgroup walks a CONTIGUOUS range of rounds (a round = WAVES adjacent units): adjacent waves still hold adjacent units for
-    // the mel-major store, and a wave stays inside one clip for many rounds, so the image's min / max keys (BatchDesc::d_keys) are
-    // accumulated in two registers and committed when the clip changes -- two atomics per unit cost the kernel 19 %.
-    const uint64_t total_rounds = (p.b.n_units + WAVES - 1) / WAVES;
-    const uint64_t rounds = (total_rounds + gridDim.x - 1) / gridDim.x;
-    const uint64_t r_lo = total_rounds * xcd_logical_block() / gridDim.x, r_hi = total_rounds * (xcd_logical_block() + 1) / gridDim.x;
+    const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * WAVES - 1) / ((uint64_t)gridDim.x * WAVES);
     uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * WAVES + rs.slot) * rounds : nullptr;
     unsigned noted = 0;
-    int acc_min = 0x7fffffff, acc_max = 0;
-    uint32_t acc_clip = 0;
-    for (uint64_t r = r_lo; r < r_hi; ++r) {
-        const uint64_t first = r * WAVES;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
         const uint64_t unit = first + rs.slot;
         const bool have = unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
@@ -454,17 +446,13 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
             }
         }
         if (p.b.d_keys && have) {           // wave-uniform; a frame that is recomputed reports its extremes then
-            if (loc.clip != acc_clip) {
-                image_keys_commit(p.b.d_keys + 2 * (uint64_t)acc_clip, lane, acc_min, acc_max, [](int c) { return wave_out(c); });
-                acc_min = 0x7fffffff; acc_max = 0; acc_clip = loc.clip;
-            }
-            if (!((redo >> fl3) & 1u)) { acc_min = kmin < acc_min ? kmin : acc_min; acc_max = kmax > acc_max ? kmax : acc_max; }
+            if ((redo >> fl3) & 1u) { kmin = 0x7fffffff; kmax = 0; }
+            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return wave_out(c); });
         }
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
         rs.after_round();
     }
-    if (p.b.d_keys) image_keys_commit(p.b.d_keys + 2 * (uint64_t)acc_clip, lane, acc_min, acc_max, [](int c) { return wave_out(c); });
     // the units whose frames tripped the precision guard, again, in f64 (no barrier of the rounds involved any more)
     unsigned redone = 0;
     FixTw tw;
@@ -517,16 +505,10 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
     const bool guard = p.fix.tab != nullptr;
     RoundSync<kSixWaves> rs(p.b.sync_rounds, wave, arrive);
-    // a contiguous range of rounds per workgroup, the image keys accumulated per wave until the clip changes (see whisper400_wave_kernel)
-    const uint64_t total_rounds = (p.b.n_units + kSixWaves - 1) / kSixWaves;
-    const uint64_t rounds = (total_rounds + gridDim.x - 1) / gridDim.x;
-    const uint64_t r_lo = total_rounds * xcd_logical_block() / gridDim.x, r_hi = total_rounds * (xcd_logical_block() + 1) / gridDim.x;
+    const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * kSixWaves - 1) / ((uint64_t)gridDim.x * kSixWaves);
     uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * kSixWaves + rs.slot) * rounds : nullptr;
     unsigned noted = 0;
-    int acc_min = 0x7fffffff, acc_max = 0;
-    uint32_t acc_clip = 0;
-    for (uint64_t r = r_lo; r < r_hi; ++r) {
-        const uint64_t first = r * kSixWaves;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
         const uint64_t unit = first + rs.slot;
         const bool have = unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
@@ -575,15 +557,11 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             }
         }
         if (p.b.d_keys && have) {           // wave-uniform; a frame that is recomputed reports its extremes then
-            if (loc.clip != acc_clip) {
-                image_keys_commit(p.b.d_keys + 2 * (uint64_t)acc_clip, lane, acc_min, acc_max, [](int c) { return six_out(c); });
-                acc_min = 0x7fffffff; acc_max = 0; acc_clip = loc.clip;
-            }
-            if (!((redo >> fl) & 1u)) { acc_min = kmin < acc_min ? kmin : acc_min; acc_max = kmax > acc_max ? kmax : acc_max; }
+            if ((redo >> fl) & 1u) { kmin = 0x7fffffff; kmax = 0; }
+            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return six_out(c); });
         }
         rs.after_round();
     }
-    if (p.b.d_keys) image_keys_commit(p.b.d_keys + 2 * (uint64_t)acc_clip, lane, acc_min, acc_max, [](int c) { return six_out(c); });
     unsigned redone = 0;
     FixTw tw;
     // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
@@ -904,17 +882,11 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, 0);
         return;
     }
-    // layouts: a contiguous range of rounds per workgroup, the image keys accumulated per wave (see whisper400_wave_kernel)
-    const uint64_t total_rounds = (p.b.n_units + WAVES - 1) / WAVES;
-    const uint64_t r_hi = total_rounds * (xcd_logical_block() + 1) / gridDim.x;
-    int acc_min = 0x7fffffff, acc_max = 0;
-    uint32_t acc_clip = 0;
-    for (uint64_t r = total_rounds * xcd_logical_block() / gridDim.x;; ++r) {
-        const uint64_t first = r * WAVES;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES;; first += (uint64_t)gridDim.x * WAVES) {
         if (RUNS) {
             if (cr.unit >= cr.end) break;
             cr.enter(p.b);
-        } else if (r >= r_hi) {
+        } else if (first >= p.b.n_units) {
             break;
         }
         const uint64_t unit = first + rs.slot;
@@ -950,18 +922,12 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         else
             flag = wave_phase4<NSLOTS, LAYOUT, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && p.b.mel_major && p.b.d_keys && have) {
-            if (loc.clip != acc_clip) {
-                image_keys_commit(p.b.d_keys + 2 * (uint64_t)acc_clip, lane, acc_min, acc_max, [](int c) { return wave_out(c); });
-                acc_min = 0x7fffffff; acc_max = 0; acc_clip = loc.clip;
-            }
-            acc_min = kmin < acc_min ? kmin : acc_min; acc_max = kmax > acc_max ? kmax : acc_max;
-        }
+        if (LAYOUT && p.b.mel_major && p.b.d_keys && have)
+            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return wave_out(c); });
         if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(__builtin_amdgcn_ballot_w64(flag))));
         if (LAYOUT) rs.after_round();
         if (RUNS) ++cr.unit;
     }
-    if (LAYOUT && p.b.d_keys) image_keys_commit(p.b.d_keys + 2 * (uint64_t)acc_clip, lane, acc_min, acc_max, [](int c) { return wave_out(c); });
     guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, flagged);
 }
 
