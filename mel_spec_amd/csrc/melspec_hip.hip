@@ -2282,7 +2282,7 @@ int melspec_stream_flush_host(melspec_stream *st, const uint32_t *ids, uint32_t 
 struct melspec_tga {
     DeviceInfo dev;
     hipStream_t stream = nullptr;
-    DevBuf keys, ranges, h2d, d2h;
+    DevBuf keys, ranges, h2d, d2h, unit_ext;       // unit_ext: the mel kernel's per-unit extremes (melspec_tga_encode_pcm_uniform_device)
     // the min/max keys are one scratch buffer per handle, used in stream order: a call on another stream first waits for
     // the stream that used it last
     hipStream_t keys_stream = nullptr;
@@ -2394,7 +2394,7 @@ void melspec_tga_destroy(melspec_tga *q) {
     if (!q) return;
     if (q->dev.device >= 0) (void)hipSetDevice(q->dev.device);
     if (q->stream) { (void)hipStreamSynchronize(q->stream); (void)hipStreamDestroy(q->stream); }
-    q->keys.release(); q->ranges.release(); q->h2d.release(); q->d2h.release();
+    q->keys.release(); q->ranges.release(); q->h2d.release(); q->d2h.release(); q->unit_ext.release();
     delete q;
 }
 
@@ -2416,9 +2416,9 @@ int melspec_tga_encode_device(melspec_tga *q, const float *d_images, size_t imag
                         stream ? static_cast<hipStream_t>(stream) : q->stream);
 }
 
-// PCM -> TGA bytes with the image read once: the mel kernel folds every image's {min, max} into the quantiser's keys while it stores
-// the image (mel-major, BatchDesc::d_keys: one wave-wide reduction and two atomics per work unit), so only the encoding pass reads
-// it again -- 5 B/pixel moved for 5 B/pixel algorithmic, where minmax + encode moved 9 ("4x smaller D2H").  The bytes are
+// PCM -> TGA bytes with the image read once: while it stores the image (mel-major) the mel kernel leaves the extremes of every work
+// unit behind (BatchDesc::d_unit_ext: one wave-wide reduction and one 8-byte store per unit), a one-wave-per-image kernel folds them
+// into the quantiser's keys, so only the encoding pass reads the image again -- 5 B/pixel moved for 5 B/pixel algorithmic, where minmax + encode moved 9 ("4x smaller D2H").  The bytes are
 // those of melspec_compute_uniform_device_interleaved(.., major_column_order = 0, min_width) followed by melspec_tga_encode_device.
 int melspec_tga_encode_pcm_uniform_device(melspec_tga *q, melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                           uint32_t n_clips, uint64_t min_width, float *d_images, uint8_t *d_blobs, size_t blob_stride,
@@ -2447,10 +2447,12 @@ int melspec_tga_encode_pcm_uniform_device(melspec_tga *q, melspec_ctx *c, const 
     d.img = d_images; d.blob = d_blobs; d.ranges = nullptr;
     if (q->keys_used && q->keys_stream != s) HIP_TRY(hipStreamSynchronize(q->keys_stream));
     q->keys_used = true; q->keys_stream = s;
-    hipLaunchKernelGGL(quant_init_keys_kernel, dim3((items + 255) / 256), dim3(256), 0, s, d.keys, items);
     BatchPlan pl = plan_uniform(d_pcm, d_images, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c), width, true);
-    pl.desc.d_keys = d.keys;                          // one chunk per image: item == clip
+    if ((rc = q->unit_ext.ensure(static_cast<size_t>(pl.desc.n_units) * 2 * sizeof(int) + 16))) return rc;
+    pl.desc.d_unit_ext = static_cast<int *>(q->unit_ext.p);
     if ((rc = launch_ctx(c, pl.desc, s))) return rc;
+    // one chunk per image: item == clip; its units' records -> its keys
+    hipLaunchKernelGGL(quant_keys_from_units_kernel, dim3(n_clips), dim3(64), 0, s, pl.desc.d_unit_ext, pl.desc.units_per_clip, n_clips, d.keys);
     hipLaunchKernelGGL(quant_encode_kernel, dim3(items * bdw), dim3(kQuantThreads), 0, s, d, bdw);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;

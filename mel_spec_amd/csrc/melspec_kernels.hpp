@@ -56,8 +56,8 @@ struct BatchDesc {
                                     // n_units above is the host's upper bound (grid and scratch sizes)
     const uint32_t *d_order;        // ragged, host-planned, optional: the clips longest first (whole-clip kernels take them in this order)
     uint32_t *d_ticket;             //   and the counter they take them from (zero when the launch starts)
-    uint32_t *d_keys;               // uniform mel-major layouts, optional: [n_clips][2] ordered keys of {min, max} of every clip's image, folded
-                                    //   with atomics as the image is stored (the TGA quantiser's first pass, tga_quant.hpp); initialised by the caller
+    int *d_unit_ext;                // uniform mel-major layouts, optional: [n_units][2] = {smallest, largest} biased value (phase 4) every work unit
+                                    //   stored -- the TGA quantiser's first pass (tga_quant.hpp) then reads 8 bytes per unit instead of the image
 };
 
 __device__ __forceinline__ uint64_t batch_n_units(const BatchDesc &b) { return b.d_n_units ? *b.d_n_units : b.n_units; }
@@ -183,7 +183,7 @@ __device__ __forceinline__ float wave_shift_down1(float v) {
 }
 
 
-// ---- min / max keys of the stored images (BatchDesc::d_keys) ------------------------------------------------------------------
+// ---- extremes of the stored images, per work unit (BatchDesc::d_unit_ext) -------------------------------------------------------
 // Wave-wide minimum / maximum of non-negative ints (the biased values of phase 4): an inclusive scan inside each row of 16 lanes
 // (row_shr 1, 2, 4, 8), then row_bcast:15 / :31 carry the row results up; lane 63 holds the result.
 template <bool MAX>
@@ -198,19 +198,21 @@ __device__ __forceinline__ int wave_reduce_int(int v) {
     v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));
     return __builtin_amdgcn_readlane(v, 63);
 }
-// order-preserving map f32 -> u32 (ordered_key of tga_quant.hpp)
-__device__ __forceinline__ uint32_t image_key(float v) {
-    const uint32_t b = __builtin_bit_cast(uint32_t, v);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-// kmin / kmax: this lane's extremes of the biased values it stored for the clip (0x7fffffff / 0 when it stored nothing, or when its
-// frame is going to be recomputed and will report then); every lane of the wave calls this.  out(c) = the float that was stored.
-template <class OUT>
-__device__ __forceinline__ void image_keys_commit(uint32_t *keys, int lane, int kmin, int kmax, OUT out) {
+// kmin / kmax: this lane's extremes of the biased values it stored for the unit (0x7fffffff / 0 when it stored nothing, or when its
+// frame is going to be recomputed and reports then); every lane of the wave calls these.  Two atomics per unit on the image's keys
+// instead of the 8-byte record cost the mel-major kernel 19 %; accumulating in registers over a contiguous range of rounds per
+// workgroup (so that a wave stays inside a clip) took the atomics away and cost 30 %: the interleaved rounds are what keeps the
+// 24-byte pieces of the stores of all CUs inside one compact region.
+__device__ __forceinline__ void unit_ext_store(int *ext, int lane, int kmin, int kmax) {
     const int lo = wave_reduce_int<false>(kmin), hi = wave_reduce_int<true>(kmax);
-    if (lane == 0 && hi != 0) {
-        atomicMin(keys, image_key(out(lo)));
-        atomicMax(keys + 1, image_key(out(hi)));
+    if (lane == 0) *reinterpret_cast<int2 *>(ext) = make_int2(lo, hi);
+}
+// the recompute tail: the frames it recomputed join the record its own wave wrote in the unit loop
+__device__ __forceinline__ void unit_ext_merge(int *ext, int lane, int kmin, int kmax) {
+    const int lo = wave_reduce_int<false>(kmin), hi = wave_reduce_int<true>(kmax);
+    if (lane == 0) {
+        const int2 old = *reinterpret_cast<const int2 *>(ext);
+        *reinterpret_cast<int2 *>(ext) = make_int2(lo < old.x ? lo : old.x, hi > old.y ? hi : old.y);
     }
 }
 
@@ -255,7 +257,7 @@ __device__ __forceinline__ unsigned frame_mask(uint64_t any) {
 template <int NSLOTS, class Lens, bool LAYOUT>
 __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
                                           const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w,
-                                          uint32_t *keys = nullptr /* LAYOUT: the clip's {min, max} keys, or nullptr */) {
+                                          int *ext = nullptr /* LAYOUT: the unit's record in BatchDesc::d_unit_ext, or nullptr */) {
     const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
     const bool in = lane < kSixFrames * kSixLanes;
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
@@ -283,7 +285,7 @@ __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int ho
         int kmin = 0x7fffffff, kmax = 0;
         six_phase4<NSLOTS, LAYOUT, false, LAYOUT>(fl, j, act, act, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && keys) image_keys_commit(keys, lane, kmin, kmax, [](int c) { return six_out(c); });
+        if (LAYOUT && ext) unit_ext_merge(ext, lane, kmin, kmax);
     }
     return static_cast<unsigned>(__builtin_popcount(mask));      // frames recomputed (the caller adds them up: one atomic per wave, not per
                                                                   // frame -- a million atomics on one address took 10 ms)
@@ -293,7 +295,7 @@ __device__ __forceinline__ unsigned six_fix_unit(unsigned mask, int lane, int ho
 template <int NSLOTS, class Lens, bool LAYOUT>
 __device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int hop, int n_mels, const MelSlots &ms, const float *blob, float *slice,
                                            const FixSink &fix, const FixTw &tw, const float *src, float *out_tile, long long row_w,
-                                           uint32_t *keys = nullptr) {
+                                           int *ext = nullptr) {
     const int fl3 = lane / 12, j3 = lane - fl3 * 12;
     const bool in3 = lane < kFPW * 12;
     const int *starts = reinterpret_cast<const int *>(blob + FastBlob::kMelStart) + j3;
@@ -320,7 +322,7 @@ __device__ __forceinline__ unsigned wave_fix_unit(unsigned mask, int lane, int h
         int kmin = 0x7fffffff, kmax = 0;
         wave_phase4<NSLOTS, LAYOUT, false, LAYOUT>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && keys) image_keys_commit(keys, lane, kmin, kmax, [](int c) { return wave_out(c); });
+        if (LAYOUT && ext) unit_ext_merge(ext, lane, kmin, kmax);
     }
     return static_cast<unsigned>(__builtin_popcount(mask));      // frames recomputed (the caller adds them up: one atomic per wave, not per
                                                                   // frame -- a million atomics on one address took 10 ms)
@@ -445,9 +447,9 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
                 ++noted;
             }
         }
-        if (p.b.d_keys && have) {           // wave-uniform; a frame that is recomputed reports its extremes then
+        if (p.b.d_unit_ext && have) {       // wave-uniform; a frame that is recomputed reports its extremes then
             if ((redo >> fl3) & 1u) { kmin = 0x7fffffff; kmax = 0; }
-            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return wave_out(c); });
+            unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
         }
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
         redone += wave_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0,
-                                          p.b.d_keys ? p.b.d_keys + 2 * (uint64_t)loc.clip : nullptr);
+                                          p.b.d_unit_ext ? p.b.d_unit_ext + 2 * unit : nullptr);
     }
     guard_wave_done(p.fix, arrive + WAVES - 2, WAVES, lane, redone);
 }
@@ -556,9 +558,9 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
                 ++noted;
             }
         }
-        if (p.b.d_keys && have) {           // wave-uniform; a frame that is recomputed reports its extremes then
+        if (p.b.d_unit_ext && have) {       // wave-uniform; a frame that is recomputed reports its extremes then
             if ((redo >> fl) & 1u) { kmin = 0x7fffffff; kmax = 0; }
-            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return six_out(c); });
+            unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
         }
         rs.after_round();
     }
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
         redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                          loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0,
-                                         p.b.d_keys ? p.b.d_keys + 2 * (uint64_t)loc.clip : nullptr);
+                                         p.b.d_unit_ext ? p.b.d_unit_ext + 2 * unit : nullptr);
     }
     guard_wave_done(p.fix, arrive + kSixWaves - 2, kSixWaves, lane, redone);
 }
@@ -922,8 +924,7 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         else
             flag = wave_phase4<NSLOTS, LAYOUT, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, loc.out + f0 * (uint64_t)n_mels, 0);
         __builtin_amdgcn_wave_barrier();
-        if (LAYOUT && p.b.mel_major && p.b.d_keys && have)
-            image_keys_commit(p.b.d_keys + 2 * (uint64_t)loc.clip, lane, kmin, kmax, [](int c) { return wave_out(c); });
+        if (LAYOUT && p.b.mel_major && p.b.d_unit_ext && have) unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
         if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(__builtin_amdgcn_ballot_w64(flag))));
         if (LAYOUT) rs.after_round();
         if (RUNS) ++cr.unit;

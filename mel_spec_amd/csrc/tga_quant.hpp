@@ -157,6 +157,31 @@ __global__ void quant_init_keys_kernel(uint32_t *keys, uint32_t items) {
     if (i < items) { keys[2 * i] = kKeyPosInf; keys[2 * i + 1] = kKeyNegInf; }
 }
 
+// The first pass when the mel kernel has left {smallest, largest} biased value of every work unit behind (BatchDesc::d_unit_ext,
+// melspec_tga_encode_pcm_uniform_device): one wave per image folds its units' records -- 8 bytes per 5 / 6 frames instead of the
+// image -- into the keys the encoding pass reads.  stored value = biased * 0.25 - 3 (six_out / wave_out), monotonic in the bias.
+__global__ __launch_bounds__(64) void quant_keys_from_units_kernel(const int *unit_ext, uint32_t units_per_image, uint32_t n_images, uint32_t *keys) {
+    const uint32_t image = blockIdx.x;
+    if (image >= n_images) return;
+    const int *e = unit_ext + 2 * static_cast<uint64_t>(image) * units_per_image;
+    int lo = 0x7fffffff, hi = 0;
+    for (uint32_t u = threadIdx.x; u < units_per_image; u += 64) {
+        const int a = e[2 * u], b = e[2 * u + 1];
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(lo, o), b = __shfl_xor(hi, o);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if (threadIdx.x == 0) {
+        keys[2 * image] = ordered_key(__int_as_float(lo) * 0.25f - 3.0f);
+        keys[2 * image + 1] = ordered_key(__int_as_float(hi) * 0.25f - 3.0f);
+    }
+}
+
 // grid.x = items * blocks_per_item; block b of an item reduces pixels [b*4096, (b+1)*4096).
 __global__ __launch_bounds__(kQuantThreads) void quant_minmax_kernel(const QuantDesc d, uint32_t blocks_per_item) {
     const uint32_t item = blockIdx.x / blocks_per_item, blk = blockIdx.x - item * blocks_per_item;

@@ -88,6 +88,8 @@ if want("quant") or want("vad"):
         report("quant_minmax_kernel + quant_encode_kernel (5 B/pixel)", ms, px, 5, "per PIXEL")
         ms = timed(lambda: q.decode_device(blobs.ptr, stride, 80, W, n_clips, back.ptr, 80 * W), q.synchronize)
         report("quant_decode_kernel (5 B/pixel)", ms, px, 5, "per PIXEL")
+        ms2 = timed(lambda: q.encode_pcm_uniform_device(m, pcm.ptr, clip_len, clip_len, n_clips, 2, img.ptr, blobs.ptr, stride), m.synchronize)
+        report("PCM -> TGA fused: mel-major kernel leaving unit extremes + keys + quant_encode_kernel", ms2, n_clips * m.num_frames(clip_len), 640 + 80, "PCM in, bytes out (720 B/frame); the image itself is an intermediate")
         blobs.free(); back.free(); q.close()
     if want("vad"):
         n = int(lib().melspec_vad_mask_len(80, W))
