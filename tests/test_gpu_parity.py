@@ -593,7 +593,8 @@ def test_cpp_host_mirror(gpu, oracle, tmp_path):
 
 def _check_nemo_normalised(gpu, oracle, kw, x, got, want, valid):
     """normalize_per_feature output `got` against (a) the oracle end to end on the rows where that comparison is meaningful -- the
-    division by std turns a 1e-6 difference of the un-normalised values into 1e-6 / std, so rows with std >= 0.1 are gated at the
+    division by std turns a 1e-6 difference of the un-normalised values -- and the ~1e-5 of rounding noise that the f32 left fold of the mean
+    draws differently on the two sides -- into that over std, so rows with std >= 0.5 (ordinary log-mel rows have 1..3) are gated at the
     tolerance -- and (b) on EVERY row, ill-conditioned ones included, the reference's literal f32 folds (src/mel.rs:721-749) applied
     to the device's own un-normalised rows: same input bits, same fold order for the mean, so only the variance's summation order and
     one rounding of the reciprocal separate the two (a few 1e-6 of |out|)."""
@@ -608,7 +609,7 @@ def _check_nemo_normalised(gpu, oracle, kw, x, got, want, valid):
     scale = np.maximum(1.0, np.abs(lit))
     assert (np.abs(got - lit) / scale).max() <= 2e-5, float((np.abs(got - lit) / scale).max())
     std = raw_want[:, :valid].astype(np.float64).std(axis=1, ddof=1) if valid > 1 else np.zeros(raw_want.shape[0])
-    good = std >= 0.1
+    good = std >= 0.5
     if good.any():
         assert np.abs(got[good] - want[good]).max() <= TOL, float(np.abs(got[good] - want[good]).max())
     return int(good.sum())

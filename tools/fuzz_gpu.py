@@ -138,7 +138,7 @@ def case_nemo():
     else:
         # (v - mean) / (std + 1e-5) turns a 1e-6 difference of the un-normalised values into 1e-6 / std: (a) the un-normalised rows
         # against the oracle, (b) EVERY normalised row, ill-conditioned ones included, against the reference's literal f32 folds
-        # (src/mel.rs:721-749) applied to the device's own un-normalised rows, (c) rows with std >= 0.1 against the oracle end to end
+        # (src/mel.rs:721-749) applied to the device's own un-normalised rows, (c) rows with std >= 0.5 against the oracle end to end (the f32 left fold of the mean has ~1e-5 of rounding noise of its own, which the two sides draw differently)
         kw2 = dict(kw, normalize_per_feature=False)
         fe2 = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(**kw2)); raw = fe2.compute(x); fe2.close()
         raw_want = O.blm_compute(x, O.blm_default_config(**kw2), True)[0]
@@ -149,11 +149,11 @@ def case_nemo():
         assert d1 <= 2e-5, ("nemo normaliser vs the literal f32 folds", kw, len(x), d1)
         note("nemo_norm_vs_literal_folds", d1)
         std = raw_want[:, :valid].astype(np.float64).std(axis=1, ddof=1) if valid > 1 else np.zeros(raw_want.shape[0])
-        good = std >= 0.1
+        good = std >= 0.5
         if good.any():
             d2 = float(np.abs(got[good] - want[good]).max())
             assert d2 <= 1e-4, ("nemo normalised, well-conditioned rows", kw, len(x), d2)
-            note("nemo_norm_rows_std>=0.1", d2)
+            note("nemo_norm_rows_std>=0.5", d2)
         note("nemo", d0)
     fe.close()
 
