@@ -43,6 +43,22 @@ public:
         detail::check(melspec_create(&ctx_, device, static_cast<int>(fft_size), static_cast<int>(hop_size), sampling_rate,
                                      static_cast<int>(n_mels)), true);
     }
+    // MelSpectrogram over SparseMelFilterbank::from_mel(sr, n_fft, n_mels, f_min, f_max, htk, norm) (src/mel.rs:73-87); f_min < 0 / f_max <= 0 == None
+    static HipMelSpectrogram with_filterbank(std::size_t fft_size, std::size_t hop_size, double sampling_rate, std::size_t n_mels, double f_min,
+                                             double f_max, bool htk, bool norm, int device = -1) {
+        HipMelSpectrogram m;
+        detail::check(melspec_create_with_filterbank(&m.ctx_, device, static_cast<int>(fft_size), static_cast<int>(hop_size), sampling_rate,
+                                                     static_cast<int>(n_mels), f_min, f_max, htk ? 1 : 0, norm ? 1 : 0), true);
+        return m;
+    }
+    // ... over SparseMelFilterbank::from_dense (src/mel.rs:48-71): filters = [n_mels][fft_size / 2 + 1], row-major
+    static HipMelSpectrogram with_dense_filterbank(std::size_t fft_size, std::size_t hop_size, double sampling_rate, std::size_t n_mels,
+                                                   const std::vector<double> &filters, int device = -1) {
+        HipMelSpectrogram m;
+        detail::check(melspec_create_with_dense_filterbank(&m.ctx_, device, static_cast<int>(fft_size), static_cast<int>(hop_size), sampling_rate,
+                                                           static_cast<int>(n_mels), filters.data(), static_cast<int>(filters.size() / (n_mels ? n_mels : 1))), true);
+        return m;
+    }
     ~HipMelSpectrogram() { melspec_destroy(ctx_); }
     HipMelSpectrogram(HipMelSpectrogram &&o) noexcept : ctx_(std::exchange(o.ctx_, nullptr)) {}
     HipMelSpectrogram &operator=(HipMelSpectrogram &&o) noexcept {
@@ -78,6 +94,9 @@ public:
     // MELSPEC_PRECISION_AUTO (default) / _F64 / _F32
     void set_precision(int mode) { detail::check(melspec_set_precision(ctx_, mode), false); }
     int precision() const { return melspec_precision(ctx_); }
+    // AUTO moves whole batches to the f64 kernel while most frames of the last finished batch needed f64; false pins the f32 kernel
+    void set_auto_adaptive(bool on) { detail::check(melspec_set_auto_adaptive(ctx_, on ? 1 : 0), false); }
+    bool auto_heavy() { int h = 0; double f = 0.0; detail::check(melspec_auto_state(ctx_, &h, &f), false); return h != 0; }
     // CudaMelSpectrogram::max_frames_per_batch (src/cuda.rs:84-86): frames per chunk of the host pipeline
     std::size_t max_frames_per_batch() const { return melspec_max_frames_per_batch(ctx_); }
 
@@ -129,6 +148,7 @@ public:
     melspec_ctx *raw() { return ctx_; }
 
 private:
+    HipMelSpectrogram() = default;          // the factories above
     melspec_ctx *ctx_ = nullptr;
 };
 

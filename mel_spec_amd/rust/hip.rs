@@ -51,6 +51,12 @@ unsafe extern "C" {
     fn melspec_synchronize(ctx: *mut Ctx, stream: *mut c_void) -> c_int;
     fn melspec_set_precise(ctx: *mut Ctx, on: c_int) -> c_int;
     fn melspec_set_precision(ctx: *mut Ctx, mode: c_int) -> c_int;
+    fn melspec_set_auto_adaptive(ctx: *mut Ctx, on: c_int) -> c_int;
+    fn melspec_auto_state(ctx: *mut Ctx, heavy: *mut c_int, fraction: *mut f64) -> c_int;
+    fn melspec_create_with_filterbank(out: *mut *mut Ctx, device: c_int, fft: c_int, hop: c_int, sr: f64, n_mels: c_int,
+                                      f_min: f64, f_max: f64, htk: c_int, norm: c_int) -> c_int;
+    fn melspec_create_with_dense_filterbank(out: *mut *mut Ctx, device: c_int, fft: c_int, hop: c_int, sr: f64, n_mels: c_int,
+                                            filters: *const f64, fft_bins: c_int) -> c_int;
     fn melspec_max_frames_per_batch(ctx: *const Ctx) -> usize;
     fn melspec_compute_batch_host(ctx: *mut Ctx, samples: *const f32, offsets: *const u64, lengths: *const u64, n_clips: u32,
                                   out: *mut f32, out_offsets: *const u64, cap: usize, total_frames: *mut u64) -> c_int;
@@ -170,13 +176,58 @@ impl HipMelSpectrogram {
         Ok(Self { ctx, n_mels })
     }
 
+    /// `MelSpectrogram` over `SparseMelFilterbank::from_mel(sr, n_fft, n_mels, f_min, f_max, htk, norm)` (src/mel.rs:73-87) instead of
+    /// `new()`'s default bank (src/mel.rs:19-24).
+    pub fn with_filterbank(fft_size: usize, hop_size: usize, sampling_rate: f64, n_mels: usize, f_min: Option<f64>, f_max: Option<f64>,
+                           htk: bool, norm: bool) -> Result<Self, HipError> {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe {
+            melspec_create_with_filterbank(&mut ctx, -1, fft_size as c_int, hop_size as c_int, sampling_rate, n_mels as c_int,
+                                           f_min.unwrap_or(-1.0), f_max.unwrap_or(-1.0), htk as c_int, norm as c_int)
+        };
+        if rc != 0 {
+            return Err(unavailable(rc));
+        }
+        Ok(Self { ctx, n_mels })
+    }
+
+    /// The same over `SparseMelFilterbank::from_dense(filters)` (src/mel.rs:48-71): `filters` is `[n_mels][fft_size / 2 + 1]`.
+    pub fn with_dense_filterbank(fft_size: usize, hop_size: usize, sampling_rate: f64, filters: &ndarray::Array2<f64>) -> Result<Self, HipError> {
+        let f = filters.as_standard_layout();
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe {
+            melspec_create_with_dense_filterbank(&mut ctx, -1, fft_size as c_int, hop_size as c_int, sampling_rate, f.nrows() as c_int,
+                                                 f.as_ptr(), f.ncols() as c_int)
+        };
+        if rc != 0 {
+            return Err(unavailable(rc));
+        }
+        Ok(Self { ctx, n_mels: f.nrows() })
+    }
+
+    /// The default precision mode moves whole batches to the f64 kernel while most frames of the last finished batch needed f64
+    /// (speech, tonal material); `false` pins it to the f32 kernel + per-frame recompute (bit-stable from call to call).
+    pub fn set_auto_adaptive(&mut self, on: bool) -> Result<(), HipError> {
+        match unsafe { melspec_set_auto_adaptive(self.ctx, on as c_int) } {
+            0 => Ok(()),
+            _ => Err(HipError::Runtime(last_error())),
+        }
+    }
+
+    /// (whole batches currently go to the f64 kernel, fraction of the frames of the last finished batch that needed f64)
+    pub fn auto_state(&mut self) -> (bool, f64) {
+        let (mut heavy, mut fraction) = (0 as c_int, 0.0f64);
+        unsafe { melspec_auto_state(self.ctx, &mut heavy, &mut fraction) };
+        (heavy != 0, fraction)
+    }
+
     /// `CudaMelSpectrogram::max_frames_per_batch` (src/cuda.rs:84-86): frames per chunk of the host pipeline.
     pub fn max_frames_per_batch(&self) -> usize {
         unsafe { melspec_max_frames_per_batch(self.ctx) }
     }
 
     /// 0: f32 FFT + f64 recompute of the frames its error bound does not cover (default, within 1e-4 on every input),
-    /// 1: f64 on every frame (the mode for batches of speech / tonal input), 2: f32 only.
+    /// 1: f64 on every frame (mode 0 moves batches of speech / tonal input there by itself), 2: f32 only.
     pub fn set_precision(&mut self, mode: i32) -> Result<(), HipError> {
         match unsafe { melspec_set_precision(self.ctx, mode as c_int) } {
             0 => Ok(()),

@@ -92,6 +92,19 @@ int main() {
         if (!(md <= 2e-6f)) { std::puts("FAIL: precise tolerance"); return 1; }
         hip.set_precise(false);
         if (hip.precision() != MELSPEC_PRECISION_AUTO || hip.max_frames_per_batch() == 0) { std::puts("FAIL: precision / max_frames_per_batch"); return 1; }
+        // a caller's filterbank: from_mel with the defaults == the default context; an HTK bank differs and is finite
+        {
+            auto same = melspec::HipMelSpectrogram::with_filterbank(400, 160, sr, 80, -1.0, -1.0, false, true);
+            same.set_auto_adaptive(false); hip.set_auto_adaptive(false);
+            const auto a = same.compute_mel_spectrogram(samples), b = hip.compute_mel_spectrogram(samples);
+            for (size_t f = 0; f < 98; ++f)
+                for (size_t m = 0; m < 80; ++m)
+                    if (a[f][m] != b[f][m]) { std::puts("FAIL: with_filterbank(defaults) != default bank"); return 1; }
+            auto htk = melspec::HipMelSpectrogram::with_filterbank(400, 160, sr, 64, 50.0, 7000.0, true, false);
+            const auto h = htk.compute_mel_spectrogram(samples);
+            if (h.size() != 98 || h[0].size() != 64 || !std::isfinite(h[5][7]) || same.auto_heavy()) { std::puts("FAIL: HTK bank"); return 1; }
+            hip.set_auto_adaptive(true);
+        }
         // additive batch call and the STFT export through the same header
         const auto batch = hip.compute_batch({samples, std::vector<float>(samples.begin(), samples.begin() + 4000), std::vector<float>(399, 0.0f)});
         if (batch.size() != 3 || batch[0].size() != 98 || batch[1].size() != 23 || !batch[2].empty()) { std::puts("FAIL: batch shape"); return 1; }
