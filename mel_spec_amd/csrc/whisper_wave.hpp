@@ -166,6 +166,7 @@ MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *sl
 #pragma unroll
     for (int q = 0; q < 10; q += 2) {
         const f4 w2 = *reinterpret_cast<const f4 *>(tw + 2 * q);
+        float pk[2], pm[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int qq = q + h;
@@ -176,10 +177,14 @@ MS_DEV void wave_phase2(int fl, int j, bool active, const float *blob, float *sl
             const cf wd = cmul(W, D);
             const float ar = S.re + wd.im, ai = S.im - wd.re;
             const float br = S.re - wd.im, bi = S.im + wd.re;
-            const float pk = ar * ar + ai * ai, pm = br * br + bi * bi;
-            p[j + 20 * qq] = pk;
-            p[200 - j - 20 * qq] = pm;
+            pk[h] = ar * ar + ai * ai;
+            pm[h] = br * br + bi * bi;
         }
+        // the two stores of a side next to each other: one ds_write2_b32 each (see six_phase2)
+        p[j + 20 * q] = pk[0];
+        p[j + 20 * q + 20] = pk[1];
+        p[200 - j - 20 * q] = pm[0];
+        p[180 - j - 20 * q] = pm[1];
     }
 }
 
