@@ -35,7 +35,8 @@ struct SixBlob {                  // float offsets inside the table blob
     static constexpr int kWin = 0;                        // [10][44] Hann
     static constexpr int kTw1 = 10 * kWinStride;
     static constexpr int kTw1Stride = 44;                 // 20 complex + 4 pad
-    static constexpr int kTw2Stride = 24;                 // 11 complex + 2 pad
+    static constexpr int kTw2Stride = 28;                 // 11 complex + 6 pad: 28 j mod 64 puts the ten rows in ten different groups of four banks
+                                                          // (24 made lanes 0 and 8 collide on every 16-byte read: 10 LDS cycles per unit in the bank model)
     static constexpr int kTw2 = kTw1 + 10 * kTw1Stride;   // [10][24]: lane j >= 1: W_400^{j+20s}, s < 10;
                                                           //   lane 0: W_400^{20s} (s <= 5), W_400^{10+20(s-6)} (s = 6..10)
     static constexpr int kMelStart = kTw2 + 10 * kTw2Stride;              // [kSixMaxSlots*10] ints
