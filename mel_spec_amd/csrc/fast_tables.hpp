@@ -239,8 +239,8 @@ inline bool build_precise_tables(const FastTables &ft, PreciseTables &out) {
     for (int j = 0; j < kMelJobs; ++j)
         for (int q = 0; q < 10; ++q) {
             const double a = -2.0 * kPi * (j + 20 * q) / N;
-            t[PreciseBlob::kTw2 + j * 20 + 2 * q] = std::cos(a);
-            t[PreciseBlob::kTw2 + j * 20 + 2 * q + 1] = std::sin(a);
+            t[PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride + 2 * q] = std::cos(a);
+            t[PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride + 2 * q + 1] = std::sin(a);
         }
     const size_t t_words = t.size() * 2;
     const size_t mel_floats = ft.blob.size() - FastBlob::kMelStart;

@@ -16,18 +16,22 @@ namespace melspec {
 
 // f64 table part, offsets in doubles (same logical tables as FastBlob's first four)
 struct PreciseBlob {
+    // Row pitches from the bank model (tools/lds_sim.py rules, 16-byte reads in groups of sixteen lanes over 64 banks): with 44 / 20 / a
+    // 464-double frame stride 39 % of the LDS cycles of phases 1-2 were conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 38 % measured);
+    // 46 / 22 / 462 leave 22 %.
     static constexpr int kWin = 0;                        // [400]
-    static constexpr int kTw1Stride = 44;
-    static constexpr int kTw1 = 400;                      // [10][44]  W_200^{t*k1}
+    static constexpr int kTw1Stride = 46;
+    static constexpr int kTw1 = 400;                      // [10][46]  W_200^{t*k1}
     static constexpr int kMod = kTw1 + 10 * kTw1Stride;   // [10] complex W_10^{n2}
-    static constexpr int kTw2 = kMod + 20;                // [11][10] complex W_400^{j+20q}
-    static constexpr int kCount = kTw2 + kMelJobs * 20;   // 1080 doubles
+    static constexpr int kTw2Stride = 22;
+    static constexpr int kTw2 = kMod + 20;                // [11][22] complex W_400^{j+20q}
+    static constexpr int kCount = kTw2 + kMelJobs * kTw2Stride;
 };
 
 struct PreciseLayout {
     static constexpr int kXRow = 22;                      // 10 complex + 1 pad: 44-word row pitch, 11 rows hit 11 bank slots
-    static constexpr int kXStride = 21 * kXRow + 2;       // 464 doubles per frame
-    static constexpr int slice_doubles() { return kFPW * kXStride; }   // 2320 doubles; power rows / maxima alias its head
+    static constexpr int kXStride = 21 * kXRow;           // 462 doubles per frame (924 words = 28 mod 64: the frames of a lane group spread over the banks)
+    static constexpr int slice_doubles() { return kFPW * kXStride; }   // 2310 doubles; power rows / maxima alias its head
 };
 
 // frame: first sample of this lane's frame (frame slot fl of the wave)
@@ -64,7 +68,7 @@ MS_DEV void precise_phase2(int fl, int j, bool active, const double *MS_RESTRICT
     }
     fft10(u);
     fft10(v);
-    const double *tw = tb + PreciseBlob::kTw2 + j * 20;
+    const double *tw = tb + PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride;
     float *p = reinterpret_cast<float *>(rows) + fl * WaveLayout::kPStride;
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
@@ -98,7 +102,7 @@ MS_DEV void precise_phase2_spectrum(int fl, int j, bool active, const double *MS
     }
     fft10(u);
     fft10(v);
-    const double *tw = tb + PreciseBlob::kTw2 + j * 20;
+    const double *tw = tb + PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride;
     const bool full = bins > 201;
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
