@@ -55,6 +55,12 @@ class ShardedMelSpectrogram:
         self._h = h
         self.n_mels, self.fft_size, self.hop_size = n_mels, fft_size, hop_size
         self.n_shards = int(lib().melspec_sharded_n_shards(h))
+        # MELSPEC_PRECISE: the test mirror's switch for the initial precision mode (see HipMelSpectrogram.__init__), on every shard
+        import os
+        env = os.environ.get("MELSPEC_PRECISE", "")[:1]
+        if env in ("1", "f"):
+            for k in range(self.n_shards):
+                _check(lib().melspec_set_precision(lib().melspec_sharded_ctx(h, k), 1 if env == "1" else 2))
 
     def num_frames(self, n: int) -> int:
         return 0 if n < self.fft_size else (n - self.fft_size) // self.hop_size + 1
