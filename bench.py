@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the consolidation of the outputs on rank 0")
     ap.add_argument("--no-traffic", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 (two short PMC passes of this "
                     "script, ~1 min); the committed profiles/traffic.json is reported instead")
+    ap.add_argument("--cfg5-clips", type=int, default=None, help="rehearsals only: shrink the config-5 leg's clip set")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal of the N > 1 code path on a 1-GPU box: every rank on GPU 0, ranks over gloo "
+                                                               "(the figures it prints mean nothing: the ranks share one GPU)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn the ranks (gloo), plan every rank's shard, run the timing protocol on a "
                                                             "sleep and print the JSON line -- the CPU test of the launch path")
     return ap.parse_args()
@@ -200,15 +203,16 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
     n_mels = (args.n_mels if primary else None) or cfg_mels
     clip_seconds = (args.clip_seconds if primary else None) or cfg_seconds
     clip_len = int(clip_seconds * SR)
-    total_or_per = (args.clips if primary else None) or cfg_clips
+    total_or_per = (args.clips if primary else (args.cfg5_clips if config == 5 else None)) or cfg_clips
     if scaling == "weak":
         n_clips, first_clip = total_or_per, rank * total_or_per          # rank r owns clips [r*n, (r+1)*n)
     else:
         lo, hi = shard_range(total_or_per, rank, world)                  # contiguous per-clip split of the fixed set
         n_clips, first_clip = hi - lo, lo
 
-    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, n_mels, device=local_rank)
+    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, n_mels, device=dev.index)
     mel.set_precision(args.precision)
+    red_dev = None if args.one_device else dev            # where the tiny reduction tensors live (gloo reduces on the host)
     fpc = mel.num_frames(clip_len)
 
     # resident share, or sub-shards walked inside the step when the share does not fit (config 5 on few GPUs)
@@ -284,12 +288,12 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
         if state["n"] == steps:
             ev1.record()
 
-    elapsed = timed_steps(timed_step, torch.cuda.synchronize, steps, 0, dist if distributed else None, dev)
+    elapsed = timed_steps(timed_step, torch.cuda.synchronize, steps, 0, dist if distributed else None, red_dev)
     my_kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
     kernel_ms = my_kernel_ms
     per_rank = [[float(frames_per_step), my_kernel_ms]]
     if distributed:
-        mine = torch.tensor([float(frames_per_step), my_kernel_ms], dtype=torch.float64, device=dev)
+        mine = torch.tensor([float(frames_per_step), my_kernel_ms], dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)                   # per-rank {frames, ms}: tiny, the only collective of the run
         per_rank = [[float(t[0].item()), float(t[1].item())] for t in allr]
@@ -377,13 +381,18 @@ def main() -> None:
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     steps = args.steps if args.steps is not None else (1000 if args.config == 2 else 20)
     warmup = args.warmup if args.warmup is not None else (100 if args.config == 2 else 3)
@@ -394,7 +403,7 @@ def main() -> None:
     mel, out, stream = w["mel"], w["out"], w["stream"]
 
     gather = None
-    if distributed and args.gather and sub == 1:
+    if distributed and args.gather and sub == 1 and not args.one_device:
         # optional consolidation on rank 0: every peer sends its share over its own xGMI link
         n_out = fpc * n_clips * n_mels
         sizes = [int(p[0]) * n_mels for p in per_rank]
@@ -455,7 +464,7 @@ def main() -> None:
         steps5, warmup5 = 10, 2
         w5 = run_workload(args, 5, False, steps5, warmup5, M, torch, dist, dev, rank, world, local_rank)
         frames5 = sum(p[0] for p in w5["per_rank"])
-        cfg5 = {"workload": f"configs[4]: {CONFIGS[5][0]} synthetic {CONFIGS[5][1]} s f32 clips @16 kHz split per clip over {world} GPU(s) "
+        cfg5 = {"workload": f"configs[4]: {w5['total_or_per']} synthetic {CONFIGS[5][1]} s f32 clips @16 kHz split per clip over {world} GPU(s) "
                             f"(mel_spec_amd.parallel.shard_range), Whisper n_fft={N_FFT} hop={HOP} n_mels={CONFIGS[5][2]}, resident in HBM",
                 "scaling": "strong", "value": frames5 * steps5 / w5["elapsed"], "unit": "mel frames/s", "steps": steps5, "warmup": warmup5,
                 "ms_per_step": w5["elapsed"] / steps5 * 1e3, "frames_per_step_all_ranks": frames5,
@@ -531,6 +540,8 @@ def main() -> None:
             res["config"]["cfg5"] = cfg5
         if gather is not None:
             res["gather_to_rank0"] = gather
+        if args.one_device:
+            res["rehearsal"] = "every rank on GPU 0 over gloo: exercises the N > 1 code path on a 1-GPU box, the figures are not measurements"
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(clip_len, n_mels, args.cpu_seconds, 1024)
             res["cpu_baseline"] = cb

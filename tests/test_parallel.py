@@ -217,3 +217,25 @@ def test_plain_bench_line_carries_the_speech_leg_and_config5():
     assert c5["scaling"] == "strong" and c5["shards"][0][0] == 0 and c5["shards"][-1][1] == 65536
     assert sum(c5["per_rank_frames"]) == 196476928
     assert "cfg5" not in run("--gpus", "2", "--config", "2")
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(gpu):
+    """The N > 1 code path of bench.py on real hardware although the box has one GPU: two ranks under torch.distributed.run, both on
+    GPU 0, rendezvous over gloo (`--one-device`).  Covers what the dry run cannot: per-rank contexts, the event-timed steps, the
+    all_gather of {frames, ms}, closing the first workload and running the config-5 leg (shrunk), one JSON line from rank 0."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--clips", "64", "--cfg5-clips", "96",
+                        "--steps", "5", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "rehearsal" in line and line["steps"] == 5
+    assert [r["frames_per_step"] for r in line["per_rank"]] == [64 * 998.0] * 2
+    assert abs(line["value"] - 2 * 64 * 998 * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-6 * line["value"]
+    assert line["parity_max_abs_diff"] <= 1e-4
+    c5 = line["config"]["cfg5"]
+    assert c5["scaling"] == "strong" and [r["frames_per_step"] for r in c5["per_rank"]] == [48 * 2998.0] * 2 and c5["parity_max_abs_diff"] <= 1e-4
+    assert "roofline" in line and "cpu_baseline" not in line            # the CPU baseline is an N = 1 figure
