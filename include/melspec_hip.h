@@ -495,6 +495,33 @@ int melspec_vad_boundaries_device(const float *d_images, size_t image_stride, in
 int melspec_vad_boundaries_host(int device, const float *image, int n_mels, size_t width, const melspec_vad_settings *settings,
                                 uint8_t *raw_out, uint8_t *smoothed_out, uint32_t *longest_run);
 
+/* ---- the detector inside the streaming bank: VoiceActivityDetector::{new, add, add_activity}, src/vad.rs:137-208, per stream ----
+ * The reference keeps the last min_x mel frames of a stream and runs vad_boundaries on that [n_mels][min_x] window for every frame
+ * it is given.  With the stage on, every push / flush of the bank also feeds its streams' detectors on the device, from the mel rows
+ * the push has just written (no copy back, no launch per frame): each frame costs one 3-column Sobel walk, the stream's state is its
+ * last two rows and 64 bits of column history in HBM.  One record per emitted frame, packed in entry order like the rows:
+ *   valid = 0 where add_activity returns None (fewer than min_x frames so far); otherwise active, leading_active_columns,
+ *   active_columns and window_columns are VoiceActivity's fields (confidence = active_columns / window_columns or 0,
+ *   frame_index = melspec_stream_vad_frames before the push + the frame's position in it).
+ * Decisions are made on the f32 mel rows the path stores, widened to f64 like the reference's arithmetic.  settings == NULL turns the
+ * stage off; turning it on (or melspec_stream_reset) starts every (listed) detector afresh.  min_x <= 66. */
+typedef struct melspec_vad_activity {
+    uint8_t valid, active;
+    uint16_t leading_active_columns, active_columns, window_columns;
+} melspec_vad_activity;
+int melspec_stream_enable_vad(melspec_stream *st, const melspec_vad_settings *settings);
+/* frames stream id has fed to its detector (the frame_index of the next one) */
+uint64_t melspec_stream_vad_frames(const melspec_stream *st, uint32_t id);
+/* melspec_stream_push_host / _flush_host / _push_device that also return the records (acts: host memory for the host calls, device
+ * memory for the device call; capacity in records >= the frames the call emits) */
+int melspec_stream_push_host_vad(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                                 float *out, size_t out_capacity_floats, uint32_t *frames_out, melspec_vad_activity *acts,
+                                 size_t acts_capacity);
+int melspec_stream_flush_host_vad(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,
+                                  uint32_t *frames_out, melspec_vad_activity *acts, size_t acts_capacity);
+int melspec_stream_push_device_vad(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
+                                   const uint64_t *out_offsets, uint32_t *frames_out, melspec_vad_activity *d_acts, void *stream);
+
 /* ---- device memory helpers for hosts with no HIP binding of their own --------------- */
 /* (what the cudaMalloc/cudaMemcpyAsync externs of src/cuda.rs:185-199 give the Rust side) */
 int melspec_malloc(void **dptr, size_t bytes);

@@ -325,6 +325,50 @@ inline bool vad_on(const EdgeInfo &e, std::size_t n) {          // src/vad.rs:22
     return n <= 1 ? e.intersected_columns.size() >= 2 : e.longest_run >= n;
 }
 
+// VoiceActivity (src/vad.rs:125-135) and the detector behind a live stream: VoiceActivityDetector::add_activity
+// (src/vad.rs:155-208) fed by RingBuffer's frames, with both on the device -- one bank stream whose detector stage is on.
+struct VoiceActivity {
+    bool active;
+    std::size_t frame_index, leading_active_columns, active_columns, window_columns;
+    double confidence;
+};
+class StreamDetector {
+public:
+    StreamDetector(HipMelSpectrogram &mel, const DetectionSettings &settings, std::size_t max_chunk = 16384) : n_mels_(mel.n_mels()) {
+        detail::check(melspec_stream_create(&st_, mel.raw(), 1, static_cast<std::uint32_t>(max_chunk)), true);
+        const int rc = melspec_stream_enable_vad(st_, &settings);
+        if (rc) { melspec_stream_destroy(st_); st_ = nullptr; detail::check(rc, true); }
+    }
+    ~StreamDetector() { melspec_stream_destroy(st_); }
+    StreamDetector(const StreamDetector &) = delete;
+    StreamDetector &operator=(const StreamDetector &) = delete;
+
+    // Feeds samples (any length <= max_chunk); one entry per frame they complete: std::nullopt where add_activity returns None.
+    // rows (optional) receives the mel rows of those frames, [frame][n_mels].
+    std::vector<std::optional<VoiceActivity>> add_frame(const std::vector<float> &samples, std::vector<float> *rows = nullptr) {
+        const std::uint32_t id = 0, len = static_cast<std::uint32_t>(samples.size());
+        const std::size_t cap = melspec_stream_frames_after(st_, 0, len);
+        const std::uint64_t first = melspec_stream_vad_frames(st_, 0);
+        std::vector<float> out(cap * n_mels_);
+        std::vector<melspec_vad_activity> acts(cap);
+        std::uint32_t frames = 0;
+        detail::check(melspec_stream_push_host_vad(st_, &id, samples.data(), &len, 1, out.data(), out.size(), &frames, acts.data(), acts.size()), false);
+        std::vector<std::optional<VoiceActivity>> res(frames);
+        for (std::uint32_t k = 0; k < frames; ++k) {
+            const melspec_vad_activity &a = acts[k];
+            if (!a.valid) continue;
+            res[k] = VoiceActivity{a.active != 0, static_cast<std::size_t>(first + k), a.leading_active_columns, a.active_columns, a.window_columns,
+                                   a.window_columns ? static_cast<double>(a.active_columns) / a.window_columns : 0.0};
+        }
+        if (rows) { out.resize(static_cast<std::size_t>(frames) * n_mels_); rows->swap(out); }
+        return res;
+    }
+
+private:
+    melspec_stream *st_ = nullptr;
+    std::size_t n_mels_;
+};
+
 // dense [n_mels][n_fft/2+1] row-major; std::nullopt == None
 inline std::vector<double> mel(double sr, std::size_t n_fft, std::size_t n_mels, std::optional<double> f_min = std::nullopt,
                                std::optional<double> f_max = std::nullopt, bool htk = false, bool norm = true) {

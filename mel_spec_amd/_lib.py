@@ -151,6 +151,11 @@ SIGNATURES = {
     "melspec_stream_flush_host": (C.c_int, [_vp, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p]),
     "melspec_stream_input_ptr": (_vp, [_vp, C.c_uint32]),
     "melspec_stream_push_device": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, _vp, _u64p, _u32p, _vp]),
+    "melspec_stream_enable_vad": (C.c_int, [_vp, C.POINTER(VadSettingsC)]),
+    "melspec_stream_vad_frames": (C.c_uint64, [_vp, C.c_uint32]),
+    "melspec_stream_push_host_vad": (C.c_int, [_vp, _u32p, _f32p, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p, _vp, C.c_size_t]),
+    "melspec_stream_flush_host_vad": (C.c_int, [_vp, _u32p, C.c_uint32, _f32p, C.c_size_t, _u32p, _vp, C.c_size_t]),
+    "melspec_stream_push_device_vad": (C.c_int, [_vp, _u32p, _u32p, C.c_uint32, _vp, _u64p, _u32p, _vp, _vp]),
     "melspec_vad_default_settings": (None, [_vp]),
     "melspec_vad_mask_len": (C.c_size_t, [C.c_int, C.c_size_t]),
     "melspec_vad_boundaries_device": (C.c_int, [_vp, C.c_size_t, C.c_int, C.c_size_t, C.c_uint32, _vp, _vp, _vp, C.c_size_t, _vp, _vp]),

@@ -2081,6 +2081,11 @@ struct melspec_stream {
     StreamBook book;                     // pending / idx per stream (host side of the state)
     DevBuf state, staging, out;
     RaggedScratch ring;                  // per-push entry tables
+    // the detector stage (melspec_stream_enable_vad): VoiceActivityDetector state per stream, in HBM
+    bool vad_on = false;
+    melspec_vad_settings vad{};
+    DevBuf vad_state, vad_prev, vad_acts;
+    std::vector<uint64_t> vad_count;     // host copy of StreamVadState::count (VoiceActivityDetector::frame_index)
 };
 
 namespace {
@@ -2103,10 +2108,16 @@ struct StreamEmit {
 
 // scatter (optional) -> frames -> carry update, all on one stream
 int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float *d_src, void *d_out, const uint64_t *h_out_off,
-               hipStream_t s, const StreamEmit &emit = StreamEmit()) {
+               hipStream_t s, const StreamEmit &emit = StreamEmit(), melspec_vad_activity *d_acts = nullptr) {
     melspec_ctx *c = st->ctx;
     HIP_TRY(hipSetDevice(c->dev.device));
     if (pl.total_frames && !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");      // before anything is queued
+    if (st->vad_on && emit.stft) return fail(MELSPEC_ERR_UNSUPPORTED, "the detector stage is on: it needs the mel rows of every push");
+    if (st->vad_on && pl.total_frames && !d_acts) {                                             // records nobody asked for: internal buffer
+        const int rc0 = st->vad_acts.ensure(pl.total_frames * sizeof(melspec_vad_activity));
+        if (rc0) return rc0;
+        d_acts = static_cast<melspec_vad_activity *>(st->vad_acts.p);
+    }
     // the entries travel like a ragged plan: pinned slot, copy kernel on the launch stream (no SDMA queue hand-over)
     RaggedSlot &sl = st->ring.slot[st->ring.next++ % RaggedScratch::kSlots];
     if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -2116,6 +2127,8 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
     if (rc) return rc;
     if ((rc = sl.dev.ensure(ebytes))) return rc;
     std::memcpy(sl.host, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry));
+    if (h_out_off)                                   // caller-placed rows: the detector stage reads them where they are
+        for (uint32_t i = 0; i < n; ++i) static_cast<StreamEntry *>(sl.host)[i].out_off = h_out_off[i];
     // from here on the slot is in use by queued work: every exit records its event (the next user of the slot waits for it)
     struct SlotGuard { RaggedSlot *sl; hipStream_t s; ~SlotGuard() { plan_ragged_done(sl, s); } } slot_guard{&sl, s};
     {
@@ -2144,6 +2157,18 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
         rc = melspec_compute_ragged_device(c, state, pl.off.data(), pl.len.data(), n, static_cast<float *>(d_out),
                                            h_out_off ? h_out_off : pl.out_off.data(), s);
         if (rc) return rc;
+        if (st->vad_on) {
+            StreamVadParams vp{};
+            vp.entries = d_e; vp.rows = static_cast<const float *>(d_out);
+            vp.state = static_cast<StreamVadState *>(st->vad_state.p); vp.prev = static_cast<float *>(st->vad_prev.p);
+            vp.acts = reinterpret_cast<VadActivity *>(d_acts);
+            vp.n_mels = st->geom.n_mels; vp.min_mel = st->vad.min_mel; vp.min_y = st->vad.min_y; vp.min_x = st->vad.min_x;
+            vp.thr = st->vad.min_energy * st->vad.min_energy;
+            uint32_t most = 0;
+            for (uint32_t i = 0; i < n; ++i) most = std::max(most, pl.frames[i]);
+            hipLaunchKernelGGL(stream_vad_kernel, dim3(n), dim3(most <= 1 ? 64 : most <= 2 ? 128 : 256), 0, s, vp);
+            HIP_TRY(hipGetLastError());
+        }
     }
     hipLaunchKernelGGL(stream_carry_kernel, dim3(n), dim3(256), 0, s, state, st->geom.stride, st->geom.in_off, d_e);
     HIP_TRY(hipGetLastError());
@@ -2180,6 +2205,7 @@ void melspec_stream_destroy(melspec_stream *st) {
     if (!st) return;
     if (st->ctx) { (void)hipSetDevice(st->ctx->dev.device); (void)hipStreamSynchronize(st->ctx->stream); }
     st->state.release(); st->ring.release(); st->staging.release(); st->out.release();
+    st->vad_state.release(); st->vad_prev.release(); st->vad_acts.release();
     delete st;
 }
 
@@ -2189,11 +2215,19 @@ int melspec_stream_reset(melspec_stream *st, const uint32_t *ids, uint32_t n) {
     if (!ids) {
         HIP_TRY(hipMemsetAsync(st->state.p, 0, static_cast<size_t>(st->geom.n_streams) * st->geom.stride * sizeof(float), st->ctx->stream));
         st->book.reset(st->geom.n_streams);
+        if (st->vad_on) {
+            HIP_TRY(hipMemsetAsync(st->vad_state.p, 0, static_cast<size_t>(st->geom.n_streams) * sizeof(StreamVadState), st->ctx->stream));
+            std::fill(st->vad_count.begin(), st->vad_count.end(), 0ull);
+        }
     } else {
         for (uint32_t i = 0; i < n; ++i) {
             if (ids[i] >= st->geom.n_streams) return fail(MELSPEC_ERR_INVALID_ARG, "stream id out of range");
             HIP_TRY(hipMemsetAsync(static_cast<float *>(st->state.p) + ids[i] * st->geom.stride, 0, st->geom.in_off * sizeof(float), st->ctx->stream));
             st->book.pending[ids[i]] = 0; st->book.idx[ids[i]] = 0;
+            if (st->vad_on) {
+                HIP_TRY(hipMemsetAsync(static_cast<StreamVadState *>(st->vad_state.p) + ids[i], 0, sizeof(StreamVadState), st->ctx->stream));
+                st->vad_count[ids[i]] = 0;
+            }
         }
     }
     HIP_TRY(hipStreamSynchronize(st->ctx->stream));
@@ -2210,24 +2244,70 @@ float *melspec_stream_input_ptr(melspec_stream *st, uint32_t id) {
     return static_cast<float *>(st->state.p) + id * st->geom.stride + st->geom.in_off;
 }
 
-int melspec_stream_push_device(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
-                               const uint64_t *h_out_offsets, uint32_t *h_frames, void *stream) {
+static_assert(sizeof(melspec_vad_activity) == 8 && sizeof(VadActivity) == 8, "the activity record is 8 bytes on both sides of the ABI");
+static void stream_vad_commit(melspec_stream *st, const uint32_t *ids, const StreamPlan &pl, uint32_t n) {
+    if (!st->vad_on) return;
+    for (uint32_t i = 0; i < n; ++i) st->vad_count[ids[i]] += pl.frames[i];
+}
+
+static int stream_push_device_impl(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
+                                   const uint64_t *h_out_offsets, uint32_t *h_frames, melspec_vad_activity *d_acts, bool want_acts,
+                                   void *stream) {
     if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    if (want_acts && !st->vad_on) return fail(MELSPEC_ERR_INVALID_ARG, "the detector stage is off (melspec_stream_enable_vad)");
     if (n == 0) return MELSPEC_OK;
     if (!ids || !lens) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
     StreamPlan pl;
     int rc = stream_plan(st, ids, lens, n, false, pl);
     if (rc) return rc;
-    rc = stream_run(st, pl, n, nullptr, d_out, h_out_offsets, stream ? static_cast<hipStream_t>(stream) : st->ctx->stream);
+    if (want_acts && pl.total_frames && !d_acts) return fail(MELSPEC_ERR_INVALID_ARG, "d_acts is NULL");
+    rc = stream_run(st, pl, n, nullptr, d_out, h_out_offsets, stream ? static_cast<hipStream_t>(stream) : st->ctx->stream, StreamEmit(), d_acts);
     if (rc) return rc;
     stream_commit(st, ids, lens, n, false);
+    stream_vad_commit(st, ids, pl, n);
     if (h_frames) std::memcpy(h_frames, pl.frames.data(), static_cast<size_t>(n) * sizeof(uint32_t));
     return MELSPEC_OK;
 }
 
-static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
-                                 bool flush, void *out, size_t out_capacity, uint32_t *h_frames, const StreamEmit &emit = StreamEmit()) {
+int melspec_stream_push_device(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
+                               const uint64_t *h_out_offsets, uint32_t *h_frames, void *stream) {
+    return stream_push_device_impl(st, ids, lens, n, d_out, h_out_offsets, h_frames, nullptr, false, stream);
+}
+
+int melspec_stream_push_device_vad(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, float *d_out,
+                                   const uint64_t *h_out_offsets, uint32_t *h_frames, melspec_vad_activity *d_acts, void *stream) {
+    return stream_push_device_impl(st, ids, lens, n, d_out, h_out_offsets, h_frames, d_acts, true, stream);
+}
+
+int melspec_stream_enable_vad(melspec_stream *st, const melspec_vad_settings *settings) {
     if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    HIP_TRY(hipSetDevice(st->ctx->dev.device));
+    HIP_TRY(hipStreamSynchronize(st->ctx->stream));
+    if (!settings) { st->vad_on = false; return MELSPEC_OK; }
+    if (settings->min_x > kStreamVadMaxX) return fail(MELSPEC_ERR_UNSUPPORTED, "min_x above 66: the column history of a stream is 64 bits");
+    if (settings->min_x < 0 || settings->min_y < 0 || settings->min_mel < 0) return fail(MELSPEC_ERR_INVALID_ARG, "negative detection setting");
+    const size_t ns = st->geom.n_streams;
+    int rc = st->vad_state.ensure(ns * sizeof(StreamVadState));
+    if (rc) return rc;
+    if ((rc = st->vad_prev.ensure(ns * 2 * st->geom.n_mels * sizeof(float) + 16))) return rc;
+    HIP_TRY(hipMemset(st->vad_state.p, 0, ns * sizeof(StreamVadState)));
+    HIP_TRY(hipMemset(st->vad_prev.p, 0, ns * 2 * st->geom.n_mels * sizeof(float)));
+    st->vad_count.assign(ns, 0ull);
+    st->vad = *settings;
+    st->vad_on = true;
+    return MELSPEC_OK;
+}
+
+uint64_t melspec_stream_vad_frames(const melspec_stream *st, uint32_t id) {
+    if (!st || !st->vad_on || id >= st->geom.n_streams) return 0;
+    return st->vad_count[id];
+}
+
+static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                                 bool flush, void *out, size_t out_capacity, uint32_t *h_frames, const StreamEmit &emit = StreamEmit(),
+                                 melspec_vad_activity *acts = nullptr, size_t acts_capacity = 0, bool want_acts = false) {
+    if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    if (want_acts && !st->vad_on) return fail(MELSPEC_ERR_INVALID_ARG, "the detector stage is off (melspec_stream_enable_vad)");
     if (n == 0) return MELSPEC_OK;
     if (!ids || (!flush && !lens)) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
     StreamPlan pl;
@@ -2238,6 +2318,8 @@ static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const 
     const size_t esz = emit.stft ? (emit.dtype == MELSPEC_STFT_F64 ? 16 : 8) : sizeof(float);
     if (need > out_capacity) return fail(MELSPEC_ERR_CAPACITY, "output buffer too small");
     if (need && !out) return fail(MELSPEC_ERR_INVALID_ARG, "out is NULL");
+    if (want_acts && pl.total_frames > acts_capacity) return fail(MELSPEC_ERR_CAPACITY, "activity buffer too small");
+    if (want_acts && pl.total_frames && !acts) return fail(MELSPEC_ERR_INVALID_ARG, "acts is NULL");
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) total += pl.entries[i].len;
     if (total && !samples) return fail(MELSPEC_ERR_INVALID_ARG, "samples is NULL");
@@ -2246,13 +2328,17 @@ static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const 
     if ((rc = st->staging.ensure(total * sizeof(float) + 16))) return rc;
     if ((rc = st->out.ensure(need * esz + 16))) return rc;
     if (total) HIP_TRY(hipMemcpyAsync(st->staging.p, samples, total * sizeof(float), hipMemcpyHostToDevice, s));
-    rc = stream_run(st, pl, n, total ? static_cast<const float *>(st->staging.p) : nullptr, st->out.p, nullptr, s, emit);
+    if (st->vad_on && pl.total_frames && (rc = st->vad_acts.ensure(pl.total_frames * sizeof(melspec_vad_activity)))) return rc;
+    rc = stream_run(st, pl, n, total ? static_cast<const float *>(st->staging.p) : nullptr, st->out.p, nullptr, s, emit,
+                    static_cast<melspec_vad_activity *>(st->vad_acts.p));
     if (rc) return rc;
     if (need) {
         HIP_TRY(hipMemcpyAsync(out, st->out.p, need * esz, hipMemcpyDeviceToHost, s));
+        if (want_acts) HIP_TRY(hipMemcpyAsync(acts, st->vad_acts.p, pl.total_frames * sizeof(melspec_vad_activity), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
     stream_commit(st, ids, lens, n, flush);
+    stream_vad_commit(st, ids, pl, n);
     if (h_frames) std::memcpy(h_frames, pl.frames.data(), static_cast<size_t>(n) * sizeof(uint32_t));
     return MELSPEC_OK;
 }
@@ -2272,6 +2358,16 @@ int melspec_stream_push_host_stft(melspec_stream *st, const uint32_t *ids, const
 int melspec_stream_flush_host(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,
                               uint32_t *h_frames) {
     return stream_push_host_impl(st, ids, nullptr, nullptr, n, true, out, out_capacity_floats, h_frames);
+}
+
+int melspec_stream_push_host_vad(melspec_stream *st, const uint32_t *ids, const float *samples, const uint32_t *lens, uint32_t n,
+                                 float *out, size_t out_capacity_floats, uint32_t *h_frames, melspec_vad_activity *acts, size_t acts_capacity) {
+    return stream_push_host_impl(st, ids, samples, lens, n, false, out, out_capacity_floats, h_frames, StreamEmit(), acts, acts_capacity, true);
+}
+
+int melspec_stream_flush_host_vad(melspec_stream *st, const uint32_t *ids, uint32_t n, float *out, size_t out_capacity_floats,
+                                  uint32_t *h_frames, melspec_vad_activity *acts, size_t acts_capacity) {
+    return stream_push_host_impl(st, ids, nullptr, nullptr, n, true, out, out_capacity_floats, h_frames, StreamEmit(), acts, acts_capacity, true);
 }
 
 }  // extern "C"

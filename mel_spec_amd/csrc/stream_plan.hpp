@@ -38,6 +38,9 @@ struct StreamEntry {      // one per pushed stream; also read by the scatter / c
     uint32_t keep;        // carry length after this push
     uint32_t zero_fill;   // flush: zeros appended after the pending samples
     uint64_t src_off;     // offset of the chunk in the flat staging buffer (host pushes)
+    uint64_t out_off;     // first float of the rows this push emits for the stream ([frame][n_mels], read by the VAD stage)
+    uint32_t frames;      // rows emitted
+    uint32_t act_base;    // index of the stream's first activity record of this push (records are packed in entry order)
 };
 
 struct StreamPlan {
@@ -91,6 +94,7 @@ inline int stream_plan_push(const StreamGeom &g, StreamBook &bk, const uint32_t 
         e.stream = s; e.len = len; e.src_off = src_cursor;
         e.zero_fill = flush && pend ? g.hop - pend : 0;
         e.keep = g.n_fft - g.hop + (flush ? 0 : pend + len - h * g.hop);
+        e.out_off = pl.out_off[i]; e.frames = frames; e.act_base = static_cast<uint32_t>(g.n_mels ? pl.out_off[i] / g.n_mels : 0);
         src_cursor += len;
     }
     pl.total_frames = g.n_mels ? cursor / g.n_mels : 0;

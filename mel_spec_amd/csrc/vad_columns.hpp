@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "device_fft.hpp"
+#include "stream_plan.hpp"
 
 namespace melspec {
 
@@ -62,6 +63,60 @@ MS_HD bool vad_smooth_at(const uint8_t *raw, uint32_t n, uint32_t i) {
     return c * 2 >= end - start;
 }
 
+// ---- the detector inside the streaming bank (VoiceActivityDetector::add_activity, src/vad.rs:155-208) -------------------------------
+// The reference classifies, for every frame it is given, the window of the last min_x frames as a [n_mels][min_x] image: raw[x] is
+// the Sobel count of window columns x..x+2, x < min_x - 2, smoothed by the +-4 vote, `active` = column 0 survives.  raw[x] of the
+// window ending at frame f is a property of the three frames g..g+2, g = f - min_x + 1 + x, alone: R[g].  So a stream needs R of its
+// past min_x - 2 triples (bits of `hist`: bit i = R[count - 3 - i]) and its last two mel rows; every new frame costs one Sobel walk.
+struct StreamVadState {        // per stream, in HBM next to the bank's sample state
+    uint64_t count;            // frames this stream has emitted (VoiceActivityDetector::frame_index)
+    uint64_t hist;             // bit i = R[count - 3 - i]
+};
+struct VadActivity {           // melspec_vad_activity: what add_activity returns for one frame (VoiceActivity, src/vad.rs:127-135)
+    uint8_t valid;             // 0: the reference returns None (fewer than min_x frames so far)
+    uint8_t active;
+    uint16_t leading_active_columns, active_columns, window_columns;
+};
+constexpr int kStreamVadMaxX = 66;     // min_x - 2 <= 64 history bits
+
+// R for the triple whose columns are the mel rows c0, c1, c2 ([n_mels] each): classify_columns_across_frames, src/vad.rs:417-468
+MS_HD bool vad_classify_triple(const float *c0, const float *c1, const float *c2, uint32_t height, int min_mel, int min_y, double thr) {
+    if (min_y == 0) return true;
+    const uint32_t start_y = static_cast<uint32_t>(min_mel) < height - 2 ? static_cast<uint32_t>(min_mel) : height - 2;
+    int count = 0;
+    for (uint32_t y = start_y; y < height - 2; ++y) {
+        if (sobel_gradient_sq(c0[y], c1[y], c2[y], c0[y + 1], c2[y + 1], c0[y + 2], c1[y + 2], c2[y + 2]) >= thr && ++count >= min_y) return true;
+    }
+    return false;
+}
+
+// The record of the stream's frame f (0-based count of emitted frames).  rw[-j], j = 0..min_x-3, is R of the triple j back from
+// the one that ends at frame f (rw[0] = R[f - 2]).
+MS_HD VadActivity vad_stream_activity(uint64_t f, const uint8_t *rw, uint32_t height, int min_x) {
+    VadActivity a{};
+    if (min_x <= 0 || f + 1 < static_cast<uint64_t>(min_x)) return a;            // mel_buffer.len() < min_x: None
+    a.valid = 1;
+    if (height < 3 || min_x < 3) return a;                                        // vad_boundaries returns an empty EdgeInfo
+    const int n = min_x - 2;
+    uint64_t raw = 0;                                                             // bit x = raw[x] = R[f - min_x + 1 + x]
+    for (int x = 0; x < n; ++x) raw |= static_cast<uint64_t>(rw[-(n - 1 - x)] != 0) << x;
+    int act = 0, lead = 0;
+    bool leading = true;
+    for (int i = 0; i < n; ++i) {                                                 // smooth_mask(.., 4), src/vad.rs:343-360
+        const int s = i >= 4 ? i - 4 : 0, e = i + 5 < n ? i + 5 : n;
+        int c = 0;
+        for (int q = s; q < e; ++q) c += static_cast<int>((raw >> q) & 1u);
+        const bool on = c * 2 >= e - s;
+        act += on;
+        if (leading && on) ++lead; else leading = false;
+        if (i == 0) a.active = on;
+    }
+    a.leading_active_columns = static_cast<uint16_t>(lead);
+    a.active_columns = static_cast<uint16_t>(act);
+    a.window_columns = static_cast<uint16_t>(n);
+    return a;
+}
+
 #if defined(__HIPCC__)
 
 // one thread per (image, column); grid.x = n_images * blocks_per_image
@@ -105,6 +160,81 @@ __global__ __launch_bounds__(64) void vad_run_kernel(const VadDesc d) {
         }
         if (carry > b) b = carry;
         d.longest[image] = b;
+    }
+}
+
+// The detector stage of a push: one workgroup per pushed stream, after the mel kernel has written the stream's new rows.
+// rwin = [64 triples of history][R of the new frames, a chunk at a time]; every new frame costs one Sobel walk over three rows.
+struct StreamVadParams {
+    const StreamEntry *entries;
+    const float *rows;          // the push's output buffer, [frame][n_mels] rows at entries[i].out_off
+    StreamVadState *state;      // [n_streams]
+    float *prev;                // [n_streams][2][n_mels]: the last two rows every stream emitted
+    VadActivity *acts;          // [total frames of the push], packed in entry order
+    uint32_t n_mels;
+    int min_mel, min_y, min_x;
+    double thr;
+};
+constexpr uint32_t kStreamVadChunk = 2048;
+// blockDim.x = 64 * waves.  A wave takes one new frame at a time and spreads the Sobel walk over its lanes (lane = mel row): the
+// reference's early exit at the min_y-th strong row is an optimisation of `count >= min_y`, which is what the ballots add up.
+__global__ __launch_bounds__(256) void stream_vad_kernel(const StreamVadParams p) {
+    const StreamEntry e = p.entries[blockIdx.x];
+    const uint32_t F = e.frames, tid = threadIdx.x, H = p.n_mels, nt = blockDim.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6, waves = nt >> 6;
+    if (F == 0) return;
+    __shared__ uint8_t rwin[64 + kStreamVadChunk];
+    const StreamVadState st = p.state[e.stream];
+    const float *rows = p.rows + e.out_off;
+    float *pv = p.prev + static_cast<uint64_t>(e.stream) * 2 * H;
+    if (tid < 64) rwin[63 - tid] = static_cast<uint8_t>((st.hist >> tid) & 1u);
+    const uint32_t start_y = H >= 3 ? (static_cast<uint32_t>(p.min_mel) < H - 2 ? static_cast<uint32_t>(p.min_mel) : H - 2) : 0;
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < F; b += kStreamVadChunk) {
+        m = F - b < kStreamVadChunk ? F - b : kStreamVadChunk;
+        for (uint32_t k = wave; k < m; k += waves) {
+            const uint32_t q = b + k;                                      // new frame q closes the triple (q-2, q-1, q)
+            bool r = false;
+            if (st.count + q >= 2 && H >= 3) {
+                const float *c2 = rows + static_cast<uint64_t>(q) * H;
+                const float *c1 = q >= 1 ? c2 - H : pv + H;
+                const float *c0 = q >= 2 ? c2 - 2 * static_cast<uint64_t>(H) : (q == 1 ? pv + H : pv);
+                if (p.min_y == 0) {
+                    r = true;
+                } else {
+                    int count = 0;
+                    for (uint32_t y0 = start_y; y0 < H - 2; y0 += 64) {
+                        const uint32_t y = y0 + lane;
+                        bool strong = false;
+                        if (y < H - 2)
+                            strong = sobel_gradient_sq(c0[y], c1[y], c2[y], c0[y + 1], c2[y + 1], c0[y + 2], c1[y + 2], c2[y + 2]) >= p.thr;
+                        count += __popcll(__ballot(strong));
+                    }
+                    r = count >= p.min_y;
+                }
+            }
+            if (lane == 0) rwin[64 + k] = r;
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < m; k += nt) p.acts[e.act_base + b + k] = vad_stream_activity(st.count + b + k, rwin + 64 + k, H, p.min_x);
+        __syncthreads();
+        if (b + m < F) {                                                   // the chunk's last 64 become the history of the next
+            const uint8_t v = tid < 64 ? rwin[m + tid] : 0;
+            __syncthreads();
+            if (tid < 64) rwin[tid] = v;
+            __syncthreads();
+        }
+    }
+    // state for the next push: the newest 64 triples, the last two rows (every read of pv above is behind a barrier)
+    if (wave == 0) {
+        const uint64_t hist = __ballot((rwin[64 + m - 1 - lane] & 1u) != 0);
+        if (lane == 0) p.state[e.stream] = StreamVadState{st.count + F, hist};
+    }
+    for (uint32_t y = tid; y < H; y += nt) {
+        const float last = rows[static_cast<uint64_t>(F - 1) * H + y];
+        const float before = F >= 2 ? rows[static_cast<uint64_t>(F - 2) * H + y] : pv[H + y];
+        pv[y] = before;
+        pv[H + y] = last;
     }
 }
 

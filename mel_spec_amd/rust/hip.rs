@@ -94,6 +94,10 @@ unsafe extern "C" {
     fn melspec_stream_create(out: *mut *mut Stream, ctx: *mut Ctx, n_streams: u32, max_chunk: u32) -> c_int;
     fn melspec_stream_destroy(st: *mut Stream);
     fn melspec_stream_frames_after(st: *const Stream, id: u32, n_new: u32) -> usize;
+    fn melspec_stream_enable_vad(st: *mut Stream, settings: *const VadSettingsC) -> c_int;
+    fn melspec_stream_vad_frames(st: *const Stream, id: u32) -> u64;
+    fn melspec_stream_push_host_vad(st: *mut Stream, ids: *const u32, samples: *const f32, lens: *const u32, n: u32, out: *mut f32,
+                                    out_capacity_floats: usize, frames_out: *mut u32, acts: *mut VadActivityC, acts_capacity: usize) -> c_int;
     fn melspec_stream_push_host(st: *mut Stream, ids: *const u32, samples: *const f32, lens: *const u32, n: u32,
                                 out: *mut f32, cap: usize, frames_out: *mut u32) -> c_int;
 }
@@ -151,6 +155,16 @@ struct VadSettingsC {
     min_y: c_int,
     min_x: c_int,
     min_mel: c_int,
+}
+/// melspec_vad_activity: one record per emitted frame
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+struct VadActivityC {
+    valid: u8,
+    active: u8,
+    leading_active_columns: u16,
+    active_columns: u16,
+    window_columns: u16,
 }
 #[repr(C)]
 struct Stream {
@@ -449,6 +463,48 @@ impl<'a> HipStream<'a> {
             return Err(HipError::Runtime(last_error()));
         }
         Ok(flat.chunks(self.n_mels).take(frames as usize).map(|c| c.to_vec()).collect())
+    }
+}
+impl HipStream<'_> {
+    /// Turns the detector stage on: from now on `add_frame_activity` also returns what
+    /// `VoiceActivityDetector::add_activity` (src/vad.rs:155-208) gives for every frame, computed on the device from the rows
+    /// the push has just written.
+    pub fn enable_vad(&mut self, settings: &crate::vad::DetectionSettings) -> Result<(), HipError> {
+        let s = VadSettingsC { min_energy: settings.min_energy, min_y: settings.min_y as c_int, min_x: settings.min_x as c_int, min_mel: settings.min_mel as c_int };
+        match unsafe { melspec_stream_enable_vad(self.st, &s) } {
+            0 => Ok(()),
+            _ => Err(HipError::Runtime(last_error())),
+        }
+    }
+    /// `add_frame` + one `Option<VoiceActivity>` per completed frame (`None` until min_x frames have been seen).
+    pub fn add_frame_activity(&mut self, samples: &[f32]) -> Result<(Vec<Vec<f32>>, Vec<Option<crate::vad::VoiceActivity>>), HipError> {
+        let (id, len) = (0u32, samples.len() as u32);
+        let frames_cap = unsafe { melspec_stream_frames_after(self.st, 0, len) };
+        let first = unsafe { melspec_stream_vad_frames(self.st, 0) } as usize;
+        let mut flat = vec![0f32; frames_cap * self.n_mels];
+        let mut acts = vec![VadActivityC::default(); frames_cap];
+        let mut frames = 0u32;
+        if unsafe { melspec_stream_push_host_vad(self.st, &id, samples.as_ptr(), &len, 1, flat.as_mut_ptr(), flat.len(), &mut frames,
+                                                  acts.as_mut_ptr(), acts.len()) } != 0 {
+            return Err(HipError::Runtime(last_error()));
+        }
+        let rows = flat.chunks(self.n_mels).take(frames as usize).map(|c| c.to_vec()).collect();
+        let acts = acts.iter().take(frames as usize).enumerate().map(|(k, a)| {
+            if a.valid == 0 {
+                return None;
+            }
+            let (n, w) = (a.active_columns as usize, a.window_columns as usize);
+            Some(crate::vad::VoiceActivity {
+                active: a.active != 0,
+                frame_index: first + k,
+                leading_active_columns: a.leading_active_columns as usize,
+                active_columns: n,
+                window_columns: w,
+                confidence: if w == 0 { 0.0 } else { n as f64 / w as f64 },
+                timestamps: None,
+            })
+        }).collect();
+        Ok((rows, acts))
     }
 }
 impl Drop for HipStream<'_> {

@@ -9,6 +9,11 @@ import numpy as np
 
 from ._lib import lib
 from .hip import HipMelSpectrogram, _check, _f32, _fp
+from .vad import DetectionSettings, VoiceActivity
+
+# melspec_vad_activity (include/melspec_hip.h): one 8-byte record per emitted frame
+ACTIVITY_DTYPE = np.dtype([("valid", "u1"), ("active", "u1"), ("leading_active_columns", "<u2"), ("active_columns", "<u2"),
+                           ("window_columns", "<u2")])
 
 _u32p = C.POINTER(C.c_uint32)
 
@@ -91,6 +96,61 @@ class StreamBank:
         _check(lib().melspec_stream_flush_host(self._h, a.ctypes.data_as(_u32p), a.shape[0], _fp(out), out.size, frames.ctypes.data_as(_u32p)))
         return self._collect(out, frames)
 
+    # ---- the detector stage: VoiceActivityDetector::add_activity per stream, inside the push (src/vad.rs:155-208) ----
+    def enable_vad(self, settings: Optional[DetectionSettings]) -> None:
+        """Every push / flush from now on also feeds each stream's detector on the device; None turns the stage off."""
+        if settings is None:
+            _check(lib().melspec_stream_enable_vad(self._h, None))
+        else:
+            c = settings._c()
+            _check(lib().melspec_stream_enable_vad(self._h, C.byref(c)))
+
+    def vad_frames(self, stream: int) -> int:
+        """frames the stream has fed to its detector: VoiceActivityDetector::frame_index of the next one"""
+        return int(lib().melspec_stream_vad_frames(self._h, stream))
+
+    def _activities(self, ids: np.ndarray, first: Sequence[int], acts: np.ndarray, frames: np.ndarray) -> List[List[Optional[VoiceActivity]]]:
+        res, cur = [], 0
+        for i in range(ids.shape[0]):
+            rows = []
+            for k in range(int(frames[i])):
+                a = acts[cur + k]
+                if not a["valid"]:
+                    rows.append(None)                   # add_activity returned None: fewer than min_x frames so far
+                    continue
+                w, n = int(a["window_columns"]), int(a["active_columns"])
+                rows.append(VoiceActivity(bool(a["active"]), first[i] + k, int(a["leading_active_columns"]), n, w, 0.0 if w == 0 else n / w))
+            res.append(rows)
+            cur += int(frames[i])
+        return res
+
+    def push_vad(self, ids: Sequence[int], chunks: Sequence):
+        """push() that also returns, per stream, what add_activity gives for each emitted frame (None or VoiceActivity)."""
+        a = _u32(ids)
+        xs = [_f32(c).ravel() for c in chunks]
+        assert len(xs) == a.shape[0]
+        lens = _u32([x.shape[0] for x in xs])
+        flat = np.concatenate(xs) if xs else np.zeros(0, np.float32)
+        cap = sum(self.frames_after(int(s), int(n)) for s, n in zip(a, lens))
+        first = [self.vad_frames(int(s)) for s in a]
+        out = np.empty((cap, self.n_mels), np.float32)
+        acts = np.zeros(cap, ACTIVITY_DTYPE)
+        frames = np.zeros(a.shape[0], np.uint32)
+        _check(lib().melspec_stream_push_host_vad(self._h, a.ctypes.data_as(_u32p), _fp(flat), lens.ctypes.data_as(_u32p), a.shape[0],
+                                                  _fp(out), out.size, frames.ctypes.data_as(_u32p), acts.ctypes.data_as(C.c_void_p), cap))
+        assert int(frames.sum()) == cap
+        return self._collect(out, frames), self._activities(a, first, acts, frames)
+
+    def flush_vad(self, ids: Sequence[int]):
+        a = _u32(ids)
+        first = [self.vad_frames(int(s)) for s in a]
+        out = np.empty((a.shape[0], self.n_mels), np.float32)
+        acts = np.zeros(a.shape[0], ACTIVITY_DTYPE)
+        frames = np.zeros(a.shape[0], np.uint32)
+        _check(lib().melspec_stream_flush_host_vad(self._h, a.ctypes.data_as(_u32p), a.shape[0], _fp(out), out.size, frames.ctypes.data_as(_u32p),
+                                                   acts.ctypes.data_as(C.c_void_p), acts.shape[0]))
+        return self._collect(out, frames), self._activities(a, first, acts, frames)
+
     # ---- device producers -----------------------------------------------------------------
     def input_ptr(self, stream: int) -> int:
         return int(lib().melspec_stream_input_ptr(self._h, stream) or 0)
@@ -102,6 +162,16 @@ class StreamBank:
         _check(lib().melspec_stream_push_device(self._h, a.ctypes.data_as(_u32p), ln.ctypes.data_as(_u32p), a.shape[0], C.c_void_p(d_out),
                                                 None if oo is None else oo.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                 frames.ctypes.data_as(_u32p), C.c_void_p(stream)))
+        return frames
+
+    def push_device_vad(self, ids: Sequence[int], lens: Sequence[int], d_out: int, d_acts: int, out_offsets=None, stream: int = 0) -> np.ndarray:
+        """push_device whose activity records (ACTIVITY_DTYPE, packed in entry order) go to device memory at d_acts."""
+        a, ln = _u32(ids), _u32(lens)
+        frames = np.zeros(a.shape[0], np.uint32)
+        oo = None if out_offsets is None else np.ascontiguousarray(out_offsets, np.uint64)
+        _check(lib().melspec_stream_push_device_vad(self._h, a.ctypes.data_as(_u32p), ln.ctypes.data_as(_u32p), a.shape[0], C.c_void_p(d_out),
+                                                    None if oo is None else oo.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                    frames.ctypes.data_as(_u32p), C.c_void_p(d_acts), C.c_void_p(stream)))
         return frames
 
 

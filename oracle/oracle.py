@@ -279,6 +279,30 @@ def vad_on(smoothed, n: int) -> bool:
     return int(lib().oracle_vad_longest_run(_p(m, C.c_uint8), m.shape[0])) >= n
 
 
+def voice_activity_stream(frames, min_energy=0.98, min_y=11, min_x=5, min_mel=2):
+    """VoiceActivityDetector::add_activity (src/vad.rs:155-208) fed the rows of `frames` ([F, n_mels]) one by one: per frame None
+    (fewer than min_x frames so far, :169-171) or the tuple (active, frame_index, leading_active_columns, active_columns,
+    window_columns) computed from vad_boundaries over the window of the last min_x frames (:174-186).  The buffer trimming of
+    :163-168 never changes that window."""
+    x = _f32(frames)
+    out = []
+    for f in range(x.shape[0]):
+        if f + 1 < min_x:
+            out.append(None)
+            continue
+        window = np.ascontiguousarray(x[f + 1 - min_x:f + 1].T) if min_x > 0 else np.zeros((x.shape[1], 0), np.float32)
+        sm = vad_boundaries(window, min_energy, min_y, min_x, min_mel)[1]         # empty when height < 3 or width < 3 (:268-270)
+        inter = np.nonzero(sm)[0]
+        lead = 0
+        for c in inter:                                                          # leading_active_columns, :216-227
+            if c == lead:
+                lead += 1
+            elif c > lead:
+                break
+        out.append((bool(inter.size and inter[0] == 0), f, int(lead), int(inter.size), int(sm.size)))
+    return out
+
+
 def max_threads() -> int:
     return int(lib().oracle_max_threads())
 

@@ -153,6 +153,21 @@ int main() {
         for (long x = 0; x < nmask; ++x) set += sm[x];
         if (nmask != 96 || e.intersected().size() != set || e.intersected().size() + e.non_intersected().size() != 96) { std::puts("FAIL: vad mask"); return 1; }
         for (size_t x : e.intersected()) if (!sm[x]) { std::puts("FAIL: vad column"); return 1; }
+        // the detector behind a live stream: None for the first min_x - 1 frames, then one record per frame with consecutive indices;
+        // a detector with min_y = 0 calls every column intersected (src/vad.rs:381-384)
+        melspec::StreamDetector det(hip, melspec::DetectionSettings(1.0, 0, 5, 0), 16000);
+        std::vector<float> rows;
+        size_t seen = 0;
+        for (int p = 0; p < 16000; p += 4000) {
+            const auto acts = det.add_frame(std::vector<float>(samples.begin() + p, samples.begin() + p + 4000), &rows);
+            if (rows.size() != acts.size() * 80) { std::puts("FAIL: detector rows"); return 1; }
+            for (const auto &a : acts) {
+                if (seen < 4 ? a.has_value() : !(a && a->active && a->frame_index == seen && a->window_columns == 3 && a->active_columns == 3 &&
+                                                 a->leading_active_columns == 3 && a->confidence == 1.0)) { std::puts("FAIL: detector record"); return 1; }
+                ++seen;
+            }
+        }
+        if (seen != static_cast<size_t>(nf)) { std::puts("FAIL: detector frames"); return 1; }
     }
     std::puts("OK");
     return 0;

@@ -525,6 +525,38 @@ extern "C" long long emu_vad_boundaries(const float *img, uint32_t height, uint3
     return n;
 }
 
+// The detector stage of the streaming bank (stream_vad_kernel), one stream, the workgroup's steps in sequence: `rows` = the F new
+// [n_mels] rows of one push; state = {count, hist}; prev = [2][n_mels]; acts = F records of 8 bytes.
+extern "C" void emu_stream_vad_push(const float *rows, uint32_t F, uint32_t H, int min_mel, int min_y, int min_x, double min_energy,
+                                    uint64_t *state /* count, hist */, float *prev, uint8_t *acts) {
+    if (F == 0) return;
+    std::vector<uint8_t> rwin(64 + F);
+    const uint64_t count = state[0], hist = state[1];
+    for (uint32_t i = 0; i < 64; ++i) rwin[63 - i] = static_cast<uint8_t>((hist >> i) & 1u);
+    for (uint32_t q = 0; q < F; ++q) {
+        bool r = false;
+        if (count + q >= 2 && H >= 3) {
+            const float *c2 = rows + static_cast<uint64_t>(q) * H;
+            const float *c1 = q >= 1 ? c2 - H : prev + H;
+            const float *c0 = q >= 2 ? c2 - 2 * static_cast<uint64_t>(H) : (q == 1 ? prev + H : prev);
+            r = vad_classify_triple(c0, c1, c2, H, min_mel, min_y, min_energy * min_energy);
+        }
+        rwin[64 + q] = r;
+    }
+    for (uint32_t q = 0; q < F; ++q) {
+        const VadActivity a = vad_stream_activity(count + q, rwin.data() + 64 + q, H, min_x);
+        std::memcpy(acts + 8 * static_cast<size_t>(q), &a, 8);
+    }
+    uint64_t h2 = 0;
+    for (uint32_t i = 0; i < 64; ++i) h2 |= static_cast<uint64_t>(rwin[64 + F - 1 - i] & 1u) << i;
+    state[0] = count + F; state[1] = h2;
+    for (uint32_t y = 0; y < H; ++y) {
+        const float last = rows[static_cast<uint64_t>(F - 1) * H + y];
+        const float before = F >= 2 ? rows[static_cast<uint64_t>(F - 2) * H + y] : prev[H + y];
+        prev[y] = before; prev[H + y] = last;
+    }
+}
+
 // ---- Whisper flavour of the fused 512-point kernel (w512_phase1 / fb_phase2_* / fb_phase3_sums / w512_phase3_log / w512_phase4) ----
 extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
     using T = double;

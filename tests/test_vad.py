@@ -135,3 +135,148 @@ def test_gpu_mel_to_vad_and_streaming_detector(gpu, oracle, jfk):
         assert d.frame_index == k and d.window_columns == 3 and d.active_columns == len(inter)
         assert d.active == (len(inter) > 0 and inter[0] == 0)
     m.close()
+
+
+# ---- the detector stage of the streaming bank (melspec_stream_enable_vad): VoiceActivityDetector::add_activity per stream ----------
+def _emu_stream_vad():
+    L = C.CDLL(os.path.join(os.path.dirname(__file__), "emu", "libmelspec_emu.so"))
+    L.emu_stream_vad_push.restype = None
+    L.emu_stream_vad_push.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+def _mel_like(rng, frames, n_mels):
+    """rows in Whisper's output range with speech-like structure: bursts of harmonic ridges over a noisy floor"""
+    x = rng.uniform(-1.0, -0.97, (frames, n_mels)).astype(np.float32)
+    t = 0
+    while t < frames:
+        d = int(rng.integers(3, 40))
+        if rng.random() < 0.5:
+            for m in rng.integers(0, n_mels, 6):
+                x[t:t + d, m:m + 2] += np.float32(rng.uniform(0.8, 2.0))
+        t += d
+    return x
+
+
+@pytest.mark.parametrize("kw", [dict(min_energy=1.0, min_y=3, min_x=5, min_mel=0), dict(min_energy=0.98, min_y=11, min_x=5, min_mel=2),
+                                dict(min_energy=0.7, min_y=2, min_x=12, min_mel=1), dict(min_energy=0.5, min_y=1, min_x=66, min_mel=0),
+                                dict(min_energy=1.0, min_y=0, min_x=7, min_mel=0), dict(min_energy=1.0, min_y=3, min_x=2, min_mel=0),
+                                dict(min_energy=1.0, min_y=3, min_x=3, min_mel=0), dict(min_energy=1.0, min_y=2, min_x=1, min_mel=0)])
+def test_stream_detector_steps_match_the_oracle(oracle, kw):
+    """The steps of stream_vad_kernel in their host form (the kernel spreads the Sobel walk over a wave's lanes; same sums), run over pushes of irregular size (1 frame, several, more than the
+    history), give for every frame what the reference's detector gives when fed the same rows one at a time."""
+    L = _emu_stream_vad()
+    rng = np.random.default_rng(11 + kw["min_x"])
+    for n_mels in (80, 5, 2):
+        rows = _mel_like(rng, 400, n_mels)
+        want = oracle.voice_activity_stream(rows, **kw)
+        state = np.zeros(2, np.uint64)
+        prev = np.zeros((2, n_mels), np.float32)
+        got, t = [], 0
+        while t < rows.shape[0]:
+            f = int(min(rows.shape[0] - t, rng.choice([1, 1, 2, 3, 7, 70, 130])))
+            chunk = np.ascontiguousarray(rows[t:t + f])
+            acts = np.zeros(f, np.dtype([("valid", "u1"), ("active", "u1"), ("lead", "<u2"), ("n", "<u2"), ("w", "<u2")]))
+            L.emu_stream_vad_push(chunk.ctypes.data, f, n_mels, kw["min_mel"], kw["min_y"], kw["min_x"], float(kw["min_energy"]),
+                                  state.ctypes.data, prev.ctypes.data, acts.ctypes.data)
+            got += [None if not a["valid"] else (bool(a["active"]), t + k, int(a["lead"]), int(a["n"]), int(a["w"])) for k, a in enumerate(acts)]
+            t += f
+        assert int(state[0]) == rows.shape[0]
+        assert got == want, (kw, n_mels, next(i for i, (a, b) in enumerate(zip(got, want)) if a != b))
+        if kw["min_x"] >= 3 and n_mels == 80 and kw["min_y"] > 0 and kw["min_x"] < 60:
+            assert any(w is not None and w[0] for w in want) and any(w is not None and not w[0] for w in want)      # both answers occur
+
+
+@pytest.mark.gpu
+def test_gpu_stream_bank_detectors(gpu, oracle, jfk):
+    """melspec_stream_enable_vad: every push of the bank also feeds its streams' detectors on the device.  Three streams (speech,
+    the same speech later, near-silence) pushed in chunks of irregular size: the rows equal the bank's rows without the stage, and
+    every frame's record equals what the reference's detector returns when it is fed those rows one by one."""
+    kw = dict(min_energy=1.0, min_y=10, min_x=5, min_mel=0)
+    m = gpu.HipMelSpectrogram(400, 160, 16000.0, 80)
+    bank = gpu.StreamBank(m, 3, 8000)
+    plain = gpu.StreamBank(m, 3, 8000)
+    bank.enable_vad(gpu.DetectionSettings(**kw))
+    src = [jfk[:60000], jfk[40000:120000], oracle.synth_pcm(1, 50000) * np.float32(1e-4)]
+    pos, rows, acts = [0, 0, 0], [[], [], []], [[], [], []]
+    rng = np.random.default_rng(3)
+    while any(p < len(s) for p, s in zip(pos, src)):
+        ids = [i for i in range(3) if pos[i] < len(src[i]) and rng.random() < 0.8]
+        if not ids:
+            continue
+        chunks = []
+        for i in ids:
+            n = int(min(len(src[i]) - pos[i], rng.choice([37, 160, 161, 800, 4000, 8000])))
+            chunks.append(src[i][pos[i]:pos[i] + n]); pos[i] += n
+        first = [bank.vad_frames(i) for i in ids]
+        r, a = bank.push_vad(ids, chunks)
+        r0 = plain.push(ids, chunks)
+        for i, ri, ai, r0i, f0 in zip(ids, r, a, r0, first):
+            assert np.array_equal(ri, r0i) and len(ai) == ri.shape[0]
+            assert all(x is None or x.frame_index == f0 + k for k, x in enumerate(ai))
+            rows[i].append(ri); acts[i] += ai
+    r, a = bank.flush_vad([0, 1, 2])                       # the zero-padded last frame feeds the detector too
+    for i in range(3):
+        rows[i].append(r[i]); acts[i] += a[i]
+    seen_active = False
+    for i in range(3):
+        x = np.concatenate(rows[i])
+        want = oracle.voice_activity_stream(x, **kw)
+        got = [None if v is None else (v.active, v.frame_index, v.leading_active_columns, v.active_columns, v.window_columns) for v in acts[i]]
+        assert bank.vad_frames(i) == x.shape[0] == len(got)
+        assert got == want, (i, next(k for k, (p, q) in enumerate(zip(got, want)) if p != q))
+        assert all(v is None or v.confidence == (v.active_columns / v.window_columns if v.window_columns else 0.0) for v in acts[i])
+        if i < 2:
+            seen_active |= any(w is not None and w[0] for w in want)
+        else:
+            assert not any(w is not None and w[0] for w in want)      # the silent stream never fires
+    assert seen_active
+    # reset starts the listed detectors afresh; the stage can be turned off again
+    bank.reset([1])
+    assert bank.vad_frames(1) == 0 and bank.vad_frames(0) > 0
+    r, a = bank.push_vad([1], [jfk[:4000]])
+    assert [v for v in a[0][:4]] == [None] * 4 and a[0][4] is not None and a[0][4].frame_index == 4
+    with pytest.raises(Exception):
+        bank.push_stft([0], [jfk[:800]])                   # the stage needs mel rows
+    bank.enable_vad(None)
+    with pytest.raises(Exception):
+        bank.push_vad([0], [jfk[:800]])
+    bank.push([0], [jfk[:800]])
+    bank.close(); plain.close(); m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stream_detectors_device_push_many_streams(gpu, oracle):
+    """The device-producer form at scale: 1024 streams, one hop per push written straight into the slots, rows and records to device
+    memory; per stream the records equal the reference's detector over the rows the pushes emitted."""
+    from mel_spec_amd.stream import ACTIVITY_DTYPE
+    kw = dict(min_energy=0.8, min_y=10, min_x=6, min_mel=1)
+    n_streams, hop, pushes = 1024, 160, 42
+    m = gpu.HipMelSpectrogram(400, hop, 16000.0, 80)
+    bank = gpu.StreamBank(m, n_streams, hop)
+    bank.enable_vad(gpu.DetectionSettings(**kw))
+    ids = np.arange(n_streams, dtype=np.uint32)
+    out = gpu.DeviceBuffer(n_streams * 80 * 4)
+    acts = gpu.DeviceBuffer(n_streams * 8)
+    p0 = bank.input_ptr(0)
+    slot = bank.input_ptr(1) - p0
+    rows, recs = [], []
+    for k in range(pushes):
+        gpu.synth_pcm_window(p0, slot // 4, hop, k * hop, n_streams)
+        fr = bank.push_device_vad(ids, np.full(n_streams, hop, np.uint32), out.ptr, acts.ptr)
+        assert (fr == (1 if k >= 2 else 0)).all()
+        if k >= 2:
+            rows.append(out.download((n_streams, 80)))
+            recs.append(acts.download((n_streams,), ACTIVITY_DTYPE))
+    fired = quiet = 0
+    for s in list(range(0, n_streams, 37)) + [n_streams - 1]:
+        x = np.stack([r[s] for r in rows])
+        want = oracle.voice_activity_stream(x, **kw)
+        got = [None if not a[s]["valid"] else (bool(a[s]["active"]), k, int(a[s]["leading_active_columns"]), int(a[s]["active_columns"]),
+                                               int(a[s]["window_columns"])) for k, a in enumerate(recs)]
+        assert got == want, s
+        assert bank.vad_frames(s) == len(rows)
+        fired += sum(1 for w in want if w is not None and w[0])
+        quiet += sum(1 for w in want if w is not None and not w[0])
+    assert fired > 0 and quiet > 0
+    out.free(); acts.free(); bank.close(); m.close()

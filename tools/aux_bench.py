@@ -105,8 +105,12 @@ if want("quant") or want("vad"):
 
 if want("stream"):
     m = M.HipMelSpectrogram(400, 160, 16000.0, 80)
-    for n_streams, chunk in ((4096, 160), (4096, 1600)):
+    for n_streams, chunk, vad in ((4096, 160, False), (4096, 160, True), (4096, 1600, False), (4096, 1600, True)):
         bank = M.StreamBank(m, n_streams, chunk)
+        acts = M.DeviceBuffer(n_streams * (chunk // 160 + 1) * 8)
+        if vad:
+            bank.enable_vad(M.DetectionSettings())
+        push = (lambda: bank.push_device_vad(ids, lens, out.ptr, acts.ptr)) if vad else (lambda: bank.push_device(ids, lens, out.ptr))
         ids = np.arange(n_streams, dtype=np.uint32)
         lens = np.full(n_streams, chunk, np.uint32)
         out = M.DeviceBuffer(n_streams * (chunk // 160 + 1) * 80 * 4)
@@ -114,14 +118,15 @@ if want("stream"):
         slot = (bank.input_ptr(1) - p0) // 4
         k = 0
         for _ in range(8):
-            M.synth_pcm_window(p0, slot, chunk, k * chunk, n_streams); bank.push_device(ids, lens, out.ptr); k += 1
+            M.synth_pcm_window(p0, slot, chunk, k * chunk, n_streams); push(); k += 1
         dt = 0.0
         for _ in range(ITERS):
             M.synth_pcm_window(p0, slot, chunk, k * chunk, n_streams); M.device_synchronize()
-            t0 = time.perf_counter(); bank.push_device(ids, lens, out.ptr); dt += time.perf_counter() - t0; k += 1
+            t0 = time.perf_counter(); push(); dt += time.perf_counter() - t0; k += 1
         ms = dt / ITERS * 1e3
-        report(f"stream push {n_streams} streams x {chunk // 160} hop(s) (plan + frames + carry, host-inclusive)", ms, n_streams * (chunk // 160), 960)
-        out.free(); bank.close()
+        report(f"stream push {n_streams} streams x {chunk // 160} hop(s) (plan + frames{' + detector stage' if vad else ''} + carry, host-inclusive)", ms,
+               n_streams * (chunk // 160), 960)
+        out.free(); acts.free(); bank.close()
     m.close()
 
 if want("flavours"):
