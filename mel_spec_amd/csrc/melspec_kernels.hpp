@@ -1170,9 +1170,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     T *slice = reinterpret_cast<T *>(ldsw + p.blob_words) + wave * L::slice_elems();
     const int fl = lane / kFbLanes, j = lane - fl * kFbLanes;
     const bool in = lane < kFbFPW * kFbLanes;
+    // first bin of this lane's interval per slot: held across the unit loop by the compile-time banks; the run-time-lens variants
+    // re-read the ten words in front of phase 3 instead (they sit at the 256-VGPR limit: holding them spilled inside the loop)
     int st[NSLOTS];
-    {
-        const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+    const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+    if (Lens::kStatic) {
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
     }
@@ -1238,6 +1240,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(2);
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+        if (!Lens::kStatic) {
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
+        }
         fb_phase3_sums<T, NSLOTS, Lens>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
