@@ -257,7 +257,7 @@ MS_DEV void fb_phase2_dft(int fl, int r, bool active, const T *slice, cpx<T> (&o
 // phase 2b: Hermitian split with W_512, 4*power (or 2*magnitude) as f32 to LDS (the power rows are written
 // over the exchange rows of the same wave).  part[i] = the partner lane's own[8 + i].
 //   pair s: Z[k], k = r + 16s, with Z[256-k] = partner[15 - s]; for r == 0 the partner index is 16 - s
-//   (mod 16: Z[256 - 16s]), i.e. own[0] for s = 0 and part[8 - s] for s = 1..8.
+//   (mod 16: Z[256 - 16s]), i.e. own[0] for s = 0 and part[8 - s] for s = 1..7; s = 8 is Z[128] with itself.
 //   POWER == false (FbankConfig::use_power off: magnitudes) is a compile-time variant: as a run-time select the compiler
 //   evaluated the 17 IEEE square roots of every lane unconditionally (~170 instructions per unit, 7 % of the kernel).
 template <class T, bool POWER = true>
@@ -290,7 +290,12 @@ MS_DEV void fb_phase2_split(int fl, int r, bool active, const T *MS_RESTRICT tbl
         const cpx<T> zm = {lane0 ? part[8 - s].re : part[7 - s].re, lane0 ? part[8 - s].im : part[7 - s].im};
         pair(s, own[s], zm);
     }
-    if (lane0) pair(8, own[8], part[0]);
+    // lane 0's ninth value is Z[128], its own partner: W_512^128 = -i makes X[128] = conj(Z[128]), so the split is |Z[128]|^2
+    if (lane0) {
+        float pk = static_cast<float>(T(4) * (own[8].re * own[8].re + own[8].im * own[8].im));
+        if (!POWER) pk = __builtin_sqrtf(pk);
+        p[128] = pk;
+    }
 }
 
 // Compile-time slot lengths of the default filterbanks over 16-lane groups (any other bank: LensRuntime).  With them the
