@@ -326,7 +326,7 @@ inline bool vad_on(const EdgeInfo &e, std::size_t n) {          // src/vad.rs:22
 }
 
 // VoiceActivity (src/vad.rs:125-135) and the detector behind a live stream: VoiceActivityDetector::add_activity
-// (src/vad.rs:155-208) fed by RingBuffer's frames, with both on the device -- one bank stream whose detector stage is on.
+// (src/vad.rs:155-205) fed by RingBuffer's frames, with both on the device -- one bank stream whose detector stage is on.
 struct VoiceActivity {
     bool active;
     std::size_t frame_index, leading_active_columns, active_columns, window_columns;

@@ -4,11 +4,12 @@ wavey-ai/mel-spec's GPU plugin slot.  All compute runs in hand-written HIP kerne
 from .hip import (BatchLogMelConfig, BatchLogMelError, BatchLogMelSpectrogram, DeviceBuffer, HostBuffer, Fbank, FbankConfig, HipError, HipMelSpectrogram, HipRuntimeError, HipUnavailable, SparseMelFilterbank,
                   device_count, device_synchronize, hann_window, kaldi_mel_filterbank, mel, synth_pcm_device, synth_pcm_window)
 from .parallel import ShardedMelSpectrogram, gather_peer, shard_by_samples, shard_range
-from .quant import QuantizationRange, TgaCodec, to_array2
+from .quant import QuantizationRange, TgaCodec, chunk_frames_into_strides, to_array2
 from .stream import RingBuffer, StreamBank
-from .vad import DetectionSettings, EdgeInfo, VoiceActivity, VoiceActivityDetector, vad_boundaries, vad_on
+from .vad import (DetectionSettings, EdgeInfo, VadFrameTiming, VoiceActivity, VoiceActivityDetector, VoiceActivityTimestamps, duration_ms_for_n_frames,
+                  format_milliseconds, n_frames_for_duration, vad_boundaries, vad_on)
 
 __all__ = ["BatchLogMelConfig", "BatchLogMelError", "BatchLogMelSpectrogram", "DeviceBuffer", "HostBuffer", "Fbank", "FbankConfig", "HipError", "HipMelSpectrogram", "HipRuntimeError", "SparseMelFilterbank",
            "HipUnavailable", "device_count", "device_synchronize", "hann_window", "kaldi_mel_filterbank", "mel",
-           "synth_pcm_device", "synth_pcm_window", "shard_range", "shard_by_samples", "ShardedMelSpectrogram", "gather_peer", "QuantizationRange", "TgaCodec", "to_array2", "RingBuffer", "StreamBank", "DetectionSettings", "EdgeInfo", "VoiceActivity", "VoiceActivityDetector",
+           "synth_pcm_device", "synth_pcm_window", "shard_range", "shard_by_samples", "ShardedMelSpectrogram", "gather_peer", "QuantizationRange", "TgaCodec", "to_array2", "chunk_frames_into_strides", "RingBuffer", "StreamBank", "DetectionSettings", "EdgeInfo", "VoiceActivity", "VoiceActivityDetector", "VadFrameTiming", "VoiceActivityTimestamps", "n_frames_for_duration", "duration_ms_for_n_frames", "format_milliseconds",
            "vad_boundaries", "vad_on"]

@@ -63,7 +63,7 @@ MS_HD bool vad_smooth_at(const uint8_t *raw, uint32_t n, uint32_t i) {
     return c * 2 >= end - start;
 }
 
-// ---- the detector inside the streaming bank (VoiceActivityDetector::add_activity, src/vad.rs:155-208) -------------------------------
+// ---- the detector inside the streaming bank (VoiceActivityDetector::add_activity, src/vad.rs:155-205) -------------------------------
 // The reference classifies, for every frame it is given, the window of the last min_x frames as a [n_mels][min_x] image: raw[x] is
 // the Sobel count of window columns x..x+2, x < min_x - 2, smoothed by the +-4 vote, `active` = column 0 survives.  raw[x] of the
 // window ending at frame f is a property of the three frames g..g+2, g = f - min_x + 1 + x, alone: R[g].  So a stream needs R of its
@@ -72,14 +72,14 @@ struct StreamVadState {        // per stream, in HBM next to the bank's sample s
     uint64_t count;            // frames this stream has emitted (VoiceActivityDetector::frame_index)
     uint64_t hist;             // bit i = R[count - 3 - i]
 };
-struct VadActivity {           // melspec_vad_activity: what add_activity returns for one frame (VoiceActivity, src/vad.rs:127-135)
+struct VadActivity {           // melspec_vad_activity: what add_activity returns for one frame (VoiceActivity, src/vad.rs:126-135)
     uint8_t valid;             // 0: the reference returns None (fewer than min_x frames so far)
     uint8_t active;
     uint16_t leading_active_columns, active_columns, window_columns;
 };
 constexpr int kStreamVadMaxX = 66;     // min_x - 2 <= 64 history bits
 
-// R for the triple whose columns are the mel rows c0, c1, c2 ([n_mels] each): classify_columns_across_frames, src/vad.rs:417-468
+// R for the triple whose columns are the mel rows c0, c1, c2 ([n_mels] each): classify_columns_across_frames, src/vad.rs:417-470
 MS_HD bool vad_classify_triple(const float *c0, const float *c1, const float *c2, uint32_t height, int min_mel, int min_y, double thr) {
     if (min_y == 0) return true;
     const uint32_t start_y = static_cast<uint32_t>(min_mel) < height - 2 ? static_cast<uint32_t>(min_mel) : height - 2;

@@ -125,3 +125,17 @@ def to_array2(frames, n_mels: int) -> np.ndarray:
     """to_array2 (src/quant.rs:168-174): back to (n_mels, width) f64."""
     x = np.asarray(frames, np.float32)
     return x.reshape(n_mels, x.shape[0] // n_mels).astype(np.float64)
+
+
+def chunk_frames_into_strides(frames, n_mels: int, stride_size: int) -> List[np.ndarray]:
+    """chunk_frames_into_strides (src/quant.rs:100-136): the [n_mels][width] image cut into stride_size x stride_size tiles in
+    row-major tile order, each tile flattened row-major; the whole image when stride_size == width.  Host utility (tga_8bit's
+    chunking itself happens in the encoder's layout on the device)."""
+    x = _f32(frames).ravel()
+    width = x.shape[0] // n_mels
+    if stride_size == width:
+        return [x]
+    img = x.reshape(n_mels, width)
+    return [np.ascontiguousarray(img[y:y + stride_size, c:c + stride_size]).ravel()
+            for y in range(0, n_mels, stride_size) for c in range(0, width, stride_size)]
+

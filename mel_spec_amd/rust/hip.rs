@@ -467,7 +467,7 @@ impl<'a> HipStream<'a> {
 }
 impl HipStream<'_> {
     /// Turns the detector stage on: from now on `add_frame_activity` also returns what
-    /// `VoiceActivityDetector::add_activity` (src/vad.rs:155-208) gives for every frame, computed on the device from the rows
+    /// `VoiceActivityDetector::add_activity` (src/vad.rs:155-205) gives for every frame, computed on the device from the rows
     /// the push has just written.
     pub fn enable_vad(&mut self, settings: &crate::vad::DetectionSettings) -> Result<(), HipError> {
         let s = VadSettingsC { min_energy: settings.min_energy, min_y: settings.min_y as c_int, min_x: settings.min_x as c_int, min_mel: settings.min_mel as c_int };

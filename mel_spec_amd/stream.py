@@ -9,7 +9,7 @@ import numpy as np
 
 from ._lib import lib
 from .hip import HipMelSpectrogram, _check, _f32, _fp
-from .vad import DetectionSettings, VoiceActivity
+from .vad import DetectionSettings, VadFrameTiming, VoiceActivity
 
 # melspec_vad_activity (include/melspec_hip.h): one 8-byte record per emitted frame
 ACTIVITY_DTYPE = np.dtype([("valid", "u1"), ("active", "u1"), ("leading_active_columns", "<u2"), ("active_columns", "<u2"),
@@ -96,9 +96,11 @@ class StreamBank:
         _check(lib().melspec_stream_flush_host(self._h, a.ctypes.data_as(_u32p), a.shape[0], _fp(out), out.size, frames.ctypes.data_as(_u32p)))
         return self._collect(out, frames)
 
-    # ---- the detector stage: VoiceActivityDetector::add_activity per stream, inside the push (src/vad.rs:155-208) ----
-    def enable_vad(self, settings: Optional[DetectionSettings]) -> None:
-        """Every push / flush from now on also feeds each stream's detector on the device; None turns the stage off."""
+    # ---- the detector stage: VoiceActivityDetector::add_activity per stream, inside the push (src/vad.rs:155-205) ----
+    def enable_vad(self, settings: Optional[DetectionSettings], timing: Optional[VadFrameTiming] = None) -> None:
+        """Every push / flush from now on also feeds each stream's detector on the device; None turns the stage off.
+        timing (VoiceActivityDetector::new_with_timing, src/vad.rs:149-153): records then carry their timestamps."""
+        self._vad_timing = timing
         if settings is None:
             _check(lib().melspec_stream_enable_vad(self._h, None))
         else:
@@ -119,7 +121,9 @@ class StreamBank:
                     rows.append(None)                   # add_activity returned None: fewer than min_x frames so far
                     continue
                 w, n = int(a["window_columns"]), int(a["active_columns"])
-                rows.append(VoiceActivity(bool(a["active"]), first[i] + k, int(a["leading_active_columns"]), n, w, 0.0 if w == 0 else n / w))
+                t = getattr(self, "_vad_timing", None)
+                rows.append(VoiceActivity(bool(a["active"]), first[i] + k, int(a["leading_active_columns"]), n, w, 0.0 if w == 0 else n / w,
+                                          None if t is None else t.timestamps_for_frame(first[i] + k)))
             res.append(rows)
             cur += int(frames[i])
         return res

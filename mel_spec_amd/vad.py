@@ -2,6 +2,7 @@
 vad_boundaries -> EdgeInfo, vad_on, VoiceActivityDetector.  The column classification (Sobel stencil, count,
 majority vote) runs on the device; list building and the detector's window bookkeeping are host logic."""
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -73,23 +74,73 @@ def leading_active_columns(intersected: Sequence[int]) -> int:
 
 
 @dataclass
+class VoiceActivityTimestamps:
+    """VoiceActivityTimestamps (src/vad.rs:119-124)."""
+    start_ms: int
+    center_ms: int
+    end_ms: int
+
+
+def _sample_to_ms(sample: int, sampling_rate: float) -> int:
+    return int(math.floor(sample / sampling_rate * 1000.0 + 0.5))        # f64::round of a non-negative value (src/vad.rs:208-210)
+
+
+@dataclass
+class VadFrameTiming:
+    """VadFrameTiming (src/vad.rs:90-117): where frame i of the STFT sits in the stream."""
+    fft_size: int
+    hop_size: int
+    sampling_rate: float
+
+    def timestamps_for_frame(self, frame_index: int) -> VoiceActivityTimestamps:
+        start = frame_index * self.hop_size
+        return VoiceActivityTimestamps(_sample_to_ms(start, self.sampling_rate), _sample_to_ms(start + self.fft_size // 2, self.sampling_rate),
+                                       _sample_to_ms(start + self.fft_size, self.sampling_rate))
+
+
+@dataclass
 class VoiceActivity:
+    """VoiceActivity (src/vad.rs:126-135)."""
     active: bool
     frame_index: int
     leading_active_columns: int
     active_columns: int
     window_columns: int
     confidence: float
+    timestamps: Optional[VoiceActivityTimestamps] = None
+
+
+def n_frames_for_duration(hop_size: int, sampling_rate: float, duration_ms: int) -> int:
+    """FFT frames needed for duration_ms (src/vad.rs:579-583; the reference computes this one in f32)."""
+    frame_duration = np.float32(hop_size) / np.float32(sampling_rate) * np.float32(1000.0)
+    return int(np.ceil(np.float32(duration_ms) / frame_duration))
+
+
+def duration_ms_for_n_frames(hop_size: int, sampling_rate: float, total_frames: int) -> int:
+    """milliseconds total_frames FFT frames represent (src/vad.rs:586-589)."""
+    return int(total_frames * (hop_size / sampling_rate * 1000.0))
+
+
+def format_milliseconds(milliseconds: int) -> str:
+    """HH:MM:SS.mmm (src/vad.rs:592-601)."""
+    total_seconds, ms = divmod(int(milliseconds), 1000)
+    total_minutes, seconds = divmod(total_seconds, 60)
+    hours, minutes = divmod(total_minutes, 60)
+    return f"{hours:02}:{minutes:02}:{seconds:02}.{ms:03}"
 
 
 class VoiceActivityDetector:
     """VoiceActivityDetector::{new, add, add_activity} (src/vad.rs:137-208): the last min_x single-column frames
     form the window that vad_boundaries classifies."""
 
-    def __init__(self, settings: DetectionSettings, device: int = -1):
-        self.settings, self.device = settings, device
+    def __init__(self, settings: DetectionSettings, device: int = -1, timing: Optional[VadFrameTiming] = None):
+        self.settings, self.device, self.timing = settings, device, timing
         self.mel_buffer: List[np.ndarray] = []
         self.frame_index = 0
+
+    @classmethod
+    def new_with_timing(cls, settings: DetectionSettings, timing: VadFrameTiming, device: int = -1) -> "VoiceActivityDetector":
+        return cls(settings, device, timing)                  # src/vad.rs:149-153
 
     def add(self, frame) -> Optional[bool]:
         a = self.add_activity(frame)
@@ -108,4 +159,5 @@ class VoiceActivityDetector:
         inter = e.intersected()
         window = len(inter) + len(e.non_intersected())
         return VoiceActivity(bool(inter) and inter[0] == 0, idx, leading_active_columns(inter), len(inter), window,
-                             0.0 if window == 0 else len(inter) / window)
+                             0.0 if window == 0 else len(inter) / window,
+                             None if self.timing is None else self.timing.timestamps_for_frame(idx))

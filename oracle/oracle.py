@@ -280,10 +280,10 @@ def vad_on(smoothed, n: int) -> bool:
 
 
 def voice_activity_stream(frames, min_energy=0.98, min_y=11, min_x=5, min_mel=2):
-    """VoiceActivityDetector::add_activity (src/vad.rs:155-208) fed the rows of `frames` ([F, n_mels]) one by one: per frame None
-    (fewer than min_x frames so far, :169-171) or the tuple (active, frame_index, leading_active_columns, active_columns,
-    window_columns) computed from vad_boundaries over the window of the last min_x frames (:174-186).  The buffer trimming of
-    :163-168 never changes that window."""
+    """VoiceActivityDetector::add_activity (src/vad.rs:162-205) fed the rows of `frames` ([F, n_mels]) one by one: per frame None
+    (fewer than min_x frames so far, :173-175) or the tuple (active, frame_index, leading_active_columns, active_columns,
+    window_columns) computed from vad_boundaries over the window of the last min_x frames (:178-188).  The buffer trimming of
+    :168-172 never changes that window."""
     x = _f32(frames)
     out = []
     for f in range(x.shape[0]):
@@ -291,10 +291,10 @@ def voice_activity_stream(frames, min_energy=0.98, min_y=11, min_x=5, min_mel=2)
             out.append(None)
             continue
         window = np.ascontiguousarray(x[f + 1 - min_x:f + 1].T) if min_x > 0 else np.zeros((x.shape[1], 0), np.float32)
-        sm = vad_boundaries(window, min_energy, min_y, min_x, min_mel)[1]         # empty when height < 3 or width < 3 (:268-270)
+        sm = vad_boundaries(window, min_energy, min_y, min_x, min_mel)[1]         # empty when height < 3 or width < 3 (:265-267)
         inter = np.nonzero(sm)[0]
         lead = 0
-        for c in inter:                                                          # leading_active_columns, :216-227
+        for c in inter:                                                          # leading_active_columns, :212-222
             if c == lead:
                 lead += 1
             elif c > lead:

@@ -273,3 +273,12 @@ def test_gpu_pcm_to_tga_with_the_minmax_folded_into_the_mel_store(gpu, codec, or
     for buf in (pcm, img, img2, blobs, blobs2):
         buf.free()
     m.close()
+
+
+def test_chunk_frames_into_strides_mirror(oracle):
+    """chunk_frames_into_strides (src/quant.rs:100-136), host utility of the mirror, against the oracle's restatement."""
+    import mel_spec_amd as M
+    x = np.arange(80 * 25, dtype=np.float32)
+    for st in (25, 10, 80, 7, 1000):
+        a, b = M.chunk_frames_into_strides(x, 80, st), oracle.chunk_frames_into_strides(x, 80, st)
+        assert len(a) == len(b) and all(np.array_equal(p, q) for p, q in zip(a, b)), st

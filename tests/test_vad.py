@@ -280,3 +280,35 @@ def test_gpu_stream_detectors_device_push_many_streams(gpu, oracle):
         quiet += sum(1 for w in want if w is not None and not w[0])
     assert fired > 0 and quiet > 0
     out.free(); acts.free(); bank.close(); m.close()
+
+
+def test_reference_stage_test_and_timing_helpers(oracle):
+    """test_stage (src/vad.rs:731-758): quantized_mel_golden.tga fed to a detector one column at a time, settings (1.0, 3, 3, 0) -- here
+    through the host form of the bank's detector stage against the restated add_activity; plus VadFrameTiming / the duration helpers
+    (src/vad.rs:97-117, 579-601) on hand-checked values."""
+    import mel_spec_amd as M
+    with open(os.path.join(GOLDEN, "quantized_mel_golden.tga"), "rb") as f:
+        img = oracle.parse_tga_8bit(f.read()).reshape(80, -1)
+    rows = np.ascontiguousarray(img.T)
+    kw = dict(min_energy=1.0, min_y=3, min_x=3, min_mel=0)
+    want = oracle.voice_activity_stream(rows, **kw)
+    L = _emu_stream_vad()
+    state, prev = np.zeros(2, np.uint64), np.zeros((2, 80), np.float32)
+    got = []
+    for t in range(rows.shape[0]):                                      # chunk_size = 1, as the reference's test does
+        acts = np.zeros(1, np.dtype([("valid", "u1"), ("active", "u1"), ("lead", "<u2"), ("n", "<u2"), ("w", "<u2")]))
+        L.emu_stream_vad_push(rows[t:t + 1].ctypes.data, 1, 80, kw["min_mel"], kw["min_y"], kw["min_x"], kw["min_energy"],
+                              state.ctypes.data, prev.ctypes.data, acts.ctypes.data)
+        a = acts[0]
+        got.append(None if not a["valid"] else (bool(a["active"]), t, int(a["lead"]), int(a["n"]), int(a["w"])))
+    assert got == want and got[0] is None and got[1] is None and got[2] is not None and got[2][4] == 1
+    assert any(g is not None and g[0] for g in got) and any(g is not None and not g[0] for g in got)
+    t = M.VadFrameTiming(400, 160, 16000.0)
+    ts = t.timestamps_for_frame(3)                                      # samples 480 / 680 / 880 -> 30 / 42.5 -> 43 / 55 ms
+    assert (ts.start_ms, ts.center_ms, ts.end_ms) == (30, 43, 55)
+    assert M.VadFrameTiming(512, 160, 16000.0).timestamps_for_frame(0).center_ms == 16
+    assert M.n_frames_for_duration(160, 16000.0, 1000) == 100 and M.n_frames_for_duration(160, 16000.0, 1001) == 101
+    assert M.duration_ms_for_n_frames(160, 16000.0, 100) == 1000 and M.duration_ms_for_n_frames(160, 16000.0, 3) == 30
+    assert M.format_milliseconds(3723004) == "01:02:03.004" and M.format_milliseconds(0) == "00:00:00.000"
+    det = M.VoiceActivityDetector.new_with_timing(M.DetectionSettings(**kw), t)
+    assert det.timing is t and det.frame_index == 0
