@@ -274,6 +274,12 @@ int melspec_mel_filterbank(double sr, int n_fft, int n_mels, double f_min, doubl
                            int htk, int norm, double *out);
 /* hann_window (src/stft.rs:141-145), periodic, f64. */
 int melspec_hann_window(int n, double *out);
+/* hz_to_mel / mel_to_hz / mel_frequencies / fft_frequencies (src/mel.rs:591-643): the scale the filterbank above is built on
+ * (Slaney, or HTK when htk != 0); mel_frequencies fills n_mels values, fft_frequencies n_fft/2 + 1.  Host only. */
+double melspec_hz_to_mel(double frequency, int htk);
+double melspec_mel_to_hz(double mel, int htk);
+int melspec_mel_frequencies(int n_mels, double fmin, double fmax, int htk, double *out);
+int melspec_fft_frequencies(double sr, int n_fft, double *out);
 /* kaldi_mel_filterbank (src/fbank.rs:253-301): dense [num_mel_bins][fft_size/2+1] f64. */
 int melspec_kaldi_mel_filterbank(double sample_rate, int fft_size, int num_mel_bins,
                                  double low_freq, double high_freq, double *out);

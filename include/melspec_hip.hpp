@@ -378,4 +378,17 @@ inline std::vector<double> mel(double sr, std::size_t n_fft, std::size_t n_mels,
     return w;
 }
 
+inline double hz_to_mel(double frequency, bool htk = false) { return melspec_hz_to_mel(frequency, htk); }     // src/mel.rs:591-607
+inline double mel_to_hz(double mel_value, bool htk = false) { return melspec_mel_to_hz(mel_value, htk); }      // src/mel.rs:609-625
+inline std::vector<double> mel_frequencies(std::size_t n_mels, double fmin, double fmax, bool htk = false) {   // src/mel.rs:631-637
+    std::vector<double> f(n_mels);
+    detail::check(melspec_mel_frequencies(static_cast<int>(n_mels), fmin, fmax, htk, f.data()), false);
+    return f;
+}
+inline std::vector<double> fft_frequencies(double sr, std::size_t n_fft) {                                     // src/mel.rs:639-643
+    std::vector<double> f(n_fft / 2 + 1);
+    detail::check(melspec_fft_frequencies(sr, static_cast<int>(n_fft), f.data()), false);
+    return f;
+}
+
 }  // namespace melspec

@@ -111,6 +111,10 @@ SIGNATURES = {
     "melspec_synchronize": (C.c_int, [_vp, _vp]),
     "melspec_mel_filterbank": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _f64p]),
     "melspec_hann_window": (C.c_int, [C.c_int, _f64p]),
+    "melspec_hz_to_mel": (C.c_double, [C.c_double, C.c_int]),
+    "melspec_mel_to_hz": (C.c_double, [C.c_double, C.c_int]),
+    "melspec_mel_frequencies": (C.c_int, [C.c_int, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]),
+    "melspec_fft_frequencies": (C.c_int, [C.c_double, C.c_int, C.POINTER(C.c_double)]),
     "melspec_kaldi_mel_filterbank": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, _f64p]),
     "melspec_fbank_default_config": (None, [C.POINTER(FbankConfigC)]),
     "melspec_fbank_create": (C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(FbankConfigC)]),

@@ -1723,6 +1723,25 @@ int melspec_mel_filterbank(double sr, int n_fft, int n_mels, double f_min, doubl
     return MELSPEC_OK;
 }
 
+double melspec_hz_to_mel(double frequency, int htk) { return hz_to_mel(frequency, htk != 0); }
+double melspec_mel_to_hz(double mel_v, int htk) { return mel_to_hz(mel_v, htk != 0); }
+
+int melspec_mel_frequencies(int n_mels, double fmin, double fmax, int htk, double *out) {
+    if (!out || n_mels < 1) return fail(MELSPEC_ERR_INVALID_ARG, "bad mel_frequencies argument");
+    // Array1::linspace(min_mel, max_mel, n_mels) mapped through mel_to_hz (src/mel.rs:631-637)
+    const double lo = hz_to_mel(fmin, htk != 0), hi = hz_to_mel(fmax, htk != 0);
+    const double step = n_mels > 1 ? (hi - lo) / (n_mels - 1) : 0.0;
+    for (int i = 0; i < n_mels; ++i) out[i] = mel_to_hz(lo + step * i, htk != 0);
+    return MELSPEC_OK;
+}
+
+int melspec_fft_frequencies(double sr, int n_fft, double *out) {
+    if (!out || n_fft < 1) return fail(MELSPEC_ERR_INVALID_ARG, "bad fft_frequencies argument");
+    const double step = sr / n_fft;
+    for (int i = 0; i <= n_fft / 2; ++i) out[i] = step * i;
+    return MELSPEC_OK;
+}
+
 int melspec_hann_window(int n, double *out) {
     if (!out || n < 1) return fail(MELSPEC_ERR_INVALID_ARG, "bad hann_window argument");
     const std::vector<double> w = hann_window(n);

@@ -795,6 +795,35 @@ def mel(sr: float, n_fft: int, n_mels: int, f_min=None, f_max=None, htk: bool = 
     return out
 
 
+def hz_to_mel(frequency: float, htk: bool = False) -> float:
+    """hz_to_mel (src/mel.rs:591-607)."""
+    return float(lib().melspec_hz_to_mel(float(frequency), int(htk)))
+
+
+def mel_to_hz(mel_value: float, htk: bool = False) -> float:
+    """mel_to_hz (src/mel.rs:609-625)."""
+    return float(lib().melspec_mel_to_hz(float(mel_value), int(htk)))
+
+
+def mels_to_hz(mels, htk: bool = False) -> np.ndarray:
+    """mels_to_hz (src/mel.rs:627-629)."""
+    return np.array([mel_to_hz(m, htk) for m in np.asarray(mels, np.float64).ravel()], np.float64)
+
+
+def mel_frequencies(n_mels: int, fmin: float, fmax: float, htk: bool = False) -> np.ndarray:
+    """mel_frequencies (src/mel.rs:631-637)."""
+    out = np.empty(int(n_mels), np.float64)
+    _check(lib().melspec_mel_frequencies(int(n_mels), float(fmin), float(fmax), int(htk), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def fft_frequencies(sr: float, n_fft: int) -> np.ndarray:
+    """fft_frequencies (src/mel.rs:639-643)."""
+    out = np.empty(int(n_fft) // 2 + 1, np.float64)
+    _check(lib().melspec_fft_frequencies(float(sr), int(n_fft), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
 def hann_window(n: int) -> np.ndarray:
     out = np.empty(n, np.float64)
     _check(lib().melspec_hann_window(n, out.ctypes.data_as(C.POINTER(C.c_double))))

@@ -116,3 +116,25 @@ def test_library_is_built_from_these_sources(tmp_path):
     stale.write_bytes(blob.replace(B.HASH_MARKER + B.source_hash().encode(), B.HASH_MARKER + b"0" * 32))
     assert B.built_hash(str(stale)) == "0" * 32 != B.source_hash()
     assert B.built_hash(str(tmp_path / "missing.so")) is None
+
+
+def test_mel_scale_helpers_reproduce_the_references_known_answers():
+    """hz_to_mel / mel_to_hz / mels_to_hz / mel_frequencies / fft_frequencies through the C ABI (host only, no device needed) on the
+    values the reference's own tests pin (src/mel.rs:786-834, librosa's doc examples), and against the oracle's restatement."""
+    import numpy as np
+    import mel_spec_amd as M
+    from oracle import oracle as O
+    assert abs(M.hz_to_mel(60.0) - 0.9) <= 1e-3 and M.mel_to_hz(3.0) == 200.0
+    assert np.abs(M.mels_to_hz([1.0, 2.0, 3.0, 4.0, 5.0]) - [66.667, 133.333, 200.0, 266.667, 333.333]).max() <= 1e-3
+    want = [0., 85.317, 170.635, 255.952, 341.269, 426.586, 511.904, 597.221, 682.538, 767.855, 853.173, 938.49, 1024.856, 1119.114,
+            1222.042, 1334.436, 1457.167, 1591.187, 1737.532, 1897.337, 2071.84, 2262.393, 2470.47, 2697.686, 2945.799, 3216.731,
+            3512.582, 3835.643, 4188.417, 4573.636, 4994.285, 5453.621, 5955.205, 6502.92, 7101.009, 7754.107, 8467.272, 9246.028,
+            10096.408, 11025.]
+    assert np.abs(M.mel_frequencies(40, 0.0, 11025.0) - want).max() <= 5e-3
+    assert np.abs(M.fft_frequencies(22050.0, 16) - [0., 1378.125, 2756.25, 4134.375, 5512.5, 6890.625, 8268.75, 9646.875, 11025.]).max() <= 1e-3
+    for htk in (False, True):
+        for f in (0.0, 60.0, 999.9, 1000.0, 4000.0, 8000.0):
+            assert abs(M.hz_to_mel(f, htk) - O.hz_to_mel(f, htk)) <= 1e-12 * max(1.0, abs(O.hz_to_mel(f, htk)))
+            assert abs(M.mel_to_hz(M.hz_to_mel(f, htk), htk) - f) <= 1e-9 * max(1.0, f)
+        assert np.abs(M.mel_frequencies(82, 0.0, 8000.0, htk) - O.mel_frequencies(82, 0.0, 8000.0, htk)).max() <= 1e-9
+    assert np.array_equal(M.fft_frequencies(16000.0, 400), O.fft_frequencies(16000.0, 400))
