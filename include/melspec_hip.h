@@ -252,6 +252,9 @@ void melspec_bank_destroy(melspec_bank *bank);
 int melspec_bank_n_mels(const melspec_bank *bank);              /* n_mels()            src/mel.rs:89-91  */
 int melspec_bank_fft_bins(const melspec_bank *bank);            /* fft_bins()          src/mel.rs:93-95  */
 int melspec_bank_non_zero_weights(const melspec_bank *bank);    /* non_zero_weights()  src/mel.rs:97-99  */
+/* weights_for_mel(mel_idx) (src/mel.rs:102-104): the row's SparseMelWeight { bin, weight } entries in ascending bin order, at most
+ * `capacity` of them copied; returns the row's entry count (-1: bad index).  bins / weights may be NULL. */
+int melspec_bank_weights_for_mel(const melspec_bank *bank, int mel_idx, int *bins, double *weights, int capacity);
 /* project_power_f64 / project_power_f32 (src/mel.rs:106-146) for n_frames rows: power [n_frames][fft_bins] -> [n_frames][n_mels] */
 int melspec_bank_project_power_device(melspec_bank *bank, const void *d_power, int dtype, uint64_t n_frames, void *d_out, void *stream);
 int melspec_bank_project_power_host(melspec_bank *bank, const void *power, int dtype, size_t n_frames, void *out);

@@ -58,6 +58,7 @@ SIGNATURES = {
     "melspec_bank_n_mels": (C.c_int, [_vp]),
     "melspec_bank_fft_bins": (C.c_int, [_vp]),
     "melspec_bank_non_zero_weights": (C.c_int, [_vp]),
+    "melspec_bank_weights_for_mel": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int]),
     "melspec_bank_project_power_device": (C.c_int, [_vp, _vp, C.c_int, C.c_uint64, _vp, _vp]),
     "melspec_bank_project_power_host": (C.c_int, [_vp, _vp, C.c_int, C.c_size_t, _vp]),
     "melspec_bank_log_mel_device": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_uint64, _vp, _vp]),

@@ -1541,6 +1541,8 @@ struct melspec_bank {
     hipStream_t stream = nullptr;
     int n_mels = 0, fft_bins = 0, nnz = 0;
     DevBuf row_ptr, bin, w, wf, key, tmp_in, tmp_out;
+    std::vector<int> h_row_ptr, h_bin;             // the sparse rows on the host (weights_for_mel)
+    std::vector<double> h_w;
     BankDesc desc() const {
         return BankDesc{static_cast<const int *>(row_ptr.p), static_cast<const int *>(bin.p), static_cast<const double *>(w.p),
                         static_cast<const float *>(wf.p), n_mels, fft_bins};
@@ -1570,6 +1572,7 @@ int bank_create(melspec_bank **out, int device, const std::vector<double> &dense
         row_ptr[m + 1] = static_cast<int>(bins.size());
     }
     b->nnz = static_cast<int>(bins.size());
+    b->h_row_ptr = row_ptr; b->h_bin = bins; b->h_w = w;
     if ((rc = upload(b->row_ptr, row_ptr)) || (rc = upload(b->bin, bins)) || (rc = upload(b->w, w)) || (rc = upload(b->wf, wf))) return bail(rc);
     if ((rc = b->key.ensure(16))) return bail(rc);
     *out = b;
@@ -1614,6 +1617,16 @@ void melspec_bank_destroy(melspec_bank *b) {
 int melspec_bank_n_mels(const melspec_bank *b) { return b ? b->n_mels : 0; }
 int melspec_bank_fft_bins(const melspec_bank *b) { return b ? b->fft_bins : 0; }
 int melspec_bank_non_zero_weights(const melspec_bank *b) { return b ? b->nnz : 0; }
+
+int melspec_bank_weights_for_mel(const melspec_bank *b, int mel_idx, int *bins, double *weights, int capacity) {
+    if (!b || mel_idx < 0 || mel_idx >= b->n_mels) return -1;
+    const int lo = b->h_row_ptr[mel_idx], n = b->h_row_ptr[mel_idx + 1] - lo;
+    for (int i = 0; i < n && i < capacity; ++i) {
+        if (bins) bins[i] = b->h_bin[lo + i];
+        if (weights) weights[i] = b->h_w[lo + i];
+    }
+    return n;
+}
 
 int melspec_bank_project_power_device(melspec_bank *b, const void *d_power, int dtype, uint64_t n_frames, void *d_out, void *stream) {
     if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "bank is NULL");

@@ -739,6 +739,15 @@ class SparseMelFilterbank:
     def dense_weights(self) -> int:
         return self.n_mels * self.fft_bins
 
+    def weights_for_mel(self, mel_idx: int):
+        """weights_for_mel (src/mel.rs:102-104): [(bin, weight), ...] of one row, ascending bins"""
+        n = int(lib().melspec_bank_weights_for_mel(self._h, int(mel_idx), None, None, 0))
+        if n < 0:
+            raise IndexError(mel_idx)
+        bins, w = np.zeros(n, np.int32), np.zeros(n, np.float64)
+        lib().melspec_bank_weights_for_mel(self._h, int(mel_idx), bins.ctypes.data_as(C.POINTER(C.c_int)), w.ctypes.data_as(C.POINTER(C.c_double)), n)
+        return list(zip(bins.tolist(), w.tolist()))
+
     @staticmethod
     def _dt(a):
         if a.dtype not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.complex64), np.dtype(np.complex128)):

@@ -1221,6 +1221,12 @@ def test_sparse_filterbank_helpers(gpu, oracle, jfk, kw):
     fb = gpu.SparseMelFilterbank.from_mel(**kw)
     filters = oracle.mel_filterbank(kw["sample_rate"], kw["n_fft"], kw["n_mels"], kw.get("f_min"), kw.get("f_max"), kw.get("htk", False), kw.get("norm", True))
     assert (fb.n_mels, fb.fft_bins, fb.non_zero_weights) == (kw["n_mels"], kw["n_fft"] // 2 + 1, int(np.count_nonzero(filters)))
+    assert fb.dense_weights() == filters.size
+    for m in (0, kw["n_mels"] // 2, kw["n_mels"] - 1):                       # weights_for_mel (:102-104): the row's non-zeros, ascending bins
+        nz = np.nonzero(filters[m])[0]
+        assert fb.weights_for_mel(m) == [(int(k), float(filters[m, k])) for k in nz]
+    with pytest.raises(IndexError):
+        fb.weights_for_mel(kw["n_mels"])
     spec = oracle.compute_all_cpu(jfk[:30000], kw["n_fft"], kw["n_fft"] // 2)
     power = (spec.real ** 2 + spec.imag ** 2)[:, :fb.fft_bins]
     for T in (np.float64, np.float32):
