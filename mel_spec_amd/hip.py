@@ -436,6 +436,12 @@ class Fbank:
     def num_frames(self, n_samples: int) -> int:
         return int(lib().melspec_fbank_num_frames(self._h, n_samples))
 
+    def dense_filterbank(self) -> np.ndarray:
+        """dense_filterbank (src/fbank.rs:244-246): the Kaldi weights [num_mel_bins, fft_size/2 + 1] the projection is built from
+        (high_freq == 0 means Nyquist, :108-112)."""
+        c = self.config
+        return kaldi_mel_filterbank(c.sample_rate, c.fft_size(), c.num_mel_bins, c.low_freq, c.high_freq if c.high_freq != 0.0 else c.sample_rate / 2.0)
+
     @property
     def uses_fast_path(self) -> bool:
         return bool(lib().melspec_fbank_uses_fast_path(self._h))
@@ -607,6 +613,17 @@ class BatchLogMelSpectrogram:
 
     def padded_frames(self, n_samples: int) -> int:
         return int(lib().melspec_blm_padded_frames(self._h, n_samples))
+
+    def filters(self, device: int = -1) -> "SparseMelFilterbank":
+        """filters (src/mel.rs:286-288): the sparse bank BatchLogMelSpectrogram::new builds (:254-263)."""
+        c = self.config
+        return SparseMelFilterbank.from_mel(float(c.sample_rate), c.n_fft, c.n_mels, c.f_min, c.sample_rate / 2.0 if c.f_max is None else c.f_max,
+                                            c.htk, c.norm, device)
+
+    def compute_flat(self, samples):
+        """compute_flat (src/mel.rs:304-307) -> BatchLogMelOutput as (data, rows, cols): the feature-major values, flat."""
+        a = self.compute(samples)
+        return a.reshape(-1), a.shape[0], a.shape[1]
 
     def compute(self, samples) -> np.ndarray:
         """&[f32] -> Array2<f32> (n_mels, cols), feature-major (src/mel.rs:299-302)."""

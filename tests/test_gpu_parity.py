@@ -1254,3 +1254,22 @@ def test_sparse_filterbank_helpers(gpu, oracle, jfk, kw):
     dense = gpu.SparseMelFilterbank.from_dense(filters)
     assert dense.non_zero_weights == fb.non_zero_weights and np.array_equal(dense.project_power(power), fb.project_power(power))
     dense.close(); fb.close()
+
+
+@pytest.mark.gpu
+def test_accessors_of_the_fbank_and_nemo_objects(gpu, oracle, jfk):
+    """Fbank::{config, dense_filterbank} (src/fbank.rs:239-246), BatchLogMelSpectrogram::{config, filters, compute_flat}
+    (src/mel.rs:282-307): what the objects were built from, as the reference exposes it."""
+    fb = gpu.Fbank(gpu.FbankConfig(num_mel_bins=40, low_freq=100.0))
+    assert fb.config.num_mel_bins == 40
+    want = oracle.kaldi_mel_filterbank(16000.0, 512, 40, 100.0, 8000.0)
+    assert fb.dense_filterbank().shape == (40, 257) and np.array_equal(fb.dense_filterbank(), want)
+    fb.close()
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_mels=64, f_min=50.0))
+    bank = fe.filters()
+    dense = oracle.mel_filterbank(16000.0, 512, 64, 50.0, 8000.0, False, True)
+    assert (bank.n_mels, bank.fft_bins, bank.non_zero_weights) == (64, 257, int(np.count_nonzero(dense)))
+    data, rows, cols = fe.compute_flat(jfk[:16000])
+    a = fe.compute(jfk[:16000])
+    assert (rows, cols) == a.shape == (64, fe.padded_frames(16000)) and np.array_equal(data, a.reshape(-1))
+    bank.close(); fe.close()
