@@ -219,7 +219,8 @@ struct PreciseTables {
     int mel_off_words = 0;
 };
 
-inline bool build_precise_tables(const FastTables &ft, PreciseTables &out) {
+// power_split: the blob of the mel kernels (precise_phase2); false: the blob of the spectrum export (precise_phase2_spectrum)
+inline bool build_precise_tables(const FastTables &ft, PreciseTables &out, bool power_split) {
     if (!ft.interval) return false;
     constexpr int N = 400, M = 200;
     std::vector<double> t(PreciseBlob::kCount, 0.0);
@@ -239,8 +240,8 @@ inline bool build_precise_tables(const FastTables &ft, PreciseTables &out) {
     for (int j = 0; j < kMelJobs; ++j)
         for (int q = 0; q < 10; ++q) {
             const double a = -2.0 * kPi * (j + 20 * q) / N;
-            t[PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride + 2 * q] = std::cos(a);
-            t[PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride + 2 * q + 1] = std::sin(a);
+            t[PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride + 2 * q] = power_split ? 2.0 * std::sin(a) : std::cos(a);
+            t[PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride + 2 * q + 1] = power_split ? 4.0 * std::cos(a) : std::sin(a);
         }
     const size_t t_words = t.size() * 2;
     const size_t mel_floats = ft.blob.size() - FastBlob::kMelStart;

@@ -20,7 +20,7 @@ struct FbankFastTables {
 // needs more than `max_slots` slots of 15 intervals.
 template <class T>
 inline bool build_fused512_tables(const std::vector<double> &window, const std::vector<double> &dense, int n_mels,
-                                  double scale, int max_slots, FbankFastTables &out, int bin_limit = 257) {
+                                  double scale, int max_slots, FbankFastTables &out, int bin_limit = 257, bool power_split = false) {
     constexpr int N = 512;
     const int FL = static_cast<int>(window.size());       // 400 taps (Kaldi, NeMo) or 512 (Whisper flavour)
     if (n_mels < 1 || n_mels > kFbOwn * max_slots - 1 || (FL != 400 && FL != 512)) return false;
@@ -35,8 +35,9 @@ inline bool build_fused512_tables(const std::vector<double> &window, const std::
     for (int r = 0; r < 16; ++r)
         for (int q = 0; q < 9; ++q) {
             const double a = -2.0 * kPi * (r + 16 * q) / N;
-            t[FbankBlob::kTw2 + r * FbankBlob::kTw2Stride + 2 * q] = static_cast<T>(std::cos(a));
-            t[FbankBlob::kTw2 + r * FbankBlob::kTw2Stride + 2 * q + 1] = static_cast<T>(std::sin(a));
+            // power_split (the Whisper flavour, fb_phase2_split<.., FAST>): (2 sin, 4 cos) of the same angle
+            t[FbankBlob::kTw2 + r * FbankBlob::kTw2Stride + 2 * q] = static_cast<T>(power_split ? 2.0 * std::sin(a) : std::cos(a));
+            t[FbankBlob::kTw2 + r * FbankBlob::kTw2Stride + 2 * q + 1] = static_cast<T>(power_split ? 4.0 * std::cos(a) : std::sin(a));
         }
     const int bins = N / 2 + 1;
     std::vector<float> mel(FbankBlob::kMelW, 0.0f);
@@ -83,7 +84,7 @@ inline bool build_blm_fast_tables(int sample_rate, int n_mels, double f_min, dou
 // project_stft_log10 uses those below n_fft/2 = 256 (src/mel.rs:155-163).
 template <class T>
 inline bool build_whisper512_tables(const std::vector<double> &dense /* [n_mels][257] */, int n_mels, FbankFastTables &out) {
-    return build_fused512_tables<T>(hann_window(512), dense, n_mels, 0.25, kBlmSlots, out, 256);
+    return build_fused512_tables<T>(hann_window(512), dense, n_mels, 0.25, kBlmSlots, out, 256, true);
 }
 template <class T>
 inline bool build_whisper512_tables(double sample_rate, int n_mels, FbankFastTables &out) {

@@ -260,14 +260,27 @@ MS_DEV void fb_phase2_dft(int fl, int r, bool active, const T *slice, cpx<T> (&o
 //   (mod 16: Z[256 - 16s]), i.e. own[0] for s = 0 and part[8 - s] for s = 1..7; s = 8 is Z[128] with itself.
 //   POWER == false (FbankConfig::use_power off: magnitudes) is a compile-time variant: as a run-time select the compiler
 //   evaluated the 17 IEEE square roots of every lane unconditionally (~170 instructions per unit, 7 % of the kernel).
-template <class T, bool POWER = true>
+//   FAST (the Whisper flavour only; its table holds (2 sin, 4 cos), build_whisper512_tables): the two powers straight from
+//   |S|^2 + |D|^2 +- 2 Im(conj(S) D w) -- 12 operations per pair instead of 16, at the price of a difference of large numbers in the
+//   weaker bin, which only a clamped output can afford (precise_phase2, whisper_wave_f64.hpp).
+template <class T, bool POWER = true, bool FAST = false>
 MS_DEV void fb_phase2_split(int fl, int r, bool active, const T *MS_RESTRICT tblob, const cpx<T> (&own)[16],
                             const cpx<T> (&part)[8], T *slice) {
+    static_assert(POWER || !FAST, "the direct form computes powers");
     if (!active) return;
     const T *tw = tblob + FbankBlob::kTw2 + r * FbankBlob::kTw2Stride;
     float *p = reinterpret_cast<float *>(slice) + fl * FbankLayout<T>::kPStride;
     const bool lane0 = r == 0;
     auto pair = [&](int s, cpx<T> zk, cpx<T> zm) {
+        if (FAST) {
+            const T a = zk.re * zk.re + zk.im * zk.im, b = zm.re * zm.re + zm.im * zm.im;
+            const T c = zk.re * zm.im + zm.re * zk.im;
+            const cpx<T> t = ldc(tw + 2 * s);
+            const T s2 = a + b, x = (a - b) * t.re + c * t.im;
+            p[r + 16 * s] = static_cast<float>(T(2) * s2 + x);
+            p[256 - r - 16 * s] = static_cast<float>(T(2) * s2 - x);
+            return;
+        }
         const cpx<T> S = {zk.re + zm.re, zk.im - zm.im};
         const cpx<T> D = {zk.re - zm.re, zk.im + zm.im};
         const cpx<T> wd = cmul(ldc(tw + 2 * s), D);

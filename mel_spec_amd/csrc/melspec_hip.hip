@@ -511,7 +511,7 @@ struct melspec_ctx {
     // f64 FFT build of the n_fft = 400 kernel: the whole batch (MELSPEC_PRECISION_F64) or the queued frames (AUTO)
     int precision = MELSPEC_PRECISION_AUTO;
     PreciseTables pt;
-    DevBuf d_blob64;
+    DevBuf d_blob64, d_blob64s;      // f64 tables: of the mel kernels (power split) / of the spectrum export
     size_t precise_lds = 0;
     FixState fix;
     // generic path
@@ -811,7 +811,7 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         if (runtime_lens) c->lens_kind = 0;
         c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(kWaveWaves) * WaveLayout::slice_floats() + kWaveWaves);   // + RoundSync counters
         PreciseTables pt;
-        const bool pt_ok = build_precise_tables(c->ft, pt);
+        const bool pt_ok = build_precise_tables(c->ft, pt, true);
         c->precise_lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double) +
                          kPreciseWaves * sizeof(uint32_t);   // + RoundSync counters
         if (c->fast_lds > kLdsLimit || !pt_ok || c->precise_lds > kLdsLimit) c->fast = false;
@@ -836,6 +836,12 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
         if ((rc = upload(c->d_blob64, c->pt.blob))) return bail(rc);
+        {
+            PreciseTables ps;
+            if (!build_precise_tables(c->ft, ps, false)) return bail(fail(MELSPEC_ERR_INTERNAL, "spectrum tables"));
+            ps.blob.resize(static_cast<size_t>(PreciseBlob::kCount) * 2);          // the f64 tables only
+            if ((rc = upload(c->d_blob64s, ps.blob))) return bail(rc);
+        }
         if ((rc = upload(c->fix.tab, build_fix_tables()))) return bail(rc);
         if ((rc = upload(c->fix.count, std::vector<uint64_t>(8, 0ull)))) return bail(rc);
     }
@@ -883,7 +889,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release();
     c->fix.release();
     c->dplan.release();
     c->pipe.release();
@@ -1225,7 +1231,7 @@ int launch_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipS
         }
         StftParams p{};
         p.b = desc;
-        p.d_blob = static_cast<const uint32_t *>(c->d_blob64.p);
+        p.d_blob = static_cast<const uint32_t *>(c->d_blob64s.p);
         p.blob_words = PreciseBlob::kCount * 2;                    // the f64 tables only, not the mel section behind them
         p.hop = c->hop_size; p.bins = bins; p.words_per_frame = words;
         const size_t lds = static_cast<size_t>(p.blob_words) * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double);

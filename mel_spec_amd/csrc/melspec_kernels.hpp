@@ -1234,7 +1234,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             fb_phase2_dft<T>(fl, j, act, slice, own);
 #pragma unroll
             for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
-            if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
+            if (FLAVOR == kFlavorWhisper) fb_phase2_split<T, true, true>(fl, j, act, tblob, own, part, slice);
+            else if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
             else fb_phase2_split<T, false>(fl, j, act, tblob, own, part, slice);
         }
         __builtin_amdgcn_wave_barrier();

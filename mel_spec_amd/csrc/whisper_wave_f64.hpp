@@ -24,7 +24,8 @@ struct PreciseBlob {
     static constexpr int kTw1 = 400;                      // [10][46]  W_200^{t*k1}
     static constexpr int kMod = kTw1 + 10 * kTw1Stride;   // [10] complex W_10^{n2}
     static constexpr int kTw2Stride = 22;
-    static constexpr int kTw2 = kMod + 20;                // [11][22] complex W_400^{j+20q}
+    static constexpr int kTw2 = kMod + 20;                // [11][22] per k = j+20q: the mel kernels' blob holds (2 sin, 4 cos) of W_400^k's angle
+                                                          // (the power split below), the spectrum export's blob W_400^k itself
     static constexpr int kCount = kTw2 + kMelJobs * kTw2Stride;
 };
 
@@ -68,18 +69,24 @@ MS_DEV void precise_phase2(int fl, int j, bool active, const double *MS_RESTRICT
     }
     fft10(u);
     fft10(v);
+    // Hermitian split straight to the two powers.  With S = zk + conj(zm), D = zk - conj(zm) and w = W_400^k (|w| = 1):
+    //   4|X[k]|^2, 4|X[200-k]|^2 = |S|^2 + |D|^2 +- 2 Im(conj(S) D w),   |S|^2 + |D|^2 = 2(|zk|^2 + |zm|^2),
+    //   conj(S) D = (|zk|^2 - |zm|^2) + 2i (zk.re zm.im + zm.re zk.im)
+    // -- 12 operations per pair instead of 16 (S, D, w D, A, B, |A|^2, |B|^2).  The difference of two large numbers in the weaker of
+    // the two bins costs 1.1e-16 * P_strong / P_weak of relative accuracy; Whisper's clamp at max - 8 decades (src/mel.rs:645-654) bounds
+    // what matters of that ratio by ~1e8 per band, so the result moves by <= 1e-8 -- the f32 kernels cannot afford this form (6e-8 * 1e8),
+    // nor can the fbank flavours of the 512-point kernel (no clamp).
     const double *tw = tb + PreciseBlob::kTw2 + j * PreciseBlob::kTw2Stride;
     float *p = reinterpret_cast<float *>(rows) + fl * WaveLayout::kPStride;
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
         const cd zk = u[q], zm = v[9 - q];
-        const cd S = {zk.re + zm.re, zk.im - zm.im};
-        const cd D = {zk.re - zm.re, zk.im + zm.im};
-        const cd wd = cmul(ldc(tw + 2 * q), D);
-        const double ar = S.re + wd.im, ai = S.im - wd.re;
-        const double br = S.re - wd.im, bi = S.im + wd.re;
-        p[j + 20 * q] = static_cast<float>(ar * ar + ai * ai);
-        p[200 - j - 20 * q] = static_cast<float>(br * br + bi * bi);
+        const double a = zk.re * zk.re + zk.im * zk.im, b = zm.re * zm.re + zm.im * zm.im;
+        const double c = zk.re * zm.im + zm.re * zk.im;
+        const cd t = ldc(tw + 2 * q);                       // (2 sin, 4 cos)
+        const double s2 = a + b, x = (a - b) * t.re + c * t.im;
+        p[j + 20 * q] = static_cast<float>(2.0 * s2 + x);
+        p[200 - j - 20 * q] = static_cast<float>(2.0 * s2 - x);
     }
 }
 

@@ -280,7 +280,7 @@ extern "C" long long emu_whisper_precise(const float *pcm, long long n, int hop,
     FastTables T;
     if (!build_fast_tables(sr, n_mels, T, true) || !T.interval) return -1;
     PreciseTables P;
-    if (!build_precise_tables(T, P)) return -2;
+    if (!build_precise_tables(T, P, true)) return -2;
     const double *tb = reinterpret_cast<const double *>(P.blob.data());
     const float *fblob = reinterpret_cast<const float *>(P.blob.data() + P.mel_off_words) - FastBlob::kMelStart;
     if (n < 400) return 0;
@@ -354,7 +354,7 @@ extern "C" long long emu_stft400(const float *pcm, long long n, int hop, int bin
     FastTables T;
     if (!build_fast_tables(16000.0, 80, T, true) || !T.interval) return -1;
     PreciseTables P;
-    if (!build_precise_tables(T, P)) return -2;
+    if (!build_precise_tables(T, P, false)) return -2;
     const double *tb = reinterpret_cast<const double *>(P.blob.data());
     if (n < 400) return 0;
     const long long frames = (n - 400) / hop + 1;
@@ -595,7 +595,7 @@ extern "C" long long emu_w512_wave(const float *pcm, long long n, int hop, int n
             cpx<T> part[8];
             const int src = (lane & ~15) | ((16 - (lane & 15)) & 15);
             for (int i = 0; i < 8; ++i) part[i] = own[static_cast<size_t>(src) * 16 + 8 + i];
-            fb_phase2_split<T, true>(fl, j, act, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]), part, tmp.data());
+            fb_phase2_split<T, true, true>(fl, j, act, tblob, *reinterpret_cast<const cpx<T>(*)[16]>(&own[static_cast<size_t>(lane) * 16]), part, tmp.data());
             const uint32_t *a = reinterpret_cast<const uint32_t *>(tmp.data()), *b0 = reinterpret_cast<const uint32_t *>(snap.data());
             uint32_t *d = reinterpret_cast<uint32_t *>(next.data());
             for (size_t i = 0; i < tmp.size() * sizeof(T) / 4; ++i) if (a[i] != b0[i]) d[i] = a[i];
