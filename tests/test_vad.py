@@ -312,3 +312,24 @@ def test_reference_stage_test_and_timing_helpers(oracle):
     assert M.format_milliseconds(3723004) == "01:02:03.004" and M.format_milliseconds(0) == "00:00:00.000"
     det = M.VoiceActivityDetector.new_with_timing(M.DetectionSettings(**kw), t)
     assert det.timing is t and det.frame_index == 0
+
+
+@pytest.mark.gpu
+def test_gpu_stream_detector_long_pushes(gpu, oracle, jfk):
+    """Pushes that emit more frames than the detector kernel keeps in LDS at a time (2048): the history is carried from piece to piece."""
+    kw = dict(min_energy=1.0, min_y=8, min_x=9, min_mel=0)
+    m = gpu.HipMelSpectrogram(400, 160, 16000.0, 80)
+    bank = gpu.StreamBank(m, 2, 400000)
+    bank.enable_vad(gpu.DetectionSettings(**kw))
+    x = np.tile(jfk, 3)[:520000]
+    rows, acts = [], []
+    for lo, hi in ((0, 390000), (390000, 390100), (390100, 520000)):
+        r, a = bank.push_vad([1], [x[lo:hi]])
+        rows.append(r[0]); acts += a[0]
+    rows = np.concatenate(rows)
+    assert rows.shape[0] > 3000
+    want = oracle.voice_activity_stream(rows, **kw)
+    got = [None if v is None else (v.active, v.frame_index, v.leading_active_columns, v.active_columns, v.window_columns) for v in acts]
+    assert got == want
+    assert any(w is not None and w[0] for w in want) and any(w is not None and not w[0] for w in want)
+    bank.close(); m.close()
