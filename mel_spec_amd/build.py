@@ -11,10 +11,15 @@ LIB_PATH = os.path.join(PKG_DIR, "libmelspec_hip.so")
 import glob
 
 LAB_LIB_PATH = os.path.join(PKG_DIR, "libmelspec_hip_lab.so")   # -DMELSPEC_LAB: tuning switches for tools/, never loaded by default
-SOURCES = ["melspec_hip.hip"]
+# translation units and the flags only they get: melspec_runs.hip holds the run-per-wave f32 Whisper kernels, scheduled for ILP
+# (csrc/melspec_runs.hip says why; the default strategy is the better one for everything else)
+SOURCES = ["melspec_hip.hip", "melspec_runs.hip"]
+UNIT_FLAGS = {"melspec_runs.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _inputs():
+    # (the flags of every unit are part of what the library is: hashed through this file's own text would be too broad, so they are
+    # appended to the hash explicitly in source_hash)
     return ([os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp")))
             + sorted(glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))))
 
@@ -35,6 +40,7 @@ def source_hash() -> str:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:
             h.update(fh.read())
+    h.update(repr(sorted(UNIT_FLAGS.items())).encode())
     return h.hexdigest()[:32]
 
 
@@ -71,16 +77,32 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False, defines
         return LIB_PATH
     import json, time
     src_hash = source_hash()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f'-DMELSPEC_SOURCE_HASH="{src_hash}"'] + (["-DMELSPEC_LAB"] if lab else []) + [f"-D{d}" for d in defines] + [
-           # no SLP packing: v_pk_*_f32 issues at half the rate of the plain op on gfx950 (measured,
-           # tools/valu_rate.hip) and pairing registers costs ~250 v_mov per kernel
-           "-fno-slp-vectorize",
-           "-Wall", "-Wno-unused-function",
-           "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
+    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f'-DMELSPEC_SOURCE_HASH="{src_hash}"'] + (["-DMELSPEC_LAB"] if lab else []) + [f"-D{d}" for d in defines] + [
+              # no SLP packing: v_pk_*_f32 issues at half the rate of the plain op on gfx950 (measured,
+              # tools/valu_rate.hip) and pairing registers costs ~250 v_mov per kernel
+              "-fno-slp-vectorize",
+              "-Wall", "-Wno-unused-function"]
+    import tempfile
     t0 = time.time()
-    subprocess.check_call(cmd)
+    cmds = []
+    with tempfile.TemporaryDirectory(prefix="melspec_build_") as tmp:
+        objs, procs = [], []
+        for src in SOURCES:                                   # one object per translation unit, compiled side by side
+            obj = os.path.join(tmp, os.path.splitext(src)[0] + ".o")
+            c = common + UNIT_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            cmds.append(" ".join(c))
+            if verbose:
+                print(cmds[-1])
+            objs.append(obj)
+            procs.append(subprocess.Popen(c))
+        if any(p.wait() != 0 for p in procs):
+            raise subprocess.CalledProcessError(1, cmds[0])
+        link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+        cmds.append(" ".join(link[:6] + [os.path.basename(o) for o in objs]))
+        if verbose:
+            print(cmds[-1])
+        subprocess.check_call(link)
+    cmd = [common[0]]
     if not lab:
         # what was compiled, by what, where: printed by __graft_entry__.smoke() so that the record of a run shows which build it used
         import hashlib, platform
@@ -93,7 +115,7 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False, defines
         with open(INFO_PATH, "w") as fh:
             json.dump({"library": os.path.basename(out), "source_hash": src_hash, "library_sha256_32": so_hash, "hipcc": ver,
                        "seconds": round(time.time() - t0, 1), "host": platform.node(), "built_at": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
-                       "gpu_visible_at_build": os.path.exists("/dev/kfd"), "command": " ".join(cmd)}, fh, indent=1)
+                       "gpu_visible_at_build": os.path.exists("/dev/kfd"), "commands": cmds}, fh, indent=1)
     return out
 
 

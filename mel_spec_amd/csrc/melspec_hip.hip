@@ -23,6 +23,12 @@
 #include "fast_tables.hpp"
 #include "fbank_tables.hpp"
 #include "melspec_kernels.hpp"
+namespace melspec {
+// emitted by melspec_runs.hip (compiled with its own scheduling strategy; see there)
+extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>(const FastParams);
+extern template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
+extern template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);
+}  // namespace melspec
 #include "mel_bank.hpp"
 #include "host_pipe.hpp"
 #include "stream_plan.hpp"

@@ -1643,6 +1643,7 @@ __device__ __forceinline__ void blm_row_stats_slow(const float *r, uint64_t vali
     sd = __builtin_sqrtf(f32_div_rn(q, denom)) + 1e-5f;
 }
 
+#ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
 __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const BlmNormParams p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
@@ -1809,6 +1810,7 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const Bl
         row0 += nr;
     }
 }
+#endif  // MELSPEC_TEMPLATE_KERNELS_ONLY
 
 // The same pass for ragged batches (clips of different lengths in one launch): rows are described per clip (first output float, row
 // width, valid frames), a group of R rows is taken from a device counter (rows of long and short clips cost differently, so a static
@@ -1824,6 +1826,7 @@ struct BlmNormRaggedParams {
     unsigned *ctr;          // zero at launch
 };
 
+#ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
 __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(const BlmNormRaggedParams p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
@@ -1952,6 +1955,7 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(c
         __syncthreads();
     }
 }
+#endif  // MELSPEC_TEMPLATE_KERNELS_ONLY
 
 // ------------------------------------------------------------------------------------
 // The mel stage on its own: MelSpectrogram::add(&fft) (src/mel.rs:13-32) = SparseMelFilterbank::project_stft_log10
@@ -2389,6 +2393,7 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
 // plus the samples RingBuffer has accumulated towards the next hop (< hop).  Frames are computed in place
 // by the batch kernels on carry ++ chunk; afterwards the tail of that span becomes the new carry.
 // copies host-pushed chunks (one flat staging buffer) into the slots; optionally zero-pads (flush)
+#ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
 __global__ __launch_bounds__(256) void stream_scatter_kernel(float *state, uint64_t stride, uint32_t in_off, const StreamEntry *entries,
                                                              const float *src) {
     const StreamEntry e = entries[blockIdx.x];
@@ -2397,10 +2402,12 @@ __global__ __launch_bounds__(256) void stream_scatter_kernel(float *state, uint6
         for (uint32_t i = threadIdx.x; i < e.len; i += 256) dst[i] = src[e.src_off + i];
     for (uint32_t i = threadIdx.x; i < e.zero_fill; i += 256) dst[e.len + i] = 0.0f;
 }
+#endif  // MELSPEC_TEMPLATE_KERNELS_ONLY
 
 // new carry = the last `keep` samples before in_off + len (+ zero_fill), moved so that they end at in_off:
 // a shift to lower addresses by the chunk length.  Ascending 256-sample pieces, each read completely
 // before it is written, never touch the source of a later piece.
+#ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
 __global__ __launch_bounds__(256) void stream_carry_kernel(float *state, uint64_t stride, uint32_t in_off, const StreamEntry *entries) {
     const StreamEntry e = entries[blockIdx.x];
     const uint32_t n = e.len + e.zero_fill;
@@ -2416,6 +2423,7 @@ __global__ __launch_bounds__(256) void stream_carry_kernel(float *state, uint64_
         __syncthreads();
     }
 }
+#endif  // MELSPEC_TEMPLATE_KERNELS_ONLY
 
 // Ragged batch whose descriptors live in device memory (melspec_*_ragged_device_desc): the plan the host builds for
 // melspec_compute_ragged_device (plan_ragged in melspec_hip.hip), built by one workgroup instead -- per-clip frame counts,
@@ -2432,6 +2440,7 @@ struct PlanParams {
     uint64_t max_blocks;                           // capacity of the block table
 };
 
+#ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
 __global__ __launch_bounds__(1024) void plan_ragged_device_kernel(const PlanParams q) {
     __shared__ uint64_t part_units[1024], part_out[1024];
     const uint32_t n = q.n_clips, tid = threadIdx.x;
@@ -2471,6 +2480,7 @@ __global__ __launch_bounds__(1024) void plan_ragged_device_kernel(const PlanPara
         so += f * q.words_per_frame;
     }
 }
+#endif  // MELSPEC_TEMPLATE_KERNELS_ONLY
 
 // Hash-noise PCM (murmur3 finaliser) of SURVEY.md §8(d); the CPU tests regenerate the same bits.
 __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
@@ -2478,6 +2488,7 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
+#ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
 __global__ __launch_bounds__(256) void synth_pcm_kernel(float *out, uint64_t clip_stride, uint64_t clip_len,
                                                         uint64_t first_clip, uint32_t n_clips, uint32_t seed, uint64_t first_sample) {
     const uint64_t total = (uint64_t)n_clips * clip_len;
@@ -2489,5 +2500,6 @@ __global__ __launch_bounds__(256) void synth_pcm_kernel(float *out, uint64_t cli
         out[c * clip_stride + i] = u * (1.0f / (float)(1u << (clip & 7u)));
     }
 }
+#endif  // MELSPEC_TEMPLATE_KERNELS_ONLY
 
 }  // namespace melspec

@@ -1,0 +1,21 @@
+// melspec_runs.hip -- the run-per-wave f32 Whisper kernels (plain frame-major batches: config 2, 4, 5), as a translation unit of
+// their own so that they can be compiled with their own instruction-scheduling strategy.
+//
+// hipcc's default scheduler balances register pressure against latency for the whole file; `-mllvm -amdgpu-sched-strategy=max-ilp`
+// schedules for instruction-level parallelism first.  Measured same-box per kernel (tools/ab_run.py, profiles/r03_sched.txt): the
+// 5-frame run kernel with the compile-time 128-mel bank (config 4) -6.2 %, the six-frame run kernel (config 2, 5) -0.7 %; the
+// run-time-lens variants of the same kernels +0.1...+2 %, the f64 kernels +5...+11 %, the layout kernel of the six-frame family
+// +25 % -- so the flag cannot be given to the library, only to these specialisations.  There is no
+// source-level spelling of the per-function attribute ("amdgpu-sched-strategy"), hence the file: melspec_hip.hip declares these
+// specialisations `extern template`, their device code and host stubs are emitted here, and mel_spec_amd/build.py compiles the two
+// files to objects with their own flags and links them into libmelspec_hip.so.
+#define MELSPEC_TEMPLATE_KERNELS_ONLY      // the plain (non-template) kernels of the header belong to melspec_hip.hip
+#include "melspec_kernels.hpp"
+
+namespace melspec {
+
+template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>(const FastParams);
+template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
+template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);
+
+}  // namespace melspec

@@ -28,8 +28,8 @@ def wall(fn, sync, iters):
         sync()
         best = min(best, (time.perf_counter() - t0) / iters * 1e3)
     return best
-if case in ("cfg2", "cfg4", "f64", "mm", "f32"):
-    nm = 128 if case == "cfg4" else 80
+if case in ("cfg2", "cfg4", "f64", "mm", "f32") or case.startswith("nm"):
+    nm = 128 if case == "cfg4" else (int(case[2:]) if case.startswith("nm") else 80)      # nm<k>: k mels (run-time-lens kernels for non-default banks)
     m = M.HipMelSpectrogram(400, 160, 16000.0, nm)
     if case == "f64": m.set_precision("f64")
     if case == "f32": m.set_precision("f32")

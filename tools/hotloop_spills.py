@@ -5,8 +5,14 @@ A spill in the tail is cheap; one in the loop is paid per unit (the mel-major ke
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(tempfile.gettempdir(), "melspec_hotloop.s")
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
-                os.path.join(ROOT, "mel_spec_amd", "csrc", "melspec_hip.hip")], check=True, stderr=subprocess.DEVNULL)
+sys.path.insert(0, ROOT)
+from mel_spec_amd.build import SOURCES, UNIT_FLAGS          # every translation unit with the flags the library build gives it
+with open(out, "w") as cat:
+    for src in SOURCES:
+        part = out + "." + src
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", part,
+                        os.path.join(ROOT, "mel_spec_amd", "csrc", src)] + UNIT_FLAGS.get(src, []), check=True, stderr=subprocess.DEVNULL)
+        cat.write(open(part).read())
 name, body, bad = None, [], 0
 def report(name, body):
     prio = [i for i, l in enumerate(body) if "s_setprio" in l]

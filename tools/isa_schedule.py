@@ -4,9 +4,13 @@
 import os, re, subprocess, sys, textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 asm = "/tmp/melspec_isa.s"
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
-                os.path.join(ROOT, "mel_spec_amd", "csrc", "melspec_hip.hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL, cwd="/tmp")
-s = open(asm).read()
+sys.path.insert(0, ROOT)
+from mel_spec_amd.build import SOURCES, UNIT_FLAGS          # every translation unit with the flags the library build gives it
+s = ""
+for src in SOURCES:
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "mel_spec_amd", "csrc", src), "-o", asm] + UNIT_FLAGS.get(src, []), check=True, stderr=subprocess.DEVNULL, cwd="/tmp")
+    s += open(asm).read()
 def cls(l):
     op = l.split()[0]
     if op.endswith(':'): return '|'

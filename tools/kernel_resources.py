@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
-"""Compiles csrc/melspec_hip.hip with -Rpass-analysis=kernel-resource-usage and prints one line per kernel:
+"""Compiles the translation units of the library (mel_spec_amd/build.py: SOURCES, UNIT_FLAGS) with -Rpass-analysis=kernel-resource-usage and prints one line per kernel:
 VGPRs / SGPRs / scratch bytes / occupancy.  Usage: tools/kernel_resources.py [substring filter] [extra hipcc flags]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-c", "-Rpass-analysis=kernel-resource-usage",
-       os.path.join(ROOT, "mel_spec_amd", "csrc", "melspec_hip.hip"), "-o", "/dev/null"] + sys.argv[2:]
-err = subprocess.run(cmd, capture_output=True, text=True).stderr
+sys.path.insert(0, ROOT)
+from mel_spec_amd.build import SOURCES, UNIT_FLAGS          # every translation unit with the flags the library build gives it
+err = ""
+for src in SOURCES:
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-c", "-Rpass-analysis=kernel-resource-usage",
+           os.path.join(ROOT, "mel_spec_amd", "csrc", src), "-o", "/dev/null"] + UNIT_FLAGS.get(src, []) + sys.argv[2:]
+    err += subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
 rows = {}
 for line in err.splitlines():
