@@ -97,6 +97,7 @@ MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *MS_RESTRICT tblob
 template <class T>
 MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_first, const T *tblob, T *xo /* &row[0][n2] */) {
     cpx<T> x[16];
+    const T dc = (T(1) - preemph) * mean;
     // every load first and unconditional: 13 pairs (lanes n2 >= 8 have no 13th pair: they re-read pair 0 and drop it) and
     // the sample in front of each pair (the first sample of a clip has none: it re-reads itself and the value is unused)
     f2 c[13];
@@ -114,10 +115,11 @@ MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_
             const int i = 32 * n1 + 2 * n2;
             // frame_buf[i] = x[i] - mean; frame_buf[i] -= preemph * frame_buf[i-1]  (src/fbank.rs:165-181);
             // the first sample of a clip gets no pre-emphasis
-            const T b0 = static_cast<T>(c[n1].x) - mean, b1 = static_cast<T>(c[n1].y) - mean;
-            const T pe = b0 - preemph * (static_cast<T>(prev[n1]) - mean);
-            const T y0 = (n1 == 0 && patch_first) ? b0 : pe;
-            const T y1 = b1 - preemph * b0;
+            // = (x[i] - m) - a (x[i-1] - m) = x[i] - a x[i-1] - (1 - a) m: two operations per sample (dc = (1 - a) m)
+            const T x0 = static_cast<T>(c[n1].x), x1 = static_cast<T>(c[n1].y);
+            const T pe = (x0 - preemph * static_cast<T>(prev[n1])) - dc;
+            const T y0 = (n1 == 0 && patch_first) ? x0 - mean : pe;
+            const T y1 = (x1 - preemph * x0) - dc;
             const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
             x[n1] = {y0 * w.re, y1 * w.im};
         }
@@ -125,6 +127,8 @@ MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_
     fb_column_finish<T>(x, n2, tblob, xo);
 }
 
+// (The sample in front of each pair as a row_ror:1 DPP move of the left neighbour's second sample instead of 12 more loads per lane:
+// 0.7101 vs 0.7103 ms, neutral -- the loads hit L1.)
 // (Loading the samples once for both the frame sum and the column -- one round trip, 26 conversions and 13 loads fewer per unit --
 // was measured: no difference, 0.733 ms either way, and 20 more VGPRs.  The second read hits L1 and two waves hide it.)
 // phase 1 (after the frame mean is known): lane t does column n2 = t (13 non-zero inputs for t < 8, else 12).
@@ -242,6 +246,29 @@ MS_DEV double partner16(double v) {
 }
 #else
 template <class T> MS_DEV T partner16(T v) { return v; }      // host pass of the kernel source only; tests/emu exchanges explicitly
+#endif
+
+// Sum of the 16 values of the caller's row in the fixed tree ((p0+p1)+(p2+p3))+((p4+p5)+(p6+p7)) + (the same over 8..15), delivered to
+// every lane of the row: four butterfly levels of DPP moves (swap within pairs, swap pairs within quads, row_half_mirror, row_mirror)
+// -- a + b == b + a exactly, so the lane that adds "the other half first" gets the same bits.  Replaces 16 partial sums through LDS
+// and 15 f64 additions per lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL> MS_DEV double dpp_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> MS_DEV float dpp_f64(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <class T> MS_DEV T row_sum16(T v) {
+    v = v + dpp_f64<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = v + dpp_f64<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = v + dpp_f64<0x141>(v);       // row_half_mirror
+    v = v + dpp_f64<0x140>(v);       // row_mirror
+    return v;
+}
+#else
+template <class T> MS_DEV T row_sum16(T v) { return v; }      // host pass of the kernel source only; tests/emu sums the partials itself
 #endif
 
 // phase 2a: this lane's row of the exchange buffer through a 16-point DFT: own[k2] = Z[r + 16*k2]

@@ -1206,17 +1206,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         MS_PRIO(0);
         if (FLAVOR == kFlavorKaldi) {
             const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            // frame mean (src/fbank.rs:165-166): 16 partial sums of 24-26 samples through LDS, fixed tree
-            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
-            __builtin_amdgcn_wave_barrier();
-            T mean = 0;
-            if (act) {
-                const T *ps = slice + L::kSumOff + fl * kFbLanes;
-                const T a = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
-                const T b = ((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15]));
-                mean = (a + b) / T(400);
-            }
-            __builtin_amdgcn_wave_barrier();
+            // frame mean (src/fbank.rs:165-166): the 16 partial sums of the frame's lanes in a fixed tree, over DPP (row_sum16)
+            const T mean = row_sum16<T>(act ? fb_partial_sum<T>(frame, j) : T(0)) / T(400);
             fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
         } else if (FLAVOR == kFlavorWhisper) {
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
@@ -1470,16 +1461,8 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             const bool act = fl < nv;
             MS_PRIO(0);
             const float *frame = pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            slice[L::kSumOff + lane] = act ? fb_partial_sum<T>(frame, j) : T(0);
-            __builtin_amdgcn_wave_barrier();
-            T mean = 0;
-            if (act) {
-                const T *ps = slice + L::kSumOff + fl * kFbLanes;
-                const T a = ((ps[0] + ps[1]) + (ps[2] + ps[3])) + ((ps[4] + ps[5]) + (ps[6] + ps[7]));
-                const T b = ((ps[8] + ps[9]) + (ps[10] + ps[11])) + ((ps[12] + ps[13]) + (ps[14] + ps[15]));
-                mean = (a + b) / T(400);
-            }
-            __builtin_amdgcn_wave_barrier();
+            // frame mean (src/fbank.rs:165-166): the 16 partial sums of the frame's lanes in a fixed tree, over DPP (row_sum16)
+            const T mean = row_sum16<T>(act ? fb_partial_sum<T>(frame, j) : T(0)) / T(400);
             fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(1);
