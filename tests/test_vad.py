@@ -333,3 +333,30 @@ def test_gpu_stream_detector_long_pushes(gpu, oracle, jfk):
     assert got == want
     assert any(w is not None and w[0] for w in want) and any(w is not None and not w[0] for w in want)
     bank.close(); m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_mels,kw", [(8, dict(min_energy=0.3, min_y=2, min_x=3, min_mel=0)), (80, dict(min_energy=1.0, min_y=0, min_x=7, min_mel=0)),
+                                       (80, dict(min_energy=0.6, min_y=3, min_x=66, min_mel=1)), (80, dict(min_energy=0.5, min_y=1, min_x=5, min_mel=500)),
+                                       (128, dict(min_energy=0.98, min_y=11, min_x=5, min_mel=2)), (80, dict(min_energy=1.0, min_y=3, min_x=2, min_mel=0)),
+                                       (5, dict(min_energy=0.2, min_y=1, min_x=4, min_mel=0))])
+def test_gpu_stream_detector_settings_and_banks(gpu, oracle, jfk, n_mels, kw):
+    """The detector stage at the edges of its settings (min_y = 0: every column intersected; min_x = 66: the whole 64-bit history;
+    min_x = 2: windows too narrow for the stencil; min_mel beyond the image) and on other banks (8 / 128 mels on the fused kernels,
+    5 mels on the generic one), against the restated add_activity."""
+    m = gpu.HipMelSpectrogram(400, 160, 16000.0, n_mels)
+    bank = gpu.StreamBank(m, 1, 16000)
+    bank.enable_vad(gpu.DetectionSettings(**kw))
+    rows, acts = [], []
+    rng = np.random.default_rng(n_mels + kw["min_x"])
+    pos = 0
+    x = jfk[:120000]
+    while pos < len(x):
+        n = int(min(len(x) - pos, rng.choice([160, 320, 1000, 7000, 16000])))
+        r, a = bank.push_vad([0], [x[pos:pos + n]])
+        rows.append(r[0]); acts += a[0]; pos += n
+    rows = np.concatenate(rows)
+    want = oracle.voice_activity_stream(rows, **kw)
+    got = [None if v is None else (v.active, v.frame_index, v.leading_active_columns, v.active_columns, v.window_columns) for v in acts]
+    assert got == want, next(k for k, (p, q) in enumerate(zip(got, want)) if p != q)
+    bank.close(); m.close()
