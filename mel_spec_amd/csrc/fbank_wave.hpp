@@ -61,7 +61,7 @@ struct FbankLayout {
     static constexpr int kXRow = sizeof(T) == 8 ? 34 : 32;
     static constexpr int kXStride = 16 * kXRow;            // lanes of different frames never share an LDS access group
     static constexpr int kPStride = 259;                   // f32 power rows (bins 0..256), aliased over the rows
-    static constexpr int kSumOff = 0;                      // 64 partial sums (units of T): dead before phase 1 writes the rows
+    static constexpr int kSumOff = 0;                      // 64 partial sums (units of T): the host form of the frame mean in tests/emu (the kernels: row_sum16)
     static constexpr int slice_elems() { return (kFbFPW * kXStride + 1) & ~1; }   // units of T
 };
 
