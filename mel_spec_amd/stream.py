@@ -222,3 +222,43 @@ class RingBuffer:
 
     def close(self) -> None:
         self._bank.close()
+
+
+class Spectrogram:
+    """Spectrogram::{new, add} (src/stft.rs:25-86) with the overlap-save state on the device: add(frames) takes at most hop_size
+    samples and returns the [fft_size] complex128 spectrum of the window that ends with them once fft_size samples have been seen,
+    else None.  A block shorter than hop_size is zero-padded like the reference's (:57-60); the reference then advances its sample
+    count by the real samples only, this mirror by a whole hop -- which matters only for when the very first frame of a stream
+    appears.  compute_all_cpu is HipMelSpectrogram.compute_all."""
+
+    def __init__(self, fft_size: int, hop_size: int, device: int = -1):
+        self.fft_size, self.hop_size = int(fft_size), int(hop_size)
+        self._mel = HipMelSpectrogram(self.fft_size, self.hop_size, 16000.0, 1, device=device)     # geometry only: no mel stage is run
+        self._bank = StreamBank(self._mel, 1, self.hop_size)
+
+    def add(self, frames) -> Optional[np.ndarray]:
+        x = _f32(frames).ravel()
+        assert x.shape[0] <= self.hop_size, "frames must be <= hop_size"
+        if x.shape[0] < self.hop_size:
+            x = np.concatenate([x, np.zeros(self.hop_size - x.shape[0], np.float32)])
+        out = self._bank.push_stft([0], [x], np.complex128, True)[0]
+        return out[0] if out.shape[0] else None
+
+    def close(self) -> None:
+        self._bank.close(); self._mel.close()
+
+
+class MelSpectrogram:
+    """MelSpectrogram::{new, add} (src/mel.rs:13-32): add(fft) projects one spectrum ([fft_size] complex, what Spectrogram::add
+    returns) onto the Slaney bank, log10, per-frame normalisation -> (n_mels, 1) float64 like the reference's Array2<f64>."""
+
+    def __init__(self, fft_size: int, sampling_rate: float, n_mels: int, device: int = -1):
+        self._mel = HipMelSpectrogram(int(fft_size), max(1, int(fft_size) // 2), float(sampling_rate), int(n_mels), device=device)
+
+    def add(self, fft) -> np.ndarray:
+        a = np.ascontiguousarray(fft, np.complex128).reshape(1, -1)
+        return self._mel.mel_from_stft(a)[0].astype(np.float64).reshape(-1, 1)
+
+    def close(self) -> None:
+        self._mel.close()
+

@@ -611,7 +611,10 @@ def _check_nemo_normalised(gpu, oracle, kw, x, got, want, valid):
     std = raw_want[:, :valid].astype(np.float64).std(axis=1, ddof=1) if valid > 1 else np.zeros(raw_want.shape[0])
     good = std >= 0.5
     if good.any():
-        assert np.abs(got[good] - want[good]).max() <= TOL, float(np.abs(got[good] - want[good]).max())
+        # relative to max(1, |z|): a large z-score (an outlier frame in an otherwise flat row) carries the relative error of the row's
+        # std, a few 1e-6, as an absolute one (found by tools/fuzz_gpu.py: |z| ~ 40, 1.08e-4 absolute)
+        d = np.abs(got[good] - want[good]) / np.maximum(1.0, np.abs(want[good]))
+        assert d.max() <= TOL, float(d.max())
     return int(good.sum())
 
 

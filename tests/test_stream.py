@@ -223,3 +223,33 @@ def test_gpu_device_producer_path_and_many_streams(gpu, oracle):
         mine = np.stack([g[s] for g in got])
         assert mine.shape == want.shape == (4, 80) and np.abs(mine - want).max() <= TOL
     out.free(); bank.close(); m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_spectrogram_and_mel_spectrogram_objects(gpu, oracle, jfk):
+    """The reference's per-frame pair (README usage): Spectrogram::add hop by hop (src/stft.rs:48-86) feeding MelSpectrogram::add
+    (src/mel.rs:26-32).  Spectra equal compute_all_cpu on the samples from the stream's first frame on; mel columns equal the
+    streaming restatement."""
+    fft, hop = 400, 160
+    sg = gpu.Spectrogram(fft, hop)
+    ms = gpu.MelSpectrogram(fft, SR, 80)
+    x = jfk[:16000]
+    specs, mels = [], []
+    for p in range(0, len(x) - hop + 1, hop):
+        f = sg.add(x[p:p + hop])
+        if f is not None:
+            assert f.shape == (fft,) and f.dtype == np.complex128
+            specs.append(f)
+            col = ms.add(f)
+            assert col.shape == (80, 1) and col.dtype == np.float64
+            mels.append(col[:, 0])
+    first = ((fft + hop - 1) // hop) * hop - fft                       # 80: the first window ends at the third hop
+    want = oracle.compute_all_cpu(x[first:], fft, hop)
+    assert len(specs) == want.shape[0] == 98
+    assert np.abs(np.stack(specs) - want).max() <= 1e-9 * np.abs(want).max()
+    want_mel = oracle.stream_mel(x, fft, hop, 80, SR)
+    assert np.abs(np.stack(mels) - want_mel).max() <= TOL
+    assert sg.add(x[:37]) is not None                                   # a short block is zero-padded (src/stft.rs:57-60)
+    with pytest.raises(AssertionError):
+        sg.add(x[:hop + 1])
+    sg.close(); ms.close()
