@@ -360,3 +360,38 @@ def test_gpu_stream_detector_settings_and_banks(gpu, oracle, jfk, n_mels, kw):
     got = [None if v is None else (v.active, v.frame_index, v.leading_active_columns, v.active_columns, v.window_columns) for v in acts]
     assert got == want, next(k for k, (p, q) in enumerate(zip(got, want)) if p != q)
     bank.close(); m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_stream_detector_argument_errors(gpu, jfk):
+    """Error behaviour of the detector stage: settings the 64-bit history cannot serve, negative settings, calls for records while the
+    stage is off, a records buffer that is too small or missing -- each a library error, none a crash, and the bank stays usable."""
+    import ctypes as C2
+    from mel_spec_amd import _lib
+    from mel_spec_amd.stream import ACTIVITY_DTYPE
+    m = gpu.HipMelSpectrogram(400, 160, 16000.0, 80)
+    bank = gpu.StreamBank(m, 2, 4000)
+    with pytest.raises(gpu.HipError):
+        bank.enable_vad(gpu.DetectionSettings(min_x=67))
+    with pytest.raises(gpu.HipError):
+        bank.enable_vad(gpu.DetectionSettings(min_y=-1))
+    with pytest.raises(gpu.HipError):
+        bank.push_vad([0], [jfk[:1600]])                              # the stage is off
+    bank.enable_vad(gpu.DetectionSettings(min_x=66))                   # the largest window there is
+    L = _lib.lib()
+    ids = np.array([0], np.uint32); lens = np.array([1600], np.uint32)
+    out = np.zeros((10, 80), np.float32); frames = np.zeros(1, np.uint32); acts = np.zeros(1, ACTIVITY_DTYPE)
+    x = np.ascontiguousarray(jfk[:1600])
+    rc = L.melspec_stream_push_host_vad(bank._h, ids.ctypes.data_as(C2.POINTER(C2.c_uint32)), x.ctypes.data_as(C2.POINTER(C2.c_float)),
+                                        lens.ctypes.data_as(C2.POINTER(C2.c_uint32)), 1, out.ctypes.data_as(C2.POINTER(C2.c_float)), out.size,
+                                        frames.ctypes.data_as(C2.POINTER(C2.c_uint32)), acts.ctypes.data_as(C2.c_void_p), 1)
+    assert rc == _lib.ERR_CAPACITY                                     # 8 frames come out of 1600 samples at this point, room for one record
+    assert bank.vad_frames(0) == 0                                      # nothing was committed
+    r, a = bank.push_vad([0], [x])
+    assert r[0].shape[0] == len(a[0]) == 8 and all(v is None for v in a[0]) and bank.vad_frames(0) == 8
+    d_out = gpu.DeviceBuffer(2 * 30 * 80 * 4)
+    with pytest.raises(gpu.HipError):
+        bank.push_device_vad([1], [0], d_out.ptr, 0)                   # no frames -> fine; but a NULL records pointer with frames is an error:
+        gpu.synth_pcm_window(bank.input_ptr(1), 1, 1600, 0, 1)
+        bank.push_device_vad([1], [1600], d_out.ptr, 0)
+    d_out.free(); bank.close(); m.close()
