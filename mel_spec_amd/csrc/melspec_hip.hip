@@ -2130,6 +2130,21 @@ struct melspec_stream {
     melspec_vad_settings vad{};
     DevBuf vad_state, vad_prev, vad_acts;
     std::vector<uint64_t> vad_count;     // host copy of StreamVadState::count (VoiceActivityDetector::frame_index)
+    // Steady state of a live bank: the same streams pushing the same number of samples from the same pending count, every stream past
+    // its first window.  Such a push has the entry table and the ragged plan of the previous one -- both are still on the device --
+    // so neither is built or uploaded again (4096 streams x 1 hop: 0.089 -> 0.05 ms per push).
+    struct PushCache {
+        bool valid = false;
+        uint32_t n = 0;
+        int fpu = 0;
+        const void *d_out = nullptr;
+        std::vector<uint32_t> ids, lens, pend;
+        std::vector<uint64_t> out_off;       // the caller's row offsets (empty: packed)
+        StreamPlan pl;
+        const StreamEntry *d_e = nullptr;    // the entries in the ring slot of the push that filled the cache
+        BatchPlan plan;
+    } cache;
+    RaggedScratch plan_ring;             // the ragged plans of the pushes (the context's own ring serves its other callers)
 };
 
 namespace {
@@ -2151,8 +2166,22 @@ struct StreamEmit {
 };
 
 // scatter (optional) -> frames -> carry update, all on one stream
+// does this push repeat the cached one?  (ids / lens / pending before the push; every stream was past its first window when the cache
+// was filled and idx only grows, resets invalidate)
+bool stream_cache_hit(melspec_stream *st, const uint32_t *ids, const uint32_t *lens, uint32_t n, const void *d_out, const uint64_t *h_out_off) {
+    const melspec_stream::PushCache &k = st->cache;
+    if (!k.valid || k.n != n || k.d_out != d_out || k.out_off.empty() != (h_out_off == nullptr)) return false;
+    if (k.fpu != ctx_frames_per_unit(st->ctx)) return false;            // AUTO changed its regime: another unit size
+    for (uint32_t i = 0; i < n; ++i)
+        if (ids[i] != k.ids[i] || lens[i] != k.lens[i] || st->book.pending[ids[i]] != k.pend[i]) return false;
+    return h_out_off == nullptr || std::memcmp(h_out_off, k.out_off.data(), static_cast<size_t>(n) * sizeof(uint64_t)) == 0;
+}
+
+// reuse: `pl` is st->cache.pl and the device still holds its entries and plan (stream_cache_hit); ids / lens: the push's arguments,
+// for filling the cache (NULL: do not, e.g. a flush)
 int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float *d_src, void *d_out, const uint64_t *h_out_off,
-               hipStream_t s, const StreamEmit &emit = StreamEmit(), melspec_vad_activity *d_acts = nullptr) {
+               hipStream_t s, const StreamEmit &emit = StreamEmit(), melspec_vad_activity *d_acts = nullptr, bool reuse = false,
+               const uint32_t *ids = nullptr, const uint32_t *lens = nullptr) {
     melspec_ctx *c = st->ctx;
     HIP_TRY(hipSetDevice(c->dev.device));
     if (pl.total_frames && !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "d_out is NULL");      // before anything is queued
@@ -2162,27 +2191,31 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
         if (rc0) return rc0;
         d_acts = static_cast<melspec_vad_activity *>(st->vad_acts.p);
     }
+    int rc = MELSPEC_OK;
     // the entries travel like a ragged plan: pinned slot, copy kernel on the launch stream (no SDMA queue hand-over)
-    RaggedSlot &sl = st->ring.slot[st->ring.next++ % RaggedScratch::kSlots];
-    if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    if (sl.pending) { HIP_TRY(hipEventSynchronize(sl.ev)); sl.pending = false; }
-    const size_t ebytes = (static_cast<size_t>(n) * sizeof(StreamEntry) + 15) & ~static_cast<size_t>(15);
-    int rc = sl.ensure_host(ebytes);
-    if (rc) return rc;
-    if ((rc = sl.dev.ensure(ebytes))) return rc;
-    std::memcpy(sl.host, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry));
-    if (h_out_off)                                   // caller-placed rows: the detector stage reads them where they are
-        for (uint32_t i = 0; i < n; ++i) static_cast<StreamEntry *>(sl.host)[i].out_off = h_out_off[i];
-    // from here on the slot is in use by queued work: every exit records its event (the next user of the slot waits for it)
-    struct SlotGuard { RaggedSlot *sl; hipStream_t s; ~SlotGuard() { plan_ragged_done(sl, s); } } slot_guard{&sl, s};
-    {
+    struct SlotGuard { RaggedSlot *sl; hipStream_t s; ~SlotGuard() { plan_ragged_done(sl, s); } } slot_guard{nullptr, s};
+    const StreamEntry *d_e = st->cache.d_e;
+    if (!reuse) {
+        st->cache.valid = false;                     // whatever happens below, the slot the cache points into may be the next one taken
+        RaggedSlot &sl = st->ring.slot[st->ring.next++ % RaggedScratch::kSlots];
+        if (!sl.ev) HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        if (sl.pending) { HIP_TRY(hipEventSynchronize(sl.ev)); sl.pending = false; }
+        const size_t ebytes = (static_cast<size_t>(n) * sizeof(StreamEntry) + 15) & ~static_cast<size_t>(15);
+        rc = sl.ensure_host(ebytes);
+        if (rc) return rc;
+        if ((rc = sl.dev.ensure(ebytes))) return rc;
+        std::memcpy(sl.host, pl.entries.data(), static_cast<size_t>(n) * sizeof(StreamEntry));
+        if (h_out_off)                                   // caller-placed rows: the detector stage reads them where they are
+            for (uint32_t i = 0; i < n; ++i) static_cast<StreamEntry *>(sl.host)[i].out_off = h_out_off[i];
+        // from here on the slot is in use by queued work: every exit records its event (the next user of the slot waits for it)
+        slot_guard.sl = &sl;
         const size_t n16 = ebytes / 16;
         const unsigned blocks = static_cast<unsigned>((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
         hipLaunchKernelGGL(plan_upload_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, static_cast<const uint4 *>(sl.host),
                            static_cast<uint4 *>(sl.dev.p), n16);
         HIP_TRY(hipGetLastError());
+        d_e = static_cast<const StreamEntry *>(sl.dev.p);
     }
-    const StreamEntry *d_e = static_cast<const StreamEntry *>(sl.dev.p);
     float *state = static_cast<float *>(st->state.p);
     bool any_fill = d_src != nullptr;
     for (uint32_t i = 0; i < n && !any_fill; ++i) any_fill = pl.entries[i].zero_fill != 0;
@@ -2198,8 +2231,32 @@ int stream_run(melspec_stream *st, const StreamPlan &pl, uint32_t n, const float
         rc = melspec_stft_ragged_device(c, state, pl.off.data(), pl.len.data(), n, d_out, h_out_off ? h_out_off : oo.data(), emit.dtype, emit.full, s);
         if (rc) return rc;
     } else if (pl.total_frames) {
-        rc = melspec_compute_ragged_device(c, state, pl.off.data(), pl.len.data(), n, static_cast<float *>(d_out),
-                                           h_out_off ? h_out_off : pl.out_off.data(), s);
+        if (reuse) {
+            rc = launch_ctx(c, st->cache.plan.desc, s);
+        } else {
+            // melspec_compute_ragged_device with the plan kept: frames per entry are the plan's, the ring is the bank's own
+            std::vector<uint64_t> fr(n);
+            for (uint32_t i = 0; i < n; ++i) fr[i] = pl.frames[i];
+            RaggedSlot *pslot = nullptr;
+            const int fpu = ctx_frames_per_unit(c);
+            rc = plan_ragged(st->plan_ring, s, state, static_cast<float *>(d_out), pl.off.data(), fr, h_out_off ? h_out_off : pl.out_off.data(), n,
+                             c->n_mels, fpu, st->cache.plan, pslot);
+            if (!rc) rc = launch_ctx(c, st->cache.plan.desc, s);
+            plan_ragged_done(pslot, s);
+            // a push that can come again: every stream past its first window (no skipped hops), not a flush
+            bool steady = !rc && ids != nullptr && lens != nullptr;
+            for (uint32_t i = 0; i < n && steady; ++i) steady = st->book.idx[ids[i]] >= st->geom.n_fft;
+            if (steady) {
+                melspec_stream::PushCache &k = st->cache;
+                k.n = n; k.fpu = fpu; k.d_out = d_out; k.d_e = d_e;
+                k.ids.assign(ids, ids + n); k.lens.assign(lens, lens + n);
+                k.pend.resize(n);
+                for (uint32_t i = 0; i < n; ++i) k.pend[i] = st->book.pending[ids[i]];
+                if (h_out_off) k.out_off.assign(h_out_off, h_out_off + n); else k.out_off.clear();
+                k.pl = pl;
+                k.valid = true;
+            }
+        }
         if (rc) return rc;
         if (st->vad_on) {
             StreamVadParams vp{};
@@ -2249,12 +2306,13 @@ void melspec_stream_destroy(melspec_stream *st) {
     if (!st) return;
     if (st->ctx) { (void)hipSetDevice(st->ctx->dev.device); (void)hipStreamSynchronize(st->ctx->stream); }
     st->state.release(); st->ring.release(); st->staging.release(); st->out.release();
-    st->vad_state.release(); st->vad_prev.release(); st->vad_acts.release();
+    st->vad_state.release(); st->vad_prev.release(); st->vad_acts.release(); st->plan_ring.release();
     delete st;
 }
 
 int melspec_stream_reset(melspec_stream *st, const uint32_t *ids, uint32_t n) {
     if (!st) return fail(MELSPEC_ERR_INVALID_ARG, "stream bank is NULL");
+    st->cache.valid = false;
     HIP_TRY(hipSetDevice(st->ctx->dev.device));
     if (!ids) {
         HIP_TRY(hipMemsetAsync(st->state.p, 0, static_cast<size_t>(st->geom.n_streams) * st->geom.stride * sizeof(float), st->ctx->stream));
@@ -2301,11 +2359,14 @@ static int stream_push_device_impl(melspec_stream *st, const uint32_t *ids, cons
     if (want_acts && !st->vad_on) return fail(MELSPEC_ERR_INVALID_ARG, "the detector stage is off (melspec_stream_enable_vad)");
     if (n == 0) return MELSPEC_OK;
     if (!ids || !lens) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
-    StreamPlan pl;
-    int rc = stream_plan(st, ids, lens, n, false, pl);
+    StreamPlan fresh;
+    const bool reuse = stream_cache_hit(st, ids, lens, n, d_out, h_out_offsets);
+    int rc = reuse ? MELSPEC_OK : stream_plan(st, ids, lens, n, false, fresh);
     if (rc) return rc;
+    const StreamPlan &pl = reuse ? st->cache.pl : fresh;
     if (want_acts && pl.total_frames && !d_acts) return fail(MELSPEC_ERR_INVALID_ARG, "d_acts is NULL");
-    rc = stream_run(st, pl, n, nullptr, d_out, h_out_offsets, stream ? static_cast<hipStream_t>(stream) : st->ctx->stream, StreamEmit(), d_acts);
+    rc = stream_run(st, pl, n, nullptr, d_out, h_out_offsets, stream ? static_cast<hipStream_t>(stream) : st->ctx->stream, StreamEmit(), d_acts,
+                    reuse, ids, lens);
     if (rc) return rc;
     stream_commit(st, ids, lens, n, false);
     stream_vad_commit(st, ids, pl, n);
@@ -2354,9 +2415,11 @@ static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const 
     if (want_acts && !st->vad_on) return fail(MELSPEC_ERR_INVALID_ARG, "the detector stage is off (melspec_stream_enable_vad)");
     if (n == 0) return MELSPEC_OK;
     if (!ids || (!flush && !lens)) return fail(MELSPEC_ERR_INVALID_ARG, "ids/lens is NULL");
-    StreamPlan pl;
-    int rc = stream_plan(st, ids, lens, n, flush, pl);
+    StreamPlan fresh;
+    const bool reuse = !flush && !emit.stft && stream_cache_hit(st, ids, lens, n, st->out.p, nullptr);
+    int rc = reuse ? MELSPEC_OK : stream_plan(st, ids, lens, n, flush, fresh);
     if (rc) return rc;
+    const StreamPlan &pl = reuse ? st->cache.pl : fresh;
     // elements the caller receives: floats (mel rows) or complex values (spectra)
     const uint64_t need = pl.total_frames * (emit.stft ? melspec_stft_bins(st->ctx, emit.full) : static_cast<uint64_t>(st->ctx->n_mels));
     const size_t esz = emit.stft ? (emit.dtype == MELSPEC_STFT_F64 ? 16 : 8) : sizeof(float);
@@ -2373,8 +2436,10 @@ static int stream_push_host_impl(melspec_stream *st, const uint32_t *ids, const 
     if ((rc = st->out.ensure(need * esz + 16))) return rc;
     if (total) HIP_TRY(hipMemcpyAsync(st->staging.p, samples, total * sizeof(float), hipMemcpyHostToDevice, s));
     if (st->vad_on && pl.total_frames && (rc = st->vad_acts.ensure(pl.total_frames * sizeof(melspec_vad_activity)))) return rc;
+    // (st->out may have been re-allocated by the ensure above: the cache is keyed on its address, a stale one simply misses next time)
     rc = stream_run(st, pl, n, total ? static_cast<const float *>(st->staging.p) : nullptr, st->out.p, nullptr, s, emit,
-                    static_cast<melspec_vad_activity *>(st->vad_acts.p));
+                    static_cast<melspec_vad_activity *>(st->vad_acts.p), reuse && st->cache.d_out == st->out.p, flush || emit.stft ? nullptr : ids,
+                    flush || emit.stft ? nullptr : lens);
     if (rc) return rc;
     if (need) {
         HIP_TRY(hipMemcpyAsync(out, st->out.p, need * esz, hipMemcpyDeviceToHost, s));

@@ -253,3 +253,65 @@ def test_gpu_spectrogram_and_mel_spectrogram_objects(gpu, oracle, jfk):
     with pytest.raises(AssertionError):
         sg.add(x[:hop + 1])
     sg.close(); ms.close()
+
+
+@pytest.mark.gpu
+def test_gpu_steady_state_pushes_reuse_the_previous_plan(gpu, oracle, jfk):
+    """A push that repeats the previous one (same streams, same lengths, same pending counts, every stream past its first window) reuses
+    the entry table and the ragged plan that are still on the device.  Runs of such pushes interleaved with everything that must miss --
+    another length, a subset of the streams, a pending remainder, a reset, the host and the device form alternating, a flush -- give,
+    stream by stream, exactly the frames of the reference's streaming loop."""
+    hop = 160
+    m = gpu.HipMelSpectrogram(400, hop, SR, 80)
+    bank = gpu.StreamBank(m, 3, 4000)
+    src = [jfk[:70000], jfk[30000:100000], (oracle.synth_pcm(3, 70000) * np.float32(0.3))]
+    pos, got = [0, 0, 0], [[], [], []]
+
+    def push(ids, lens):
+        chunks = [src[i][pos[i]:pos[i] + n] for i, n in zip(ids, lens)]
+        for i, n in zip(ids, lens):
+            pos[i] += n
+        for i, r in zip(ids, bank.push(ids, chunks)):
+            got[i].append(r)
+
+    for _ in range(8): push([0, 1, 2], [hop] * 3)              # fills, then hits
+    push([0, 1, 2], [hop, 2 * hop, hop])                      # another length: miss
+    for _ in range(5): push([0, 1, 2], [hop] * 3)              # miss, then hits
+    push([0, 2], [hop, hop])                                  # a subset: miss
+    for _ in range(4): push([0, 2], [hop, hop])                # hits
+    push([0, 1, 2], [37, hop, hop])                           # leaves a remainder in stream 0: miss
+    for _ in range(4): push([0, 1, 2], [hop] * 3)              # pending 37 stays: miss once, then hits
+    push([0, 1, 2], [hop - 37, hop, hop])                     # remainder gone
+    for _ in range(6): push([0, 1, 2], [hop] * 3)
+    for i in range(3):
+        want = oracle.stream_mel(src[i][:pos[i]], 400, hop, 80, SR)
+        mine = np.concatenate(got[i])
+        assert mine.shape == want.shape and np.abs(mine - want).max() <= TOL, i
+    # a reset invalidates; the stream starts again at its first window
+    bank.reset([1])
+    pos[1], got[1] = 0, []
+    for _ in range(7): push([0, 1, 2], [hop] * 3)
+    want = oracle.stream_mel(src[1][:pos[1]], 400, hop, 80, SR)
+    assert np.concatenate(got[1]).shape == want.shape and np.abs(np.concatenate(got[1]) - want).max() <= TOL
+    # the device form between host pushes, then a flush (never cached)
+    from mel_spec_amd import _lib
+    import ctypes as C2
+    d_out = gpu.DeviceBuffer(3 * 80 * 4)
+    for _ in range(3):
+        for i in range(3):                                        # the producer writes the next hop straight into the stream's slot
+            x = np.ascontiguousarray(src[i][pos[i]:pos[i] + hop])
+            assert _lib.lib().melspec_memcpy_h2d(C2.c_void_p(bank.input_ptr(i)), x.ctypes.data_as(C2.c_void_p), x.nbytes) == 0
+            pos[i] += hop
+        fr = bank.push_device([0, 1, 2], [hop] * 3, d_out.ptr)
+        rows = d_out.download((3, 80))
+        for i in range(3):
+            assert fr[i] == 1
+            got[i].append(rows[i:i + 1].copy())
+        push([0, 1, 2], [hop] * 3)
+    tail = bank.flush([0, 1, 2])
+    for i in range(3):
+        want = oracle.stream_mel(src[i][:pos[i]], 400, hop, 80, SR)
+        mine = np.concatenate(got[i])
+        assert mine.shape == want.shape and np.abs(mine - want).max() <= TOL, i
+        assert tail[i].shape[0] == 0                              # nothing pending: a flush emits nothing
+    d_out.free(); bank.close(); m.close()
