@@ -50,7 +50,7 @@ def test_reference_golden_512_160_80(gpu, jfk):
     m = gpu.HipMelSpectrogram(512, 160, SR, 80)
     got = m.compute_mel_spectrogram(jfk[128:])
     assert got[:1097].T.shape == want.shape
-    assert np.abs(got[:1097].T - want).max() <= 2e-6
+    assert np.abs(got[:1097].T - want).max() <= 1e-6          # the reference's own gate (src/rb.rs:171-178); measured 3.6e-7
 
 
 def test_reference_gpu_parity_signal(w80, oracle, four_tone, golden):

@@ -194,7 +194,7 @@ def test_gpu_streaming_reproduces_reference_golden(gpu, jfk):
             assert c.shape == (80, 1) and c.dtype == np.float64
             cols.append(c)
     got = np.concatenate(cols, axis=1)
-    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-6      # the reference's own gate (src/rb.rs:171-178)
     rb.close(); m.close()
 
 
