@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--cfg5-clips", type=int, default=None, help="rehearsals only: shrink the config-5 leg's clip set")
     ap.add_argument("--one-device", action="store_true", help="rehearsal of the N > 1 code path on a 1-GPU box: every rank on GPU 0, ranks over gloo "
                                                                "(the figures it prints mean nothing: the ranks share one GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="N = 1: run the distributed branch anyway -- init_process_group(\"nccl\") = RCCL at world size 1, the "
+                                                               "barrier, the all_gather of {frames, ms}, the MAX-reduce, destroy_process_group -- so that the first multi-GPU "
+                                                               "run is not the first RCCL run (the line then carries `dist`)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: spawn the ranks (gloo), plan every rank's shard, run the timing protocol on a "
                                                             "sleep and print the JSON line -- the CPU test of the launch path")
     return ap.parse_args()
@@ -198,7 +201,7 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
     launches.  primary: the workload `value` is quoted on (the command line's overrides apply to it only)."""
     import numpy as np
     from mel_spec_amd.parallel import shard_range, timed_steps
-    distributed = world > 1
+    distributed = dist is not None            # also at world size 1 under --force-dist
     cfg_clips, cfg_seconds, cfg_mels, scaling = CONFIGS[config]
     n_mels = (args.n_mels if primary else None) or cfg_mels
     clip_seconds = (args.clip_seconds if primary else None) or cfg_seconds
@@ -373,12 +376,17 @@ def main() -> None:
     import mel_spec_amd as M
     from mel_spec_amd.parallel import shard_range, timed_steps
 
+    if args.force_dist and not launched:          # a one-rank job with its own rendezvous on the loopback
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.one_device:
@@ -393,6 +401,7 @@ def main() -> None:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
 
     steps = args.steps if args.steps is not None else (1000 if args.config == 2 else 20)
     warmup = args.warmup if args.warmup is not None else (100 if args.config == 2 else 3)
@@ -402,8 +411,17 @@ def main() -> None:
     n_mels, clip_seconds, clip_len, total_or_per, fpc = w["n_mels"], w["clip_seconds"], w["clip_len"], w["total_or_per"], w["fpc"]
     mel, out, stream = w["mel"], w["out"], w["stream"]
 
+    # which device every rank ran on: an N-GPU line must show N distinct devices
+    props = torch.cuda.get_device_properties(dev)
+    ident = {"rank": rank, "device_index": dev.index, "device_name": props.name,
+             "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+    idents = [ident]
+    if distributed:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+
     gather = None
-    if distributed and args.gather and sub == 1 and not args.one_device:
+    if world > 1 and args.gather and sub == 1 and not args.one_device:
         # optional consolidation on rank 0: every peer sends its share over its own xGMI link
         n_out = fpc * n_clips * n_mels
         sizes = [int(p[0]) * n_mels for p in per_rank]
@@ -456,7 +474,7 @@ def main() -> None:
     if rank == 0 and world == 1 and args.config == 2 and not args.no_speech and args.precision == "auto" and args.n_mels is None:
         speech = speech_leg(M, torch, dev, stream, n_clips, clip_len, n_mels)
     cfg5 = None
-    if distributed and not explicit_config and not args.no_cfg5:
+    if world > 1 and not explicit_config and not args.no_cfg5:
         kernel_name = mel.plain_kernel_name()
         mel.close()
         del w, out
@@ -519,7 +537,7 @@ def main() -> None:
                        "frames_recomputed_in_f64_per_step": queued,
                        "parallelism": f"per-clip split x{world}, no data-path collective"},
             "per_gpu_frames_per_s": value / world,
-            "per_rank": [{"frames_per_step": p[0], "kernel_ms": p[1]} for p in per_rank],
+            "per_rank": [dict({"frames_per_step": p[0], "kernel_ms": p[1]}, **(idents[r] or {})) for r, p in enumerate(per_rank)],
             "realtime_x": value * (HOP / SR),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -540,6 +558,8 @@ def main() -> None:
             res["config"]["cfg5"] = cfg5
         if gather is not None:
             res["gather_to_rank0"] = gather
+        if distributed:
+            res["dist"] = dict(dist_info, distinct_devices=len({(i or {}).get("uuid") or (i or {}).get("device_index") for i in idents}))
         if args.one_device:
             res["rehearsal"] = "every rank on GPU 0 over gloo: exercises the N > 1 code path on a 1-GPU box, the figures are not measurements"
         if world == 1 and not args.no_cpu_baseline:

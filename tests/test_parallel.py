@@ -239,3 +239,76 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu(gpu):
     c5 = line["config"]["cfg5"]
     assert c5["scaling"] == "strong" and [r["frames_per_step"] for r in c5["per_rank"]] == [48 * 2998.0] * 2 and c5["parity_max_abs_diff"] <= 1e-4
     assert "roofline" in line and "cpu_baseline" not in line            # the CPU baseline is an N = 1 figure
+
+
+@pytest.mark.gpu
+def test_bench_distributed_branch_runs_on_rccl_at_world_size_one(gpu):
+    """the only code that calls init_process_group("nccl", device_id=...) had never executed anywhere.
+    `bench.py --gpus 1 --force-dist` runs the distributed branch on RCCL at world size 1 -- barrier, the all_gather of
+    {frames, ms}, the MAX-reduce of the elapsed time, all_gather_object of the device identities, destroy_process_group -- so the
+    first multi-GPU run is not the first RCCL run.  The line says which backend ran and which device every rank was on."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--clips", "64", "--steps", "5", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["dist"]["backend"] == "nccl" and line["dist"]["world_size"] == 1 and line["dist"]["distinct_devices"] == 1
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["parity_max_abs_diff"] <= 1e-4
+    r0 = line["per_rank"][0]
+    assert r0["rank"] == 0 and r0["device_index"] == 0 and ("MI355" in r0["device_name"] or "gfx950" in r0["device_name"] or r0["device_name"])
+    assert r0["frames_per_step"] == 64 * 998.0
+    assert abs(line["value"] - 64 * 998 * 5 / (line["ms_per_step"] * 5e-3)) <= 1e-6 * line["value"]
+
+
+RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch                               # before the HIP library: one HIP runtime per process (torch's), as in bench.py
+import torch.distributed as dist
+from mel_spec_amd.parallel import timed_steps
+import mel_spec_amd as M
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+mel = M.HipMelSpectrogram(400, 160, 16000.0, 80, device=0)
+pcm = torch.empty(8 * 16000, dtype=torch.float32, device=dev)
+out = torch.empty(8 * mel.num_frames(16000) * 80, dtype=torch.float32, device=dev)
+stream = torch.cuda.current_stream().cuda_stream
+M.synth_pcm_device(pcm.data_ptr(), 16000, 16000, 0, 8, stream=stream)
+calls = []
+step = lambda: (calls.append(1), mel.compute_uniform_device(pcm.data_ptr(), 16000, 16000, 8, out.data_ptr(), stream=stream))
+el = timed_steps(step, torch.cuda.synchronize, 4, 2, dist, dev)
+assert len(calls) == 6 and 0.0 < el < 5.0
+mine = torch.tensor([998.0, 0.25], dtype=torch.float64, device=dev)
+allr = [torch.zeros_like(mine)]
+dist.all_gather(allr, mine)
+assert allr[0].tolist() == [998.0, 0.25]
+objs = [None]
+dist.all_gather_object(objs, {"device": torch.cuda.get_device_properties(dev).name})
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK", dist.is_initialized(), objs[0]["device"], float(out.abs().sum().item()) > 0.0)
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_of_the_bench_protocol(gpu, tmp_path):
+    """The collectives the bench uses, on backend "nccl" (= RCCL) at world size 1 next to the library's own launches on the same
+    stream: barrier, all_gather of a 2-vector on the device, all_reduce(MAX) through mel_spec_amd.parallel.timed_steps (the helper
+    bench.py times with), all_gather_object, destroy_process_group.  In a process of its own: torch must load its HIP runtime before
+    the library does (as in bench.py); the test session has already loaded the library."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RCCL_OK")][0].split(maxsplit=2)
+    assert line[1] == "False" and line[2].endswith("True")
