@@ -90,12 +90,15 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
  *                   exceed 1e-4 (calibrated with tools/flag_calib.py / flag_calib2.py, soaked by tools/fuzz_gpu.py) -- and a
  *                   frame that fails it is recomputed in f64 by the wavefront that owns it (same launch).  Noise-like input
  *                   never takes that branch (the bench workload runs at the f32 rate).  Speech and tonal material trip the
- *                   guard on 40-100 % of their frames; the context notices (the kernels publish the tripped fraction of every
- *                   launch into host-mapped memory, nothing is added to the stream) and, while the last finished batch tripped
- *                   it on more than 12.5 % of its frames, runs the f64 kernel on whole batches (the F64 rate) until the
- *                   fraction falls under 6.25 % again.  Results are within 1e-4 in either regime; a frame the guard does not
- *                   trip carries f32 bits in one regime and f64 bits in the other, so AUTO is not bit-stable across a change of
- *                   regime -- F32 and F64 are, and melspec_set_auto_adaptive(ctx, 0) pins AUTO to the f32 regime.
+ *                   guard on 40-100 % of their frames, which is slower than computing everything in f64 -- so the launch takes a
+ *                   vote first: the first work unit of every wavefront is the sample, and when more than 1/8 of the sampled
+ *                   frames trip the guard the f32 kernel stands down and the f64 kernel queued behind it (a second launch that
+ *                   returns at once otherwise) computes the whole batch at the F64 rate.  Plain [clip][frame][mel] batches,
+ *                   uniform and ragged; the padded / mel-major layouts keep the f32 kernel + recompute.  The vote happens inside
+ *                   the batch's own launch and nobody waits for it: the result of a call is a function of its input alone (same
+ *                   batch -> same bits, whatever the context computed before; round 3 chose from the previous batch's
+ *                   statistics).  A clip's bits can differ between two different batches (f32 regime in one, f64 in the other,
+ *                   both within 1e-4); F32 and F64 do not have that, nor AUTO after melspec_set_auto_adaptive(ctx, 0).
  *   F64             window, FFT and |X|^2 in f64 for every frame: ~4e-7 from the reference, about 60 % of the f32 rate.
  *   F32             the f32 kernel alone: ~3e-5 on speech and noise, up to ~5e-4 on a line over a floor 70..90 dB down.
  * Geometries on the generic kernel and the fused n_fft = 512 kernel always compute in f64. */
@@ -109,11 +112,12 @@ int melspec_set_precise(melspec_ctx *ctx, int on);
 int melspec_is_precise(const melspec_ctx *ctx);
 /* Name of the kernel(s) a plain [clip][frame][mel] batch of this context runs on (for profiles and bench lines). */
 const char *melspec_plain_kernel_name(const melspec_ctx *ctx);
-/* Frames that tripped AUTO's guard since the context was created (f32 regime: recomputed in f64; f64 regime: counted only).
+/* Frames that tripped AUTO's guard since the context was created (f32 kernel: recomputed in f64; f64 kernel: counted only).
  * Synchronises the device. */
 int melspec_guard_count(melspec_ctx *ctx, uint64_t *frames);
-/* AUTO's adaptive dispatch (default on).  melspec_auto_state: *heavy = 1 while whole batches go to the f64 kernel, *fraction =
- * the tripped fraction of the last finished window of launches (>= 256 frames); does not synchronise. */
+/* AUTO's vote (default on; 0: the f32 kernel + per-frame recompute whatever the input).  melspec_auto_state reports, without
+ * synchronising: *heavy = 1 when the last FINISHED AUTO batch ran on the f64 kernel, *fraction = the fraction of its frames that tripped
+ * the guard (batches of >= 256 frames).  Reporting only: nothing is decided from it. */
 int melspec_set_auto_adaptive(melspec_ctx *ctx, int on);
 int melspec_auto_state(melspec_ctx *ctx, int *heavy, double *fraction);
 

@@ -467,26 +467,28 @@ bool fb_lens_match(const MelSlots &ms) {
 // ------------------------------------------------------------------------------------
 // MELSPEC_PRECISION_AUTO state (FixSink in melspec_kernels.hpp): the f64 tables of the in-kernel recompute and its counter.
 struct FixState {
-    DevBuf tab, count, list;              // count: {u64 frames that tripped the guard, u64 accumulator of the launch in flight}
+    DevBuf tab, count, list;              // count: {u64 frames that tripped the guard, u64 accumulator of the launch in flight, u64 tally of the vote}
+    DevBuf verdicts;                      // FixSink::decision: kVoteSlots copies of the last vote's verdict
     hipStream_t last_stream = nullptr;    // the note list is used in stream order: a call on another stream first waits for this one
     bool used = false;
     // Statistics of the guarded launches, published by the kernels into host-mapped memory (FixSink::host) and read here without
-    // touching the stream.  They drive the adaptive dispatch of MELSPEC_PRECISION_AUTO: a context whose recent batches tripped the
-    // guard on more than kAutoUp of their frames (speech, tonal material: DESIGN.md section 5) runs the f64 kernel on whole batches --
-    // 0.50 ms instead of 1.2 ms at config 2 -- until the fraction falls under kAutoDown again.  The f64 kernel counts the frames that
-    // WOULD trip the guard with the same test, so the fraction is known in either state and nothing has to be re-probed.
-    unsigned long long *host = nullptr;   // {seq << 40 | tripped, seq << 40 | frames} of the last finished launch
+    // touching the stream (melspec_auto_state, melspec_guard_count's cheap sibling).  They no longer decide anything: since round 4
+    // the kernel a batch runs on is decided by a vote inside the batch's own launch (FixSink::vote in melspec_kernels.hpp), so the
+    // result of a call is a function of its input alone -- round 3 chose from the statistics of the last FINISHED batch, which made
+    // the bits of a batch depend on what the context had seen before and on how far the host was ahead of the GPU.
+    unsigned long long *host = nullptr;   // {seq << 40 | tripped, seq << 40 | frames (bit 39: published by the gated f64 launch)} of the last finished launch
     uint32_t seq = 0, seen_seq = 0;
-    bool adaptive = true, heavy = false;
+    bool adaptive = true;                 // the vote is on (melspec_set_auto_adaptive); off: the f32 kernel + recompute tail whatever the input
+    bool heavy = false;                   // the last finished AUTO batch ran on the f64 kernel (reporting only)
     double fraction = 0.0;                // of the last finished launch of >= kAutoMinFrames frames
     void release() {
-        tab.release(); count.release(); list.release(); used = false; last_stream = nullptr;
+        tab.release(); count.release(); list.release(); verdicts.release(); used = false; last_stream = nullptr;
         if (host) (void)hipHostFree(host);
         host = nullptr;
     }
 };
-constexpr double kAutoUp = 0.125, kAutoDown = 0.0625;     // crossover of (f32 + recompute tail) and the f64 kernel: 14 % at 80 mels, 10 % at 128
 constexpr unsigned long long kAutoMinFrames = 256;
+constexpr unsigned long long kStatFromGated = 1ull << 39;
 
 struct melspec_ctx {
     DeviceInfo dev;
@@ -533,7 +535,7 @@ struct melspec_ctx {
 
 namespace {
 
-// MELSPEC_PRECISION_AUTO: take in what the finished launches published and move between the two regimes
+// MELSPEC_PRECISION_AUTO: take in what the finished launches published (reporting only: melspec_auto_state)
 void auto_poll(melspec_ctx *c) {
     FixState &fx = c->fix;
     if (!fx.host) return;
@@ -542,22 +544,16 @@ void auto_poll(melspec_ctx *c) {
     const uint32_t seq = static_cast<uint32_t>(a >> kStatShift);
     if (seq != static_cast<uint32_t>(b >> kStatShift) || seq == fx.seen_seq) return;     // a launch is publishing right now, or nothing new
     fx.seen_seq = seq;
-    const unsigned long long tripped = a & kStatMask, frames = b & kStatMask;
+    const unsigned long long tripped = a & kStatMask, frames = b & kStatMask & ~kStatFromGated;
+    fx.heavy = (b & kStatFromGated) != 0;
     if (frames < kAutoMinFrames) return;
     fx.fraction = static_cast<double>(tripped) / static_cast<double>(frames);
-    if (!fx.heavy && fx.fraction > kAutoUp) fx.heavy = true;
-    else if (fx.heavy && fx.fraction < kAutoDown) fx.heavy = false;
 }
 
-// AUTO in its heavy regime: whole batches on the f64 kernel
-bool ctx_auto_heavy(const melspec_ctx *c) { return c->precision == MELSPEC_PRECISION_AUTO && c->fix.adaptive && c->fix.heavy; }
-
-// frames per work unit of the kernel a batch will run on (called once per batch, before it is planned)
+// frames per work unit of the kernel a batch is planned for (called once per batch, before it is planned).  AUTO plans for the f32
+// kernel: when the batch's vote says "heavy", the f64 kernel walks the same plan (whisper400_precise_kernel, MODE 2).
 int ctx_frames_per_unit(melspec_ctx *c) {
-    if (c->fast) {
-        if (c->precision == MELSPEC_PRECISION_AUTO) auto_poll(c);
-        return (c->six && c->precision != MELSPEC_PRECISION_F64 && !ctx_auto_heavy(c)) ? kSixFrames : kFPW;
-    }
+    if (c->fast) return (c->six && c->precision != MELSPEC_PRECISION_F64) ? kSixFrames : kFPW;
     return c->fast512 ? kFbFPW : 1;
 }
 
@@ -589,33 +585,41 @@ PreciseParams precise_params(melspec_ctx *c, const BatchDesc &desc, const FixSin
     return pp;
 }
 
-// the f64 kernel on the whole batch (MELSPEC_PRECISION_F64)
+// the f64 kernel on the whole batch: MELSPEC_PRECISION_F64 (the plan is its own, kFPW frames per unit), or -- gate != nullptr -- AUTO's
+// second launch, which runs only when the f32 launch in front of it voted "heavy" and walks THAT launch's plan (plain batches)
 template <int NSLOTS, class Lens>
-int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream) {
+int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream, const unsigned *gate, unsigned gate_value) {
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, false>, "hipFuncSetAttribute(whisper400_precise_kernel)");
-        if (!rc) rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, true>, "hipFuncSetAttribute(whisper400_precise_kernel, runs)");
+        int rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, 0>, "hipFuncSetAttribute(whisper400_precise_kernel)");
+        if (!rc) rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, 1>, "hipFuncSetAttribute(whisper400_precise_kernel, runs)");
+        if (!rc) rc = allow_big_lds(&whisper400_precise_kernel<NSLOTS, Lens, 2>, "hipFuncSetAttribute(whisper400_precise_kernel, gated)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const uint64_t blocks = (desc.n_units + kPreciseWaves - 1) / kPreciseWaves;
+    const uint64_t steps = gate ? (desc.n_units * static_cast<uint64_t>(desc.frames_per_unit) + kFPW - 1) / kFPW : desc.n_units;
+    const uint64_t blocks = (steps + kPreciseWaves - 1) / kPreciseWaves;
     static const int per_cu = lab_int("MELSPEC_PRECISE_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
-    const PreciseParams pp = precise_params(c, desc, sink_armed(c, stat, desc, grid));
+    FixSink armed = sink_armed(c, stat, desc, grid);
+    if (gate) armed.frames |= kStatFromGated;
+    PreciseParams pp = precise_params(c, desc, armed);
+    pp.gate = gate; pp.gate_value = gate_value; pp.plan_fpu = desc.frames_per_unit;
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-    if (layout)
-        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, false>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
+    if (gate)
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, 2>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
+    else if (layout)
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, 0>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
     else
-        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, true>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
+        hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, 1>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
 
-int launch_precise(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream) {
+int launch_precise(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream, const unsigned *gate = nullptr, unsigned gate_value = 0) {
     if (c->ft.slots.n_slots <= 8)
-        return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stat, stream) : launch_precise_t<8, LensRuntime>(c, desc, stat, stream);
-    return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stat, stream) : launch_precise_t<12, LensRuntime>(c, desc, stat, stream);
+        return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stat, stream, gate, gate_value) : launch_precise_t<8, LensRuntime>(c, desc, stat, stream, gate, gate_value);
+    return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stat, stream, gate, gate_value) : launch_precise_t<12, LensRuntime>(c, desc, stat, stream, gate, gate_value);
 }
 
 FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf &blob, melspec_ctx *c, const FixSink &sink) {
@@ -645,7 +649,9 @@ int launch_wave_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hi
     // two workgroups are resident per CU; 4 per CU measured best (8192 x 15..45 s x 128 mels: 9.17 vs 9.50 ms)
     static const int per_cu = lab_int("MELSPEC_GRID_PER_CU", 4, 1, 64);
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
-    const FastParams fp = fast_params(desc, c->ft, c->d_blob, c, sink_armed(c, sink, desc, grid));
+    FixSink armed = sink_armed(c, sink, desc, grid);
+    armed.vote_groups = std::min<unsigned>(grid, static_cast<unsigned>(c->dev.cus));           // workgroups that are certainly resident when the launch starts
+    const FastParams fp = fast_params(desc, c->ft, c->d_blob, c, armed);
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     if (layout)
         hipLaunchKernelGGL((whisper400_wave_kernel<NSLOTS, Lens>), dim3(grid), dim3(kWaveWaves * 64), c->fast_lds, stream, fp);
@@ -673,7 +679,9 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
     const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
     static const int per_cu = lab_int("MELSPEC_SIX_GRID_PER_CU", 1, 1, 4096);     // one 16-wave workgroup per CU
     const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
-    const FastParams fp = fast_params(desc, c->ft6, c->d_blob6, c, sink_armed(c, sink, desc, grid.x));
+    FixSink armed = sink_armed(c, sink, desc, grid.x);
+    armed.vote_groups = std::min<unsigned>(grid.x, static_cast<unsigned>(c->dev.cus));        // the workgroups resident when the launch starts (one per CU)
+    const FastParams fp = fast_params(desc, c->ft6, c->d_blob6, c, armed);
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     // plain batches, uniform and ragged, take the run-per-wave kernel (no division per unit, the clip record in scalar registers, a
     // wave re-reads its own frame-tail halo): cfg2 0.3105 -> 0.3055 ms, 8192 x 30 s 7.55 -> 7.42 ms against the round-robin deal
@@ -686,15 +694,12 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (desc_in.n_units == 0) return MELSPEC_OK;
     BatchDesc desc = desc_in;
-    // AUTO's regime for this batch: a six-frame context planned it for the kernel it meant (ctx_frames_per_unit); the others have
-    // one unit size and decide here
-    const bool heavy = c->fast && c->precision == MELSPEC_PRECISION_AUTO &&
-                       (c->six ? desc.frames_per_unit != kSixFrames : ctx_auto_heavy(c));
+    const bool layout_batch = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     if (desc.sync_rounds < 0) {
         // measured (profiles/r01_variants.txt): six-frame kernel, 16 waves: four waves 4 apart; precise kernel, 8 waves:
         // consecutive pairs; 5-frame kernel, two 8-wave workgroups per CU: pairs 4 apart
         if (c->fast && desc.frames_per_unit == kSixFrames) desc.sync_rounds = 20;
-        else if (c->fast && (c->precision == MELSPEC_PRECISION_F64 || heavy)) desc.sync_rounds = 2;
+        else if (c->fast && c->precision == MELSPEC_PRECISION_F64) desc.sync_rounds = 2;
         else if (c->fast) desc.sync_rounds = 18;
         else desc.sync_rounds = 1;
     }
@@ -716,19 +721,18 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, 0, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, FixSink{}, stream);
     FixSink sink{};
+    bool vote = false;
     if (c->precision == MELSPEC_PRECISION_AUTO) {
         FixState &fx = c->fix;
         if (fx.used && fx.last_stream != stream) HIP_TRY(hipStreamSynchronize(fx.last_stream));
-        if (!heavy) {
-            const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
-            if (need > fx.list.cap) {
-                if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
-                int rc = fx.list.ensure(need);
-                if (rc) return rc;
-            }
-            sink.tab = static_cast<const double *>(fx.tab.p);
-            sink.list = static_cast<uint64_t *>(fx.list.p);
+        const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
+        if (need > fx.list.cap) {
+            if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
+            int rc = fx.list.ensure(need);
+            if (rc) return rc;
         }
+        sink.tab = static_cast<const double *>(fx.tab.p);
+        sink.list = static_cast<uint64_t *>(fx.list.p);
         if (!fx.host) {
             HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&fx.host), 64, hipHostMallocMapped | hipHostMallocCoherent));
             std::memset(fx.host, 0, 64);
@@ -737,11 +741,25 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         sink.count = static_cast<unsigned long long *>(fx.count.p);
         sink.acc = sink.count + 1;
         sink.host = fx.host;
-        if (heavy) return launch_precise(c, desc, sink, stream);
+        // The vote (FixSink::vote): plain batches.  The padded / mel-major layouts deal their units round-robin and keep the f32 kernel
+        // + recompute tail whatever the input (MELSPEC_PRECISION_F64 is the fast mode for speech there).
+        vote = fx.adaptive && !layout_batch;
+        if (vote) {
+            sink.vote = sink.count + 2;
+            sink.decision = static_cast<unsigned *>(fx.verdicts.p);
+        }
     }
+    int rc;
     if (c->six && desc.frames_per_unit == kSixFrames)
-        return c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
-    return launch_wave(c, desc, sink, stream);
+        rc = c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
+    else
+        rc = launch_wave(c, desc, sink, stream);
+    if (rc || !vote) return rc;
+    // AUTO's second launch: returns at its first instruction unless the launch above voted "heavy" (its number is c->fix.seq)
+    const unsigned gate_value = (c->fix.seq & 0xffffffu) << 2 | kVoteDecided | kVoteHeavy;
+    FixSink stat{};
+    stat.count = sink.count; stat.acc = sink.acc; stat.host = sink.host;
+    return launch_precise(c, desc, stat, stream, sink.decision, gate_value);
 }
 
 template <class Lens>
@@ -850,6 +868,7 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         }
         if ((rc = upload(c->fix.tab, build_fix_tables()))) return bail(rc);
         if ((rc = upload(c->fix.count, std::vector<uint64_t>(8, 0ull)))) return bail(rc);
+        if ((rc = upload(c->fix.verdicts, std::vector<uint32_t>(static_cast<size_t>(kVoteSlots) * kVoteSlotStride, 0u)))) return bail(rc);
     }
     if (!c->fast) {          // the generic kernel also serves the layouts the fused 512 build does not store
         const int bins = fft_size / 2 + 1;
@@ -936,7 +955,7 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
         if (c->fast512) return "melspec::fbank512_wave_kernel<double, 8, 1, kFlavorWhisper, RUNS> (n_fft = 512, f64)";
         return "melspec::generic_frame_kernel<256> (f64 direct DFT)";
     }
-    if (c->precision == MELSPEC_PRECISION_F64 || ctx_auto_heavy(c))
+    if (c->precision == MELSPEC_PRECISION_F64)
         return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";
     const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
     if (c->six)
@@ -961,14 +980,13 @@ int melspec_guard_count(melspec_ctx *c, uint64_t *frames) {
 int melspec_set_auto_adaptive(melspec_ctx *c, int on) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
     c->fix.adaptive = on != 0;
-    if (!on) c->fix.heavy = false;
     return MELSPEC_OK;
 }
 
 int melspec_auto_state(melspec_ctx *c, int *heavy, double *fraction) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
     if (c->fast && c->precision == MELSPEC_PRECISION_AUTO) auto_poll(c);
-    if (heavy) *heavy = ctx_auto_heavy(c) ? 1 : 0;
+    if (heavy) *heavy = (c->fast && c->precision == MELSPEC_PRECISION_AUTO && c->fix.heavy) ? 1 : 0;
     if (fraction) *fraction = c->fix.fraction;
     return MELSPEC_OK;
 }

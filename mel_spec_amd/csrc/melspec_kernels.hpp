@@ -141,11 +141,31 @@ struct FixSink {
     unsigned n_groups;           // workgroups of this launch
     unsigned seq;                // number of this launch (24 bits)
     unsigned long long frames;   // frames of this launch (ragged batches: the host's upper bound)
+    // The vote of MELSPEC_PRECISION_AUTO (round 4): which kernel computes THIS batch is decided from the batch itself, inside the
+    // launch.  The first work unit of every wave of the first `vote_groups` workgroups (all of them resident when the launch starts)
+    // is the sample; each of those workgroups adds {frames that tripped the guard, frames, 1} to `vote` with one relaxed atomic, the
+    // workgroup that completes the tally writes `decision` = seq << 2 | 2 | heavy (heavy: more than 1/8 of the sampled frames
+    // tripped) and zeroes the tally.  Nobody waits: a wave looks at `decision` after each unit until it carries this launch's number;
+    // on "heavy" it stops -- the f64 kernel queued behind this launch (gated on the same word) computes the whole batch, otherwise
+    // that launch returns at once and this one finishes with its recompute tail.  The outcome is a function of the batch alone.
+    unsigned long long *vote;    // nullptr: no vote (the f32 kernel + recompute tail whatever the input)
+    unsigned *decision;          // kVoteSlots copies of the verdict, kVoteSlotStride words apart: workgroup g reads copy g % kVoteSlots (every
+                                 // poller of the launch reading ONE word made that word's memory channel the bottleneck: the agent-scope
+                                 // loads are served by memory, not by an L2, and queued for tens of microseconds)
+    unsigned vote_groups;
 };
+constexpr unsigned kVoteSlots = 256, kVoteSlotStride = 64;      // 256 B apart
+
+__device__ __forceinline__ uint64_t scalar64(uint64_t v) {
+    // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+}
 
 constexpr int kStatShift = 40;
 constexpr unsigned long long kStatMask = (1ull << kStatShift) - 1;
 
+__device__ __forceinline__ unsigned vote_poll(const FixSink &fx);
+constexpr unsigned kVoteDecided = 2u, kVoteHeavy = 1u;
 // A wave of a guarded launch is through (every wave calls this, also one without units).  wg: two zeroed LDS words of the
 // workgroup {frames that tripped the guard, waves through}.
 __device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg, int waves, int lane, unsigned flagged) {
@@ -158,10 +178,68 @@ __device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg,
     if ((old >> kStatShift) + 1 != fx.n_groups) return;
     const unsigned long long tripped = ((old & kStatMask) + total) & kStatMask;
     __hip_atomic_store(fx.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // every other workgroup of the launch has been here
+    if (fx.vote && (vote_poll(fx) & kVoteHeavy)) return;       // a voting launch that stood down: the f64 launch behind it reports the batch
     if (tripped) __hip_atomic_fetch_add(fx.count, tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long tag = static_cast<unsigned long long>(fx.seq & 0xffffffu) << kStatShift;
     __hip_atomic_store(fx.host, tag | tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(fx.host + 1, tag | (fx.frames & kStatMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- the vote (FixSink::vote) ----------------------------------------------------------------------------------------------------
+constexpr int kVoteFramesShift = 24, kVoteGroupsShift = 48;        // tally word: tripped | frames << 24 | groups << 48
+// heavy: the sample says the f64 kernel is the cheaper way to the tolerance (crossover of f32 + tail against it: 14 % of the frames at
+// 80 mels, 10 % at 128)
+__device__ __forceinline__ bool vote_is_heavy(unsigned long long tripped, unsigned long long frames) { return tripped * 8 > frames; }
+
+// 0: not known yet; kVoteDecided (| kVoteHeavy): this launch's verdict.  Wave-uniform.
+__device__ __forceinline__ unsigned vote_poll(const FixSink &fx) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(fx.decision + (blockIdx.x % kVoteSlots) * kVoteSlotStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return (d >> 2) == (fx.seq & 0xffffffu) ? (d & 3u) : 0u;
+}
+// A wave of a sampling workgroup reports its first unit (also a wave without units: 0, 0); every lane of the wave calls this.  wg: three
+// zeroed LDS words of the workgroup {tripped, frames, waves that have reported}.
+__device__ __forceinline__ void vote_cast(const FixSink &fx, unsigned *wg, int waves, int lane, unsigned tripped, unsigned frames) {
+#ifdef MELSPEC_VOTE_NOCAST
+    return;
+#endif
+    unsigned long long sum = 0;
+    bool last = false;
+    if (lane == 0) {
+        if (tripped) __hip_atomic_fetch_add(wg, tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // LDS operations of a lane execute in order
+        if (frames) __hip_atomic_fetch_add(wg + 1, frames, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_fetch_add(wg + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1 == static_cast<unsigned>(waves)) {
+            const unsigned long long t = __hip_atomic_load(wg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long f = __hip_atomic_load(wg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long mine = t | (f << kVoteFramesShift) | (1ull << kVoteGroupsShift);
+            sum = __hip_atomic_fetch_add(fx.vote, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+            last = (sum >> kVoteGroupsShift) == fx.vote_groups;
+            if (last) __hip_atomic_store(fx.vote, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // every sampling workgroup has been here
+        }
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
+    sum = scalar64(sum);
+    const bool heavy = vote_is_heavy(sum & ((1ull << kVoteFramesShift) - 1), (sum >> kVoteFramesShift) & ((1ull << kVoteFramesShift) - 1));
+    const unsigned verdict = (fx.seq & 0xffffffu) << 2 | kVoteDecided | (heavy ? kVoteHeavy : 0u);
+#pragma unroll
+    for (unsigned k = 0; k < kVoteSlots; k += 64)                      // the wave that completes the tally publishes every copy
+        __hip_atomic_store(fx.decision + (k + lane) * kVoteSlotStride, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// What a wave does after a unit while the verdict is unknown.  wg[3]: the workgroup's copy of the verdict (0 until one of its waves
+// has seen it): one ds_read per unit.  The global word is read by one wave in four per unit (the waves of a workgroup start together and
+// stay roughly in step, so that is one wave per SIMD and unit): waiting for that load also waits for the stores the wave has in flight
+// -- gfx950 counts both in vmcnt -- and with every wave polling after every unit all four waves of a SIMD stalled together (+12 us on
+// the 290 us launch of config 2; this form: see profiles/r04_vote.txt).
+__device__ __forceinline__ unsigned vote_check(const FixSink &fx, unsigned *wg, unsigned units_done, int wave) {
+#ifdef MELSPEC_VOTE_NOPOLL
+    return 0;
+#endif
+    unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(wg + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    if (v == 0 && ((static_cast<unsigned>(wave) ^ units_done) & 3u) == 0) {
+        v = vote_poll(fx);
+        if (v) __hip_atomic_store(wg + 3, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return v;
 }
 
 struct FastParams {
@@ -214,11 +292,6 @@ __device__ __forceinline__ void unit_ext_merge(int *ext, int lane, int kmin, int
         const int2 old = *reinterpret_cast<const int2 *>(ext);
         *reinterpret_cast<int2 *>(ext) = make_int2(lo < old.x ? lo : old.x, hi > old.y ? hi : old.y);
     }
-}
-
-__device__ __forceinline__ uint64_t scalar64(uint64_t v) {
-    // the builtin returns a signed int: without the casts a low word with bit 31 set sign-extends over the high word
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
 constexpr int kSixFixOff = 1408;      // float offset of the f64 scratch (400 doubles) inside a six-frame slice: behind power rows and maxima
@@ -657,8 +730,8 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
-    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());   // guard_wave_done's two words
-    if (tid < 2) wg_done[tid] = 0;
+    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());   // guard_wave_done's two words,
+    if (tid < 6) wg_done[tid] = 0;                                                                                 // vote_cast's three, vote_check's one
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -674,16 +747,19 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
 
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) {
+        if (guard && p.fix.vote != nullptr && blockIdx.x < p.fix.vote_groups) vote_cast(p.fix, wg_done + 2, kSixWaves, lane, 0, 0);
         guard_wave_done(p.fix, wg_done, kSixWaves, lane, 0);
         return;
     }
     uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;        // this wave's notes: the entries its own run indexes
     unsigned noted = 0;
-    for (; cr.unit < cr.end; ++cr.unit) {
+    int nv = 0;
+    // one work unit: phases 1-4 and the note for the tail; returns the lanes whose guard tripped
+    auto unit = [&]() __attribute__((always_inline)) -> uint64_t {
         cr.enter(p.b);
         const uint64_t f0 = (cr.unit - cr.c_start) * kSixFrames;
         const uint64_t left = cr.c_frames - f0;
-        const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
         const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv;
         MS_PRIO(0);
@@ -708,14 +784,37 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         float *out_tile = cr.c_out + f0 * (uint64_t)n_mels;
         const bool flag = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice, vals, out_tile, 0);
         __builtin_amdgcn_wave_barrier();
+        uint64_t any = 0;
         if (guard) {
-            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            any = __builtin_amdgcn_ballot_w64(flag);
             if (any != 0) {
                 if (lane == 0) notes[noted] = (cr.unit << 8) | frame_mask<kSixLanes, kSixFrames>(any);
                 ++noted;
             }
         }
+        return any;
+    };
+    // AUTO's vote (FixSink::vote).  The first units of a voting launch run in a loop of their own until the verdict is known: the
+    // same code in the unit loop proper -- a handful of scalar branches that are never taken after the second unit -- cost that loop
+    // 19 % (same-box A/B, round 4: the register allocator and the scheduler see one more loop-carried state and two more exits).
+    if (guard && p.fix.vote != nullptr) {
+        bool sample = blockIdx.x < p.fix.vote_groups;                  // the first unit of every wave of the first vote_groups workgroups is the sample
+        unsigned verdict = 0, polled = 0;
+        for (; cr.unit < cr.end && verdict == 0; ++cr.unit) {
+            const uint64_t any = unit();
+            if (sample) {
+                vote_cast(p.fix, wg_done + 2, kSixWaves, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(any))), static_cast<unsigned>(nv));
+                sample = false;
+            }
+            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
+        }
+        if (verdict == 0) verdict = vote_poll(p.fix);                  // a run shorter than the vote
+        if (verdict & kVoteHeavy) {                                    // the f64 kernel behind this launch computes the whole batch
+            guard_wave_done(p.fix, wg_done, kSixWaves, lane, 0);
+            return;
+        }
     }
+    for (; cr.unit < cr.end; ++cr.unit) unit();
     // the units whose frames tripped the precision guard, again, in f64
     unsigned redone = 0;
     FixTw tw;
@@ -746,8 +845,8 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
-    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // guard_wave_done's two words
-    if (tid < 2) wg_done[tid] = 0;
+    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // guard_wave_done's two words, vote_cast's three
+    if (tid < 6) wg_done[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -764,16 +863,18 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     const bool guard = p.fix.tab != nullptr;
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) {
+        if (guard && p.fix.vote != nullptr && blockIdx.x < p.fix.vote_groups) vote_cast(p.fix, wg_done + 2, WAVES, lane, 0, 0);
         guard_wave_done(p.fix, wg_done, WAVES, lane, 0);
         return;
     }
     uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;
     unsigned noted = 0;
-    for (; cr.unit < cr.end; ++cr.unit) {
+    int nv = 0;
+    auto unit = [&]() __attribute__((always_inline)) -> uint64_t {
         cr.enter(p.b);
         const uint64_t f0 = (cr.unit - cr.c_start) * kFPW;
         const uint64_t left = cr.c_frames - f0;
-        const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
         const bool act = in && fl < nv, act3 = in3 && fl3 < nv;
         MS_PRIO(0);
@@ -798,14 +899,34 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
         float *out_tile = cr.c_out + f0 * (uint64_t)n_mels;
         const bool flag = wave_phase4<NSLOTS, false, true>(fl3, j3, act3, act3, n_mels, slice, vals, out_tile, 0);
         __builtin_amdgcn_wave_barrier();
+        uint64_t any = 0;
         if (guard) {
-            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            any = __builtin_amdgcn_ballot_w64(flag);
             if (any != 0) {
                 if (lane == 0) notes[noted] = (cr.unit << 8) | frame_mask<12, kFPW>(any);
                 ++noted;
             }
         }
+        return any;
+    };
+    if (guard && p.fix.vote != nullptr) {                              // AUTO's vote, as in whisper400_six_runs_kernel
+        bool sample = blockIdx.x < p.fix.vote_groups;
+        unsigned verdict = 0, polled = 0;
+        for (; cr.unit < cr.end && verdict == 0; ++cr.unit) {
+            const uint64_t any = unit();
+            if (sample) {
+                vote_cast(p.fix, wg_done + 2, WAVES, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(any))), static_cast<unsigned>(nv));
+                sample = false;
+            }
+            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
+        }
+        if (verdict == 0) verdict = vote_poll(p.fix);
+        if (verdict & kVoteHeavy) {
+            guard_wave_done(p.fix, wg_done, WAVES, lane, 0);
+            return;
+        }
     }
+    for (; cr.unit < cr.end; ++cr.unit) unit();
     unsigned redone = 0;
     FixTw tw;
     // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
@@ -841,16 +962,25 @@ struct PreciseParams {
     MelSlots slots;       // woff[] as in the f32 blob (float offsets from FastBlob's base)
     FixSink stat;         // MELSPEC_PRECISION_AUTO running this kernel on a whole batch (most of whose frames trip the guard): the frames
                           // that would have tripped it are counted and published like the f32 kernels do (tab and list unused)
+    // MODE 2 (AUTO, queued behind the voting f32 launch): runs only when *gate == gate_value -- the f32 launch's "heavy" verdict --
+    // and walks the plan of THAT launch, whose units are plan_fpu frames long (6 on the six-frame contexts), in steps of kFPW frames
+    const unsigned *gate;
+    unsigned gate_value;
+    int plan_fpu;
 };
 
 constexpr int kPreciseWaves = 8;    // one workgroup per CU
 
-// RUNS: plain [frame][mel] output, a contiguous run of units per wave (ClipRun); otherwise the padded / mel-major layouts in
-// workgroup-uniform rounds (see whisper400_wave_kernel).
-template <int NSLOTS, class Lens, bool RUNS>
+// MODE 1 (runs): plain [frame][mel] output, a contiguous run of units per wave (ClipRun); MODE 0: the padded / mel-major layouts in
+// workgroup-uniform rounds (see whisper400_wave_kernel); MODE 2: plain output over the plan of the f32 launch in front of it, gated
+// on that launch's vote (PreciseParams::gate) -- a wave takes a contiguous run of THAT plan's units and walks the frames they cover
+// five at a time, clip by clip (one partial step per clip segment of a run: 1.6 % at config 2, nothing on long runs).
+template <int NSLOTS, class Lens, int MODE>
 __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(const PreciseParams p) {
     constexpr int WAVES = kPreciseWaves;
+    constexpr bool RUNS = MODE != 0, WALK = MODE == 2;
     constexpr bool LAYOUT = !RUNS;
+    if (WALK && *p.gate != p.gate_value) return;        // the batch was light: the f32 launch has finished it
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
@@ -884,8 +1014,20 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, 0);
         return;
     }
+    uint64_t wf0 = 0, wfb = 0;                          // WALK: next frame / end of the clip segment the wave is in
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES;; first += (uint64_t)gridDim.x * WAVES) {
-        if (RUNS) {
+        if (WALK) {
+            if (wf0 >= wfb) {                           // next clip segment of the run
+                if (cr.unit >= cr.end) break;
+                cr.enter(p.b);
+                const uint64_t seg_end = cr.c_end < cr.end ? cr.c_end : cr.end;
+                wf0 = (cr.unit - cr.c_start) * (uint64_t)p.plan_fpu;
+                wfb = (seg_end - cr.c_start) * (uint64_t)p.plan_fpu;
+                if (wfb > cr.c_frames) wfb = cr.c_frames;
+                cr.unit = seg_end;
+                if (wf0 >= wfb) continue;
+            }
+        } else if (RUNS) {
             if (cr.unit >= cr.end) break;
             cr.enter(p.b);
         } else if (first >= p.b.n_units) {
@@ -894,8 +1036,8 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         const uint64_t unit = first + rs.slot;
         const bool have = RUNS || unit < p.b.n_units;
         const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
-        const uint64_t f0 = loc.unit * kFPW;
-        const uint64_t left = (RUNS || (have && f0 < loc.frames)) ? loc.frames - f0 : 0;
+        const uint64_t f0 = WALK ? wf0 : loc.unit * kFPW;
+        const uint64_t left = WALK ? wfb - wf0 : ((RUNS || (have && f0 < loc.frames)) ? loc.frames - f0 : 0);
         const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
         const uint64_t width = (LAYOUT && p.b.d_unit_prefix == nullptr) ? p.b.out_width : loc.frames;
@@ -927,7 +1069,8 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         if (LAYOUT && p.b.mel_major && p.b.d_unit_ext && have) unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
         if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(__builtin_amdgcn_ballot_w64(flag))));
         if (LAYOUT) rs.after_round();
-        if (RUNS) ++cr.unit;
+        if (WALK) wf0 += kFPW;
+        else if (RUNS) ++cr.unit;
     }
     guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, flagged);
 }

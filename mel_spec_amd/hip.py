@@ -259,11 +259,12 @@ class HipMelSpectrogram:
         return int(n.value)
 
     def set_auto_adaptive(self, on: bool = True) -> None:
-        """melspec_set_auto_adaptive: "auto" may move whole batches to the f64 kernel while most frames trip its guard (default on)"""
+        """melspec_set_auto_adaptive: "auto" lets a vote inside each batch's launch send the whole batch to the f64 kernel when more than 1/8 of the
+        sampled frames trip the guard (default on); off: the f32 kernel + per-frame recompute whatever the input"""
         _check(lib().melspec_set_auto_adaptive(self._h, int(on)))
 
     def auto_state(self):
-        """melspec_auto_state -> (heavy, fraction of the frames of the last finished launches that tripped the guard)"""
+        """melspec_auto_state -> (the last finished "auto" batch ran on the f64 kernel, fraction of its frames that tripped the guard)"""
         h, f = C.c_int(0), C.c_double(0.0)
         _check(lib().melspec_auto_state(self._h, C.byref(h), C.byref(f)))
         return bool(h.value), float(f.value)

@@ -33,6 +33,7 @@ if case in ("cfg2", "cfg4", "f64", "mm", "f32") or case.startswith("nm"):
     m = M.HipMelSpectrogram(400, 160, 16000.0, nm)
     if case == "f64": m.set_precision("f64")
     if case == "f32": m.set_precision("f32")
+    if os.environ.get("AB_NOVOTE"): m.set_auto_adaptive(False)      # variant "name+nv": AUTO without the vote (one launch per call)
     nf = m.num_frames(clip_len)
     out = M.DeviceBuffer(n_clips * (nf + 8) * nm * 4)
     if case == "mm":
@@ -70,7 +71,9 @@ reps = int(os.environ.get("AB_REPS", "3"))
 res = {n: [] for n in args}
 for r in range(reps):
     for n in args:
-        env = dict(os.environ, MELSPEC_LIB=os.path.join(ROOT, "mel_spec_amd", "ab", f"lib_{n}.so"))
+        env = dict(os.environ, MELSPEC_LIB=os.path.join(ROOT, "mel_spec_amd", "ab", f"lib_{n.split('+')[0]}.so"))
+        if n.endswith("+nv"):
+            env["AB_NOVOTE"] = "1"
         p = subprocess.run([sys.executable, "-c", WORKER, ROOT, case], env=env, capture_output=True, text=True, timeout=600)
         ms = [float(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("MS")]
         if not ms:
