@@ -357,6 +357,7 @@ struct LensFbStatic {
     }
 };
 using LensKaldi80 = LensFbStatic<2, 2, 3, 5, 7, 9>;              // Kaldi mel scale, 80 bins, 20 Hz .. 8 kHz at 16 kHz (FbankConfig::default)
+using LensKaldi40 = LensFbStatic<4, 9, 16>;                      // the same scale, 40 bins (the other common Kaldi fbank width)
 using LensSlaney80 = LensFbStatic<2, 2, 3, 5, 8, 10>;            // NeMo: Slaney, 80 mels, 0 .. 8 kHz, bins 0..256
 using LensSlaney80W = LensFbStatic<2, 2, 3, 5, 8, 9>;            // Whisper at n_fft 512: the same bank over bins < 256
 using LensSlaney128 = LensFbStatic<1, 1, 1, 2, 2, 3, 4, 5, 7>;   // 128 mels, both

@@ -26,6 +26,7 @@
 namespace melspec {
 // emitted by melspec_runs.hip (compiled with its own scheduling strategy; see there)
 extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>(const FastParams);
+extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix40>(const FastParams);
 extern template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
 extern template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);
 }  // namespace melspec
@@ -506,7 +507,7 @@ struct melspec_ctx {
     int lens_kind = 0;      // 0 runtime slot lengths, 1 static Whisper-80, 2 static Whisper-128
     // six-frames-per-wave build (whisper400_six_*): <= 80 mels, every batch shape and layout while the context computes in f32
     bool six = false;
-    int six_static = 0;     // 1: LensSix80 matches the tables
+    int six_static = 0;     // the compile-time bank that matches the tables: 1 LensSix80, 2 LensSix64, 3 LensSix40 (0: run-time slot lengths)
     FastTables ft6;
     DevBuf d_blob6;
     size_t lds6 = 0;
@@ -751,7 +752,8 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     }
     int rc;
     if (c->six && desc.frames_per_unit == kSixFrames)
-        rc = c->six_static ? launch_six_t<LensSix80>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
+        rc = c->six_static == 1 ? launch_six_t<LensSix80>(c, desc, sink, stream) : c->six_static == 2 ? launch_six_t<LensSix64>(c, desc, sink, stream)
+           : c->six_static == 3 ? launch_six_t<LensSix40>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
     else
         rc = launch_wave(c, desc, sink, stream);
     if (rc || !vote) return rc;
@@ -851,10 +853,8 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
     if (c->fast && build_six_tables(c->dense, n_mels, c->ft6)) {
         c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves);   // + arrival counters
         c->six = c->lds6 <= kLdsLimit;
-        bool st = c->ft6.slots.n_slots == LensSix80::kSlots && n_mels == LensSix80::kMels;
-        for (int i = 0; st && i < LensSix80::kSlots; ++i)
-            st = c->ft6.slots.len[i] == LensSix80::len(i) && c->ft6.slots.woff[i] == LensSix80::woff(i);
-        c->six_static = st && !runtime_lens;
+        c->six_static = runtime_lens ? 0 : lens_match<LensSix80>(c->ft6.slots, n_mels) ? 1 : lens_match<LensSix64>(c->ft6.slots, n_mels) ? 2
+                        : lens_match<LensSix40>(c->ft6.slots, n_mels) ? 3 : 0;
         if (c->six && (rc = upload(c->d_blob6, c->ft6.blob))) return bail(rc);
     }
     if (c->fast) {
@@ -959,7 +959,9 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
         return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";
     const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
     if (c->six)
-        return c->six_static ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix80> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix80>")
+        return c->six_static == 1 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix80> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix80>")
+             : c->six_static == 2 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix64> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix64>")
+             : c->six_static == 3 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix40> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix40>")
                              : (fix ? "melspec::whisper400_six_runs_kernel<9, LensRuntime> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensRuntime>");
     if (c->ft.slots.n_slots <= 8) return fix ? "melspec::whisper400_wave_runs_kernel<8, .> (precision guard on)" : "melspec::whisper400_wave_runs_kernel<8, .>";
     return fix ? "melspec::whisper400_wave_runs_kernel<12, .> (precision guard on)" : "melspec::whisper400_wave_runs_kernel<12, .>";
@@ -1954,6 +1956,8 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
                 if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensRuntime>, "hipFuncSetAttribute(fbank512_clip_kernel)");
                 if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi80, true>, "hipFuncSetAttribute(fbank512_clip_kernel)");
                 if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensRuntime, true>, "hipFuncSetAttribute(fbank512_clip_kernel)");
+                if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi40>, "hipFuncSetAttribute(fbank512_clip_kernel)");
+                if (!rc) rc = allow_big_lds(&fbank512_clip_kernel<kFbSlots, LensKaldi40, true>, "hipFuncSetAttribute(fbank512_clip_kernel)");
                 if (rc) return rc;
                 mark_device_done(attr_done);
             }
@@ -1964,11 +1968,13 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
             q.lab_skip = clip_skip;
             const size_t lds = fb->fast_lds + sizeof(ClipCmnShared<8>);
             if (lds <= kLdsLimit) {
-                const bool k80 = fb_lens_match<LensKaldi80>(fb->ft.slots);
+                const bool k80 = fb_lens_match<LensKaldi80>(fb->ft.slots), k40 = fb_lens_match<LensKaldi40>(fb->ft.slots);
                 if (ragged_by_clip) {
                     if (k80) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80, true>), dim3(cus), dim3(512), lds, s, q);
+                    else if (k40) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi40, true>), dim3(cus), dim3(512), lds, s, q);
                     else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime, true>), dim3(cus), dim3(512), lds, s, q);
                 } else if (k80) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi80>), dim3(cus), dim3(512), lds, s, q);
+                else if (k40) hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensKaldi40>), dim3(cus), dim3(512), lds, s, q);
                 else hipLaunchKernelGGL((fbank512_clip_kernel<kFbSlots, LensRuntime>), dim3(cus), dim3(512), lds, s, q);
                 HIP_TRY(hipGetLastError());
                 return MELSPEC_OK;
@@ -1976,6 +1982,8 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         }
         if (fb_lens_match<LensKaldi80>(fb->ft.slots))
             rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi80>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
+        else if (fb_lens_match<LensKaldi40>(fb->ft.slots))
+            rc = launch_fused512<double, kFlavorKaldi, kFbSlots, LensKaldi40>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         else
             rc = launch_fused512<double, kFlavorKaldi, kFbSlots>(fb->waves, fp, fb->fast_lds, fb->dev.cus, s);
         if (rc) return rc;

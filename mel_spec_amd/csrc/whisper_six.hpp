@@ -82,6 +82,10 @@ struct LensSixStatic {
     }
 };
 using LensSix80 = LensSixStatic<80, 1, 1, 1, 2, 2, 3, 4, 6, 7>;
+// Whisper-style banks of 64 and 40 mels at 16 kHz (mel(16000, 400, n_mels), src/mel.rs:547-643): with run-time slot lengths the mel
+// phase pays one LDS round trip per bin (64 mels: 0.378 ms at 1024 x 10 s against 0.292 for the 80-mel bank, profiles/r03_sched.txt)
+using LensSix64 = LensSixStatic<64, 2, 2, 2, 3, 4, 6, 10, 10>;
+using LensSix40 = LensSixStatic<40, 2, 3, 5, 11, 14>;
 
 // ---- phase 1: window, DFT-20 over n1 of column t, twiddle W_200^{t*k1}, 20 exchange rows ----------------------
 MS_DEV void six_phase1(int fl, int t, bool active, int hop, const float *blob, const float *gsrc /* unit's first sample */,
@@ -198,6 +202,12 @@ MS_DEV void six_phase3_sums(int fl, int j, bool active, const MelSlots &ms, cons
                     const float pv = pp[r];
                     if (r == 0) { ar = wv.x * pv; af = wv.y * pv; }
                     else { ar += wv.x * pv; af += wv.y * pv; }
+                    // long slots (banks of fewer mels: 10..14 bins per lane) in pieces of five: with every read of a slot issued up
+                    // front the 64-mel bank spilled 121 VGPRs and ran slower than the run-time loop (0.3885 against 0.3741 ms)
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (Lens::len(i < Lens::kSlots ? i : 0) > 7 && r % 5 == 4 && r + 1 < Lens::len(i < Lens::kSlots ? i : 0))
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             }
         } else if (i < ms.n_slots) {

@@ -203,9 +203,9 @@ extern "C" long long emu_fbank_wave(const float *pcm, long long n, int shift, in
 }
 
 // NeMo flavour of the fused 512 kernel (nemo_phase1 / nemo_phase3_store), f64 arithmetic.  out = [n_mels][cols].
-extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_mels, int sample_rate, double f_min, double f_max,
-                                  int htk, int norm, float preemph, int center, float guard, long long cols, float *out) {
-    using T = double;
+template <class T>
+static long long run_blm(const float *pcm, long long n, int hop, int n_mels, int sample_rate, double f_min, double f_max,
+                         int htk, int norm, float preemph, int center, float guard, long long cols, float *out) {
     using L = FbankLayout<T>;
     constexpr int NS = kBlmSlots;
     FbankFastTables F;
@@ -273,6 +273,16 @@ extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_
         }
     }
     return valid;
+}
+
+extern "C" long long emu_blm_wave(const float *pcm, long long n, int hop, int n_mels, int sample_rate, double f_min, double f_max,
+                                  int htk, int norm, float preemph, int center, float guard, long long cols, float *out) {
+    return run_blm<double>(pcm, n, hop, n_mels, sample_rate, f_min, f_max, htk, norm, preemph, center, guard, cols, out);
+}
+// the same kernel source instantiated in f32 (not shipped: tools/nemo_f32_calib.py measures what an f32 NeMo kernel would cost in accuracy)
+extern "C" long long emu_blm_wave_f32(const float *pcm, long long n, int hop, int n_mels, int sample_rate, double f_min, double f_max,
+                                      int htk, int norm, float preemph, int center, float guard, long long cols, float *out) {
+    return run_blm<float>(pcm, n, hop, n_mels, sample_rate, f_min, f_max, htk, norm, preemph, center, guard, cols, out);
 }
 
 // Precise kernel (whisper_wave_f64.hpp): f64 phases 1-2, shared f32 interval mel phases.
