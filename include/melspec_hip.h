@@ -316,8 +316,9 @@ size_t melspec_fbank_num_frames(const melspec_fbank *fb, size_t n_samples); /* s
 int melspec_fbank_num_mel_bins(const melspec_fbank *fb);
 /* 1 if this configuration runs on the fused 512-point kernel, 0 if on the generic f64 kernel. */
 int melspec_fbank_uses_fast_path(const melspec_fbank *fb);
-/* on != 0: run this object on the generic f64 direct-DFT kernel (an independent device path, kept as the on-device
- * cross-check of the fused kernel; ~60x slower). */
+/* on != 0: run this object on the any-geometry f64 path (an independent device path, kept as the on-device cross-check of the fused
+ * kernel): 1 = whatever that path picks for the geometry (power-of-two frame sizes: pow2_frame_kernel), 2 = the workgroup-per-frame
+ * kernel whatever the geometry (~60x slower than the fused kernel). */
 int melspec_fbank_use_generic(melspec_fbank *fb, int on);
 /* Fbank::compute(&self, samples) -> Array2<f32> (frames, num_mel_bins) (src/fbank.rs:141-236). */
 int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n_samples,

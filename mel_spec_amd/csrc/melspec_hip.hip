@@ -150,7 +150,8 @@ int upload(DevBuf &buf, const std::vector<T> &v) {
 // Tables of the generic (f64 DFT) kernel.
 struct GenericTables {
     DevBuf win, tw, mstart, mlen, moff, mw;
-    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0;
+    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0, mw_count = 0;
+    bool force_generic = false;     // the workgroup-per-frame kernel whatever the geometry (cross-checks)
     FftPlan plan{};
     size_t lds_bytes = 0;
     int build(int n_fft_, int frame_len_, int n_bins_, const std::vector<double> &window,
@@ -164,12 +165,17 @@ struct GenericTables {
         }
         const BandedFilterbank fb = band_filterbank(dense, n_mels, dense_bins, n_bins);
         int rc;
-        if ((rc = upload(win, window))) return rc;
+        {
+            std::vector<double> padded(window);          // n_fft entries, zero from frame_len on: pow2_frame_kernel reads them unconditionally
+            if (static_cast<int>(padded.size()) < n_fft) padded.resize(n_fft, 0.0);
+            if ((rc = upload(win, padded))) return rc;
+        }
         if ((rc = upload(tw, twv))) return rc;
         if ((rc = upload(mstart, fb.start))) return rc;
         if ((rc = upload(mlen, fb.len))) return rc;
         if ((rc = upload(moff, fb.offset))) return rc;
         if ((rc = upload(mw, fb.w))) return rc;
+        mw_count = static_cast<int>(fb.w.size());
         // power-of-two transforms run as an in-LDS FFT over n_fft/2 complex points (the frame slot then holds n_fft doubles)
         fft_log2 = 0;
         if (n_fft >= 8 && (n_fft & (n_fft - 1)) == 0 && frame_len <= n_fft) {
@@ -390,6 +396,29 @@ unsigned grid_for_xcd(uint64_t units, int cus, int per_cu) {
     return (g + 7u) & ~7u;
 }
 
+template <int LOGM, int FLAVOR>
+int launch_pow2(const GenericParams &gp, int cus, hipStream_t stream) {
+    using S = Pow2Shape<LOGM>;
+    if (gp.n_mels > S::kMelsPerLane * S::LF) return -1;
+    if (gp.mw_count < 1 || gp.mw_count >= (1 << 20) || gp.n_bins > 4095) return -1;
+    const size_t bank = ((static_cast<size_t>(gp.mw_count) + (static_cast<size_t>(gp.mw_count) + gp.n_mels + 1) / 2 + 1) & ~static_cast<size_t>(1));
+    const size_t frame = static_cast<size_t>(S::frame_doubles()) + ((static_cast<size_t>(gp.n_mels) + 1) & ~static_cast<size_t>(1));
+    const size_t lds = sizeof(double) * ((S::M <= 256 ? 4 : 2) * static_cast<size_t>(S::M) + bank + static_cast<size_t>(S::kWaves) * S::FW * frame);
+    if (lds > kLdsLimit) return -1;
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&pow2_frame_kernel<LOGM, FLAVOR>, "hipFuncSetAttribute(pow2_frame_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const uint64_t groups = (gp.b.n_units + S::kWaves * S::FW - 1) / (S::kWaves * S::FW);
+    const int per_cu = std::max<int>(1, static_cast<int>(kLdsLimit / lds)) * 2;      // persistent: about two rounds of resident workgroups
+    const unsigned grid = grid_for(groups, cus, per_cu);
+    hipLaunchKernelGGL((pow2_frame_kernel<LOGM, FLAVOR>), dim3(grid), dim3(S::kWaves * 64), lds, stream, gp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
 int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int flavour /* 0 Whisper, 1 Kaldi fbank, 2 NeMo */, int use_log, int use_power,
                    double preemph, double floor_v, int cus, hipStream_t stream, long long clip_len = 0, int pad = 0) {
     if (desc.n_units == 0) return MELSPEC_OK;
@@ -407,6 +436,22 @@ int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int 
     gp.d_mlen = static_cast<const int *>(gt.mlen.p);
     gp.d_moff = static_cast<const int *>(gt.moff.p);
     gp.d_mw = static_cast<const double *>(gt.mw.p);
+    gp.mw_count = gt.mw_count;
+    // power-of-two frame sizes 128 .. 2048: frames owned by lane groups of a wave (pow2_frame_kernel); lab builds: MELSPEC_POW2=0 keeps
+    // the workgroup-per-frame kernel, which is also the on-device cross-check of the tests (melspec_*_use_generic)
+    static const bool pow2_on = lab_int("MELSPEC_POW2", 1, 0, 1) != 0;
+    if (pow2_on && !gt.force_generic && gt.fft_log2 >= 7 && gt.fft_log2 <= 11) {
+        int rc = -1;
+        switch (gt.fft_log2 * 4 + flavour) {
+#define MS_POW2_CASE(LOG2, LOGM) \
+            case LOG2 * 4 + 0: rc = launch_pow2<LOGM, 0>(gp, cus, stream); break; \
+            case LOG2 * 4 + 1: rc = launch_pow2<LOGM, 1>(gp, cus, stream); break; \
+            case LOG2 * 4 + 2: rc = launch_pow2<LOGM, 2>(gp, cus, stream); break;
+            MS_POW2_CASE(7, 6) MS_POW2_CASE(8, 7) MS_POW2_CASE(9, 8) MS_POW2_CASE(10, 9) MS_POW2_CASE(11, 10)
+#undef MS_POW2_CASE
+        }
+        if (rc >= 0) return rc;          // -1: the bank is wider than the kernel's lanes cover
+    }
     const unsigned grid = grid_for(desc.n_units, cus, 8);
     hipLaunchKernelGGL(generic_frame_kernel<kGenericNT>, dim3(grid), dim3(kGenericNT), gt.lds_bytes, stream, gp);
     HIP_TRY(hipGetLastError());
@@ -1901,6 +1946,7 @@ int melspec_fbank_uses_fast_path(const melspec_fbank *fb) { return fb && fb->fas
 int melspec_fbank_use_generic(melspec_fbank *fb, int on) {
     if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
     fb->use_generic = on != 0;
+    fb->gt.force_generic = on == 2;      // 2: the workgroup-per-frame kernel also where pow2_frame_kernel would take the geometry
     return MELSPEC_OK;
 }
 

@@ -16,6 +16,7 @@
 #include "whisper_six.hpp"
 #include "whisper_fix64.hpp"
 #include "stream_plan.hpp"
+#include "pow2_wave.hpp"
 
 // Issue priority of the wave (s_setprio 0..3).  The persistent kernels raise it as a unit progresses (loads + first FFT
 // stage 0, second stage 1, mel / log / store 2): the waves sharing a SIMD then stop advancing in lock-step through the
@@ -2167,6 +2168,7 @@ struct GenericParams {
     const int *d_mlen;     // [n_mels]
     const int *d_moff;     // [n_mels] offset into d_mw
     const double *d_mw;    // concatenated spans
+    int mw_count;          // doubles in d_mw (pow2_frame_kernel stages the bank in LDS)
 };
 
 template <int NT>
@@ -2340,6 +2342,289 @@ __global__ __launch_bounds__(NT) void generic_frame_kernel(const GenericParams p
             for (int m = tid; m < p.n_mels; m += NT) o[m * ostep] = (float)mv[m];      // feature-major rows (src/mel.rs:366)
         } else {
             for (int m = tid; m < p.n_mels; m += NT) o[m] = (float)mv[m];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// pow2_frame_kernel: the power-of-two frame sizes on wave-owned frames (pow2_wave.hpp).  Same parameters, flavours, tables and
+// results contract as generic_frame_kernel; units == frames.  LDS (doubles): [tw: W_N^q, q < M][WAVES x FW x frame region].
+// ------------------------------------------------------------------------------------
+
+// The samples a lane needs for one frame, as they come from memory: pairs (x[2n], x[2n + 1]) of its P complex points and, for the
+// flavours with pre-emphasis, the sample in front of each pair.  Loaded one frame AHEAD of their use (the next frame's loads are in
+// flight while this frame's transform runs): at two or three waves per SIMD nothing else hides a 1-2 us HBM round trip.
+template <int P, int FLAVOR> struct Pow2Raw {
+    f2 pair[P];
+    float before[FLAVOR == 0 ? 1 : P];
+};
+
+template <int LOGM, int FLAVOR>
+__global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kernel(const GenericParams p) {
+    using S = Pow2Shape<LOGM>;
+    constexpr int M = S::M, LF = S::LF, FW = S::FW, P = S::P, kPow2Waves = S::kWaves;
+    constexpr bool kAhead = P == 8;                      // M = 1024 holds 16 points per lane and has no registers to spare
+    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    double *tw = ldsd;                                   // 2 * M: W_N^q, q < M
+    constexpr bool kWinLds = M <= 256;                   // above that the 8 / 16 KB of the window cost a resident workgroup: read from L1 / L2
+    double *lwin = tw + 2 * M;                           // 2 * M: the window, zero from frame_len on
+    double *lmw = lwin + (kWinLds ? 2 * M : 0);          // the banded filterbank, mel after mel: mw_count weights, then per weight
+    int *lent = reinterpret_cast<int *>(lmw + p.mw_count);   //   {bin | mel << 12}, then per mel {first entry | entries << 20}
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * M; i += kPow2Waves * 64) {
+        tw[i] = p.d_tw[i];
+        if (kWinLds) lwin[i] = p.d_win[i];
+    }
+    for (int i = tid; i < p.mw_count; i += kPow2Waves * 64) lmw[i] = p.d_mw[i];
+    for (int m = tid; m < p.n_mels; m += kPow2Waves * 64) {
+        const int st = p.d_mstart[m], len = p.d_mlen[m], off = p.d_moff[m];
+        for (int r = 0; r < len; ++r) lent[off + r] = (st + r) | (m << 12);
+        lent[p.mw_count + m] = off | (len << 20);
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int fs = lane / LF, l = lane - fs * LF;        // frame slot of the wave, lane of the frame
+    const int acc_doubles = (p.n_mels + 1) & ~1;
+    double *z = lmw + ((p.mw_count + (p.mw_count + p.n_mels + 1) / 2 + 1) & ~1) + (wave * FW + fs) * (S::frame_doubles() + acc_doubles);
+    double *pw = z + 2 * S::kZ;                          // [M + 1]
+    double *acc = pw + M + 2;                            // [n_mels] band energies of the frame
+    const int last = p.frame_len - 1;
+
+    // the twiddles of pass 2 depend on the lane only: W_{8 R1}^{k r}, k = l mod R1 (kept in registers; pass 3's come from the LDS table)
+    cpx<double> tw2[kAhead ? 7 : 1];
+    if (kAhead) {
+        const int k2 = l & (S::R1 - 1);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) tw2[r - 1] = pow2_root(tw, r * k2 * (2 * M / (S::R1 * 8)), M);
+    }
+
+    struct Frame {                                       // where a frame is, per lane group
+        const float *pcm, *x;
+        float *o;
+        uint64_t ostep, start;
+        bool have, real;
+    };
+    const uint64_t n_units = batch_n_units(p.b);
+    const uint64_t stride = (uint64_t)gridDim.x * kPow2Waves * FW;
+    auto place = [&](uint64_t base) {
+        Frame f;
+        const uint64_t unit = base + fs;
+        f.have = unit < n_units;
+        const UnitLoc loc = locate_unit(p.b, f.have ? unit : base);
+        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+        f.o = p.b.mel_major ? loc.out + loc.unit : loc.out + loc.unit * (uint64_t)p.n_mels;
+        f.ostep = p.b.mel_major ? width : 1;
+        f.real = f.have && loc.unit < loc.frames;        // otherwise: a zero column of a padded layout (uniform batches), or nothing
+        f.start = loc.unit * (uint64_t)p.hop;
+        f.pcm = loc.pcm;
+        f.x = loc.pcm + f.start;
+        return f;
+    };
+    // Every load is unconditional (clamped index, the value selected afterwards): a load behind its own branch is a serialised memory
+    // round trip, and the first form of this kernel -- one predicate per sample -- spent 80 % of its time in them.
+    auto fetch = [&](const Frame &f, Pow2Raw<P, FLAVOR> &raw) {
+        if (!f.real) return;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int i0 = 2 * (l + r * LF);
+            if (FLAVOR == 2) {                           // sample s of the frame = clip[start + s - pad], zero outside the clip
+                const long long s0 = (long long)f.start + i0 - p.pad, hi = p.clip_len - 1;
+                const long long c0 = s0 < 0 ? 0 : (s0 > hi ? hi : s0), c1 = s0 + 1 < 0 ? 0 : (s0 + 1 > hi ? hi : s0 + 1);
+                raw.pair[r] = f2{f.pcm[c0], f.pcm[c1]};
+                raw.before[r] = f.pcm[c0 > 0 ? c0 - 1 : 0];
+            } else {
+                const int pi = i0 + 1 <= last ? i0 : (last >= 1 ? last - 1 : 0);     // never past the frame's last sample
+                raw.pair[r] = load2_unaligned(f.x + pi);
+                if (FLAVOR == 1) raw.before[r] = (pi > 0 || f.start > 0) ? f.x[pi - 1] : f.x[0];
+            }
+        }
+    };
+
+    uint64_t base = ((uint64_t)blockIdx.x * kPow2Waves + wave) * FW;
+    if (base >= n_units) return;
+    Frame cur = place(base);
+    Pow2Raw<P, FLAVOR> raw;
+    fetch(cur, raw);
+    for (;;) {
+        const uint64_t nbase = base + stride;
+        const bool more = nbase < n_units;               // wave-uniform
+        Frame nxt = cur;
+        Pow2Raw<P, FLAVOR> nraw;
+        if (kAhead && more) {
+            nxt = place(nbase);
+            fetch(nxt, nraw);
+        }
+        if (cur.have && !cur.real) {
+            for (int m = l; m < p.n_mels; m += LF) cur.o[m * cur.ostep] = 0.0f;
+        }
+        if (cur.real) {
+            // ---- framing: DC removal / pre-emphasis / window per flavour -> the lane's P complex points z[l + r LF] -----------------
+            cpx<double> reg[P];
+            double v[2 * P];
+            if (FLAVOR == 0) {                           // frame_windows: x[start + i] as f64 (src/stft.rs:160-165)
+#pragma unroll
+                for (int r = 0; r < P; ++r) { v[2 * r] = (double)raw.pair[r].x; v[2 * r + 1] = (double)raw.pair[r].y; }
+            } else if (FLAVOR == 2) {                    // src/mel.rs:696-706: whole-clip pre-emphasis in f32, two roundings; zero centre padding
+                const float coeff = (float)p.preemph;
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    const long long s0 = (long long)cur.start + 2 * (l + r * LF) - p.pad;
+                    const float a = raw.pair[r].x, b0 = raw.pair[r].y;
+                    const float pa = a - f32_mul_rn(coeff, raw.before[r]), pb = b0 - f32_mul_rn(coeff, a);
+                    const float fa = (coeff != 0.0f && s0 > 0) ? pa : a, fb = (coeff != 0.0f && s0 + 1 > 0) ? pb : b0;
+                    v[2 * r] = (s0 >= 0 && s0 < p.clip_len) ? (double)fa : 0.0;
+                    v[2 * r + 1] = (s0 + 1 >= 0 && s0 + 1 < p.clip_len) ? (double)fb : 0.0;
+                }
+            } else {                                     // src/fbank.rs:164-190: DC removal, pre-emphasis
+                double xa[P], xb[P];
+                double part = 0.0;
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    const int i0 = 2 * (l + r * LF);
+                    xa[r] = (double)(i0 + 1 <= last ? raw.pair[r].x : raw.pair[r].y);     // i0 == last: the clamped pair holds x[last] second
+                    xb[r] = (double)raw.pair[r].y;
+                    part += i0 <= last ? xa[r] : 0.0;
+                    part += i0 + 1 <= last ? xb[r] : 0.0;
+                }
+                // (the frame's lanes are all inside this branch or all outside it: a frame owns a whole lane group)
+#pragma unroll
+                for (int d = 1; d < LF; d <<= 1) part += __shfl_xor(part, d, 64);
+                const double mean = part / (double)p.frame_len;
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    const int i0 = 2 * (l + r * LF);
+                    double ta = xa[r] - mean, tb = xb[r] - mean;
+                    if (p.preemph > 0.0) {
+                        tb -= p.preemph * (xa[r] - mean);
+                        if (i0 > 0 || cur.start > 0) ta -= p.preemph * ((double)raw.before[r] - mean);
+                    }
+                    v[2 * r] = ta; v[2 * r + 1] = tb;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const d2 w = *reinterpret_cast<const d2 *>((kWinLds ? lwin : p.d_win) + 2 * (l + r * LF));
+                reg[r] = {v[2 * r] * w.x, v[2 * r + 1] * w.y};
+            }
+            // ---- the complex M-point transform: Stockham passes, in place in the frame's LDS region --------------------------------
+            pow2_pass<LOGM, S::R1, true>(l, 1, tw, z, reg, nullptr);
+#ifndef MELSPEC_P2_SKIP_PASSES
+            pow2_pass<LOGM, 8, false>(l, S::R1, tw, z, nullptr, kAhead ? tw2 : nullptr);
+            if (S::R3 > 1) pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, tw, z, nullptr, nullptr);
+#endif
+            // ---- the real-FFT split X[k] = E[k] + W_N^k O[k] and the power row ------------------------------------------------------
+            auto power = [&](int k) {
+                const int ka = k == M ? 0 : k, kb = (M - k) & (M - 1);        // Z[M] = Z[0]; partner Z[M - k]
+                const cpx<double> a = ldc(z + 2 * pow2_pad(ka)), b0 = ldc(z + 2 * pow2_pad(kb));
+                const double br = b0.re, bi = -b0.im;                       // conj
+                const double er = 0.5 * (a.re + br), ei = 0.5 * (a.im + bi);
+                const double dr = 0.5 * (a.re - br), di = 0.5 * (a.im - bi);
+                double c = -1.0, sn = 0.0;                                  // W_N^M
+                if (k < M) { const cpx<double> w = ldc(tw + 2 * k); c = w.re; sn = w.im; }
+                const double orr = di, oi = -dr;
+                const double re = er + (orr * c - oi * sn), im = ei + (orr * sn + oi * c);
+                const double ns = re * re + im * im;
+                return (FLAVOR == 1 && !p.use_power) ? sqrt(ns) : ns;
+            };
+            double pk[P];
+#ifdef MELSPEC_P2_SKIP_POWER
+#pragma unroll
+            for (int r = 0; r < P; ++r) pk[r] = z[2 * pow2_pad(l + r * LF)];
+#else
+#pragma unroll
+            for (int r = 0; r < P; ++r) pk[r] = power(l + r * LF);
+#endif
+#pragma unroll
+            for (int r = 0; r < P; ++r) pw[l + r * LF] = pk[r];
+            if (l == 0 && p.n_bins > M) pw[M] = power(M);
+        }
+        // ---- banded mel sums, log, per-flavour epilogue ---------------------------------------------------------------------------
+        // One mel per lane and step: the reference's left fold over the band (src/mel.rs:155-163), eight LDS loads in flight at a time.
+        // (Tried and slower, round 4: every lane folding the same number of consecutive (mel, bin, weight) entries with ds_add_f64 at the
+        // mel boundaries -- balanced, but 20 divergent branch sites per frame: n_fft 1024 2.05 -> 3.5 ms.)
+        constexpr int kMaxPer = Pow2Shape<LOGM>::kMelsPerLane;            // this lane's mels m = l + LF i (the host checks n_mels <= kMelsPerLane * LF)
+        auto mel_step = [&](int i) __attribute__((always_inline)) {
+            const int rem = p.n_mels - LF * i;                 // mels of this step
+            if (rem <= 0) return;                              // wave-uniform
+            // a last step with few mels (80 mels on 64 lanes: the 16 widest bands) gives every mel g lanes, each folding a g-th of the band
+            int g = 1;
+            while (2 * g * rem <= LF) g *= 2;
+            const int mi = l / g, part = l - mi * g, m = LF * i + mi;
+            double e = 0.0;
+            if (cur.real && mi < rem) {
+                const int info = lent[p.mw_count + m];         // {first entry | entries << 20}
+                const int off = info & 0xfffff, len = info >> 20;
+                const int r0 = len * part / g, r1 = len * (part + 1) / g;
+                const double *w = lmw + off, *pp = pw + (lent[off] & 0xfff);
+                int r = r0;
+                for (; r + 8 <= r1; r += 8) {
+                    const double w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3], w4 = w[r + 4], w5 = w[r + 5], w6 = w[r + 6], w7 = w[r + 7];
+                    const double p0 = pp[r], p1 = pp[r + 1], p2 = pp[r + 2], p3 = pp[r + 3], p4 = pp[r + 4], p5 = pp[r + 5], p6 = pp[r + 6], p7 = pp[r + 7];
+                    e += w0 * p0; e += w1 * p1; e += w2 * p2; e += w3 * p3; e += w4 * p4; e += w5 * p5; e += w6 * p6; e += w7 * p7;
+                }
+                for (; r + 4 <= r1; r += 4) {
+                    const double w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3];
+                    const double p0 = pp[r], p1 = pp[r + 1], p2 = pp[r + 2], p3 = pp[r + 3];
+                    e += w0 * p0; e += w1 * p1; e += w2 * p2; e += w3 * p3;
+                }
+                for (; r < r1; ++r) e += w[r] * pp[r];
+            }
+            for (int d = 1; d < g; d <<= 1) e += __shfl_xor(e, d, 64);        // g: wave-uniform
+            if (cur.real && mi < rem && part == 0) acc[m] = e;
+        };
+        if (kMaxPer <= 4) {                                    // 64 lanes per frame: the steps unrolled (n_fft 1024: 2.7 -> see profiles/r04_pow2.txt)
+#pragma unroll
+            for (int i = 0; i < (kMaxPer <= 4 ? kMaxPer : 1); ++i) mel_step(i);
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < kMaxPer; ++i) mel_step(i);
+        }
+        // log2 through v_log_f32 (1 ulp: <= 1.2e-6 of a log10 / ln value, 3e-7 after Whisper's / 4), like the fused kernels
+        float mv[kMaxPer];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int m = l + LF * i;
+            mv[i] = 0.0f;
+            if (cur.real && m < p.n_mels) {
+                const double e = acc[m];
+                float vv;
+                if (FLAVOR == 0) {
+                    vv = fast_log2((float)(e > 1e-10 ? e : 1e-10)) * 0.30102999566398120f;          // src/mel.rs:166
+                } else if (FLAVOR == 2) {
+                    vv = fast_log2((float)(e + p.floor_v)) * 0.69314718055994531f;                  // src/mel.rs:365-368
+                } else {
+                    const float t = (float)(e > p.floor_v ? e : p.floor_v);                           // src/fbank.rs:210-218
+                    vv = p.use_log ? fast_log2(t) * 0.69314718055994531f : t;
+                }
+                mv[i] = vv;
+                mx = mx > vv ? mx : vv;
+            }
+        }
+        if (FLAVOR == 0) {                                     // src/mel.rs:645-654: clamp at the frame's maximum - 8, (x + 4) / 4
+#pragma unroll
+            for (int d = 1; d < LF; d <<= 1) { const float t = __shfl_xor(mx, d, 64); mx = mx > t ? mx : t; }
+            const float lo = mx - 8.0f;
+#pragma unroll
+            for (int i = 0; i < kMaxPer; ++i) {
+                const int m = l + LF * i;
+                if (cur.real && m < p.n_mels) cur.o[m * cur.ostep] = ((mv[i] > lo ? mv[i] : lo) + 4.0f) * 0.25f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kMaxPer; ++i) {
+                const int m = l + LF * i;
+                if (cur.real && m < p.n_mels) cur.o[m * cur.ostep] = mv[i];
+            }
+        }
+        if (!more) break;
+        base = nbase;
+        if (kAhead) {
+            cur = nxt;
+            raw = nraw;
+        } else {
+            cur = place(base);
+            fetch(cur, raw);
         }
     }
 }

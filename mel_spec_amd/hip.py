@@ -514,7 +514,7 @@ class Fbank:
 
     def use_generic(self, on: bool = True) -> None:
         """run on the generic f64 direct-DFT kernel (the on-device cross-check of the fused kernel)"""
-        _check(lib().melspec_fbank_use_generic(self._h, int(on)))
+        _check(lib().melspec_fbank_use_generic(self._h, int(on)))      # 2: the workgroup-per-frame kernel whatever the geometry
 
     def compute(self, samples) -> np.ndarray:
         """&[f32] -> Array2<f32> (num_frames, num_mel_bins)."""

@@ -485,6 +485,61 @@ def test_sample_offsets_beyond_32_bits(gpu, w80, oracle):
     pcm.free(); out.free()
 
 
+# ---- the power-of-two frame sizes off the 400- / 512-point kernels (pow2_frame_kernel, round 4) -----------------------------------
+
+@pytest.mark.parametrize("sr,bins", [(8000.0, 40), (8000.0, 23), (32000.0, 80), (44100.0, 80), (22050.0, 64), (48000.0, 128)])
+def test_pow2_kernel_kaldi_rates_against_oracle_and_the_workgroup_kernel(gpu, oracle, jfk, sr, bins):
+    """Kaldi fbank at 8 / 22.05 / 32 / 44.1 / 48 kHz = fft sizes 256 / 1024 / 1024 / 2048 / 2048 (src/fbank.rs:66-82), frame lengths 200 ...
+    1200 (1103 at 44.1 kHz: odd), on pow2_frame_kernel: against the oracle, and against generic_frame_kernel -- an independent
+    transform (radix-2 passes behind barriers) on the same device -- single clips, a ragged batch with short and empty clips, CMN on."""
+    x = np.resize(jfk, int(sr * 3.3)).astype(np.float32)
+    cfg = gpu.FbankConfig(sample_rate=sr, num_mel_bins=bins)
+    oc = oracle.fbank_default_config(); oc.sample_rate = sr; oc.num_mel_bins = bins
+    fb = gpu.Fbank(cfg)
+    assert not fb.uses_fast_path and cfg.fft_size() in (256, 1024, 2048)
+    got = fb.compute(x)
+    want = oracle.fbank_compute(x, oc)
+    assert got.shape == want.shape and np.abs(got - want).max() <= TOL
+    fb.use_generic(2)
+    slow = fb.compute(x)
+    fb.use_generic(False)
+    assert np.abs(got - slow).max() <= 2e-5            # the f32 logarithm of the fused form (1 ulp of log2) against the f64 one
+    fl = cfg.frame_length_samples()
+    lens = [0, fl - 1, fl, fl + 1, 3 * fl + 7, len(x), 5 * cfg.frame_shift_samples() + fl]
+    rag = fb.compute_ragged([x[:n] for n in lens])
+    for n, g in zip(lens, rag):
+        w = oracle.fbank_compute(x[:n], oc)
+        assert g.shape == w.shape and (w.size == 0 or np.abs(g - w).max() <= TOL), n
+    fb.close()
+
+
+@pytest.mark.parametrize("fft,hop,n_mels,sr", [(128, 32, 20, 8000.0), (128, 64, 40, 8000.0), (256, 64, 40, 8000.0), (256, 100, 80, 16000.0),
+                                               (1024, 256, 80, 16000.0), (1024, 160, 128, 22050.0), (2048, 512, 128, 44100.0), (2048, 441, 80, 44100.0)])
+def test_pow2_kernel_whisper_style(gpu, oracle, jfk, fft, hop, n_mels, sr):
+    """Whisper-style log-mel at n_fft 128 / 256 / 1024 / 2048: uniform batches (frames of several clips share a wave at n_fft <= 512),
+    ragged batches, the padded and mel-major layouts -- all against the oracle at the f64 paths' gate."""
+    m = gpu.HipMelSpectrogram(fft, hop, sr, n_mels)
+    assert not m.uses_fast_path
+    n = 3 * fft + 11 * hop + 5
+    clips = np.stack([jfk[3000 * c:3000 * c + n] for c in range(5)] + [oracle.synth_pcm(c, n) for c in range(4)])
+    want = [oracle.compute_mel_spectrogram_cpu(c, fft, hop, n_mels, sr) for c in clips]
+    got = m.compute_batch(clips)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and np.abs(g - w).max() <= 2e-6
+    lens = [0, fft - 1, fft, fft + hop - 1, fft + hop, n, n - 1, 2 * fft, n]
+    for g, c, k in zip(m.compute_ragged([c[:k] for c, k in zip(clips, lens)]), clips, lens):
+        w = oracle.compute_mel_spectrogram_cpu(c[:k], fft, hop, n_mels, sr)
+        assert g.shape == w.shape and (w.size == 0 or np.abs(g - w).max() <= 2e-6), k
+    for mco in (False, True):
+        img = m.compute_batch_interleaved(clips, mco, 40)
+        for c, w in enumerate(want):
+            g = img[c][: w.shape[0]] if mco else img[c].T[: w.shape[0]]
+            assert np.abs(g - w).max() <= 2e-6
+            pad = img[c][w.shape[0]:] if mco else img[c].T[w.shape[0]:]
+            assert not pad.size or np.all(pad == 0.0)
+    m.close()
+
+
 # ---- Kaldi fbank -----------------------------------------------------------------------------
 
 def test_fbank_jfk(gpu, oracle, jfk, golden):
