@@ -334,6 +334,7 @@ int plan_ragged(RaggedScratch &rs, hipStream_t stream, const float *d_pcm, float
         b.d_ticket = const_cast<uint32_t *>(b.d_order) + n_clips;
     }
     pl.total_frames = total;
+    b.stat_frames = total;
     return MELSPEC_OK;
 }
 // behind the launch (or the failed attempt) that used the slot
@@ -611,8 +612,9 @@ int ctx_num_frames(const melspec_ctx *c, uint64_t n, uint64_t &frames) {
 // the launch-specific part of a guarded launch's statistics sink (the grid is only known where the launch is made)
 FixSink sink_armed(melspec_ctx *c, FixSink sink, const BatchDesc &desc, unsigned grid) {
     if (!sink.acc) return sink;
-    sink.frames = desc.d_unit_prefix == nullptr ? static_cast<uint64_t>(desc.n_clips) * desc.frames_per_clip
-                                                : desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);   // ragged: upper bound
+    sink.frames = desc.stat_frames ? desc.stat_frames
+                : desc.d_unit_prefix == nullptr ? static_cast<uint64_t>(desc.n_clips) * desc.frames_per_clip
+                                                : desc.n_units * static_cast<uint64_t>(desc.frames_per_unit);   // device-planned ragged: upper bound
     sink.n_groups = grid;
     sink.seq = (c->fix.seq = (c->fix.seq + 1) & 0xffffffu) ? c->fix.seq : (c->fix.seq = 1);      // never 0: the host's "nothing seen yet"
     return sink;
@@ -1618,6 +1620,8 @@ struct melspec_bank {
     hipStream_t stream = nullptr;
     int n_mels = 0, fft_bins = 0, nnz = 0;
     DevBuf row_ptr, bin, w, wf, key, tmp_in, tmp_out;
+    hipStream_t key_stream = nullptr;              // norm_mel's scratch word is used in stream order: a call on another stream first waits for this one
+    bool key_used = false;
     std::vector<int> h_row_ptr, h_bin;             // the sparse rows on the host (weights_for_mel)
     std::vector<double> h_w;
     BankDesc desc() const {
@@ -1750,6 +1754,10 @@ int melspec_bank_norm_mel_device(melspec_bank *b, const void *d_in, int dtype, u
     HIP_TRY(hipSetDevice(b->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : b->stream;
     unsigned long long *key = static_cast<unsigned long long *>(b->key.p);
+    // the three launches of a call (init, max, map) share ONE scratch word per bank: two calls on different streams would race on it
+    //  -- like FixState::last_stream, a change of stream waits for the previous one
+    if (b->key_used && b->key_stream != s) HIP_TRY(hipStreamSynchronize(b->key_stream));
+    b->key_used = true; b->key_stream = s;
     return dtype == MELSPEC_STFT_F64 ? norm_launch<double>(static_cast<const double *>(d_in), n_values, static_cast<double *>(d_out), key, b->dev.cus, s)
                                      : norm_launch<float>(static_cast<const float *>(d_in), n_values, static_cast<float *>(d_out), key, b->dev.cus, s);
 }

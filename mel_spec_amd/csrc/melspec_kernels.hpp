@@ -57,6 +57,8 @@ struct BatchDesc {
                                     // n_units above is the host's upper bound (grid and scratch sizes)
     const uint32_t *d_order;        // ragged, host-planned, optional: the clips longest first (whole-clip kernels take them in this order)
     uint32_t *d_ticket;             //   and the counter they take them from (zero when the launch starts)
+    uint64_t stat_frames;           // frames of the batch as the planner counted them (host-planned ragged batches: the true total; 0: not set) -- the
+                                    //   denominator of the guard statistics (n_units * frames_per_unit over-counts short clips up to 6 x)
     int *d_unit_ext;                // uniform mel-major layouts, optional: [n_units][2] = {smallest, largest} biased value (phase 4) every work unit
                                     //   stored -- the TGA quantiser's first pass (tga_quant.hpp) then reads 8 bytes per unit instead of the image
 };

@@ -178,6 +178,48 @@ def test_auto_is_a_function_of_the_batch(gpu, oracle, jfk):
     pcm_s.free(); pcm_n.free(); out.free(); m.close()
 
 
+@pytest.mark.parametrize("mode,tol", [("auto", TOL), ("f64", 2e-6), ("f32", TOL)])
+@pytest.mark.parametrize("n_mels", [80, 128, 64])
+def test_every_precision_mode_through_every_batch_shape(gpu, oracle, jfk, n_mels, mode, tol):
+    """VERDICT r03 "next" 7: the driver runs the suite once, in the default mode -- so one test takes all three modes of
+    melspec_set_precision through what the rest of the suite exercises in AUTO only: single clip, uniform batch, ragged batch with
+    short and empty clips, both interleaved layouts with padding, the host pipeline's batch call, the clip table in device memory and
+    the streaming bank.  Speech and noise (where the bare f32 FFT holds the tolerance too: DESIGN section 5)."""
+    m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+    m.set_precision(mode)
+    assert m.precision == mode
+    n = 24000
+    clips = np.stack([jfk[9000 * c:9000 * c + n] for c in range(6)] + [oracle.synth_pcm(c, n) for c in range(3)])
+    want = [oracle.compute_mel_spectrogram_cpu(c, 400, 160, n_mels, SR) for c in clips]
+    assert np.abs(m.compute_mel_spectrogram(clips[1]) - want[1]).max() <= tol
+    for g, w in zip(m.compute_batch(clips), want):
+        assert g.shape == w.shape and np.abs(g - w).max() <= tol
+    lens = [0, 399, 400, 559, 560, n, n - 161, 4000, n]
+    rag_in = [c[:k] for c, k in zip(clips, lens)]
+    rag_want = [oracle.compute_mel_spectrogram_cpu(c, 400, 160, n_mels, SR) for c in rag_in]
+    for g, w in zip(m.compute_ragged(rag_in), rag_want):
+        assert g.shape == w.shape and (w.size == 0 or np.abs(g - w).max() <= tol)
+    for mco in (False, True):
+        img = m.compute_batch_interleaved(clips, mco, 200)
+        for c, w in enumerate(want):
+            g = img[c][: w.shape[0]] if mco else img[c].T[: w.shape[0]]
+            assert np.abs(g - w).max() <= tol
+    flat = np.concatenate(rag_in)
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    out = np.empty(sum(w.shape[0] for w in rag_want) * n_mels, np.float32)
+    m.compute_batch_host(flat, offs, np.array(lens, np.uint64), out)
+    cur = 0
+    for w in rag_want:
+        assert w.size == 0 or np.abs(out[cur:cur + w.size].reshape(w.shape) - w).max() <= tol
+        cur += w.size
+    bank = gpu.StreamBank(m, 2, 4000)
+    for s_id in range(2):
+        parts = [bank.push([s_id], [clips[s_id][q:q + 4000]])[0] for q in range(0, n, 4000)]
+        assert np.abs(np.concatenate(parts) - oracle.stream_mel(clips[s_id], 400, 160, n_mels, SR)).max() <= tol
+    bank.close()
+    m.close()
+
+
 def _hard_signals(n, sr, seed=42):
     rng = np.random.default_rng(seed)
     t = np.arange(n) / sr
