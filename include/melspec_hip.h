@@ -94,7 +94,8 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
  *                   vote first: the first work unit of every wavefront is the sample, and when more than 1/8 of the sampled
  *                   frames trip the guard the f32 kernel stands down and the f64 kernel queued behind it (a second launch that
  *                   returns at once otherwise) computes the whole batch at the F64 rate.  Plain [clip][frame][mel] batches,
- *                   uniform and ragged; the padded / mel-major layouts keep the f32 kernel + recompute.  The vote happens inside
+ *                   uniform and ragged, and the padded / mel-major layouts (their sample is the head of the batch); only
+ *                   melspec_tga_encode_pcm_uniform_device keeps the f32 kernel + recompute whatever the input.  The vote happens inside
  *                   the batch's own launch and nobody waits for it: the result of a call is a function of its input alone (same
  *                   batch -> same bits, whatever the context computed before; round 3 chose from the previous batch's
  *                   statistics).  A clip's bits can differ between two different batches (f32 regime in one, f64 in the other,

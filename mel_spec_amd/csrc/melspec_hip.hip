@@ -645,7 +645,8 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat,
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const uint64_t steps = gate ? (desc.n_units * static_cast<uint64_t>(desc.frames_per_unit) + kFPW - 1) / kFPW : desc.n_units;
+    const bool walk = gate && !(desc.mel_major || desc.out_width != desc.frames_per_clip);      // gated layouts come with a plan of their own
+    const uint64_t steps = walk ? (desc.n_units * static_cast<uint64_t>(desc.frames_per_unit) + kFPW - 1) / kFPW : desc.n_units;
     const uint64_t blocks = (steps + kPreciseWaves - 1) / kPreciseWaves;
     static const int per_cu = lab_int("MELSPEC_PRECISE_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU
     const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
@@ -654,7 +655,7 @@ int launch_precise_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat,
     PreciseParams pp = precise_params(c, desc, armed);
     pp.gate = gate; pp.gate_value = gate_value; pp.plan_fpu = desc.frames_per_unit;
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-    if (gate)
+    if (gate && !layout)
         hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, 2>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
     else if (layout)
         hipLaunchKernelGGL((whisper400_precise_kernel<NSLOTS, Lens, 0>), dim3(grid), dim3(kPreciseWaves * 64), c->precise_lds, stream, pp);
@@ -789,9 +790,10 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         sink.count = static_cast<unsigned long long *>(fx.count.p);
         sink.acc = sink.count + 1;
         sink.host = fx.host;
-        // The vote (FixSink::vote): plain batches.  The padded / mel-major layouts deal their units round-robin and keep the f32 kernel
-        // + recompute tail whatever the input (MELSPEC_PRECISION_F64 is the fast mode for speech there).
-        vote = fx.adaptive && !layout_batch;
+        // The vote (FixSink::vote): plain batches and the padded / mel-major layouts (whose sample is the head of the batch: they deal
+        // their units round-robin).  Not where the mel kernel also leaves the image extremes for the TGA quantiser (d_unit_ext: the two
+        // kernels' units differ): PCM -> TGA keeps the f32 kernel + recompute tail whatever the input.
+        vote = fx.adaptive && (!layout_batch || desc.d_unit_ext == nullptr);
         if (vote) {
             sink.vote = sink.count + 2;
             sink.decision = static_cast<unsigned *>(fx.verdicts.p);
@@ -808,6 +810,13 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     const unsigned gate_value = (c->fix.seq & 0xffffffu) << 2 | kVoteDecided | kVoteHeavy;
     FixSink stat{};
     stat.count = sink.count; stat.acc = sink.acc; stat.host = sink.host;
+    if (layout_batch && desc.frames_per_unit != kFPW) {
+        // the layouts' f64 kernel deals units of its own size: the same (uniform) batch planned for five frames per unit
+        BatchPlan p5 = plan_uniform(desc.pcm, desc.out, desc.clip_stride, desc.frames_per_clip, desc.n_clips, c->n_mels, kFPW, desc.out_width, desc.mel_major != 0);
+        if (p5.desc.sync_rounds < 0) p5.desc.sync_rounds = 2;          // the precise kernel's measured grouping (consecutive pairs)
+        return launch_precise(c, p5.desc, stat, stream, sink.decision, gate_value);
+    }
+    if (layout_batch && desc_in.sync_rounds < 0) desc.sync_rounds = 2;
     return launch_precise(c, desc, stat, stream, sink.decision, gate_value);
 }
 
@@ -882,7 +891,7 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
     if (c->fast) {
         c->lens_kind = lens_match<LensI80>(c->ft.slots, n_mels) ? 1 : (lens_match<LensI128>(c->ft.slots, n_mels) ? 2 : 0);
         if (runtime_lens) c->lens_kind = 0;
-        c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(kWaveWaves) * WaveLayout::slice_floats() + kWaveWaves);   // + RoundSync counters
+        c->fast_lds = sizeof(float) * (c->ft.blob.size() + static_cast<size_t>(kWaveWaves) * WaveLayout::slice_floats() + kWaveWaves + 4);   // + RoundSync counters + the vote's words
         PreciseTables pt;
         const bool pt_ok = build_precise_tables(c->ft, pt, true);
         c->precise_lds = pt.blob.size() * 4 + static_cast<size_t>(kPreciseWaves) * PreciseLayout::slice_doubles() * sizeof(double) +
@@ -898,7 +907,7 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
     }
     if (c->fast && build_six_tables(c->dense, n_mels, c->ft6)) {
-        c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves);   // + arrival counters
+        c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves + 4);   // + arrival counters + the vote's words
         c->six = c->lds6 <= kLdsLimit;
         c->six_static = runtime_lens ? 0 : lens_match<LensSix80>(c->ft6.slots, n_mels) ? 1 : lens_match<LensSix64>(c->ft6.slots, n_mels) ? 2
                         : lens_match<LensSix40>(c->ft6.slots, n_mels) ? 3 : 0;

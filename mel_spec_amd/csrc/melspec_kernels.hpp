@@ -455,8 +455,8 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
     float *blob = lds;
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_len; i += WAVES * 64) blob[i] = p.d_blob[i];
-    unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // RoundSync counters
-    if (tid < WAVES) arrive[tid] = 0;
+    unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + WAVES * p.slice_floats);   // RoundSync counters, then the vote's four words
+    if (tid < WAVES + 4) arrive[tid] = 0;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -477,13 +477,14 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
     const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * WAVES - 1) / ((uint64_t)gridDim.x * WAVES);
     uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * WAVES + rs.slot) * rounds : nullptr;
     unsigned noted = 0;
-    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES; first < p.b.n_units; first += (uint64_t)gridDim.x * WAVES) {
+    int nv = 0;
+    auto round = [&](uint64_t first) __attribute__((always_inline)) -> uint64_t {
         const uint64_t unit = first + rs.slot;
         const bool have = unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kFPW;
         const uint64_t left = (have && f0 < loc.frames) ? loc.frames - f0 : 0;
-        const int nv = left < (uint64_t)kFPW ? (int)left : kFPW;
+        nv = left < (uint64_t)kFPW ? (int)left : kFPW;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         const uint64_t wleft = have ? width - f0 : 0;
@@ -515,8 +516,9 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         const bool flag = wave_phase4<NSLOTS, true, true, true>(fl3, j3, in3 && fl3 < ns, act3, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
         unsigned redo = 0;                  // frames of this unit that the tail recomputes
+        uint64_t any = 0;
         if (guard) {
-            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            any = __builtin_amdgcn_ballot_w64(flag);
             if (any != 0) {
                 redo = frame_mask<12, kFPW>(any);
                 if (lane == 0) notes[noted] = (unit << 8) | redo;
@@ -530,7 +532,31 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         // mel-major: the 8 waves hold 8 adjacent 20-byte pieces of every row; kept in step, the pieces of a cache line
         // reach L2 within microseconds of each other and leave it as one full line
         rs.after_round();
+        return any;
+    };
+    uint64_t first = (uint64_t)xcd_logical_block() * WAVES;
+    const uint64_t step = (uint64_t)gridDim.x * WAVES;
+    if (guard && p.fix.vote != nullptr) {                              // AUTO's vote, as in whisper400_six_kernel
+        unsigned *votew = arrive + WAVES;
+        bool sample = blockIdx.x < p.fix.vote_groups;
+        unsigned verdict = 0, polled = 0;
+        for (; first < p.b.n_units && verdict == 0; first += step) {
+            const uint64_t any = round(first);
+            if (sample) {
+                vote_cast(p.fix, votew, WAVES, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(any))), static_cast<unsigned>(nv));
+                sample = false;
+            }
+            (void)vote_check(p.fix, votew, ++polled, wave);
+            __syncthreads();
+            verdict = __builtin_amdgcn_readfirstlane(__hip_atomic_load(votew + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            __syncthreads();
+        }
+        if (verdict & kVoteHeavy) {
+            guard_wave_done(p.fix, arrive + WAVES - 2, WAVES, lane, 0);
+            return;
+        }
     }
+    for (; first < p.b.n_units; first += step) round(first);
     // the units whose frames tripped the precision guard, again, in f64 (no barrier of the rounds involved any more)
     unsigned redone = 0;
     FixTw tw;
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
     // arrival counters of the sub-group barrier (mel-major stores), behind the last slice
     unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());
-    if (tid < kSixWaves) arrive[tid] = 0;
+    if (tid < kSixWaves + 4) arrive[tid] = 0;                          // + the vote's four words
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -586,13 +612,15 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
     const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * kSixWaves - 1) / ((uint64_t)gridDim.x * kSixWaves);
     uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * kSixWaves + rs.slot) * rounds : nullptr;
     unsigned noted = 0;
-    for (uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves; first < p.b.n_units; first += (uint64_t)gridDim.x * kSixWaves) {
+    int nv = 0;
+    // one round of the workgroup: this wave's unit through phases 1-4; returns the lanes whose guard tripped
+    auto round = [&](uint64_t first) __attribute__((always_inline)) -> uint64_t {
         const uint64_t unit = first + rs.slot;
         const bool have = unit < p.b.n_units;
         const UnitLoc loc = locate_unit(p.b, have ? unit : first);
         const uint64_t f0 = loc.unit * kSixFrames;
         const uint64_t left = (have && f0 < loc.frames) ? loc.frames - f0 : 0;
-        const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
         // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
         const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
         const uint64_t wleft = have ? width - f0 : 0;
@@ -626,8 +654,9 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         const bool flag = six_phase4<NSLOTS, true, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
         __builtin_amdgcn_wave_barrier();
         unsigned redo = 0;                  // frames of this unit that the tail recomputes
+        uint64_t any = 0;
         if (guard) {
-            const uint64_t any = __builtin_amdgcn_ballot_w64(flag);
+            any = __builtin_amdgcn_ballot_w64(flag);
             if (any != 0) {
                 redo = frame_mask<kSixLanes, kSixFrames>(any);
                 if (lane == 0) notes[noted] = (unit << 8) | redo;
@@ -639,7 +668,34 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
             unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
         }
         rs.after_round();
+        return any;
+    };
+    uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves;
+    const uint64_t step = (uint64_t)gridDim.x * kSixWaves;
+    // AUTO's vote (FixSink::vote), layouts: the sample is the first round of the first vote_groups workgroups, and the workgroup
+    // leaves TOGETHER -- its waves wait for each other in RoundSync, so the verdict is read behind a workgroup barrier.  In a loop of
+    // its own, like the run-per-wave kernels' (the same code inside the round loop proper cost that loop 19 %).
+    if (guard && p.fix.vote != nullptr) {
+        unsigned *votew = arrive + kSixWaves;                          // vote_cast's three words, the workgroup's copy of the verdict
+        bool sample = blockIdx.x < p.fix.vote_groups;
+        unsigned verdict = 0, polled = 0;
+        for (; first < p.b.n_units && verdict == 0; first += step) {
+            const uint64_t any = round(first);
+            if (sample) {
+                vote_cast(p.fix, votew, kSixWaves, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(any))), static_cast<unsigned>(nv));
+                sample = false;
+            }
+            (void)vote_check(p.fix, votew, ++polled, wave);
+            __syncthreads();
+            verdict = __builtin_amdgcn_readfirstlane(__hip_atomic_load(votew + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            __syncthreads();                                           // nobody publishes a verdict between two waves' reads of it
+        }
+        if (verdict & kVoteHeavy) {                                    // the f64 kernel behind this launch computes the whole batch
+            guard_wave_done(p.fix, arrive + kSixWaves - 2, kSixWaves, lane, 0);
+            return;
+        }
     }
+    for (; first < p.b.n_units; first += step) round(first);
     unsigned redone = 0;
     FixTw tw;
     // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
@@ -983,7 +1039,7 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
     constexpr int WAVES = kPreciseWaves;
     constexpr bool RUNS = MODE != 0, WALK = MODE == 2;
     constexpr bool LAYOUT = !RUNS;
-    if (WALK && *p.gate != p.gate_value) return;        // the batch was light: the f32 launch has finished it
+    if (p.gate != nullptr && *p.gate != p.gate_value) return;        // AUTO's second launch and the batch was light: the f32 launch has finished it
     extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
     const int tid = threadIdx.x;
     for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];

@@ -220,6 +220,47 @@ def test_every_precision_mode_through_every_batch_shape(gpu, oracle, jfk, n_mels
     m.close()
 
 
+@pytest.mark.parametrize("n_mels", [80, 128])
+@pytest.mark.parametrize("mel_major", [True, False])
+def test_auto_votes_on_the_layouts_too(gpu, oracle, jfk, n_mels, mel_major):
+    """The padded / mel-major layouts take the same vote (their sample is the head of the batch): speech goes to the f64 layout kernel
+    on its first batch, noise stays on the f32 kernel, and a batch's bits do not depend on what came before it."""
+    if _ENV_MODE != "auto":
+        pytest.skip("the suite is being run with a fixed precision mode")
+    n_clips, clip_len = 128, 48000
+    speech = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(32)])
+    noise = np.stack([oracle.synth_pcm(c, clip_len) for c in range(32)])
+    m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
+    W = m.interleaved_width(clip_len, 400)
+    nf = m.num_frames(clip_len)
+    ps, pn = gpu.DeviceBuffer(n_clips * clip_len * 4), gpu.DeviceBuffer(n_clips * clip_len * 4)
+    out = gpu.DeviceBuffer(n_clips * W * n_mels * 4)
+    for r in range(n_clips // 32):
+        ps.upload(speech, offset_bytes=r * speech.nbytes)
+        pn.upload(noise, offset_bytes=r * noise.nbytes)
+
+    def run(pcm):
+        m.compute_uniform_device_interleaved(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, not mel_major, 400)
+        m.synchronize()
+        return out.download((n_clips, n_mels, W) if mel_major else (n_clips, W, n_mels))
+
+    def rows(img, c):
+        return img[c].T[:nf] if mel_major else img[c][:nf]
+
+    s1 = run(ps)
+    assert m.auto_state()[0]                                   # the f64 kernel computed it
+    n1 = run(pn)
+    assert not m.auto_state()[0]
+    s2 = run(ps); s3 = run(ps); n2 = run(pn)
+    assert np.array_equal(s1, s2) and np.array_equal(s1, s3) and np.array_equal(n1, n2)
+    for c in (0, 33, n_clips - 1):
+        assert np.abs(rows(s1, c) - oracle.compute_mel_spectrogram_cpu(speech[c % 32], 400, 160, n_mels, SR)).max() <= 2e-6
+        assert np.abs(rows(n1, c) - oracle.compute_mel_spectrogram_cpu(noise[c % 32], 400, 160, n_mels, SR)).max() <= TOL
+        pad = s1[c][:, nf:] if mel_major else s1[c][nf:]
+        assert np.all(pad == 0.0)
+    ps.free(); pn.free(); out.free(); m.close()
+
+
 def _hard_signals(n, sr, seed=42):
     rng = np.random.default_rng(seed)
     t = np.arange(n) / sr
