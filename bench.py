@@ -100,13 +100,15 @@ def measure_traffic(config: int, timeout_s: float = 150.0):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--config", str(config), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech"]
             subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            got = []
+            per_kernel = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     if "whisper400" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                        got.append(float(r["Counter_Value"]))
-            if not got:
+                        per_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not per_kernel:
                 return None, f"no {counter} rows in the rocprofv3 output"
+            # the dominant kernel: in the default mode every f32 launch is followed by the gated f64 launch, which moves nothing on this input
+            got = max(per_kernel.values(), key=lambda v: sum(v) / len(v))
             vals[counter] = sum(got) / len(got) * 1024.0
         except Exception as e:          # a profiler that cannot run must not cost the bench line
             return None, f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"
@@ -292,7 +294,13 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
             ev1.record()
 
     elapsed = timed_steps(timed_step, torch.cuda.synchronize, steps, 0, dist if distributed else None, red_dev)
-    my_kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream
+    my_kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream: a whole step (AUTO: the f32 kernel + the gated f64 launch)
+    # the dominant kernel on its own: an event pair around the first kernel of each of 200 more calls (melspec_time_first_kernel), the
+    # figure a kernel trace reports -- `roofline.achieved` is quoted on it; the step time above stays what `value` is made of
+    first_ms = None
+    if primary and sub == 1 and args.precision != "f64":
+        torch.cuda.synchronize()
+        first_ms = mel.time_first_kernel(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), warmup=20, iters=200)
     kernel_ms = my_kernel_ms
     per_rank = [[float(frames_per_step), my_kernel_ms]]
     if distributed:
@@ -305,7 +313,7 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
     mel_name = mel.plain_kernel_name()
     res = dict(elapsed=elapsed, per_rank=per_rank, kernel_ms=kernel_ms, frames_per_step=frames_per_step, n_clips=n_clips, sub=sub,
                parity=parity, queued=queued, spinup_steps=spinup_steps, scaling=scaling, n_mels=n_mels, clip_seconds=clip_seconds,
-               clip_len=clip_len, total_or_per=total_or_per, fpc=fpc, kernel=mel_name, mel=mel, out=out, pcm=pcm, stream=stream)
+               clip_len=clip_len, total_or_per=total_or_per, fpc=fpc, kernel=mel_name, mel=mel, out=out, pcm=pcm, stream=stream, first_ms=first_ms)
     return res
 
 
@@ -313,7 +321,7 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
     """The real-input figure next to `value` (never instead of it): the reference's own fixture, tests/golden/jfk_f32le.wav
     (/root/reference/testdata/jfk_f32le.wav, the signal its README numbers are quoted on), tiled with per-clip offsets to the
     config-2 batch, resident in HBM, default precision mode, same event-timed protocol.  Speech trips AUTO's guard on most
-    frames, so after its first batch the context runs the f64 kernel on whole batches."""
+    frames, so the vote inside every launch hands the batch to the gated f64 kernel (DESIGN.md sections 4.9, 5)."""
     import numpy as np
     from oracle import oracle as O
     jfk = O.load_wav_f32(os.path.join(ROOT, "tests", "golden", "jfk_f32le.wav"))
@@ -325,7 +333,7 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
     out = torch.empty(n_clips * fpc * n_mels, dtype=torch.float32, device=dev)
     run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
     regimes = []
-    for _ in range(3):                      # the statistics of a finished batch decide the regime of the next one
+    for _ in range(3):                      # every batch decides for itself (a vote inside its launch): the first one already runs on the f64 kernel
         mel.guard_last_count()
         run(); torch.cuda.synchronize()
         tripped = mel.guard_last_count()
@@ -354,8 +362,8 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
     res = {"input": f"tests/golden/jfk_f32le.wav tiled (per-clip offsets) to {n_clips} x {clip_len / SR:.0f} s, resident in HBM, precision mode auto",
            "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
            "frames_tripping_the_guard_per_step": tripped, "fraction_tripping": tripped / frames,
-           "regime_after_each_of_the_first_batches": ["f64 kernel on whole batches" if h else "f32 kernel + f64 recompute of tripped frames" for h in regimes],
-           "kernel": mel.plain_kernel_name(), "parity_max_abs_diff": worst, "steps": k}
+           "kernel_of_each_of_the_first_batches": ["gated f64 kernel (the launch's vote: heavy)" if h else "f32 kernel + f64 recompute of tripped frames" for h in regimes],
+           "kernel": "melspec::whisper400_precise_kernel<8, ., gated walk> (f64 FFT) behind the voting f32 launch", "parity_max_abs_diff": worst, "steps": k}
     mel.close()
     del pcm, out
     return res
@@ -499,7 +507,8 @@ def main() -> None:
         value = total_frames / elapsed
         bytes_per_frame = HOP * 4 + n_mels * 4
         algo_bytes_per_launch = frames_per_step * bytes_per_frame
-        achieved = algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+        dominant_ms = w.get("first_ms") if (world == 1 and cfg5 is None and w.get("first_ms")) else kernel_ms
+        achieved = algo_bytes_per_launch / (dominant_ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
         traffic_kernel_ok = args.clips is None and args.clip_seconds is None and args.n_mels is None     # the child run repeats the default workload
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -532,7 +541,7 @@ def main() -> None:
                        "clips_per_gpu": n_clips, "frames_per_step_per_gpu": frames_per_step,
                        "sub_shards_per_step": sub,
                        "precision": f"melspec_set_precision({args.precision}): " + (
-                           "f32 FFT, frames failing the error bound recomputed in f64 inside the same launch" if args.precision == "auto" else
+                           "f32 FFT; a vote inside the launch decides between the f64 recompute of the frames failing the error bound and the gated f64 kernel for the whole batch" if args.precision == "auto" else
                            ("f64 FFT on every frame" if args.precision == "f64" else "f32 FFT, no guard")),
                        "frames_recomputed_in_f64_per_step": queued,
                        "parallelism": f"per-clip split x{world}, no data-path collective"},
@@ -542,8 +551,12 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name,
-                         "kernel_ms": kernel_ms,
-                         "kernel_ms_note": "HIP events on the launch stream around the K timed steps / K (one launch per step: the f64 recompute of guarded frames happens inside it)",
+                         "kernel_ms": dominant_ms,
+                         "step_ms_events": kernel_ms,
+                         "kernel_ms_note": ("average launch duration of the dominant kernel from a HIP event pair around it in each of 200 calls after the timed region "
+                                            "(melspec_time_first_kernel; `step_ms_events` = HIP events around the K timed steps / K, which in the default mode also "
+                                            "holds the gated f64 launch behind every f32 launch, ~5 us that return at once on this input)" if dominant_ms is not kernel_ms else
+                                            "HIP events on the launch stream around the K timed steps / K"),
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch},
             "parity_max_abs_diff": parity, "spinup_steps_untimed": spinup_steps,
         }

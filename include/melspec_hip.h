@@ -241,6 +241,12 @@ int melspec_time_uniform_device(melspec_ctx *ctx, const float *d_pcm, uint64_t c
                                 uint64_t clip_len, uint32_t n_clips, float *d_out,
                                 int warmup, int iters, float *avg_ms);
 
+/* The same calls with a HIP event pair around the FIRST kernel of every call -- in AUTO the f32 kernel, without the gated f64 launch
+ * behind it -- and the average of those pairs: the launch duration of the dominant kernel, as a profiler's kernel trace reports it
+ * (bench.py's roofline.achieved).  Fused f32 n_fft = 400 contexts only. */
+int melspec_time_first_kernel(melspec_ctx *ctx, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len, uint32_t n_clips, float *d_out,
+                              int warmup, int iters, float *avg_first_kernel_ms);
+
 /* Wait for everything this context has queued on `stream` (cudaStreamSynchronize, src/cuda.rs:129). */
 int melspec_synchronize(melspec_ctx *ctx, void *stream);
 

@@ -109,6 +109,7 @@ SIGNATURES = {
     "melspec_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
     "melspec_compute_ragged_device_desc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),
     "melspec_time_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _f32p]),
+    "melspec_time_first_kernel": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _f32p]),
     "melspec_synchronize": (C.c_int, [_vp, _vp]),
     "melspec_mel_filterbank": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, _f64p]),
     "melspec_hann_window": (C.c_int, [C.c_int, _f64p]),

@@ -569,6 +569,7 @@ struct melspec_ctx {
     DevBuf d_blob64, d_blob64s;      // f64 tables: of the mel kernels (power split) / of the spectrum export
     size_t precise_lds = 0;
     FixState fix;
+    std::vector<hipEvent_t> *first_kernel_events = nullptr;   // melspec_time_first_kernel: an event pair around the first launch of every call
     // generic path
     GenericTables gt;
     // the mel stage on its own (melspec_mel_from_stft_*): the banded filterbank in f64, built on first use
@@ -800,11 +801,18 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         }
     }
     int rc;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (c->first_kernel_events) {
+        HIP_TRY(hipEventCreate(&pe0)); HIP_TRY(hipEventCreate(&pe1));
+        c->first_kernel_events->push_back(pe0); c->first_kernel_events->push_back(pe1);
+        HIP_TRY(hipEventRecord(pe0, stream));
+    }
     if (c->six && desc.frames_per_unit == kSixFrames)
         rc = c->six_static == 1 ? launch_six_t<LensSix80>(c, desc, sink, stream) : c->six_static == 2 ? launch_six_t<LensSix64>(c, desc, sink, stream)
            : c->six_static == 3 ? launch_six_t<LensSix40>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
     else
         rc = launch_wave(c, desc, sink, stream);
+    if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
     if (rc || !vote) return rc;
     // AUTO's second launch: returns at its first instruction unless the launch above voted "heavy" (its number is c->fix.seq)
     const unsigned gate_value = (c->fix.seq & 0xffffffu) << 2 | kVoteDecided | kVoteHeavy;
@@ -1151,6 +1159,32 @@ int melspec_time_uniform_device(melspec_ctx *c, const float *d_pcm, uint64_t cli
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int melspec_time_first_kernel(melspec_ctx *c, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len, uint32_t n_clips, float *d_out,
+                              int warmup, int iters, float *avg_first_kernel_ms) {
+    if (!c || !avg_first_kernel_ms || iters < 1 || iters > 4096) return fail(MELSPEC_ERR_INVALID_ARG, "bad argument");
+    if (!c->fast || c->precision == MELSPEC_PRECISION_F64) return fail(MELSPEC_ERR_UNSUPPORTED, "the fused f32 n_fft = 400 kernels only");
+    HIP_TRY(hipSetDevice(c->dev.device));
+    int rc = MELSPEC_OK;
+    for (int i = 0; i < warmup && !rc; ++i) rc = melspec_compute_uniform_device(c, d_pcm, clip_stride, clip_len, n_clips, d_out, c->stream);
+    std::vector<hipEvent_t> ev;
+    ev.reserve(2 * static_cast<size_t>(iters));
+    c->first_kernel_events = &ev;
+    for (int i = 0; i < iters && !rc; ++i) rc = melspec_compute_uniform_device(c, d_pcm, clip_stride, clip_len, n_clips, d_out, c->stream);
+    c->first_kernel_events = nullptr;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (!rc && e != hipSuccess) rc = fail_hip(e, "hipStreamSynchronize");
+    double sum = 0.0;
+    size_t n = 0;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+        float ms = 0.0f;
+        if (!rc && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) { sum += ms; ++n; }
+    }
+    for (hipEvent_t x : ev) (void)hipEventDestroy(x);
+    if (!rc && n == 0) rc = fail(MELSPEC_ERR_INTERNAL, "no launch was timed");
+    if (!rc) *avg_first_kernel_ms = static_cast<float>(sum / static_cast<double>(n));
     return rc;
 }
 

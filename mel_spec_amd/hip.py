@@ -334,6 +334,13 @@ class HipMelSpectrogram:
                                                  C.c_void_p(d_out), warmup, iters, C.byref(ms)))
         return float(ms.value)
 
+    def time_first_kernel(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_out: int, warmup: int = 10, iters: int = 100) -> float:
+        """melspec_time_first_kernel: average launch duration (ms) of the first kernel of a call -- the f32 kernel, without "auto"'s gated
+        f64 launch behind it -- from a HIP event pair around it in every call"""
+        ms = C.c_float(0.0)
+        _check(lib().melspec_time_first_kernel(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips, C.c_void_p(d_out), warmup, iters, C.byref(ms)))
+        return float(ms.value)
+
     def compute_batch_host(self, flat: np.ndarray, offsets, lengths, out: np.ndarray | None = None, out_offsets=None):
         """melspec_compute_batch_host: clip i = flat[offsets[i] : offsets[i] + lengths[i]] -> its frames at out[out_offsets[i]:]
         (floats; None = packed).  Returns (out, total_frames).  flat / out may be pinned (HostBuffer.array)."""
