@@ -194,7 +194,10 @@ def lib() -> C.CDLL:
                 f"{path} is missing: the HIP extension has not been built "
                 "(run `python -m mel_spec_amd.build`). mel_spec_amd has no CPU fallback.")
         L = C.CDLL(path)
+        older = bool(os.environ.get("MELSPEC_LIB")) and bool(os.environ.get("MELSPEC_LIB_OLDER"))   # tools/ab_run.py against a build of an earlier round
         for name, (res, args) in SIGNATURES.items():
+            if older and not hasattr(L, name):
+                continue
             fn = getattr(L, name)   # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args

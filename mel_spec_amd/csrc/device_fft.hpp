@@ -14,6 +14,11 @@
 
 #if defined(__HIPCC__)
 #define MS_DEV __device__ __forceinline__
+// __builtin_amdgcn_sched_barrier mask behind a block of global loads: LDS operations and SALU may cross it, VALU and memory
+// instructions may not -- the loads stay in front of the arithmetic that uses them, the table reads of that arithmetic may start early
+#ifndef MS_SCHED_LOADS_FIRST
+#define MS_SCHED_LOADS_FIRST 0x108
+#endif
 #define MS_HD __host__ __device__ __forceinline__
 #else
 #define MS_DEV inline

@@ -181,7 +181,9 @@ __device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg,
     if ((old >> kStatShift) + 1 != fx.n_groups) return;
     const unsigned long long tripped = ((old & kStatMask) + total) & kStatMask;
     __hip_atomic_store(fx.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // every other workgroup of the launch has been here
+#ifndef MELSPEC_AB_NOSUPPRESS
     if (fx.vote && (vote_poll(fx) & kVoteHeavy)) return;       // a voting launch that stood down: the f64 launch behind it reports the batch
+#endif
     if (tripped) __hip_atomic_fetch_add(fx.count, tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long tag = static_cast<unsigned long long>(fx.seq & 0xffffffu) << kStatShift;
     __hip_atomic_store(fx.host, tag | tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

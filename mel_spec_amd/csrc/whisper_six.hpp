@@ -94,12 +94,21 @@ MS_DEV void six_phase1(int fl, int t, bool active, int hop, const float *blob, c
     const float *s = gsrc + fl * hop + 2 * t;
     cf x[20];
     const float *w = blob + SixBlob::kWin + t * SixBlob::kWinStride;
+    // All twenty loads first, and a scheduling barrier behind them.  Left to itself the machine scheduler sometimes sinks them into the
+    // butterflies, two at a time behind `s_waitcnt vmcnt(1)` -- twenty serialised HBM round trips per unit.  Which it does depends on
+    // code far from here: round 4 added three words to the kernel's parameter block and the mel-major kernel went from 0.339 to
+    // 0.436 ms with an unchanged unit loop source (profiles/r04_sched_flip.txt).
+    f2 sv[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) sv[n1] = load2_unaligned(s + 20 * n1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(MS_SCHED_LOADS_FIRST);
+#endif
 #pragma unroll
     for (int n1 = 0; n1 < 20; n1 += 2) {
-        const f2 s0 = load2_unaligned(s + 20 * n1), s1 = load2_unaligned(s + 20 * n1 + 20);
         const f4 wv = ld4(w + 2 * n1);
-        x[n1] = {s0.x * wv.x, s0.y * wv.y};
-        x[n1 + 1] = {s1.x * wv.z, s1.y * wv.w};
+        x[n1] = {sv[n1].x * wv.x, sv[n1].y * wv.y};
+        x[n1 + 1] = {sv[n1 + 1].x * wv.z, sv[n1 + 1].y * wv.w};
     }
     fft20(x);
     const float *tw = blob + SixBlob::kTw1 + t * SixBlob::kTw1Stride;

@@ -118,12 +118,18 @@ MS_DEV void wave_phase1(int fl, int t, bool active, int hop, const float *blob, 
     const float *w = blob + FastBlob::kWin + t * FastBlob::kWinStride;
     const float *s = gsrc + fl * hop + 2 * t;
     cf x[20];
+    // all twenty loads first, then a scheduling barrier (six_phase1, whisper_six.hpp, says why)
+    f2 sv[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) sv[n1] = load2_unaligned(s + 20 * n1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(MS_SCHED_LOADS_FIRST);
+#endif
 #pragma unroll
     for (int n1 = 0; n1 < 20; n1 += 2) {
-        const f2 s0 = load2_unaligned(s + 20 * n1), s1 = load2_unaligned(s + 20 * n1 + 20);
         const f4 wv = ld4(w + 2 * n1);
-        x[n1] = {s0.x * wv.x, s0.y * wv.y};
-        x[n1 + 1] = {s1.x * wv.z, s1.y * wv.w};
+        x[n1] = {sv[n1].x * wv.x, sv[n1].y * wv.y};
+        x[n1 + 1] = {sv[n1 + 1].x * wv.z, sv[n1 + 1].y * wv.w};
     }
     fft20(x);
     const float *tw = blob + FastBlob::kTw1 + t * FastBlob::kTw1Stride;

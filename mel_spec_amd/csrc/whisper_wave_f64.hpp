@@ -40,11 +40,17 @@ MS_DEV void precise_phase1(int fl, int t, bool active, const double *MS_RESTRICT
     if (!active) return;
     const float *s = frame + 2 * t;
     cd x[20];
+    // all twenty loads first, then a scheduling barrier (six_phase1, whisper_six.hpp, says why)
+    f2 sv[20];
+#pragma unroll
+    for (int n1 = 0; n1 < 20; ++n1) sv[n1] = load2_unaligned(s + 20 * n1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(MS_SCHED_LOADS_FIRST);
+#endif
 #pragma unroll
     for (int n1 = 0; n1 < 20; ++n1) {
-        const f2 sv = load2_unaligned(s + 20 * n1);
         const cd w = ldc(tb + PreciseBlob::kWin + 20 * n1 + 2 * t);
-        x[n1] = {static_cast<double>(sv.x) * w.re, static_cast<double>(sv.y) * w.im};   // src/stft.rs:163
+        x[n1] = {static_cast<double>(sv[n1].x) * w.re, static_cast<double>(sv[n1].y) * w.im};   // src/stft.rs:163
     }
     fft20(x);
     const double *tw = tb + PreciseBlob::kTw1 + t * PreciseBlob::kTw1Stride;
