@@ -64,12 +64,14 @@ if want("stft"):
     spec.free(); mel.free(); m.close()
 
 if want("generic"):
-    for fft, hop, clips in ((1024, 256, 64), (2048, 512, 64), (800, 200, 64)):
+    for fft, hop, clips in ((256, 64, 1024), (1024, 256, 1024), (2048, 512, 256), (800, 200, 64)):
         g = M.HipMelSpectrogram(fft, hop, 16000.0, 80)
         nf = g.num_frames(clip_len)
         out = M.DeviceBuffer(clips * nf * 80 * 4)
         ms = timed(lambda: g.compute_uniform_device(pcm.ptr, clip_len, clip_len, clips, out.ptr), g.synchronize, iters=10, warm=2)
-        report(f"generic_frame_kernel n_fft {fft} hop {hop} (in-LDS FFT, one frame per workgroup)", ms, clips * nf, hop * 4 + 320)
+        name = "pow2_frame_kernel" if fft & (fft - 1) == 0 else "generic_frame_kernel"
+        how = "frames owned by lane groups of a wave" if fft & (fft - 1) == 0 else "in-LDS FFT, one frame per workgroup"
+        report(f"{name} n_fft {fft} hop {hop}, {clips} clips ({how})", ms, clips * nf, hop * 4 + 320)
         out.free(); g.close()
 
 if want("quant") or want("vad"):
