@@ -219,8 +219,9 @@ impl HipMelSpectrogram {
         Ok(Self { ctx, n_mels: f.nrows() })
     }
 
-    /// The default precision mode moves whole batches to the f64 kernel while most frames of the last finished batch needed f64
-    /// (speech, tonal material); `false` pins it to the f32 kernel + per-frame recompute (bit-stable from call to call).
+    /// The default precision mode takes a vote inside every launch (the first work unit of every wave is the sample) and hands batches
+    /// in which more than 1/8 of the sampled frames need f64 (speech, tonal material) to the f64 kernel queued behind the launch: a
+    /// function of the batch, not of history.  `false` switches the vote off: f32 kernel + per-frame recompute whatever the input.
     pub fn set_auto_adaptive(&mut self, on: bool) -> Result<(), HipError> {
         match unsafe { melspec_set_auto_adaptive(self.ctx, on as c_int) } {
             0 => Ok(()),
@@ -228,7 +229,7 @@ impl HipMelSpectrogram {
         }
     }
 
-    /// (whole batches currently go to the f64 kernel, fraction of the frames of the last finished batch that needed f64)
+    /// (the last finished batch ran on the f64 kernel, fraction of its frames that needed f64) -- reporting only
     pub fn auto_state(&mut self) -> (bool, f64) {
         let (mut heavy, mut fraction) = (0 as c_int, 0.0f64);
         unsafe { melspec_auto_state(self.ctx, &mut heavy, &mut fraction) };
@@ -241,7 +242,7 @@ impl HipMelSpectrogram {
     }
 
     /// 0: f32 FFT + f64 recompute of the frames its error bound does not cover (default, within 1e-4 on every input),
-    /// 1: f64 on every frame (mode 0 moves batches of speech / tonal input there by itself), 2: f32 only.
+    /// 1: f64 on every frame (mode 0 sends batches of speech / tonal input there by a vote inside their own launch), 2: f32 only.
     pub fn set_precision(&mut self, mode: i32) -> Result<(), HipError> {
         match unsafe { melspec_set_precision(self.ctx, mode as c_int) } {
             0 => Ok(()),
