@@ -542,6 +542,10 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
         unsigned *votew = arrive + WAVES;
         bool sample = blockIdx.x < p.fix.vote_groups;
         unsigned verdict = 0, polled = 0;
+        if (sample && first >= p.b.n_units) {
+            vote_cast(p.fix, votew, WAVES, lane, 0, 0);
+            sample = false;
+        }
         for (; first < p.b.n_units && verdict == 0; first += step) {
             const uint64_t any = round(first);
             if (sample) {
@@ -681,6 +685,10 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
         unsigned *votew = arrive + kSixWaves;                          // vote_cast's three words, the workgroup's copy of the verdict
         bool sample = blockIdx.x < p.fix.vote_groups;
         unsigned verdict = 0, polled = 0;
+        if (sample && first >= p.b.n_units) {                          // a workgroup of the grid's round-up to the 8 XCDs: it still has to be counted
+            vote_cast(p.fix, votew, kSixWaves, lane, 0, 0);
+            sample = false;
+        }
         for (; first < p.b.n_units && verdict == 0; first += step) {
             const uint64_t any = round(first);
             if (sample) {

@@ -253,12 +253,15 @@ class MelSpectrogram:
     returns) onto the Slaney bank, log10, per-frame normalisation -> (n_mels, 1) float64 like the reference's Array2<f64>."""
 
     def __init__(self, fft_size: int, sampling_rate: float, n_mels: int, device: int = -1):
-        self._mel = HipMelSpectrogram(int(fft_size), max(1, int(fft_size) // 2), float(sampling_rate), int(n_mels), device=device)
+        from .hip import SparseMelFilterbank
+        self._bank = SparseMelFilterbank.from_mel(float(sampling_rate), int(fft_size), int(n_mels), device=device)
 
     def add(self, fft) -> np.ndarray:
+        # full f64 like the reference (project_stft_log10 src/mel.rs:148-168, then norm_mel over the frame :645-654): the device's
+        # log_mel_spectrogram + norm_mel in f64 (round 4; the mel_from_stft route returned f32 values widened, ADVICE r03)
         a = np.ascontiguousarray(fft, np.complex128).reshape(1, -1)
-        return self._mel.mel_from_stft(a)[0].astype(np.float64).reshape(-1, 1)
+        return self._bank.norm_mel(self._bank.log_mel_spectrogram(a)[0]).reshape(-1, 1)
 
     def close(self) -> None:
-        self._mel.close()
+        self._bank.close()
 

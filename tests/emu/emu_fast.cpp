@@ -15,6 +15,7 @@
 #include "../../mel_spec_amd/csrc/fbank_tables.hpp"
 #include "../../mel_spec_amd/csrc/tga_quant.hpp"
 #include "../../mel_spec_amd/csrc/vad_columns.hpp"
+#include "../../mel_spec_amd/csrc/pow2_wave.hpp"
 
 using namespace melspec;
 
@@ -835,4 +836,46 @@ extern "C" long long emu_whisper_auto(const float *pcm, long long n, int hop, in
     }
     if (n_flagged) *n_flagged = nf;
     return frames;
+}
+
+
+// ---- pow2_wave.hpp: the in-place Stockham passes of pow2_frame_kernel, lane by lane ------------------------------------------------
+// The device runs a pass as "every lane reads its inputs, then every lane writes" (one wave, LDS operations in program order); here a
+// pass is run per lane on a copy of the pass's input and the words it changed are merged -- a lane that read something another lane
+// of the same pass had already overwritten would show up as a wrong transform.
+template <int LOGM>
+static void emu_pow2_run(const double *in /* M complex */, double *out /* M complex, natural order */) {
+    using S = Pow2Shape<LOGM>;
+    constexpr int M = S::M;
+    std::vector<double> tw(2 * M);
+    for (int q = 0; q < M; ++q) { tw[2 * q] = std::cos(2.0 * kPi * q / (2.0 * M)); tw[2 * q + 1] = -std::sin(2.0 * kPi * q / (2.0 * M)); }
+    std::vector<double> z(2 * S::kZ, 1.0e300);
+    auto pass = [&](auto fn) {
+        const std::vector<double> snap(z);
+        std::vector<double> next(z);
+        for (int l = 0; l < S::LF; ++l) {
+            std::vector<double> tmp(snap);
+            fn(l, tmp.data());
+            for (size_t i = 0; i < tmp.size(); ++i) if (std::memcmp(&tmp[i], &snap[i], 8) != 0) next[i] = tmp[i];
+        }
+        z = next;
+    };
+    pass([&](int l, double *zz) {
+        cpx<double> reg[S::P];
+        for (int r = 0; r < S::P; ++r) reg[r] = {in[2 * (l + r * S::LF)], in[2 * (l + r * S::LF) + 1]};
+        pow2_pass<LOGM, S::R1, true>(l, 1, tw.data(), zz, reg, nullptr);
+    });
+    pass([&](int l, double *zz) { pow2_pass<LOGM, 8, false>(l, S::R1, tw.data(), zz, nullptr, nullptr); });
+    if (S::R3 > 1) pass([&](int l, double *zz) { pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, tw.data(), zz, nullptr, nullptr); });
+    for (int k = 0; k < M; ++k) { out[2 * k] = z[2 * pow2_pad(k)]; out[2 * k + 1] = z[2 * pow2_pad(k) + 1]; }
+}
+extern "C" int emu_pow2_fft(int logm, const double *in, double *out) {
+    switch (logm) {
+        case 6: emu_pow2_run<6>(in, out); return 0;
+        case 7: emu_pow2_run<7>(in, out); return 0;
+        case 8: emu_pow2_run<8>(in, out); return 0;
+        case 9: emu_pow2_run<9>(in, out); return 0;
+        case 10: emu_pow2_run<10>(in, out); return 0;
+    }
+    return -1;
 }

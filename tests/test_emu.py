@@ -57,6 +57,24 @@ def emu():
     return run
 
 
+@pytest.mark.parametrize("logm", [6, 7, 8, 9, 10])
+def test_pow2_stockham_passes_in_place(emu, logm):
+    """pow2_wave.hpp (round 4): the complex M-point transform of pow2_frame_kernel -- radix 8 / 16 / 2 / 4 Stockham passes written back IN
+    PLACE into the frame's padded LDS region -- run lane by lane on the host, every pass on a snapshot of its input: the transform is
+    numpy's to f64 rounding, so no lane of a pass reads a word another lane of the same pass writes."""
+    M = 1 << logm
+    rng = np.random.default_rng(logm)
+    z = rng.standard_normal(M) + 1j * rng.standard_normal(M)
+    buf = np.ascontiguousarray(z).view(np.float64).copy()
+    out = np.zeros(2 * M)
+    dp = C.POINTER(C.c_double)
+    emu.lib.emu_pow2_fft.restype = C.c_int
+    emu.lib.emu_pow2_fft.argtypes = [C.c_int, dp, dp]
+    assert emu.lib.emu_pow2_fft(logm, buf.ctypes.data_as(dp), out.ctypes.data_as(dp)) == 0
+    want = np.fft.fft(z)
+    assert np.abs(out.view(np.complex128) - want).max() <= 1e-12 * np.abs(want).max()
+
+
 @pytest.mark.parametrize("n", [8, 10, 16, 20])
 def test_small_dfts(emu, n):
     rng = np.random.default_rng(n)

@@ -248,7 +248,7 @@ def test_gpu_spectrogram_and_mel_spectrogram_objects(gpu, oracle, jfk):
     assert len(specs) == want.shape[0] == 98
     assert np.abs(np.stack(specs) - want).max() <= 1e-9 * np.abs(want).max()
     want_mel = oracle.stream_mel(x, fft, hop, 80, SR)
-    assert np.abs(np.stack(mels) - want_mel).max() <= TOL
+    assert np.abs(np.stack(mels) - want_mel).max() <= 2e-6             # f64 from the spectrum to the column (the oracle's rows are f32)
     assert sg.add(x[:37]) is not None                                   # a short block is zero-padded (src/stft.rs:57-60)
     with pytest.raises(AssertionError):
         sg.add(x[:hop + 1])

@@ -34,7 +34,7 @@ def signal(n):
     return x
 
 def case_whisper():
-    fft = int(rng.choice([400, 400, 400, 512]))
+    fft = int(rng.choice([400, 400, 400, 400, 512, 256, 1024, 128, 2048]))      # round 4: the power-of-two sizes of pow2_frame_kernel too
     hop = int(rng.choice([160, 160, 160, 80, 200, 320, int(rng.integers(40, 400))]))
     n_mels = int(rng.choice([80, 80, 128, 20, 40, 64, 96, 100]))
     sr = float(rng.choice([16000.0, 16000.0, 8000.0, 22050.0]))
@@ -81,6 +81,8 @@ def case_whisper():
             assert not g[f:].any(), (tag, "padding not zero")
             note("layout", d)
         din.free(); dout.free()
+    elif hop > fft:                                 # the streaming bank needs hop <= n_fft (the overlap-save state)
+        pass
     else:                                           # streaming bank against the batch result on samples[off:]
         n_streams = int(rng.integers(1, 12)); max_chunk = int(rng.integers(1, 6 * hop + fft))
         bank = M.StreamBank(m, n_streams, max_chunk)
@@ -103,13 +105,16 @@ def case_whisper():
     m.close()
 
 def case_fbank():
-    kw = dict(num_mel_bins=int(rng.choice([80, 80, 40, 23, 64])), preemphasis=float(rng.choice([0.97, 0.0, 0.9])),
+    kw = dict(sample_rate=float(rng.choice([16000.0, 16000.0, 16000.0, 8000.0, 32000.0, 44100.0])),      # round 4: fft sizes 256 / 1024 / 2048 (pow2_frame_kernel)
+              num_mel_bins=int(rng.choice([80, 80, 40, 23, 64])), preemphasis=float(rng.choice([0.97, 0.0, 0.9])),
               apply_cmn=bool(rng.integers(0, 2)), use_log_fbank=bool(rng.random() < 0.8), use_power=bool(rng.random() < 0.8))
     fb = M.Fbank(M.FbankConfig(**kw))
     oc = O.fbank_default_config()
+    oc.sample_rate = kw["sample_rate"]
     oc.num_mel_bins = kw["num_mel_bins"]; oc.preemphasis = kw["preemphasis"]; oc.apply_cmn = int(kw["apply_cmn"])
     oc.use_log_fbank = int(kw["use_log_fbank"]); oc.use_power = int(kw["use_power"])
-    x = signal(int(rng.choice([399, 400, 559, 560, int(rng.integers(400, 40000))])))
+    fl = fb.config.frame_length_samples() if hasattr(fb, "config") else int(round(0.025 * kw["sample_rate"]))
+    x = signal(int(rng.choice([fl - 1, fl, fl + 159, fl + 160, int(rng.integers(fl, 40000 + fl))])))
     got = fb.compute(x)
     want = O.fbank_compute(x, oc)
     assert got.shape == want.shape, ("fbank", kw, got.shape, want.shape)
