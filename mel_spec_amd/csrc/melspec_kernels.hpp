@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "whisper_fast.hpp"
 #include "whisper_wave.hpp"
@@ -823,8 +824,13 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;        // this wave's notes: the entries its own run indexes
     unsigned noted = 0;
     int nv = 0;
-    // one work unit: phases 1-4 and the note for the tail; returns the lanes whose guard tripped
-    auto unit = [&]() __attribute__((always_inline)) -> uint64_t {
+    // one work unit: phases 1-4 and the note for the tail; returns the lanes whose guard tripped.  `pre` (a std::true_type in the
+    // vote's loop): between the phases the wave looks at the verdict and leaves the unit on "heavy" -- the batch's f64 launch is
+    // waiting for this one to drain, a unit is 7 us long (stand-down 30 -> ~20 us); the unit loop proper is instantiated without it
+    unsigned verdict = 0, polled = 0;
+    bool may_leave = true;
+    auto unit = [&](auto pre) __attribute__((always_inline)) -> uint64_t {
+        constexpr bool kPre = decltype(pre)::value;
         cr.enter(p.b);
         const uint64_t f0 = (cr.unit - cr.c_start) * kSixFrames;
         const uint64_t left = cr.c_frames - f0;
@@ -834,9 +840,17 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         MS_PRIO(0);
         six_phase1(fl, j, act, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
+        if (kPre && may_leave) {
+            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
+            if (verdict & kVoteHeavy) return 0;
+        }
         MS_PRIO(1);
         six_phase2(fl, j, act, blob, slice, uoff, voff);
         __builtin_amdgcn_wave_barrier();
+        if (kPre && may_leave) {
+            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
+            if (verdict & kVoteHeavy) return 0;
+        }
         MS_PRIO(2);
         float vals[NSLOTS];
         {
@@ -868,12 +882,14 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     // 19 % (same-box A/B, round 4: the register allocator and the scheduler see one more loop-carried state and two more exits).
     if (guard && p.fix.vote != nullptr) {
         bool sample = blockIdx.x < p.fix.vote_groups;                  // the first unit of every wave of the first vote_groups workgroups is the sample
-        unsigned verdict = 0, polled = 0;
+        may_leave = !sample;                                           // a sampling wave finishes its first unit: the tally waits for it
         for (; cr.unit < cr.end && verdict == 0; ++cr.unit) {
-            const uint64_t any = unit();
+            const uint64_t any = unit(std::true_type{});
+            if (verdict & kVoteHeavy) break;
             if (sample) {
                 vote_cast(p.fix, wg_done + 2, kSixWaves, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(any))), static_cast<unsigned>(nv));
                 sample = false;
+                may_leave = true;
             }
             verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
         }
@@ -883,7 +899,7 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
             return;
         }
     }
-    for (; cr.unit < cr.end; ++cr.unit) unit();
+    for (; cr.unit < cr.end; ++cr.unit) unit(std::false_type{});
     // the units whose frames tripped the precision guard, again, in f64
     unsigned redone = 0;
     FixTw tw;
@@ -939,7 +955,10 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;
     unsigned noted = 0;
     int nv = 0;
-    auto unit = [&]() __attribute__((always_inline)) -> uint64_t {
+    unsigned verdict = 0, polled = 0;
+    bool may_leave = true;
+    auto unit = [&](auto pre) __attribute__((always_inline)) -> uint64_t {        // pre: see whisper400_six_runs_kernel
+        constexpr bool kPre = decltype(pre)::value;
         cr.enter(p.b);
         const uint64_t f0 = (cr.unit - cr.c_start) * kFPW;
         const uint64_t left = cr.c_frames - f0;
@@ -949,9 +968,17 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
         MS_PRIO(0);
         wave_phase1(fl, j, act && j < kFftJobs, p.hop, blob, src, slice);
         __builtin_amdgcn_wave_barrier();
+        if (kPre && may_leave) {
+            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
+            if (verdict & kVoteHeavy) return 0;
+        }
         MS_PRIO(1);
         wave_phase2(fl, j, act, blob, slice, uoff, voff);
         __builtin_amdgcn_wave_barrier();
+        if (kPre && may_leave) {
+            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
+            if (verdict & kVoteHeavy) return 0;
+        }
         MS_PRIO(2);
         float vals[NSLOTS];
         {
@@ -980,12 +1007,14 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
     };
     if (guard && p.fix.vote != nullptr) {                              // AUTO's vote, as in whisper400_six_runs_kernel
         bool sample = blockIdx.x < p.fix.vote_groups;
-        unsigned verdict = 0, polled = 0;
+        may_leave = !sample;
         for (; cr.unit < cr.end && verdict == 0; ++cr.unit) {
-            const uint64_t any = unit();
+            const uint64_t any = unit(std::true_type{});
+            if (verdict & kVoteHeavy) break;
             if (sample) {
                 vote_cast(p.fix, wg_done + 2, WAVES, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<12, kFPW>(any))), static_cast<unsigned>(nv));
                 sample = false;
+                may_leave = true;
             }
             verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
         }
@@ -995,7 +1024,7 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_runs_kerne
             return;
         }
     }
-    for (; cr.unit < cr.end; ++cr.unit) unit();
+    for (; cr.unit < cr.end; ++cr.unit) unit(std::false_type{});
     unsigned redone = 0;
     FixTw tw;
     // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
