@@ -182,9 +182,7 @@ __device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg,
     if ((old >> kStatShift) + 1 != fx.n_groups) return;
     const unsigned long long tripped = ((old & kStatMask) + total) & kStatMask;
     __hip_atomic_store(fx.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // every other workgroup of the launch has been here
-#ifndef MELSPEC_AB_NOSUPPRESS
     if (fx.vote && (vote_poll(fx) & kVoteHeavy)) return;       // a voting launch that stood down: the f64 launch behind it reports the batch
-#endif
     if (tripped) __hip_atomic_fetch_add(fx.count, tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long tag = static_cast<unsigned long long>(fx.seq & 0xffffffu) << kStatShift;
     __hip_atomic_store(fx.host, tag | tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2605,10 +2603,8 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
             }
             // ---- the complex M-point transform: Stockham passes, in place in the frame's LDS region --------------------------------
             pow2_pass<LOGM, S::R1, true>(l, 1, tw, z, reg, nullptr);
-#ifndef MELSPEC_P2_SKIP_PASSES
             pow2_pass<LOGM, 8, false>(l, S::R1, tw, z, nullptr, kAhead ? tw2 : nullptr);
             if (S::R3 > 1) pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, tw, z, nullptr, nullptr);
-#endif
             // ---- the real-FFT split X[k] = E[k] + W_N^k O[k] and the power row ------------------------------------------------------
             auto power = [&](int k) {
                 const int ka = k == M ? 0 : k, kb = (M - k) & (M - 1);        // Z[M] = Z[0]; partner Z[M - k]
@@ -2624,13 +2620,8 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
                 return (FLAVOR == 1 && !p.use_power) ? sqrt(ns) : ns;
             };
             double pk[P];
-#ifdef MELSPEC_P2_SKIP_POWER
-#pragma unroll
-            for (int r = 0; r < P; ++r) pk[r] = z[2 * pow2_pad(l + r * LF)];
-#else
 #pragma unroll
             for (int r = 0; r < P; ++r) pk[r] = power(l + r * LF);
-#endif
 #pragma unroll
             for (int r = 0; r < P; ++r) pw[l + r * LF] = pk[r];
             if (l == 0 && p.n_bins > M) pw[M] = power(M);
