@@ -149,8 +149,8 @@ int upload(DevBuf &buf, const std::vector<T> &v) {
 
 // Tables of the generic (f64 DFT) kernel.
 struct GenericTables {
-    DevBuf win, tw, mstart, mlen, moff, mw;
-    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0, mw_count = 0;
+    DevBuf win, tw, mstart, mlen, moff, mw, jw, job;
+    int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0, mw_count = 0, n_jobs = 0;
     bool force_generic = false;     // the workgroup-per-frame kernel whatever the geometry (cross-checks)
     FftPlan plan{};
     size_t lds_bytes = 0;
@@ -176,6 +176,21 @@ struct GenericTables {
         if ((rc = upload(moff, fb.offset))) return rc;
         if ((rc = upload(mw, fb.w))) return rc;
         mw_count = static_cast<int>(fb.w.size());
+        {
+            // pow2_frame_kernel's jobs: eight consecutive weights of one mel, the last job of a band padded with zeros
+            std::vector<double> jwv;
+            std::vector<int> jobv;
+            for (int m = 0; m < n_mels && m < 256; ++m)
+                for (int c = 0; c < fb.len[m]; c += 8) {
+                    const int cnt = std::min(8, fb.len[m] - c);
+                    jobv.push_back((fb.start[m] + c) | (m << 12) | (cnt << 20));
+                    for (int q = 0; q < 8; ++q) jwv.push_back(q < cnt ? fb.w[static_cast<size_t>(fb.offset[m]) + c + q] : 0.0);
+                }
+            n_jobs = static_cast<int>(jobv.size());
+            if (jobv.empty()) { jobv.push_back(0); jwv.assign(8, 0.0); }
+            if ((rc = upload(jw, jwv))) return rc;
+            if ((rc = upload(job, jobv))) return rc;
+        }
         // power-of-two transforms run as an in-LDS FFT over n_fft/2 complex points (the frame slot then holds n_fft doubles)
         fft_log2 = 0;
         if (n_fft >= 8 && (n_fft & (n_fft - 1)) == 0 && frame_len <= n_fft) {
@@ -198,7 +213,7 @@ struct GenericTables {
                                       n_bins + n_mels + kGenericNT);
         return MELSPEC_OK;
     }
-    void release() { win.release(); tw.release(); mstart.release(); mlen.release(); moff.release(); mw.release(); }
+    void release() { win.release(); tw.release(); mstart.release(); mlen.release(); moff.release(); mw.release(); jw.release(); job.release(); }
 };
 
 // Device-side copies of a ragged batch description.
@@ -401,8 +416,8 @@ template <int LOGM, int FLAVOR>
 int launch_pow2(const GenericParams &gp, int cus, hipStream_t stream) {
     using S = Pow2Shape<LOGM>;
     if (gp.n_mels > S::kMelsPerLane * S::LF) return -1;
-    if (gp.mw_count < 1 || gp.mw_count >= (1 << 20) || gp.n_bins > 4095) return -1;
-    const size_t bank = ((static_cast<size_t>(gp.mw_count) + (static_cast<size_t>(gp.mw_count) + gp.n_mels + 1) / 2 + 1) & ~static_cast<size_t>(1));
+    if (gp.n_jobs < 1 || gp.n_bins > 4088 || gp.n_mels > 256) return -1;
+    const size_t bank = ((8 * static_cast<size_t>(gp.n_jobs) + (static_cast<size_t>(gp.n_jobs) + 1) / 2 + 1) & ~static_cast<size_t>(1));
     const size_t frame = static_cast<size_t>(S::frame_doubles()) + ((static_cast<size_t>(gp.n_mels) + 1) & ~static_cast<size_t>(1));
     const size_t lds = sizeof(double) * ((S::M <= 256 ? 4 : 2) * static_cast<size_t>(S::M) + bank + static_cast<size_t>(S::kWaves) * S::FW * frame);
     if (lds > kLdsLimit) return -1;
@@ -438,6 +453,9 @@ int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int 
     gp.d_moff = static_cast<const int *>(gt.moff.p);
     gp.d_mw = static_cast<const double *>(gt.mw.p);
     gp.mw_count = gt.mw_count;
+    gp.d_jw = static_cast<const double *>(gt.jw.p);
+    gp.d_job = static_cast<const int *>(gt.job.p);
+    gp.n_jobs = gt.n_jobs;
     // power-of-two frame sizes 128 .. 2048: frames owned by lane groups of a wave (pow2_frame_kernel); lab builds: MELSPEC_POW2=0 keeps
     // the workgroup-per-frame kernel, which is also the on-device cross-check of the tests (melspec_*_use_generic)
     static const bool pow2_on = lab_int("MELSPEC_POW2", 1, 0, 1) != 0;

@@ -2263,7 +2263,12 @@ struct GenericParams {
     const int *d_mlen;     // [n_mels]
     const int *d_moff;     // [n_mels] offset into d_mw
     const double *d_mw;    // concatenated spans
-    int mw_count;          // doubles in d_mw (pow2_frame_kernel stages the bank in LDS)
+    int mw_count;          // doubles in d_mw
+    // pow2_frame_kernel's view of the same bank: n_jobs jobs of eight consecutive weights of one mel (the last job of a band padded with
+    // zeros), d_jw[8 * job + q] the weights, d_job[job] = first bin | mel << 12 | count << 20 (count = 1..8 real entries)
+    const double *d_jw;
+    const int *d_job;
+    int n_jobs;
 };
 
 template <int NT>
@@ -2463,26 +2468,22 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
     double *tw = ldsd;                                   // 2 * M: W_N^q, q < M
     constexpr bool kWinLds = M <= 256;                   // above that the 8 / 16 KB of the window cost a resident workgroup: read from L1 / L2
     double *lwin = tw + 2 * M;                           // 2 * M: the window, zero from frame_len on
-    double *lmw = lwin + (kWinLds ? 2 * M : 0);          // the banded filterbank, mel after mel: mw_count weights, then per weight
-    int *lent = reinterpret_cast<int *>(lmw + p.mw_count);   //   {bin | mel << 12}, then per mel {first entry | entries << 20}
+    double *ljw = lwin + (kWinLds ? 2 * M : 0);          // the banded filterbank as jobs of eight weights (GenericParams::d_jw), then the
+    int *ljob = reinterpret_cast<int *>(ljw + 8 * p.n_jobs);   //   job records {first bin | mel << 12 | count << 20}
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * M; i += kPow2Waves * 64) {
         tw[i] = p.d_tw[i];
         if (kWinLds) lwin[i] = p.d_win[i];
     }
-    for (int i = tid; i < p.mw_count; i += kPow2Waves * 64) lmw[i] = p.d_mw[i];
-    for (int m = tid; m < p.n_mels; m += kPow2Waves * 64) {
-        const int st = p.d_mstart[m], len = p.d_mlen[m], off = p.d_moff[m];
-        for (int r = 0; r < len; ++r) lent[off + r] = (st + r) | (m << 12);
-        lent[p.mw_count + m] = off | (len << 20);
-    }
+    for (int i = tid; i < 8 * p.n_jobs; i += kPow2Waves * 64) ljw[i] = p.d_jw[i];
+    for (int i = tid; i < p.n_jobs; i += kPow2Waves * 64) ljob[i] = p.d_job[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int fs = lane / LF, l = lane - fs * LF;        // frame slot of the wave, lane of the frame
     const int acc_doubles = (p.n_mels + 1) & ~1;
-    double *z = lmw + ((p.mw_count + (p.mw_count + p.n_mels + 1) / 2 + 1) & ~1) + (wave * FW + fs) * (S::frame_doubles() + acc_doubles);
+    double *z = ljw + ((8 * p.n_jobs + (p.n_jobs + 1) / 2 + 1) & ~1) + (wave * FW + fs) * (S::frame_doubles() + acc_doubles);
     double *pw = z + 2 * S::kZ;                          // [M + 1]
-    double *acc = pw + M + 2;                            // [n_mels] band energies of the frame
+    double *acc = pw + M + 2;                            // [n_mels] band energies of the frame (also what a job's last reads past pw[M] land in)
     const int last = p.frame_len - 1;
 
     // the twiddles of pass 2 depend on the lane only: W_{8 R1}^{k r}, k = l mod R1 (kept in registers; pass 3's come from the LDS table)
@@ -2627,45 +2628,33 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
             if (l == 0 && p.n_bins > M) pw[M] = power(M);
         }
         // ---- banded mel sums, log, per-flavour epilogue ---------------------------------------------------------------------------
-        // One mel per lane and step: the reference's left fold over the band (src/mel.rs:155-163), eight LDS loads in flight at a time.
-        // (Tried and slower, round 4: every lane folding the same number of consecutive (mel, bin, weight) entries with ds_add_f64 at the
-        // mel boundaries -- balanced, but 20 divergent branch sites per frame: n_fft 1024 2.05 -> 3.5 ms.)
-        constexpr int kMaxPer = Pow2Shape<LOGM>::kMelsPerLane;            // this lane's mels m = l + LF i (the host checks n_mels <= kMelsPerLane * LF)
-        auto mel_step = [&](int i) __attribute__((always_inline)) {
-            const int rem = p.n_mels - LF * i;                 // mels of this step
-            if (rem <= 0) return;                              // wave-uniform
-            // a last step with few mels (80 mels on 64 lanes: the 16 widest bands) gives every mel g lanes, each folding a g-th of the band
-            int g = 1;
-            while (2 * g * rem <= LF) g *= 2;
-            const int mi = l / g, part = l - mi * g, m = LF * i + mi;
-            double e = 0.0;
-            if (cur.real && mi < rem) {
-                const int info = lent[p.mw_count + m];         // {first entry | entries << 20}
-                const int off = info & 0xfffff, len = info >> 20;
-                const int r0 = len * part / g, r1 = len * (part + 1) / g;
-                const double *w = lmw + off, *pp = pw + (lent[off] & 0xfff);
-                int r = r0;
-                for (; r + 8 <= r1; r += 8) {
-                    const double w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3], w4 = w[r + 4], w5 = w[r + 5], w6 = w[r + 6], w7 = w[r + 7];
-                    const double p0 = pp[r], p1 = pp[r + 1], p2 = pp[r + 2], p3 = pp[r + 3], p4 = pp[r + 4], p5 = pp[r + 5], p6 = pp[r + 6], p7 = pp[r + 7];
-                    e += w0 * p0; e += w1 * p1; e += w2 * p2; e += w3 * p3; e += w4 * p4; e += w5 * p5; e += w6 * p6; e += w7 * p7;
-                }
-                for (; r + 4 <= r1; r += 4) {
-                    const double w0 = w[r], w1 = w[r + 1], w2 = w[r + 2], w3 = w[r + 3];
-                    const double p0 = pp[r], p1 = pp[r + 1], p2 = pp[r + 2], p3 = pp[r + 3];
-                    e += w0 * p0; e += w1 * p1; e += w2 * p2; e += w3 * p3;
-                }
-                for (; r < r1; ++r) e += w[r] * pp[r];
-            }
-            for (int d = 1; d < g; d <<= 1) e += __shfl_xor(e, d, 64);        // g: wave-uniform
-            if (cur.real && mi < rem && part == 0) acc[m] = e;
-        };
-        if (kMaxPer <= 4) {                                    // 64 lanes per frame: the steps unrolled (n_fft 1024: 2.7 -> see profiles/r04_pow2.txt)
+        // The bank as JOBS of eight consecutive weights of one mel (the last job of a band padded): every lane takes a job per round,
+        // folds its up-to-eight products left to right and adds the partial sum to the mel's word in LDS (ds_add_f64; the LDS executes
+        // a wave's operations in program order and an instruction's lanes in lane order, so the result is the same on every run).  No
+        // trip count depends on a band's width, every load is unconditional, all lanes are busy: a mel per lane and step (the form
+        // before) left most lanes idle while the lanes of the wide high bands walked 25 bins, with one LDS round trip per tail bin --
+        // it was 37-43 % of the kernel.  A band's energy is the reference's left fold (src/mel.rs:155-163) cut into <= 4 pieces.
+        // (A first balanced form -- the same number of consecutive ENTRIES per lane, an atomic at every mel boundary inside a lane's
+        // range -- had 20 divergent branch sites per frame and was slower than the mel-per-lane form: 3.5 against 2.05 ms.)
+        constexpr int kMaxPer = Pow2Shape<LOGM>::kMelsPerLane;            // a lane reads out the mels m = l + LF i (the host checks n_mels <= kMelsPerLane * LF)
 #pragma unroll
-            for (int i = 0; i < (kMaxPer <= 4 ? kMaxPer : 1); ++i) mel_step(i);
-        } else {
-#pragma unroll 1
-            for (int i = 0; i < kMaxPer; ++i) mel_step(i);
+        for (int i = 0; i < kMaxPer; ++i) if (l + LF * i < p.n_mels) acc[l + LF * i] = 0.0;
+        for (int jb = l; jb < p.n_jobs + l; jb += LF) {            // wave-uniform trip count
+            const bool on = cur.real && jb < p.n_jobs;
+            const int info = ljob[on ? jb : 0];
+            const int cnt = on ? info >> 20 : 0;
+            const double *w = ljw + 8 * (on ? jb : 0), *pp = pw + (info & 0xfff);
+            const d2 w01 = *reinterpret_cast<const d2 *>(w), w23 = *reinterpret_cast<const d2 *>(w + 2), w45 = *reinterpret_cast<const d2 *>(w + 4), w67 = *reinterpret_cast<const d2 *>(w + 6);
+            const double p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4], p5 = pp[5], p6 = pp[6], p7 = pp[7];
+            double e = w01.x * p0;                                  // cnt >= 1 for every real job
+            e = cnt > 1 ? e + w01.y * p1 : e;
+            e = cnt > 2 ? e + w23.x * p2 : e;
+            e = cnt > 3 ? e + w23.y * p3 : e;
+            e = cnt > 4 ? e + w45.x * p4 : e;
+            e = cnt > 5 ? e + w45.y * p5 : e;
+            e = cnt > 6 ? e + w67.x * p6 : e;
+            e = cnt > 7 ? e + w67.y * p7 : e;
+            if (on) unsafeAtomicAdd(acc + ((info >> 12) & 0xff), e);
         }
         // log2 through v_log_f32 (1 ulp: <= 1.2e-6 of a log10 / ln value, 3e-7 after Whisper's / 4), like the fused kernels
         float mv[kMaxPer];

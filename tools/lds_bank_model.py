@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""LDS bank model of pow2_frame_kernel (mel_spec_amd/csrc/pow2_wave.hpp): the byte addresses every LDS instruction of one frame issues,
+priced with the gfx950 lane groups and bank moduli of /opt/skills/guides/MI355X_MICROARCH.md (section LDS):
+
+  ds_read_b128   4 groups of 16 lanes {0-3,12-15,20-27} {4-11,16-19,28-31} (+32), bank = (a / 4) mod 64
+  ds_read_b64    2 groups of 32 lanes,                                         bank = (a / 4) mod 64
+  ds_write_b128  8 groups of 8 contiguous lanes,                               bank = (a / 4) mod 32
+  ds_write_b64   4 groups of 16 contiguous lanes,                              bank = (a / 4) mod 32
+
+A group costs one LDS cycle plus one per extra distinct address on its busiest bank (identical addresses broadcast).  The model
+reports, per access class, the cycles of a layout and the conflict-free floor; round 4 used it to replace the padded layout
+e + (e >> 3) (SQ_LDS_BANK_CONFLICT 44 % of SQ_LDS_IDX_ACTIVE at n_fft 1024) -- profiles/r04_pow2_lds.txt.
+
+Usage: tools/lds_bank_model.py [search]
+"""
+import itertools, sys
+
+RD128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+RD128 = RD128 + [[x + 32 for x in g] for g in RD128]
+RD64 = [list(range(32)), list(range(32, 64))]
+WR128 = [list(range(8 * g, 8 * g + 8)) for g in range(8)]
+WR64 = [list(range(16 * g, 16 * g + 16)) for g in range(4)]
+
+
+def cost(addrs, width, groups, banks):
+    """addrs: 64 byte addresses (None = lane off).  Returns (cycles, floor)."""
+    cyc = 0
+    for g in groups:
+        per_bank = {}
+        for lane in g:
+            a = addrs[lane]
+            if a is None:
+                continue
+            for d in range(width // 4):
+                per_bank.setdefault(((a // 4) + d) % banks, set()).add((a // 4 + d))
+        cyc += max([len(v) for v in per_bank.values()], default=1)
+    return cyc, len(groups)
+
+
+class Shape:
+    def __init__(self, logm):
+        self.M = M = 1 << logm
+        self.LF = 64 if M >= 512 else M // 8
+        self.FW = 64 // self.LF
+        self.P = M // self.LF
+        self.R1 = self.P
+        self.R3 = M // (self.R1 * 8)
+
+
+def model(logm, slot, frame_stride_bytes, tw3_table=False, half_split=False, pw_slot=None, verbose=True):
+    """slot(e) -> 16-byte slot of complex element e inside the frame's Z region; frame_stride_bytes: distance of the frames of a wave."""
+    S = Shape(logm)
+    M, LF, P = S.M, S.LF, S.P
+    tot = {}
+
+    def add(name, addrs, width, groups, banks):
+        c, f = cost(addrs, width, groups, banks)
+        t = tot.setdefault(name, [0, 0])
+        t[0] += c; t[1] += f
+
+    def zaddr(lane, e):
+        fs, _ = divmod(lane, LF)
+        return fs * frame_stride_bytes + 16 * slot(e)
+
+    TW = 1 << 22            # the tables live elsewhere: their own base (multiple of 256 B)
+    lanes = range(64)
+    L = [lane % LF for lane in lanes]
+
+    def do_pass(R, Ns, first, name):
+        NB = P // R
+        for i in range(NB):
+            if not first:
+                for r in range(R):
+                    add(name + " read", [zaddr(x, L[x] + LF * i + r * (M // R)) for x in lanes], 16, RD128, 64)
+                for r in range(1, R):
+                    if name == "pass2" and P == 8:
+                        continue                                   # registers
+                    if tw3_table:
+                        add(name + " twiddle", [TW + 16 * ((r - 1) * Ns + ((L[x] + LF * i) & (Ns - 1))) for x in lanes], 16, RD128, 64)
+                    else:
+                        q = [r * ((L[x] + LF * i) & (Ns - 1)) * (2 * M // (Ns * R)) for x in lanes]
+                        add(name + " twiddle", [TW + 16 * (v - M if v >= M else v) for v in q], 16, RD128, 64)
+            for r in range(R):
+                a = []
+                for x in lanes:
+                    j = L[x] + LF * i; k = j & (Ns - 1)
+                    a.append(zaddr(x, (j - k) * R + k + r * Ns))
+                add(name + " write", a, 16, WR128, 32)
+
+    do_pass(S.R1, 1, True, "pass1")
+    do_pass(8, S.R1, False, "pass2")
+    if S.R3 > 1:
+        do_pass(S.R3, S.R1 * 8, False, "pass3")
+    # split
+    PW = lambda lane, k: (lane // LF) * frame_stride_bytes + (pw_slot(k) if pw_slot else 16 * (M + (M >> 3) if slot(M - 1) >= M else M) + 8 * k)
+    ks = range(P // 2) if half_split else range(P)
+    for r in ks:
+        k = [L[x] + r * LF for x in lanes]
+        add("split read Z[k]", [zaddr(x, k[x]) for x in lanes], 16, RD128, 64)
+        add("split read Z[M-k]", [zaddr(x, (M - k[x]) & (M - 1)) for x in lanes], 16, RD128, 64)
+        add("split twiddle", [TW + (1 << 20) + 16 * k[x] for x in lanes], 16, RD128, 64)
+        add("split write pw", [PW(x, k[x]) for x in lanes], 8, WR64, 32)
+        if half_split:
+            add("split write pw", [PW(x, M - k[x]) for x in lanes], 8, WR64, 32)
+    if verbose:
+        c = sum(v[0] for v in tot.values()); f = sum(v[1] for v in tot.values())
+        print(f"M {M}: {c} LDS cycles per wave pass over {S.FW} frame(s), floor {f}  ({c / f:.2f} x)")
+        for k, v in tot.items():
+            print(f"   {k:20s} {v[0]:5d}  floor {v[1]:5d}")
+    return sum(v[0] for v in tot.values()), sum(v[1] for v in tot.values())
+
+
+def padded(e):
+    return e + (e >> 3)
+
+
+def xor_layout(g, sh):
+    return lambda e: e ^ g[(e >> sh) & 7]
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "search":
+        for logm in (6, 7, 8, 9, 10):
+            S = Shape(logm)
+            sh = 4 if S.R1 == 16 else 3
+            best = None
+            for stride_slots in ((0, 8, 4, 2, 1, 9) if S.FW > 1 else (0,)):
+                for g in itertools.permutations(range(8)):
+                    if g[0] != 0:
+                        continue
+                    c, f = model(logm, xor_layout(g, sh), 256 * 64 + 16 * stride_slots, tw3_table=True, half_split=True, pw_slot=lambda k: 16 * (1 << logm) + 8 * k, verbose=False)
+                    if best is None or c < best[0]:
+                        best = (c, f, g, stride_slots)
+                        if c == f:
+                            break
+                if best[0] == best[1]:
+                    break
+            print("M", S.M, "best", best)
+    else:
+        for logm in (6, 7, 8, 9, 10):
+            S = Shape(logm)
+            fd = 2 * (S.M + (S.M >> 3)) + S.M + 2 + 80
+            print("-- shipped in round 4 (padded e + (e >> 3), frame stride", 8 * fd, "B)")
+            model(logm, padded, 8 * fd)
