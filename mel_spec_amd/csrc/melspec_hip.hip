@@ -186,8 +186,67 @@ struct GenericTables {
                     jobv.push_back((fb.start[m] + c) | (m << 12) | (cnt << 20));
                     for (int q = 0; q < 8; ++q) jwv.push_back(q < cnt ? fb.w[static_cast<size_t>(fb.offset[m]) + c + q] : 0.0);
                 }
+#ifndef MS_POW2_JOBORDER
+#define MS_POW2_JOBORDER 1
+#endif
+#ifndef MS_POW2_JOBGROUP
+#define MS_POW2_JOBGROUP 16
+#endif
+            if (MS_POW2_JOBORDER && !jobv.empty() && n_fft >= 128) {
+                // The lanes of a round read pw[bin + q], q = 0..7, each lane for its own job, as ds_read2_b64 (the compiler pairs the
+                // reads): served 16 consecutive lanes at a time over 32 banks, i.e. 16 doubles -- the jobs that meet in such a group want
+                // first bins that differ mod 16 (mod 8 where a frame has 8 lanes: the two frames of a group sit 8 doubles apart,
+                // pow2_pw_shift).  In band order they do not -- a band's jobs are 8 bins apart, the low bands 2-3 -- and the reads were
+                // 3-4-way (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles at n_fft 2048).  So: groups of g jobs, every residue class dealt
+                // over the groups, largest class first, to the group that holds the fewest of that residue (then of that mel:
+                // ds_add_f64 to one address serialises); groups padded with empty jobs (count 0).  The order is a function of the
+                // bank, the sums stay deterministic; a band's pieces are added in a different order than before (f64: ~1e-16 relative).
+                const int half = n_fft / 2, lf = half >= 512 ? 64 : half / 8, g = std::min(lf, MS_POW2_JOBGROUP);
+                const size_t nj = jobv.size(), groups = (nj + g - 1) / g;
+                std::vector<std::vector<size_t>> cls(g), grp(groups);
+                for (size_t j = 0; j < nj; ++j) cls[(jobv[j] & 0xfff) % g].push_back(j);
+                std::vector<int> order(g);
+                for (int r = 0; r < g; ++r) order[r] = r;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a].size() > cls[b].size(); });
+                for (int r : order)
+                    for (size_t j : cls[r]) {
+                        size_t best = groups;
+                        long best_key = 0;
+                        for (size_t q = 0; q < groups; ++q) {
+                            if (grp[q].size() >= static_cast<size_t>(g)) continue;
+                            long same_res = 0, same_mel = 0;
+                            for (size_t o : grp[q]) {
+                                same_res += ((jobv[o] & 0xfff) % g) == r;
+                                same_mel += ((jobv[o] >> 12) & 0xff) == ((jobv[j] >> 12) & 0xff);
+                            }
+                            const long key = (same_res << 40) + (same_mel << 20) + static_cast<long>(grp[q].size());
+                            if (best == groups || key < best_key) { best = q; best_key = key; }
+                        }
+                        grp[best].push_back(j);
+                    }
+                std::vector<double> jw2;
+                std::vector<int> job2;
+                for (size_t q = 0; q < groups; ++q) {
+                    std::sort(grp[q].begin(), grp[q].end());
+                    for (int i = 0; i < g; ++i) {
+                        const bool have = static_cast<size_t>(i) < grp[q].size();
+                        job2.push_back(have ? jobv[grp[q][i]] : 0);
+                        for (int w = 0; w < 8; ++w) jw2.push_back(have ? jwv[8 * grp[q][i] + w] : 0.0);
+                    }
+                }
+                jobv.swap(job2);
+                jwv.swap(jw2);
+            }
             n_jobs = static_cast<int>(jobv.size());
             if (jobv.empty()) { jobv.push_back(0); jwv.assign(8, 0.0); }
+            {
+                // weight pairs (2 q, 2 q + 1) of job j at [q][j]: the lanes of a round read consecutive 16-byte slots
+                const size_t nj = jobv.size();
+                std::vector<double> t(jwv.size());
+                for (size_t j = 0; j < nj; ++j)
+                    for (int q = 0; q < 8; ++q) t[2 * ((q / 2) * nj + j) + (q & 1)] = jwv[8 * j + q];
+                jwv.swap(t);
+            }
             if ((rc = upload(jw, jwv))) return rc;
             if ((rc = upload(job, jobv))) return rc;
         }
@@ -417,9 +476,10 @@ int launch_pow2(const GenericParams &gp, int cus, hipStream_t stream) {
     using S = Pow2Shape<LOGM>;
     if (gp.n_mels > S::kMelsPerLane * S::LF) return -1;
     if (gp.n_jobs < 1 || gp.n_bins > 4088 || gp.n_mels > 256) return -1;
-    const size_t bank = ((8 * static_cast<size_t>(gp.n_jobs) + (static_cast<size_t>(gp.n_jobs) + 1) / 2 + 1) & ~static_cast<size_t>(1));
-    const size_t frame = static_cast<size_t>(S::frame_doubles()) + ((static_cast<size_t>(gp.n_mels) + 1) & ~static_cast<size_t>(1));
-    const size_t lds = sizeof(double) * ((S::M <= 256 ? 4 : 2) * static_cast<size_t>(S::M) + bank + static_cast<size_t>(S::kWaves) * S::FW * frame);
+    // one persistent workgroup per CU with as many waves as its LDS holds (the tables are paid once), at most two per SIMD (VGPRs)
+    int waves = S::kMaxWaves;
+    while (waves > 1 && sizeof(double) * static_cast<size_t>(pow2_lds<LOGM>(gp.n_jobs, gp.n_mels, waves).total) > kLdsLimit) --waves;
+    const size_t lds = sizeof(double) * static_cast<size_t>(pow2_lds<LOGM>(gp.n_jobs, gp.n_mels, waves).total);
     if (lds > kLdsLimit) return -1;
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
@@ -427,10 +487,9 @@ int launch_pow2(const GenericParams &gp, int cus, hipStream_t stream) {
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const uint64_t groups = (gp.b.n_units + S::kWaves * S::FW - 1) / (S::kWaves * S::FW);
-    const int per_cu = std::max<int>(1, static_cast<int>(kLdsLimit / lds)) * 2;      // persistent: about two rounds of resident workgroups
-    const unsigned grid = grid_for(groups, cus, per_cu);
-    hipLaunchKernelGGL((pow2_frame_kernel<LOGM, FLAVOR>), dim3(grid), dim3(S::kWaves * 64), lds, stream, gp);
+    const uint64_t groups = (gp.b.n_units + static_cast<uint64_t>(waves) * S::FW - 1) / (static_cast<uint64_t>(waves) * S::FW);
+    const unsigned grid = grid_for(groups, cus, 1);
+    hipLaunchKernelGGL((pow2_frame_kernel<LOGM, FLAVOR>), dim3(grid), dim3(waves * 64), lds, stream, gp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }

@@ -2265,7 +2265,7 @@ struct GenericParams {
     const double *d_mw;    // concatenated spans
     int mw_count;          // doubles in d_mw
     // pow2_frame_kernel's view of the same bank: n_jobs jobs of eight consecutive weights of one mel (the last job of a band padded with
-    // zeros), d_jw[8 * job + q] the weights, d_job[job] = first bin | mel << 12 | count << 20 (count = 1..8 real entries)
+    // zeros), d_jw[2 * ((q / 2) * n_jobs + job) + (q & 1)] weight q of a job, d_job[job] = first bin | mel << 12 | count << 20 (count = 1..8 real entries)
     const double *d_jw;
     const int *d_job;
     int n_jobs;
@@ -2460,38 +2460,42 @@ template <int P, int FLAVOR> struct Pow2Raw {
 };
 
 template <int LOGM, int FLAVOR>
-__global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kernel(const GenericParams p) {
+__global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_kernel(const GenericParams p) {
     using S = Pow2Shape<LOGM>;
-    constexpr int M = S::M, LF = S::LF, FW = S::FW, P = S::P, kPow2Waves = S::kWaves;
-    constexpr bool kAhead = P == 8;                      // M = 1024 holds 16 points per lane and has no registers to spare
+    constexpr int M = S::M, LF = S::LF, FW = S::FW, P = S::P;
+    constexpr bool kAhead = P == 8 || MS_POW2_AHEAD16;   // the next frame's samples are loaded while this one is transformed
+    constexpr bool kWinLds = M <= MS_POW2_WINLDS;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
-    double *tw = ldsd;                                   // 2 * M: W_N^q, q < M
-    constexpr bool kWinLds = M <= 256;                   // above that the 8 / 16 KB of the window cost a resident workgroup: read from L1 / L2
-    double *lwin = tw + 2 * M;                           // 2 * M: the window, zero from frame_len on
-    double *ljw = lwin + (kWinLds ? 2 * M : 0);          // the banded filterbank as jobs of eight weights (GenericParams::d_jw), then the
-    int *ljob = reinterpret_cast<int *>(ljw + 8 * p.n_jobs);   //   job records {first bin | mel << 12 | count << 20}
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * M; i += kPow2Waves * 64) {
-        tw[i] = p.d_tw[i];
-        if (kWinLds) lwin[i] = p.d_win[i];
-    }
-    for (int i = tid; i < 8 * p.n_jobs; i += kPow2Waves * 64) ljw[i] = p.d_jw[i];
-    for (int i = tid; i < p.n_jobs; i += kPow2Waves * 64) ljob[i] = p.d_job[i];
+    const int tid = threadIdx.x, n_threads = blockDim.x, n_waves = n_threads >> 6;     // the host picks the waves per workgroup (LDS)
+    const Pow2Lds at = pow2_lds<LOGM>(p.n_jobs, p.n_mels, n_waves);
+    double *tw = ldsd + at.tw;                           // W_N^q, q <= M / 2 (the split's twiddles)
+    double *lwin = ldsd + at.win;                        // 2 * M: the window, zero from frame_len on (M <= 256)
+    double *t2 = ldsd + at.t2, *t3 = ldsd + at.t3;       // the twiddles of passes 2 and 3, [r - 1][k]
+    double *ljw = ldsd + at.jw;                          // the banded filterbank as jobs of eight weights (GenericParams::d_jw), then the
+    int *ljob = reinterpret_cast<int *>(ldsd + at.job);  //   job records {first bin | mel << 12 | count << 20}
+    for (int i = tid; i < M + 2; i += n_threads) tw[i] = p.d_tw[i];
+    if (kWinLds) for (int i = tid; i < 2 * M; i += n_threads) lwin[i] = p.d_win[i];
+    for (int i = tid; i < S::kT2; i += n_threads) stc(t2 + 2 * i, pow2_table_entry(p.d_tw, M, 8, S::R1, i));
+    for (int i = tid; i < S::kT3; i += n_threads) stc(t3 + 2 * i, pow2_table_entry(p.d_tw, M, S::R3 > 1 ? S::R3 : 2, S::R1 * 8, i));
+    for (int i = tid; i < 8 * p.n_jobs; i += n_threads) ljw[i] = p.d_jw[i];
+    for (int i = tid; i < p.n_jobs; i += n_threads) ljob[i] = p.d_job[i];
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int fs = lane / LF, l = lane - fs * LF;        // frame slot of the wave, lane of the frame
-    const int acc_doubles = (p.n_mels + 1) & ~1;
-    double *z = ljw + ((8 * p.n_jobs + (p.n_jobs + 1) / 2 + 1) & ~1) + (wave * FW + fs) * (S::frame_doubles() + acc_doubles);
-    double *pw = z + 2 * S::kZ;                          // [M + 1]
-    double *acc = pw + M + 2;                            // [n_mels] band energies of the frame (also what a job's last reads past pw[M] land in)
+    double *z = ldsd + at.frames + (wave * FW + fs) * at.frame_stride;
+    double *pw = z + at.pw + pow2_pw_shift<LOGM>(fs);    // [M + 1]
+    double *acc = z + at.acc;                            // [n_mels] band energies of the frame
+    constexpr bool kPwAlias = M >= MS_POW2_PWALIAS;
+    if (!kPwAlias && l < 8) pw[M + 1 + l] = 0.0;         // what the last job of the top band reads past the row
     const int last = p.frame_len - 1;
 
     // the twiddles of pass 2 depend on the lane only: W_{8 R1}^{k r}, k = l mod R1 (kept in registers; pass 3's come from the LDS table)
-    cpx<double> tw2[kAhead ? 7 : 1];
-    if (kAhead) {
+    constexpr bool kTw2Reg = P == 8 && MS_POW2_TW2REG;
+    cpx<double> tw2[kTw2Reg ? 7 : 1];
+    if (kTw2Reg) {
         const int k2 = l & (S::R1 - 1);
 #pragma unroll
-        for (int r = 1; r < 8; ++r) tw2[r - 1] = pow2_root(tw, r * k2 * (2 * M / (S::R1 * 8)), M);
+        for (int r = 1; r < 8; ++r) tw2[r - 1] = pow2_root(p.d_tw, r * k2 * (2 * M / (S::R1 * 8)), M);
     }
 
     struct Frame {                                       // where a frame is, per lane group
@@ -2501,7 +2505,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
         bool have, real;
     };
     const uint64_t n_units = batch_n_units(p.b);
-    const uint64_t stride = (uint64_t)gridDim.x * kPow2Waves * FW;
+    const uint64_t stride = (uint64_t)gridDim.x * n_waves * FW;
     auto place = [&](uint64_t base) {
         Frame f;
         const uint64_t unit = base + fs;
@@ -2536,9 +2540,23 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
         }
     };
 
-    uint64_t base = ((uint64_t)blockIdx.x * kPow2Waves + wave) * FW;
+    // The lane's window values are the same for every frame, but 2 P doubles are too many to hold through the passes: read per frame
+    d2 wnd[P];
+    auto load_window = [&]() {
+#pragma unroll
+        for (int r = 0; r < P; ++r) wnd[r] = *reinterpret_cast<const d2 *>((kWinLds ? lwin : p.d_win) + 2 * (l + r * LF));
+    };
+    // the jobs of a lane are the same for every frame too: the records of its first kJ stay in registers
+    const int n_jobs = p.n_jobs;
+    constexpr int kJ = (FLAVOR != 0 && P == 8) ? MS_POW2_JOBS_F : 3;     // rounds of jobs in flight together (the Kaldi / NeMo framings hold more registers: spills)
+    int info0[kJ];
+#pragma unroll
+    for (int t = 0; t < kJ; ++t) info0[t] = l + t * LF < n_jobs ? ljob[l + t * LF] : 0;
+
+    uint64_t base = ((uint64_t)blockIdx.x * n_waves + wave) * FW;
     if (base >= n_units) return;
     Frame cur = place(base);
+    if (MS_POW2_WINEARLY) load_window();
     Pow2Raw<P, FLAVOR> raw;
     fetch(cur, raw);
     for (;;) {
@@ -2557,6 +2575,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
             // ---- framing: DC removal / pre-emphasis / window per flavour -> the lane's P complex points z[l + r LF] -----------------
             cpx<double> reg[P];
             double v[2 * P];
+            if (!MS_POW2_WINEARLY) load_window();
             if (FLAVOR == 0) {                           // frame_windows: x[start + i] as f64 (src/stft.rs:160-165)
 #pragma unroll
                 for (int r = 0; r < P; ++r) { v[2 * r] = (double)raw.pair[r].x; v[2 * r + 1] = (double)raw.pair[r].y; }
@@ -2598,35 +2617,40 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
                 }
             }
 #pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const d2 w = *reinterpret_cast<const d2 *>((kWinLds ? lwin : p.d_win) + 2 * (l + r * LF));
-                reg[r] = {v[2 * r] * w.x, v[2 * r + 1] * w.y};
-            }
+            for (int r = 0; r < P; ++r) reg[r] = {v[2 * r] * wnd[r].x, v[2 * r + 1] * wnd[r].y};
             // ---- the complex M-point transform: Stockham passes, in place in the frame's LDS region --------------------------------
-            pow2_pass<LOGM, S::R1, true>(l, 1, tw, z, reg, nullptr);
-            pow2_pass<LOGM, 8, false>(l, S::R1, tw, z, nullptr, kAhead ? tw2 : nullptr);
-            if (S::R3 > 1) pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, tw, z, nullptr, nullptr);
-            // ---- the real-FFT split X[k] = E[k] + W_N^k O[k] and the power row ------------------------------------------------------
-            auto power = [&](int k) {
-                const int ka = k == M ? 0 : k, kb = (M - k) & (M - 1);        // Z[M] = Z[0]; partner Z[M - k]
-                const cpx<double> a = ldc(z + 2 * pow2_pad(ka)), b0 = ldc(z + 2 * pow2_pad(kb));
-                const double br = b0.re, bi = -b0.im;                       // conj
-                const double er = 0.5 * (a.re + br), ei = 0.5 * (a.im + bi);
-                const double dr = 0.5 * (a.re - br), di = 0.5 * (a.im - bi);
-                double c = -1.0, sn = 0.0;                                  // W_N^M
-                if (k < M) { const cpx<double> w = ldc(tw + 2 * k); c = w.re; sn = w.im; }
-                const double orr = di, oi = -dr;
-                const double re = er + (orr * c - oi * sn), im = ei + (orr * sn + oi * c);
-                const double ns = re * re + im * im;
-                return (FLAVOR == 1 && !p.use_power) ? sqrt(ns) : ns;
+            pow2_pass<LOGM, S::R1, true>(l, 1, nullptr, z, reg, nullptr);
+            pow2_pass<LOGM, 8, false>(l, S::R1, t2, z, nullptr, kTw2Reg ? tw2 : nullptr);
+            if (S::R3 > 1) pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, t3, z, nullptr, nullptr);
+            // ---- the real-FFT split X[k] = E[k] + W_N^k O[k], E = (Z[k] + conj Z[M-k]) / 2, O = -i (Z[k] - conj Z[M-k]) / 2, and the
+            // power row.  X[M-k] comes from the same two points (E -> conj E, O -> conj O, W_N^{M-k} = -conj W_N^k):
+            //   X[k] = (er + t1) + i (ei + t2),   X[M-k] = (er - t1) - i (ei - t2),   t1 = di c + dr s,  t2 = di s - dr c
+            // so a lane takes the pairs k = l + r LF < M / 2 (k = 0 gives bins 0 and M); bin M / 2 is its own partner.
+            auto power2 = [&](int k, double &lo, double &hi) {
+                const cpx<double> a = ldc(z + 2 * pow2_slot<LOGM>(k)), b0 = ldc(z + 2 * pow2_slot<LOGM>((M - k) & (M - 1)));
+                const cpx<double> w = ldc(tw + 2 * k);
+                const double er = 0.5 * (a.re + b0.re), ei = 0.5 * (a.im - b0.im);
+                const double dr = 0.5 * (a.re - b0.re), di = 0.5 * (a.im + b0.im);
+                const double t1 = di * w.re + dr * w.im, t2v = di * w.im - dr * w.re;
+                const double ar = er + t1, ai = ei + t2v, br = er - t1, bi = ei - t2v;
+                lo = ar * ar + ai * ai;
+                hi = br * br + bi * bi;
+                if (FLAVOR == 1 && !p.use_power) { lo = sqrt(lo); hi = sqrt(hi); }
             };
-            double pk[P];
+            double plo[P / 2], phi[P / 2];
 #pragma unroll
-            for (int r = 0; r < P; ++r) pk[r] = power(l + r * LF);
+            for (int r = 0; r < P / 2; ++r) power2(l + r * LF, plo[r], phi[r]);
+            double pmid, pmid2;
+            power2(M / 2, pmid, pmid2);                  // every lane, one address: a broadcast
 #pragma unroll
-            for (int r = 0; r < P; ++r) pw[l + r * LF] = pk[r];
-            if (l == 0 && p.n_bins > M) pw[M] = power(M);
+            for (int r = 0; r < P / 2; ++r) {
+                pw[l + r * LF] = plo[r];
+                pw[M - (l + r * LF)] = phi[r];
+            }
+            if (l == 0) pw[M / 2] = pmid;
+            if (kPwAlias && l < 8) pw[M + 1 + l] = 0.0;      // (the row is where the points were)
         }
+        if (MS_POW2_WINEARLY && more) load_window();
         // ---- banded mel sums, log, per-flavour epilogue ---------------------------------------------------------------------------
         // The bank as JOBS of eight consecutive weights of one mel (the last job of a band padded): every lane takes a job per round,
         // folds its up-to-eight products left to right and adds the partial sum to the mel's word in LDS (ds_add_f64; the LDS executes
@@ -2639,22 +2663,36 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kWaves * 64) void pow2_frame_kerne
         constexpr int kMaxPer = Pow2Shape<LOGM>::kMelsPerLane;            // a lane reads out the mels m = l + LF i (the host checks n_mels <= kMelsPerLane * LF)
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) if (l + LF * i < p.n_mels) acc[l + LF * i] = 0.0;
-        for (int jb = l; jb < p.n_jobs + l; jb += LF) {            // wave-uniform trip count
-            const bool on = cur.real && jb < p.n_jobs;
-            const int info = ljob[on ? jb : 0];
-            const int cnt = on ? info >> 20 : 0;
-            const double *w = ljw + 8 * (on ? jb : 0), *pp = pw + (info & 0xfff);
-            const d2 w01 = *reinterpret_cast<const d2 *>(w), w23 = *reinterpret_cast<const d2 *>(w + 2), w45 = *reinterpret_cast<const d2 *>(w + 4), w67 = *reinterpret_cast<const d2 *>(w + 6);
-            const double p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3], p4 = pp[4], p5 = pp[5], p6 = pp[6], p7 = pp[7];
-            double e = w01.x * p0;                                  // cnt >= 1 for every real job
-            e = cnt > 1 ? e + w01.y * p1 : e;
-            e = cnt > 2 ? e + w23.x * p2 : e;
-            e = cnt > 3 ? e + w23.y * p3 : e;
-            e = cnt > 4 ? e + w45.x * p4 : e;
-            e = cnt > 5 ? e + w45.y * p5 : e;
-            e = cnt > 6 ? e + w67.x * p6 : e;
-            e = cnt > 7 ? e + w67.y * p7 : e;
-            if (on) unsafeAtomicAdd(acc + ((info >> 12) & 0xff), e);
+        // kJ = three rounds at a time: their 36 loads are in flight together (the transform's registers are free here), one LDS round trip
+        // instead of three -- at two waves per SIMD the kernel is a chain of such round trips, not of arithmetic
+        auto job_triple = [&](const int (&info)[kJ], int jb0) {
+            d2 w[kJ][4];
+            double pv[kJ][8];
+            const int jstep = 2 * n_jobs;
+#pragma unroll
+            for (int t = 0; t < kJ; ++t) {
+                const int jb = jb0 + t * LF;
+                const double *wp = ljw + 2 * (jb < n_jobs ? jb : 0), *pp = pw + (info[t] & 0xfff);      // weights 2 q, 2 q + 1 of job j at [q][j]: consecutive lanes, consecutive slots
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[t][q] = *reinterpret_cast<const d2 *>(wp + q * jstep);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pv[t][q] = pp[q];      // (the compiler pairs them: four ds_read2_b64, served 16 consecutive lanes at a time over 32 banks)
+            }
+#pragma unroll
+            for (int t = 0; t < kJ; ++t) {
+                // (a job's weights past its count are +0 and what it reads past the row is +0: e + 0 * p = e, no selects)
+                double e = w[t][0].x * pv[t][0];
+                e += w[t][0].y * pv[t][1]; e += w[t][1].x * pv[t][2]; e += w[t][1].y * pv[t][3];
+                e += w[t][2].x * pv[t][4]; e += w[t][2].y * pv[t][5]; e += w[t][3].x * pv[t][6]; e += w[t][3].y * pv[t][7];
+                if (cur.real && (info[t] >> 20) > 0) unsafeAtomicAdd(acc + ((info[t] >> 12) & 0xff), e);       // (count 0: the host's padding, or past the last job)
+            }
+        };
+        job_triple(info0, l);
+        for (int jb0 = l + kJ * LF; jb0 < n_jobs + l; jb0 += kJ * LF) {            // wave-uniform trip count
+            int info[kJ];
+#pragma unroll
+            for (int t = 0; t < kJ; ++t) info[t] = jb0 + t * LF < n_jobs ? ljob[jb0 + t * LF] : 0;
+            job_triple(info, jb0);
         }
         // log2 through v_log_f32 (1 ulp: <= 1.2e-6 of a log10 / ln value, 3e-7 after Whisper's / 4), like the fused kernels
         float mv[kMaxPer];

@@ -7,7 +7,7 @@
 //   Stockham autosort passes of radix 8 (16 for the first pass of M = 1024), the last pass of radix 2 / 4 / 8, each pass: read the inputs
 //   from the frame's LDS region into registers, twiddle, butterfly, write back IN PLACE -- the LDS operations of a wave execute in
 //   program order and every lane's reads of a pass are issued before any write of that pass, so no barrier and no second buffer;
-//   the Hermitian split to |X[k]|^2, the banded mel sums (one mel per lane and step), log / clamp / store.
+//   the Hermitian split to |X[k]|^2 (a pair k, M - k per step), the banded mel sums (jobs of eight weights), log / clamp / store.
 //
 //   M      n_fft   lanes per frame   frames per wave   passes
 //   64     128     8                 8                 8 8
@@ -17,10 +17,44 @@
 //   1024   2048    64                1                 16 8 8
 //
 // Arithmetic: f64 from the window multiply to the mel sums, as the reference (src/stft.rs:98-111, src/mel.rs:148-168, src/fbank.rs:
-// 165-221) and generic_frame_kernel, which stays the independent on-device cross-check (tests).  Element e of a frame's M complex
-// points sits at e + (e >> 3): the pass writes of eight lanes land 9 instead of 8 elements apart (144 B: conflict-free 16-byte writes).
+// 165-221) and generic_frame_kernel, which stays the independent on-device cross-check (tests).
+//
+// LDS banks (tools/lds_bank_model.py prices every access of a frame with gfx950's lane groups; profiles/r04_pow2_lds.txt holds the
+// counters before and after).  Element e of a frame's M complex points sits in the 16-byte slot e ^ ((e >> log2 R1) & 7): an XOR
+// inside every aligned block of eight, by the index of the block.  The first pass writes e = R1 j + r from eight consecutive lanes j
+// (ds_write_b128 is served eight lanes at a time over 32 banks: the XOR turns eight times the same slot into eight different ones);
+// every later access is to consecutive elements from consecutive lanes, which the XOR only permutes inside a block, and the 16-lane
+// groups of ds_read_b128 {0-3, 12-15, 20-27}, ... meet each of the 16 slots of a 256-byte row once.  The first layout, e + (e >> 3),
+// made the same writes conflict-free and every read two-way; the twiddles of the later passes came from the half-circle table at a
+// stride of 2 r k slots (2- to 16-way); together 44 % of the LDS cycles at n_fft 1024.  Now the twiddles of a pass are a table of
+// their own, [r][k] with k along the lanes.  The frames of a wave are a multiple of 256 bytes apart (128 mod 256 for M = 64, whose
+// read groups hold lanes of four frames).
 #pragma once
 #include "device_fft.hpp"
+#ifndef MS_POW2_MAXW
+#define MS_POW2_MAXW 8
+#endif
+#ifndef MS_POW2_WINLDS
+#define MS_POW2_WINLDS 512
+#endif
+#ifndef MS_POW2_AHEAD16
+#define MS_POW2_AHEAD16 1
+#endif
+#ifndef MS_POW2_WINEARLY
+#define MS_POW2_WINEARLY 0      // lab: read a frame's window values before the mel phase of the frame before (32-64 VGPRs held across it: spills, 3-90 % slower)
+#endif
+#ifndef MS_POW2_JOBS_F
+#define MS_POW2_JOBS_F 1
+#endif
+#ifndef MS_POW2_MAXW16
+#define MS_POW2_MAXW16 4       // M = 1024: 16 points per lane want the AGPRs (one wave per SIMD); at 5-6 waves the 256-VGPR cap spills 100-190 dwords: 11-13 ms against 5.0
+#endif
+#ifndef MS_POW2_PWALIAS
+#define MS_POW2_PWALIAS 1024     // from this M on the power row takes the place of the frame's points (the split has read them all)
+#endif
+#ifndef MS_POW2_TW2REG
+#define MS_POW2_TW2REG 1
+#endif
 
 namespace melspec {
 
@@ -31,19 +65,57 @@ template <int LOGM> struct Pow2Shape {
     static constexpr int P = M / LF;                         // complex points per lane (8; 16 for M = 1024)
     static constexpr int R1 = P;                             // radix of the first pass
     static constexpr int R3 = M / (R1 * 8);                  // radix of the last pass (1: two passes only)
-    static constexpr int kZ = M + (M >> 3);                  // padded complex points per frame
-    static constexpr int frame_doubles() { return 2 * kZ + M + 2; }      // Z, then the power row [M + 1] (+ 1 pad)
+    static constexpr int kShift = P == 16 ? 4 : 3;           // log2 R1
     static constexpr int kMelsPerLane = LF >= 16 ? 256 / LF : 16;            // banks of up to 256 mels (128 at M = 64)
-    static constexpr int kWaves = M >= 1024 ? 3 : 4;                         // waves per workgroup (M = 1024: 27 KB of LDS per frame)
+    static constexpr int kMaxWaves = M >= 1024 ? MS_POW2_MAXW16 : MS_POW2_MAXW;      // two per SIMD: the kernels hold 185-240 VGPRs (M = 1024: one, its LDS holds four frames and its 16 points per lane want the AGPRs)
+    static constexpr int kT2 = (P == 16 || !MS_POW2_TW2REG) ? 7 * R1 : 0;         // complex entries of the pass-2 table (P == 8: the lane keeps its seven in registers)
+    static constexpr int kT3 = R3 > 1 ? (R3 - 1) * R1 * 8 : 0;               // of the pass-3 table
 };
 
-MS_DEV int pow2_pad(int e) { return e + (e >> 3); }
+// Where everything is in the workgroup's LDS, in doubles; the host sizes the launch with the same function.
+struct Pow2Lds {
+    int tw, win, t2, t3, jw, job, frames, frame_stride, pw, acc, total;
+};
+template <int LOGM> MS_HD Pow2Lds pow2_lds(int n_jobs, int n_mels, int waves) {
+    using S = Pow2Shape<LOGM>;
+    Pow2Lds o;
+    o.tw = 0;
+    o.win = o.tw + S::M + 32;                              // W_N^q, q <= M / 2: what the split reads
+    o.t2 = o.win + (S::M <= MS_POW2_WINLDS ? 2 * S::M : 0);           // M = 1024: its 16 KB would cost one of four resident waves, read from L1 / L2
+    o.t3 = o.t2 + 2 * S::kT2;
+    o.jw = o.t3 + 2 * S::kT3;
+    o.job = o.jw + 8 * n_jobs;
+    o.frames = (o.job + (n_jobs + 1) / 2 + 31) & ~31;
+    // inside a frame: Z, the power row [M + 1] (+ 7 a job may read past it, + pad), the band sums
+    o.pw = S::M >= MS_POW2_PWALIAS ? 0 : 2 * S::M;
+    o.acc = S::M >= MS_POW2_PWALIAS ? 2 * S::M : o.pw + S::M + 10 + (S::LF < 32 ? 32 - S::LF : 0);      // (the frames of a 32-lane group start their rows LF doubles apart: pow2_pw_shift)
+    o.frame_stride = ((o.acc + n_mels + 31) & ~31) + (S::M == 64 ? 16 : 0);
+    o.total = o.frames + waves * S::FW * o.frame_stride;
+    return o;
+}
+
+// doubles by which frame slot fs of a wave shifts its power row, so that the rows of the frames that share a 32-lane group of
+// ds_read_b64 start LF doubles apart in the bank row (the frames themselves are 0, or for M = 64 16, doubles apart mod 32)
+template <int LOGM> MS_DEV int pow2_pw_shift(int fs) {
+    constexpr int LF = Pow2Shape<LOGM>::LF;
+    if (LF == 16) return (fs & 1) * 16;
+    if (LF == 8) return ((fs & 3) * 8 + (fs & 1) * 16) & 31;
+    return 0;
+}
+
+template <int LOGM> MS_DEV int pow2_slot(int e) { return e ^ ((e >> Pow2Shape<LOGM>::kShift) & 7); }
 
 // W_N^q = exp(-2 pi i q / N), N = 2 M, from the table of the half circle tw[q] = W_N^q, q < M
 MS_DEV cpx<double> pow2_root(const double *tw, int q, int M) {
     const bool neg = q >= M;
     const cpx<double> w = ldc(tw + 2 * (neg ? q - M : q));
     return neg ? cpx<double>{-w.re, -w.im} : w;
+}
+
+// entry idx = (r - 1) * Ns + k of the twiddle table of the pass of radix R after Ns points: W_{Ns R}^{k r} = W_N^{k r N / (Ns R)}, N = 2 M
+MS_DEV cpx<double> pow2_table_entry(const double *tw, int M, int R, int Ns, int idx) {
+    const int r = idx / Ns + 1, k = idx - (r - 1) * Ns;
+    return pow2_root(tw, r * k * (2 * M / (Ns * R)), M);
 }
 
 template <int R> MS_DEV void pow2_dft(cpx<double> (&v)[R]);
@@ -56,9 +128,10 @@ template <> MS_DEV void pow2_dft<16>(cpx<double> (&v)[16]) { fft16(v); }
 
 // One Stockham pass of radix R over the frame's M points (Ns = product of the radices before it), butterflies j = l + LF * i.
 // FIRST: the inputs are already in `reg` (the windowed samples of the lane, reg[r] = z[l + r * M / R]), nothing is read.
-// ltw != nullptr: the lane's twiddles of this pass from registers, ltw[i * (R - 1) + r - 1] for butterfly i.
+// The twiddles W_{Ns R}^{k r}, k = j mod Ns: from registers (ltw[i * (R - 1) + r - 1] for butterfly i) or from the pass's LDS table
+// tab[(r - 1) * Ns + k].
 template <int LOGM, int R, bool FIRST>
-MS_DEV void pow2_pass(int l, int Ns, const double *tw, double *z, cpx<double> *reg, const cpx<double> *ltw) {
+MS_DEV void pow2_pass(int l, int Ns, const double *tab, double *z, cpx<double> *reg, const cpx<double> *ltw) {
     using S = Pow2Shape<LOGM>;
     constexpr int M = S::M, NB = S::P / R;                   // butterflies per lane
     cpx<double> v[NB][R];
@@ -66,21 +139,20 @@ MS_DEV void pow2_pass(int l, int Ns, const double *tw, double *z, cpx<double> *r
     for (int i = 0; i < NB; ++i) {
         const int j = l + S::LF * i;
 #pragma unroll
-        for (int r = 0; r < R; ++r) v[i][r] = FIRST ? reg[r] : ldc(z + 2 * pow2_pad(j + r * (M / R)));
+        for (int r = 0; r < R; ++r) v[i][r] = FIRST ? reg[r] : ldc(z + 2 * pow2_slot<LOGM>(j + r * (M / R)));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = l + S::LF * i;
         const int k = j & (Ns - 1);
         if (!FIRST) {
-            const int step = k * (2 * M / (Ns * R));         // W_{Ns R}^{k r} = W_N^{k r N / (Ns R)}
 #pragma unroll
-            for (int r = 1; r < R; ++r) v[i][r] = cmul(v[i][r], ltw ? ltw[i * (R - 1) + r - 1] : pow2_root(tw, r * step, M));
+            for (int r = 1; r < R; ++r) v[i][r] = cmul(v[i][r], ltw ? ltw[i * (R - 1) + r - 1] : ldc(tab + 2 * ((r - 1) * Ns + k)));
         }
         pow2_dft<R>(v[i]);
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; ++r) stc(z + 2 * pow2_pad(j0 + r * Ns), v[i][r]);
+        for (int r = 0; r < R; ++r) stc(z + 2 * pow2_slot<LOGM>(j0 + r * Ns), v[i][r]);
     }
 }
 

@@ -887,7 +887,10 @@ static void emu_pow2_run(const double *in /* M complex */, double *out /* M comp
     constexpr int M = S::M;
     std::vector<double> tw(2 * M);
     for (int q = 0; q < M; ++q) { tw[2 * q] = std::cos(2.0 * kPi * q / (2.0 * M)); tw[2 * q + 1] = -std::sin(2.0 * kPi * q / (2.0 * M)); }
-    std::vector<double> z(2 * S::kZ, 1.0e300);
+    std::vector<double> t2(2 * 7 * S::R1), t3(2 * (S::kT3 > 0 ? S::kT3 : 1));
+    for (int i = 0; i < 7 * S::R1; ++i) { const cpx<double> w = pow2_table_entry(tw.data(), M, 8, S::R1, i); t2[2 * i] = w.re; t2[2 * i + 1] = w.im; }
+    for (int i = 0; i < S::kT3; ++i) { const cpx<double> w = pow2_table_entry(tw.data(), M, S::R3, S::R1 * 8, i); t3[2 * i] = w.re; t3[2 * i + 1] = w.im; }
+    std::vector<double> z(2 * M, 1.0e300);
     auto pass = [&](auto fn) {
         const std::vector<double> snap(z);
         std::vector<double> next(z);
@@ -901,11 +904,11 @@ static void emu_pow2_run(const double *in /* M complex */, double *out /* M comp
     pass([&](int l, double *zz) {
         cpx<double> reg[S::P];
         for (int r = 0; r < S::P; ++r) reg[r] = {in[2 * (l + r * S::LF)], in[2 * (l + r * S::LF) + 1]};
-        pow2_pass<LOGM, S::R1, true>(l, 1, tw.data(), zz, reg, nullptr);
+        pow2_pass<LOGM, S::R1, true>(l, 1, nullptr, zz, reg, nullptr);
     });
-    pass([&](int l, double *zz) { pow2_pass<LOGM, 8, false>(l, S::R1, tw.data(), zz, nullptr, nullptr); });
-    if (S::R3 > 1) pass([&](int l, double *zz) { pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, tw.data(), zz, nullptr, nullptr); });
-    for (int k = 0; k < M; ++k) { out[2 * k] = z[2 * pow2_pad(k)]; out[2 * k + 1] = z[2 * pow2_pad(k) + 1]; }
+    pass([&](int l, double *zz) { pow2_pass<LOGM, 8, false>(l, S::R1, t2.data(), zz, nullptr, nullptr); });
+    if (S::R3 > 1) pass([&](int l, double *zz) { pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, t3.data(), zz, nullptr, nullptr); });
+    for (int k = 0; k < M; ++k) { out[2 * k] = z[2 * pow2_slot<LOGM>(k)]; out[2 * k + 1] = z[2 * pow2_slot<LOGM>(k) + 1]; }
 }
 extern "C" int emu_pow2_fft(int logm, const double *in, double *out) {
     switch (logm) {

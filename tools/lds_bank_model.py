@@ -140,5 +140,9 @@ if __name__ == "__main__":
         for logm in (6, 7, 8, 9, 10):
             S = Shape(logm)
             fd = 2 * (S.M + (S.M >> 3)) + S.M + 2 + 80
-            print("-- shipped in round 4 (padded e + (e >> 3), frame stride", 8 * fd, "B)")
+            print("-- first form (element e at e + (e >> 3), twiddles from the half-circle table, a bin per step in the split; frame stride", 8 * fd, "B)")
             model(logm, padded, 8 * fd)
+            sh = 4 if S.R1 == 16 else 3
+            stride = 256 * 64 + (128 if S.M == 64 else 0)
+            print("-- shipped (e ^ ((e >> %d) & 7), a table per pass, a pair k, M - k per step; frame stride = %d mod 256 B)" % (sh, stride % 256))
+            model(logm, xor_layout(tuple(range(8)), sh), stride, tw3_table=True, half_split=True, pw_slot=lambda k, M=S.M: 16 * M + 8 * k)
