@@ -629,6 +629,40 @@ def test_pow2_kernel_whisper_style(gpu, oracle, jfk, fft, hop, n_mels, sr):
     m.close()
 
 
+@pytest.mark.parametrize("fft,hop", [(128, 64), (256, 100), (1024, 256), (2048, 512)])
+def test_pow2_kernel_with_caller_supplied_banks(gpu, oracle, jfk, fft, hop):
+    """The mel phase of pow2_frame_kernel cuts every band into jobs of eight weights, the host deals them over the rounds by their first
+    bin: banks that are nothing like triangles go through it -- rectangular bands three deep with a negative weight and interior zeros,
+    a single band over every bin (the longest chain of ds_add_f64 into one word), bands of one bin, an empty row; and a matrix too wide
+    for the kernel's LDS (every row every bin) falls back to the workgroup kernel.  All against the oracle's dense product."""
+    bins = fft // 2 + 1
+    rng = np.random.default_rng(fft)
+    x = jfk[10000:10000 + 5 * fft + 9 * hop + 3]
+    rows = 24
+    width = max(3, bins // 6)
+    filters = np.zeros((rows, bins))
+    for r in range(rows - 4):
+        lo = (r * (bins - width)) // (rows - 5)
+        filters[r, lo:lo + width] = rng.uniform(0.01, 0.05, width)
+    filters[3, filters[3].nonzero()[0][1]] = -0.004                 # a negative weight
+    filters[4, filters[4].nonzero()[0][2:5]] = 0.0                  # zeros inside a band
+    filters[rows - 4, :] = rng.uniform(0.001, 0.002, bins)          # every bin: (bins + 7) / 8 jobs into one word
+    filters[rows - 3, bins - 1] = 0.5                               # the last bin alone (the job reads seven places past the row)
+    filters[rows - 2, 0] = 0.25                                     # the first bin alone; the last row stays empty
+    m = gpu.HipMelSpectrogram(fft, hop, SR, rows, filterbank=filters)
+    want = oracle.compute_mel_spectrogram_with_filters(x, fft, hop, filters)
+    got = m.compute_mel_spectrogram(x)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    clips = np.stack([x, x[::-1].copy(), oracle.synth_pcm(7, x.size)])
+    for g, c in zip(m.compute_batch(clips), clips):
+        assert np.abs(g - oracle.compute_mel_spectrogram_with_filters(c, fft, hop, filters)).max() <= 2e-6
+    m.close()
+    dense = rng.uniform(0.001, 0.002, (200, bins))                  # 200 rows x every bin: past the LDS of the wave kernel at every size here
+    d = gpu.HipMelSpectrogram(fft, hop, SR, 200, filterbank=dense)
+    assert np.abs(d.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_with_filters(x, fft, hop, dense)).max() <= 2e-6
+    d.close()
+
+
 # ---- Kaldi fbank -----------------------------------------------------------------------------
 
 def test_fbank_jfk(gpu, oracle, jfk, golden):

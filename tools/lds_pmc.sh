@@ -13,7 +13,7 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
-    if "pow2" not in k: continue
     m = {c: sum(x) / len(x) for c, x in v.items()}
+    if m.get("SQ_LDS_IDX_ACTIVE", 0) == 0: continue
     print(k, " conflict/active %.3f  active/GRBM(per CU) %.3f  insts %.3g" % (m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1), m["SQ_LDS_IDX_ACTIVE"] / 256 / (m["GRBM_GUI_ACTIVE"] / 8), m["SQ_INSTS_LDS"]), {c: "%.3g" % x for c, x in m.items()})
 PY
