@@ -145,7 +145,8 @@ MS_HD void decode_dword(const QuantDesc &d, float *img, uint32_t c, uint32_t cw,
 }
 
 constexpr int kQuantThreads = 256;
-constexpr int kQuantPxPerBlock = kQuantThreads * 16;     // min/max pass: 4 x float4 per thread
+constexpr int kQuantMinmaxLoads = 16;                    // min/max pass: float4 loads per thread, all in flight together
+constexpr int kQuantPxPerBlock = kQuantThreads * 4 * kQuantMinmaxLoads;
 constexpr int kQuantDwPerBlock = kQuantThreads * 4;      // encode/decode: 4 dwords per thread
 
 MS_HD uint64_t quant_item_pixels(const QuantDesc &d, uint32_t c) { return static_cast<uint64_t>(d.rows) * chunk_cols(d, c); }
@@ -182,7 +183,10 @@ __global__ __launch_bounds__(64) void quant_keys_from_units_kernel(const int *un
     }
 }
 
-// grid.x = items * blocks_per_item; block b of an item reduces pixels [b*4096, (b+1)*4096).
+// grid.x = items * blocks_per_item; block b of an item reduces pixels [b * kQuantPxPerBlock, (b + 1) * kQuantPxPerBlock).
+// A block inside the item issues its sixteen 16-byte loads per thread unconditionally and together (round 3's form had each of four
+// loads behind its own range test -- four serial round trips per thread -- and two atomics per WAVE: 2.8 TB/s; a read-only pass should
+// run at the copy rate), folds its waves through LDS and sends one atomic pair.
 __global__ __launch_bounds__(kQuantThreads) void quant_minmax_kernel(const QuantDesc d, uint32_t blocks_per_item) {
     const uint32_t item = blockIdx.x / blocks_per_item, blk = blockIdx.x - item * blocks_per_item;
     const uint32_t image = item / d.chunks, c = item - image * d.chunks;
@@ -191,18 +195,28 @@ __global__ __launch_bounds__(kQuantThreads) void quant_minmax_kernel(const Quant
     const float *img = d.img + image * d.img_stride;
     const uint64_t base = static_cast<uint64_t>(blk) * kQuantPxPerBlock;
     float mn = INFINITY, mx = -INFINITY;
+    if (d.vec && base + kQuantPxPerBlock <= npx) {
+        f4 v[kQuantMinmaxLoads];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint64_t i0 = base + (static_cast<uint64_t>(k) * kQuantThreads + threadIdx.x) * 4;
-        if (i0 + 4 <= npx && d.vec) {
-            const f4 v = *reinterpret_cast<const f4 *>(img + i0);
-            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
-            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
-        } else {
-            for (uint64_t i = i0; i < i0 + 4 && i < npx; ++i) {
-                const float v = img[image_index(d, c, cw, i)];
-                mn = fminf(mn, v);
-                mx = fmaxf(mx, v);
+        for (int k = 0; k < kQuantMinmaxLoads; ++k) v[k] = *reinterpret_cast<const f4 *>(img + base + (static_cast<uint64_t>(k) * kQuantThreads + threadIdx.x) * 4);
+#pragma unroll
+        for (int k = 0; k < kQuantMinmaxLoads; ++k) {
+            mn = fminf(fminf(mn, v[k].x), fminf(v[k].y, fminf(v[k].z, v[k].w)));
+            mx = fmaxf(fmaxf(mx, v[k].x), fmaxf(v[k].y, fmaxf(v[k].z, v[k].w)));
+        }
+    } else {
+        for (int k = 0; k < kQuantMinmaxLoads; ++k) {
+            const uint64_t i0 = base + (static_cast<uint64_t>(k) * kQuantThreads + threadIdx.x) * 4;
+            if (i0 + 4 <= npx && d.vec) {
+                const f4 v = *reinterpret_cast<const f4 *>(img + i0);
+                mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+                mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+            } else {
+                for (uint64_t i = i0; i < i0 + 4 && i < npx; ++i) {
+                    const float v = img[image_index(d, c, cw, i)];
+                    mn = fminf(mn, v);
+                    mx = fmaxf(mx, v);
+                }
             }
         }
     }
@@ -211,8 +225,13 @@ __global__ __launch_bounds__(kQuantThreads) void quant_minmax_kernel(const Quant
         mn = fminf(mn, __shfl_xor(mn, o));
         mx = fmaxf(mx, __shfl_xor(mx, o));
     }
-    if ((threadIdx.x & 63) == 0) {
-        // a wave that saw only NaNs (or nothing) still holds the fold's start values: no-ops for the atomics
+    __shared__ float part[2 * (kQuantThreads / 64)];
+    if ((threadIdx.x & 63) == 0) { part[2 * (threadIdx.x >> 6)] = mn; part[2 * (threadIdx.x >> 6) + 1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kQuantThreads / 64; ++w) { mn = fminf(mn, part[2 * w]); mx = fmaxf(mx, part[2 * w + 1]); }
+        // a block that saw only NaNs (or nothing) still holds the fold's start values: no-ops for the atomics
         atomicMin(d.keys + 2 * item, ordered_key(mn));
         atomicMax(d.keys + 2 * item + 1, ordered_key(mx));
     }
