@@ -45,12 +45,29 @@ MS_HD bool vad_classify_column(const float *img, uint32_t height, uint32_t width
     double m0 = p[width], m1 = p[width + 1], m2 = p[width + 2];
     (void)m1;
     int count = 0;
-    for (uint32_t y = start_y; y < height - 2; ++y) {
-        const float *b = img + static_cast<uint64_t>(y + 2) * width + x;
-        const double b0 = b[0], b1 = b[1], b2 = b[2];
-        if (sobel_gradient_sq(t0, t1, t2, m0, m2, b0, b1, b2) >= thr && ++count >= min_y) return true;
-        t0 = m0; t1 = m1; t2 = m2;
-        m0 = b0; m1 = b1; m2 = b2;
+    // Eight rows' loads go out together (rows past the image re-read its last row), then the walk with its early exit: one load per
+    // step behind the exit test was a memory round trip per row (round 3: 0.121 ms for 1024 x 80 x 1000).
+    constexpr uint32_t kRows = 8;
+    for (uint32_t y0 = start_y; y0 < height - 2; y0 += kRows) {
+        float bv[kRows][3];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t i = 0; i < kRows; ++i) {
+            const uint32_t row = y0 + 2 + i < height ? y0 + 2 + i : height - 1;
+            const float *b = img + static_cast<uint64_t>(row) * width + x;
+            bv[i][0] = b[0]; bv[i][1] = b[1]; bv[i][2] = b[2];
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t i = 0; i < kRows; ++i) {
+            if (y0 + i >= height - 2) break;
+            const double b0 = bv[i][0], b1 = bv[i][1], b2 = bv[i][2];
+            if (sobel_gradient_sq(t0, t1, t2, m0, m2, b0, b1, b2) >= thr && ++count >= min_y) return true;
+            t0 = m0; t1 = m1; t2 = m2;
+            m0 = b0; m1 = b1; m2 = b2;
+        }
     }
     return false;
 }
