@@ -148,6 +148,79 @@ int upload(DevBuf &buf, const std::vector<T> &v) {
 }
 
 // Tables of the generic (f64 DFT) kernel.
+// The banded filterbank as JOBS for the wave kernels' mel phase (pow2_frame_kernel, mel_stage_jobs_kernel): eight consecutive weights
+// of one mel per job (the last job of a band padded with zeros), dealt over the rounds as described below; lf = lanes that share a
+// frame (a round = lf jobs).  jobv[j] = first bin | mel << 12 | count << 20; jwv: weight pairs (2 q, 2 q + 1) of job j at [q][j].
+void build_mel_jobs(const BandedFilterbank &fb, int n_mels, int lf, std::vector<double> &jwv, std::vector<int> &jobv) {
+    jwv.clear(); jobv.clear();
+    for (int m = 0; m < n_mels && m < 256; ++m)
+        for (int c = 0; c < fb.len[m]; c += 8) {
+            const int cnt = std::min(8, fb.len[m] - c);
+            jobv.push_back((fb.start[m] + c) | (m << 12) | (cnt << 20));
+            for (int q = 0; q < 8; ++q) jwv.push_back(q < cnt ? fb.w[static_cast<size_t>(fb.offset[m]) + c + q] : 0.0);
+        }
+#ifndef MS_POW2_JOBORDER
+#define MS_POW2_JOBORDER 1
+#endif
+#ifndef MS_POW2_JOBGROUP
+#define MS_POW2_JOBGROUP 16
+#endif
+    if (MS_POW2_JOBORDER && !jobv.empty() && lf >= 8) {
+        // The lanes of a round read pw[bin + q], q = 0..7, each lane for its own job, as ds_read2_b64 (the compiler pairs the
+        // reads): served 16 consecutive lanes at a time over 32 banks, i.e. 16 doubles -- the jobs that meet in such a group want
+        // first bins that differ mod 16 (mod 8 where a frame has 8 lanes: the two frames of a group sit 8 doubles apart,
+        // pow2_pw_shift).  In band order they do not -- a band's jobs are 8 bins apart, the low bands 2-3 -- and the reads were
+        // 3-4-way (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles at n_fft 2048).  So: groups of g jobs, every residue class dealt
+        // over the groups, largest class first, to the group that holds the fewest of that residue (then of that mel:
+        // ds_add_f64 to one address serialises); groups padded with empty jobs (count 0).  The order is a function of the
+        // bank, the sums stay deterministic; a band's pieces are added in a different order than before (f64: ~1e-16 relative).
+        const int g = std::min(lf, MS_POW2_JOBGROUP);
+        const size_t nj = jobv.size(), groups = (nj + g - 1) / g;
+        std::vector<std::vector<size_t>> cls(g), grp(groups);
+        for (size_t j = 0; j < nj; ++j) cls[(jobv[j] & 0xfff) % g].push_back(j);
+        std::vector<int> order(g);
+        for (int r = 0; r < g; ++r) order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a].size() > cls[b].size(); });
+        for (int r : order)
+            for (size_t j : cls[r]) {
+                size_t best = groups;
+                long best_key = 0;
+                for (size_t q = 0; q < groups; ++q) {
+                    if (grp[q].size() >= static_cast<size_t>(g)) continue;
+                    long same_res = 0, same_mel = 0;
+                    for (size_t o : grp[q]) {
+                        same_res += ((jobv[o] & 0xfff) % g) == r;
+                        same_mel += ((jobv[o] >> 12) & 0xff) == ((jobv[j] >> 12) & 0xff);
+                    }
+                    const long key = (same_res << 40) + (same_mel << 20) + static_cast<long>(grp[q].size());
+                    if (best == groups || key < best_key) { best = q; best_key = key; }
+                }
+                grp[best].push_back(j);
+            }
+        std::vector<double> jw2;
+        std::vector<int> job2;
+        for (size_t q = 0; q < groups; ++q) {
+            std::sort(grp[q].begin(), grp[q].end());
+            for (int i = 0; i < g; ++i) {
+                const bool have = static_cast<size_t>(i) < grp[q].size();
+                job2.push_back(have ? jobv[grp[q][i]] : 0);
+                for (int w = 0; w < 8; ++w) jw2.push_back(have ? jwv[8 * grp[q][i] + w] : 0.0);
+            }
+        }
+        jobv.swap(job2);
+        jwv.swap(jw2);
+    }
+    if (jobv.empty()) { jobv.push_back(0); jwv.assign(8, 0.0); }
+    {
+        // weight pairs (2 q, 2 q + 1) of job j at [q][j]: the lanes of a round read consecutive 16-byte slots
+        const size_t nj = jobv.size();
+        std::vector<double> t(jwv.size());
+        for (size_t j = 0; j < nj; ++j)
+            for (int q = 0; q < 8; ++q) t[2 * ((q / 2) * nj + j) + (q & 1)] = jwv[8 * j + q];
+        jwv.swap(t);
+    }
+}
+
 struct GenericTables {
     DevBuf win, tw, mstart, mlen, moff, mw, jw, job;
     int n_fft = 0, frame_len = 0, n_bins = 0, n_mels = 0, fft_log2 = 0, mw_count = 0, n_jobs = 0;
@@ -177,76 +250,11 @@ struct GenericTables {
         if ((rc = upload(mw, fb.w))) return rc;
         mw_count = static_cast<int>(fb.w.size());
         {
-            // pow2_frame_kernel's jobs: eight consecutive weights of one mel, the last job of a band padded with zeros
             std::vector<double> jwv;
             std::vector<int> jobv;
-            for (int m = 0; m < n_mels && m < 256; ++m)
-                for (int c = 0; c < fb.len[m]; c += 8) {
-                    const int cnt = std::min(8, fb.len[m] - c);
-                    jobv.push_back((fb.start[m] + c) | (m << 12) | (cnt << 20));
-                    for (int q = 0; q < 8; ++q) jwv.push_back(q < cnt ? fb.w[static_cast<size_t>(fb.offset[m]) + c + q] : 0.0);
-                }
-#ifndef MS_POW2_JOBORDER
-#define MS_POW2_JOBORDER 1
-#endif
-#ifndef MS_POW2_JOBGROUP
-#define MS_POW2_JOBGROUP 16
-#endif
-            if (MS_POW2_JOBORDER && !jobv.empty() && n_fft >= 128) {
-                // The lanes of a round read pw[bin + q], q = 0..7, each lane for its own job, as ds_read2_b64 (the compiler pairs the
-                // reads): served 16 consecutive lanes at a time over 32 banks, i.e. 16 doubles -- the jobs that meet in such a group want
-                // first bins that differ mod 16 (mod 8 where a frame has 8 lanes: the two frames of a group sit 8 doubles apart,
-                // pow2_pw_shift).  In band order they do not -- a band's jobs are 8 bins apart, the low bands 2-3 -- and the reads were
-                // 3-4-way (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles at n_fft 2048).  So: groups of g jobs, every residue class dealt
-                // over the groups, largest class first, to the group that holds the fewest of that residue (then of that mel:
-                // ds_add_f64 to one address serialises); groups padded with empty jobs (count 0).  The order is a function of the
-                // bank, the sums stay deterministic; a band's pieces are added in a different order than before (f64: ~1e-16 relative).
-                const int half = n_fft / 2, lf = half >= 512 ? 64 : half / 8, g = std::min(lf, MS_POW2_JOBGROUP);
-                const size_t nj = jobv.size(), groups = (nj + g - 1) / g;
-                std::vector<std::vector<size_t>> cls(g), grp(groups);
-                for (size_t j = 0; j < nj; ++j) cls[(jobv[j] & 0xfff) % g].push_back(j);
-                std::vector<int> order(g);
-                for (int r = 0; r < g; ++r) order[r] = r;
-                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a].size() > cls[b].size(); });
-                for (int r : order)
-                    for (size_t j : cls[r]) {
-                        size_t best = groups;
-                        long best_key = 0;
-                        for (size_t q = 0; q < groups; ++q) {
-                            if (grp[q].size() >= static_cast<size_t>(g)) continue;
-                            long same_res = 0, same_mel = 0;
-                            for (size_t o : grp[q]) {
-                                same_res += ((jobv[o] & 0xfff) % g) == r;
-                                same_mel += ((jobv[o] >> 12) & 0xff) == ((jobv[j] >> 12) & 0xff);
-                            }
-                            const long key = (same_res << 40) + (same_mel << 20) + static_cast<long>(grp[q].size());
-                            if (best == groups || key < best_key) { best = q; best_key = key; }
-                        }
-                        grp[best].push_back(j);
-                    }
-                std::vector<double> jw2;
-                std::vector<int> job2;
-                for (size_t q = 0; q < groups; ++q) {
-                    std::sort(grp[q].begin(), grp[q].end());
-                    for (int i = 0; i < g; ++i) {
-                        const bool have = static_cast<size_t>(i) < grp[q].size();
-                        job2.push_back(have ? jobv[grp[q][i]] : 0);
-                        for (int w = 0; w < 8; ++w) jw2.push_back(have ? jwv[8 * grp[q][i] + w] : 0.0);
-                    }
-                }
-                jobv.swap(job2);
-                jwv.swap(jw2);
-            }
-            n_jobs = static_cast<int>(jobv.size());
-            if (jobv.empty()) { jobv.push_back(0); jwv.assign(8, 0.0); }
-            {
-                // weight pairs (2 q, 2 q + 1) of job j at [q][j]: the lanes of a round read consecutive 16-byte slots
-                const size_t nj = jobv.size();
-                std::vector<double> t(jwv.size());
-                for (size_t j = 0; j < nj; ++j)
-                    for (int q = 0; q < 8; ++q) t[2 * ((q / 2) * nj + j) + (q & 1)] = jwv[8 * j + q];
-                jwv.swap(t);
-            }
+            const int half = n_fft / 2;
+            build_mel_jobs(fb, n_mels, half >= 512 ? 64 : half / 8, jwv, jobv);
+            n_jobs = jobv.size() == 1 && (jobv[0] >> 20) == 0 ? 0 : static_cast<int>(jobv.size());
             if ((rc = upload(jw, jwv))) return rc;
             if ((rc = upload(job, jobv))) return rc;
         }
@@ -650,7 +658,8 @@ struct melspec_ctx {
     // generic path
     GenericTables gt;
     // the mel stage on its own (melspec_mel_from_stft_*): the banded filterbank in f64, built on first use
-    DevBuf st_start, st_len, st_off, st_w;
+    DevBuf st_start, st_len, st_off, st_w, st_jw, st_job;
+    int st_n_jobs = 0;
     bool stage_built = false;
     // scratch
     RaggedScratch ragged;
@@ -1059,7 +1068,7 @@ void melspec_destroy(melspec_ctx *c) {
     c->fix.release();
     c->dplan.release();
     c->pipe.release();
-    c->st_start.release(); c->st_len.release(); c->st_off.release(); c->st_w.release();
+    c->st_start.release(); c->st_len.release(); c->st_off.release(); c->st_w.release(); c->st_jw.release(); c->st_job.release();
     delete c;
 }
 
@@ -1353,6 +1362,14 @@ int stage_tables(melspec_ctx *c) {
     if ((rc = upload(c->st_len, fb.len))) return rc;
     if ((rc = upload(c->st_off, fb.offset))) return rc;
     if ((rc = upload(c->st_w, fb.w))) return rc;
+    {
+        std::vector<double> jwv;
+        std::vector<int> jobv;
+        build_mel_jobs(fb, c->n_mels, 64, jwv, jobv);
+        c->st_n_jobs = jobv.size() == 1 && (jobv[0] >> 20) == 0 ? 0 : static_cast<int>(jobv.size());
+        if ((rc = upload(c->st_jw, jwv))) return rc;
+        if ((rc = upload(c->st_job, jobv))) return rc;
+    }
     c->stage_built = true;
     return MELSPEC_OK;
 }
@@ -1373,6 +1390,18 @@ int melspec_mel_from_stft_device(melspec_ctx *c, const void *d_spec, int dtype, 
     p.bin_limit = c->fft_size / 2; p.n_mels = c->n_mels;
     p.d_mstart = static_cast<const int *>(c->st_start.p); p.d_mlen = static_cast<const int *>(c->st_len.p);
     p.d_moff = static_cast<const int *>(c->st_off.p); p.d_mw = static_cast<const double *>(c->st_w.p);
+    p.d_jw = static_cast<const double *>(c->st_jw.p); p.d_job = static_cast<const int *>(c->st_job.p); p.n_jobs = c->st_n_jobs;
+    {
+        // the wave-per-frame form with the bank as jobs in LDS (banks of up to 256 mels over up to 4088 bins that fit)
+        const size_t lds = sizeof(double) * static_cast<size_t>(mel_stage_lds(p.n_jobs, p.bin_limit, p.n_mels, kMelStageWaves).total);
+        if (p.n_jobs > 0 && p.n_mels <= 256 && p.bin_limit <= 4088 && lds <= 64 * 1024) {
+            const unsigned grid = grid_for((n_frames + kMelStageWaves - 1) / kMelStageWaves, c->dev.cus, static_cast<int>(std::max<size_t>(1, std::min<size_t>(4, kLdsLimit / lds))));
+            if (dtype == MELSPEC_STFT_F64) hipLaunchKernelGGL((mel_stage_jobs_kernel<double>), dim3(grid), dim3(kMelStageWaves * 64), lds, s, p);
+            else hipLaunchKernelGGL((mel_stage_jobs_kernel<float>), dim3(grid), dim3(kMelStageWaves * 64), lds, s, p);
+            HIP_TRY(hipGetLastError());
+            return MELSPEC_OK;
+        }
+    }
     constexpr int kWaves = 4;
     const size_t lds = static_cast<size_t>(kWaves) * (p.bin_limit + p.n_mels) * sizeof(double);
     if (lds > 64 * 1024) return fail(MELSPEC_ERR_UNSUPPORTED, "geometry needs more LDS than the mel stage kernel has");

@@ -2195,7 +2195,126 @@ struct MelStageParams {
     int n_mels;
     const int *d_mstart, *d_mlen, *d_moff;
     const double *d_mw;
+    const double *d_jw;     // the same bank as jobs of eight weights (build_mel_jobs, melspec_hip.hip), for mel_stage_jobs_kernel
+    const int *d_job;
+    int n_jobs;
 };
+
+// mel_stage_jobs_kernel: a frame per wave, the bank as jobs in LDS -- the mel phase of pow2_frame_kernel (section 4.3b of DESIGN.md)
+// on spectra that come from memory.  The first form (mel_stage_kernel below, kept for banks the tables of this one do not take) read
+// every weight from global memory inside a loop whose trip count is the band's width, a lane per mel, and took an f64 log10: 26 %
+// of its roofline.  Here: the frame's bins in up to kMelStageBinLoads coalesced loads per lane, the NEXT frame's issued before this
+// frame is worked on; jobs of eight weights, two rounds in flight, one ds_add_f64 per job; v_log_f32 like every fused kernel.
+constexpr int kMelStageWaves = 8;
+constexpr int kMelStageBinLoads = 4;       // 64 lanes x 4: frames of up to 256 bins take the unrolled path
+struct MelStageLds { int jw, job, frames, frame_stride, acc, total; };
+MS_HD MelStageLds mel_stage_lds(int n_jobs, int bin_limit, int n_mels, int waves) {
+    MelStageLds o;
+    o.jw = 0;
+    o.job = 8 * n_jobs;
+    o.frames = (o.job + (n_jobs + 1) / 2 + 31) & ~31;
+    o.acc = (bin_limit + 8 + 1) & ~1;                  // a frame: the power row (+ 8 a job may read past it), the band sums
+    o.frame_stride = (o.acc + n_mels + 31) & ~31;
+    o.total = o.frames + waves * o.frame_stride;
+    return o;
+}
+
+template <class T>
+__global__ __launch_bounds__(kMelStageWaves * 64) void mel_stage_jobs_kernel(const MelStageParams p) {
+    extern __shared__ __attribute__((aligned(16))) double stage_lds[];
+    struct alignas(2 * sizeof(T)) T2 { T re, im; };
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const MelStageLds at = mel_stage_lds(p.n_jobs, p.bin_limit, p.n_mels, kMelStageWaves);
+    double *ljw = stage_lds + at.jw;
+    int *ljob = reinterpret_cast<int *>(stage_lds + at.job);
+    for (int i = tid; i < 8 * p.n_jobs; i += kMelStageWaves * 64) ljw[i] = p.d_jw[i];
+    for (int i = tid; i < p.n_jobs; i += kMelStageWaves * 64) ljob[i] = p.d_job[i];
+    double *pw = stage_lds + at.frames + wave * at.frame_stride, *acc = pw + at.acc;
+    if (lane < 8) pw[p.bin_limit + lane] = 0.0;
+    __syncthreads();
+    const int n_jobs = p.n_jobs, bins = p.bin_limit;
+    const bool small = bins <= 64 * kMelStageBinLoads;
+    const uint64_t step = (uint64_t)gridDim.x * kMelStageWaves;
+    uint64_t f = (uint64_t)blockIdx.x * kMelStageWaves + wave;
+    if (f >= p.n_frames) return;
+    auto fetch = [&](uint64_t frame, T2 (&v)[kMelStageBinLoads]) {
+        const T2 *x = reinterpret_cast<const T2 *>(static_cast<const T *>(p.spec) + 2 * frame * p.stride);
+#pragma unroll
+        for (int i = 0; i < kMelStageBinLoads; ++i) { const int k = lane + 64 * i; v[i] = x[k < bins ? k : bins - 1]; }
+    };
+    T2 cur[kMelStageBinLoads];
+    fetch(f, cur);
+    for (;;) {
+        const uint64_t nf = f + step;
+        const bool more = nf < p.n_frames;                      // wave-uniform
+        T2 nxt[kMelStageBinLoads];
+        if (more) fetch(nf, nxt);
+#pragma unroll
+        for (int i = 0; i < kMelStageBinLoads; ++i) {
+            const int k = lane + 64 * i;
+            const double re = static_cast<double>(cur[i].re), im = static_cast<double>(cur[i].im);
+            if (k < bins) pw[k] = re * re + im * im;                                   // norm_sqr, src/mel.rs:159
+        }
+        if (!small) {
+            const T2 *x = reinterpret_cast<const T2 *>(static_cast<const T *>(p.spec) + 2 * f * p.stride);
+            for (int k = lane + 64 * kMelStageBinLoads; k < bins; k += 64) {
+                const double re = static_cast<double>(x[k].re), im = static_cast<double>(x[k].im);
+                pw[k] = re * re + im * im;
+            }
+        }
+        for (int m = lane; m < p.n_mels; m += 64) acc[m] = 0.0;
+        for (int jb0 = lane; jb0 < n_jobs + lane; jb0 += 2 * 64) {            // wave-uniform trip count; ascending bins inside a job, src/mel.rs:155-163
+            int info[2];
+            d2 w[2][4];
+            double pv[2][8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) info[t] = jb0 + 64 * t < n_jobs ? ljob[jb0 + 64 * t] : 0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int jb = jb0 + 64 * t;
+                const double *wp = ljw + 2 * (jb < n_jobs ? jb : 0), *pp = pw + (info[t] & 0xfff);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[t][q] = *reinterpret_cast<const d2 *>(wp + q * 2 * n_jobs);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) pv[t][q] = pp[q];
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                double e = w[t][0].x * pv[t][0];
+                e += w[t][0].y * pv[t][1]; e += w[t][1].x * pv[t][2]; e += w[t][1].y * pv[t][3];
+                e += w[t][2].x * pv[t][4]; e += w[t][2].y * pv[t][5]; e += w[t][3].x * pv[t][6]; e += w[t][3].y * pv[t][7];
+                if ((info[t] >> 20) > 0) unsafeAtomicAdd(acc + ((info[t] >> 12) & 0xff), e);
+            }
+        }
+        // log10 through v_log_f32 (as the fused kernels), the frame's maximum, clamp, (x + 4) / 4 (src/mel.rs:166, 645-654)
+        constexpr int kPer = 4;                                  // 256 mels
+        float mv[kPer];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int m = lane + 64 * i;
+            mv[i] = 0.0f;
+            if (m < p.n_mels) {
+                const double e = acc[m];
+                mv[i] = fast_log2((float)(e > 1e-10 ? e : 1e-10)) * 0.30102999566398120f;
+                mx = mx > mv[i] ? mx : mv[i];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(mx, o, 64); mx = mx > t ? mx : t; }
+        const float lo = mx - 8.0f;
+        float *o = p.out + f * (uint64_t)p.n_mels;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            const int m = lane + 64 * i;
+            if (m < p.n_mels) o[m] = ((mv[i] > lo ? mv[i] : lo) + 4.0f) * 0.25f;
+        }
+        if (!more) break;
+        f = nf;
+#pragma unroll
+        for (int i = 0; i < kMelStageBinLoads; ++i) cur[i] = nxt[i];
+    }
+}
 
 template <class T, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void mel_stage_kernel(const MelStageParams p) {

@@ -60,7 +60,7 @@ if want("stft"):
     m.stft_uniform_device(pcm.ptr, clip_len, clip_len, clips, spec.ptr, True, False); m.synchronize()
     mel = M.DeviceBuffer(clips * nf * 80 * 4)
     ms = timed(lambda: m.mel_from_stft_device(spec.ptr, clips * nf, mel.ptr, True, False), m.synchronize, iters=20, warm=3)
-    report("mel_stage_kernel<double> (half f64 spectra -> mel rows)", ms, clips * nf, bins * 16 + 320)
+    report("mel_stage_jobs_kernel<double> (half f64 spectra -> mel rows)", ms, clips * nf, bins * 16 + 320)
     spec.free(); mel.free(); m.close()
 
 if want("generic"):
