@@ -1258,11 +1258,11 @@ def test_nemo_ragged_normaliser_long_rows(gpu, oracle, jfk):
     fe.close()
 
 
-@pytest.mark.parametrize("geom", [(400, 160, 80), (400, 160, 128), (512, 160, 80), (256, 64, 40)])
+@pytest.mark.parametrize("geom", [(400, 160, 80), (400, 160, 128), (512, 160, 80), (256, 64, 40), (1024, 256, 300)])
 def test_mel_stage_on_stft_frames(gpu, oracle, jfk, geom):
     """The reference's split API: Spectrogram::add gives complex frames, MelSpectrogram::add(&fft) (src/mel.rs:13-32) turns each into a
     mel column.  melspec_mel_from_stft_* on the frames of the STFT export (both layouts, f64 and f32 spectra, host and device) against
-    the oracle's fused pipeline."""
+    the oracle's fused pipeline.  (300 mels: past the 256 of mel_stage_jobs_kernel's job records, the row-per-lane kernel.)"""
     n_fft, hop, n_mels = geom
     m = gpu.HipMelSpectrogram(n_fft, hop, 16000.0, n_mels)
     for x in (jfk[3000:40000], oracle.synth_pcm(5, 9000), np.zeros(2000, np.float32)):
