@@ -152,73 +152,90 @@ int upload(DevBuf &buf, const std::vector<T> &v) {
 // of one mel per job (the last job of a band padded with zeros), dealt over the rounds as described below; lf = lanes that share a
 // frame (a round = lf jobs).  jobv[j] = first bin | mel << 12 | count << 20; jwv: weight pairs (2 q, 2 q + 1) of job j at [q][j].
 void build_mel_jobs(const BandedFilterbank &fb, int n_mels, int lf, std::vector<double> &jwv, std::vector<int> &jobv) {
-    jwv.clear(); jobv.clear();
-    for (int m = 0; m < n_mels && m < 256; ++m)
-        for (int c = 0; c < fb.len[m]; c += 8) {
-            const int cnt = std::min(8, fb.len[m] - c);
-            jobv.push_back((fb.start[m] + c) | (m << 12) | (cnt << 20));
-            for (int q = 0; q < 8; ++q) jwv.push_back(q < cnt ? fb.w[static_cast<size_t>(fb.offset[m]) + c + q] : 0.0);
+    // A job = eight consecutive bins FROM AN EVEN ONE (its eight powers are four aligned 16-byte LDS reads) with the weights of one mel
+    // on them, zero where the band is not; record = first bin | mel << 12 | count << 20 (count > 0: a real job).
+    struct Job { int bin, mel, lo, hi; };                    // weights of band entries [lo, hi) sit at bins bin + (entry - lo) + lead
+    std::vector<Job> jobs;
+    std::vector<int> lead;                                   // zero weights in front of a job's first entry
+    for (int m = 0; m < n_mels && m < 256; ++m) {
+        const int st = fb.start[m], len = fb.len[m];
+        if (len <= 0) continue;
+        for (int b = st & ~1; b < st + len; b += 8) {
+            const int lo = std::max(b, st) - st, hi = std::min(b + 8, st + len) - st;
+            jobs.push_back({b, m, lo, hi});
+            lead.push_back(std::max(b, st) - b);
         }
+    }
 #ifndef MS_POW2_JOBORDER
 #define MS_POW2_JOBORDER 1
 #endif
-#ifndef MS_POW2_JOBGROUP
-#define MS_POW2_JOBGROUP 16
-#endif
-    if (MS_POW2_JOBORDER && !jobv.empty() && lf >= 8) {
-        // The lanes of a round read pw[bin + q], q = 0..7, each lane for its own job, as ds_read2_b64 (the compiler pairs the
-        // reads): served 16 consecutive lanes at a time over 32 banks, i.e. 16 doubles -- the jobs that meet in such a group want
-        // first bins that differ mod 16 (mod 8 where a frame has 8 lanes: the two frames of a group sit 8 doubles apart,
-        // pow2_pw_shift).  In band order they do not -- a band's jobs are 8 bins apart, the low bands 2-3 -- and the reads were
-        // 3-4-way (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles at n_fft 2048).  So: groups of g jobs, every residue class dealt
-        // over the groups, largest class first, to the group that holds the fewest of that residue (then of that mel:
-        // ds_add_f64 to one address serialises); groups padded with empty jobs (count 0).  The order is a function of the
-        // bank, the sums stay deterministic; a band's pieces are added in a different order than before (f64: ~1e-16 relative).
-        const int g = std::min(lf, MS_POW2_JOBGROUP);
-        const size_t nj = jobv.size(), groups = (nj + g - 1) / g;
-        std::vector<std::vector<size_t>> cls(g), grp(groups);
-        for (size_t j = 0; j < nj; ++j) cls[(jobv[j] & 0xfff) % g].push_back(j);
+    // The lanes of a round read their jobs' powers with ds_read_b128, which the LDS serves in groups of sixteen lanes -- {0-3, 12-15,
+    // 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- over the sixteen 16-byte slots of a 256-byte row: the jobs that meet in such a
+    // group want first bins whose halves differ mod 16 (mod 8 where a frame has eight lanes: the group then holds the same eight jobs
+    // of two pairs of frames, whose rows pow2_pw_shift sets eight slots apart).  In band order they do not -- a band's jobs are 8 bins
+    // apart, the low bands 2-3 -- and the reads were 3-4-way (SQ_LDS_BANK_CONFLICT: 25 % of the LDS cycles at n_fft 2048).  So: sets of
+    // g jobs; a job with fewer than eight entries may start 2, 4 or 6 bins early (more zeros in front); every job goes to the set that
+    // holds the fewest jobs of its residue (then of its mel: ds_add_f64 to one address serialises), fullest residue classes first;
+    // the sets padded with empty jobs (count 0) and laid onto the lane groups.  The order is a function of the bank: the sums stay
+    // deterministic; a band's pieces are added in another order than the reference's left fold (f64: ~1e-16 relative).
+    const int g = lf >= 16 ? 16 : 8;
+    const size_t nj = jobs.size(), sets = std::max<size_t>(1, (nj + g - 1) / g);
+    std::vector<std::vector<size_t>> grp(sets);
+    std::vector<int> shift(nj, 0);
+    if (MS_POW2_JOBORDER && lf >= 8) {
+        std::vector<std::vector<size_t>> cls(g);
+        for (size_t j = 0; j < nj; ++j) cls[(jobs[j].bin >> 1) % g].push_back(j);
         std::vector<int> order(g);
         for (int r = 0; r < g; ++r) order[r] = r;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cls[a].size() > cls[b].size(); });
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cls[x].size() > cls[y].size(); });
+        std::vector<std::vector<int>> used(sets, std::vector<int>(g, 0));
         for (int r : order)
             for (size_t j : cls[r]) {
-                size_t best = groups;
+                size_t best = sets;
+                int best_shift = 0;
                 long best_key = 0;
-                for (size_t q = 0; q < groups; ++q) {
-                    if (grp[q].size() >= static_cast<size_t>(g)) continue;
-                    long same_res = 0, same_mel = 0;
-                    for (size_t o : grp[q]) {
-                        same_res += ((jobv[o] & 0xfff) % g) == r;
-                        same_mel += ((jobv[o] >> 12) & 0xff) == ((jobv[j] >> 12) & 0xff);
+                const int room = 8 - (lead[j] + (jobs[j].hi - jobs[j].lo));
+                for (int sh = 0; sh <= room && sh <= jobs[j].bin; sh += 2) {
+                    const int res = ((jobs[j].bin - sh) >> 1) % g;
+                    for (size_t q = 0; q < sets; ++q) {
+                        if (grp[q].size() >= static_cast<size_t>(g)) continue;
+                        long same_mel = 0;
+                        for (size_t o : grp[q]) same_mel += jobs[o].mel == jobs[j].mel;
+                        const long key = (static_cast<long>(used[q][res]) << 40) + (same_mel << 24) + (static_cast<long>(sh) << 16) + static_cast<long>(grp[q].size());
+                        if (best == sets || key < best_key) { best = q; best_key = key; best_shift = sh; }
                     }
-                    const long key = (same_res << 40) + (same_mel << 20) + static_cast<long>(grp[q].size());
-                    if (best == groups || key < best_key) { best = q; best_key = key; }
                 }
                 grp[best].push_back(j);
+                shift[j] = best_shift;
+                used[best][((jobs[j].bin - best_shift) >> 1) % g] += 1;
             }
-        std::vector<double> jw2;
-        std::vector<int> job2;
-        for (size_t q = 0; q < groups; ++q) {
-            std::sort(grp[q].begin(), grp[q].end());
-            for (int i = 0; i < g; ++i) {
-                const bool have = static_cast<size_t>(i) < grp[q].size();
-                job2.push_back(have ? jobv[grp[q][i]] : 0);
-                for (int w = 0; w < 8; ++w) jw2.push_back(have ? jwv[8 * grp[q][i] + w] : 0.0);
-            }
-        }
-        jobv.swap(job2);
-        jwv.swap(jw2);
+    } else {
+        for (size_t j = 0; j < nj; ++j) grp[j / g].push_back(j);
     }
-    if (jobv.empty()) { jobv.push_back(0); jwv.assign(8, 0.0); }
-    {
-        // weight pairs (2 q, 2 q + 1) of job j at [q][j]: the lanes of a round read consecutive 16-byte slots
-        const size_t nj = jobv.size();
-        std::vector<double> t(jwv.size());
-        for (size_t j = 0; j < nj; ++j)
-            for (int q = 0; q < 8; ++q) t[2 * ((q / 2) * nj + j) + (q & 1)] = jwv[8 * j + q];
-        jwv.swap(t);
+    // lane positions: lf >= 32: two sets per 32 lanes, on the two lane groups of ds_read_b128; else a set = the lanes of a frame
+    static const int kLanesOfGroup[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    const size_t slots = lf >= 32 ? ((sets + 1) / 2) * 32 : sets * g;
+    std::vector<long> at(slots, -1);
+    for (size_t q = 0; q < sets; ++q) {
+        std::sort(grp[q].begin(), grp[q].end());
+        for (size_t i = 0; i < grp[q].size(); ++i)
+            at[lf >= 32 ? (q / 2) * 32 + kLanesOfGroup[q & 1][i] : q * g + i] = static_cast<long>(grp[q][i]);
     }
+    jobv.assign(nj ? slots : 1, 0);
+    std::vector<double> w8((nj ? slots : 1) * 8, 0.0);
+    for (size_t pos = 0; pos < slots && nj; ++pos) {
+        if (at[pos] < 0) continue;
+        const size_t j = static_cast<size_t>(at[pos]);
+        const Job &jb = jobs[j];
+        const int bin = jb.bin - shift[j], first = lead[j] + shift[j];
+        jobv[pos] = bin | (jb.mel << 12) | ((jb.hi - jb.lo) << 20);
+        for (int e = jb.lo; e < jb.hi; ++e) w8[8 * pos + first + (e - jb.lo)] = fb.w[static_cast<size_t>(fb.offset[jb.mel]) + e];
+    }
+    // weight pairs (2 q, 2 q + 1) of the job at position j at [q][j]: the lanes of a round read consecutive 16-byte slots
+    const size_t np = jobv.size();
+    jwv.assign(8 * np, 0.0);
+    for (size_t j = 0; j < np; ++j)
+        for (int q = 0; q < 8; ++q) jwv[2 * ((q / 2) * np + j) + (q & 1)] = w8[8 * j + q];
 }
 
 struct GenericTables {

@@ -2276,7 +2276,10 @@ __global__ __launch_bounds__(kMelStageWaves * 64) void mel_stage_jobs_kernel(con
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[t][q] = *reinterpret_cast<const d2 *>(wp + q * 2 * n_jobs);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) pv[t][q] = pp[q];
+                for (int q = 0; q < 4; ++q) {
+                    const d2 two = *reinterpret_cast<const d2 *>(pp + 2 * q);
+                    pv[t][2 * q] = two.x; pv[t][2 * q + 1] = two.y;
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -2667,7 +2670,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     };
     // the jobs of a lane are the same for every frame too: the records of its first kJ stay in registers
     const int n_jobs = p.n_jobs;
-    constexpr int kJ = (FLAVOR != 0 && P == 8) ? MS_POW2_JOBS_F : 3;     // rounds of jobs in flight together (the Kaldi / NeMo framings hold more registers: spills)
+    constexpr int kJ = (FLAVOR != 0 && P == 8) ? MS_POW2_JOBS_F : (LF < 64 ? MS_POW2_JOBS_SMALL : MS_POW2_JOBS_BIG);     // rounds of jobs in flight together (the Kaldi / NeMo framings hold more registers: spills)
     int info0[kJ];
 #pragma unroll
     for (int t = 0; t < kJ; ++t) info0[t] = l + t * LF < n_jobs ? ljob[l + t * LF] : 0;
@@ -2795,7 +2798,10 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
 #pragma unroll
                 for (int q = 0; q < 4; ++q) w[t][q] = *reinterpret_cast<const d2 *>(wp + q * jstep);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) pv[t][q] = pp[q];      // (the compiler pairs them: four ds_read2_b64, served 16 consecutive lanes at a time over 32 banks)
+                for (int q = 0; q < 4; ++q) {                      // a job starts at an even bin: four aligned ds_read_b128
+                    const d2 two = *reinterpret_cast<const d2 *>(pp + 2 * q);
+                    pv[t][2 * q] = two.x; pv[t][2 * q + 1] = two.y;
+                }
             }
 #pragma unroll
             for (int t = 0; t < kJ; ++t) {

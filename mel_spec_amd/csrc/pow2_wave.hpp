@@ -52,6 +52,12 @@
 #ifndef MS_POW2_PWALIAS
 #define MS_POW2_PWALIAS 1024     // from this M on the power row takes the place of the frame's points (the split has read them all)
 #endif
+#ifndef MS_POW2_JOBS_SMALL
+#define MS_POW2_JOBS_SMALL 1
+#endif
+#ifndef MS_POW2_JOBS_BIG
+#define MS_POW2_JOBS_BIG 3
+#endif
 #ifndef MS_POW2_TW2REG
 #define MS_POW2_TW2REG 1
 #endif
@@ -94,12 +100,12 @@ template <int LOGM> MS_HD Pow2Lds pow2_lds(int n_jobs, int n_mels, int waves) {
     return o;
 }
 
-// doubles by which frame slot fs of a wave shifts its power row, so that the rows of the frames that share a 32-lane group of
-// ds_read_b64 start LF doubles apart in the bank row (the frames themselves are 0, or for M = 64 16, doubles apart mod 32)
+// doubles by which frame slot fs of a wave shifts its power row.  M = 64: a 16-lane group of ds_read_b128 holds the same eight jobs
+// of two pairs of frames (lanes 0-3 and 24-27: frames 0 and 3, lanes 12-15 and 20-23: frames 1 and 2), whose rows must sit eight
+// 16-byte slots apart; the frames themselves are 128 bytes apart mod 256.
 template <int LOGM> MS_DEV int pow2_pw_shift(int fs) {
     constexpr int LF = Pow2Shape<LOGM>::LF;
-    if (LF == 16) return (fs & 1) * 16;
-    if (LF == 8) return ((fs & 3) * 8 + (fs & 1) * 16) & 31;
+    if (LF == 8) return ((fs & 3) == 1 || (fs & 3) == 2) ? 16 : 0;
     return 0;
 }
 
