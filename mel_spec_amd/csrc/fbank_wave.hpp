@@ -44,11 +44,20 @@ constexpr int kBlmSlots = 10;    // up to 149 mel bins (NeMo/Parakeet uses 80 or
 // Table blob: a T-typed part (offsets in units of T) followed by the f32/int mel section.
 struct FbankBlob {
     static constexpr int kWin = 0;                         // [512] window taps (400 used by the Kaldi / NeMo flavours)
-    static constexpr int kTw1Stride = 36;                  // 16 complex + 4 pad
+    // row pitches of the two twiddle tables in 16-byte slots: 17 and 9, odd -- the sixteen lanes ds_read_b128 serves together (rows
+    // {0-3, 12-15} of one frame, {4-11} of the next) hit sixteen different slots; 18 and 10 (round 3) made rows t and t + 8 collide:
+    // 2-way on every twiddle read, 120 of ~1900 LDS cycles per unit (same-box A/B: NeMo -1.7 %, fbank / Whisper-512 +-0.2 %)
+#ifndef MS_FB_TW1S
+#define MS_FB_TW1S 34
+#endif
+#ifndef MS_FB_TW2S
+#define MS_FB_TW2S 18
+#endif
+    static constexpr int kTw1Stride = MS_FB_TW1S;          // 16 complex + pad
     static constexpr int kTw1 = 512;                       // [16 n2][36] W_256^{n2*k1}
-    static constexpr int kTw2Stride = 20;                  // 9 complex + 2 pad: conflict-free 16-byte reads over a row's lanes
+    static constexpr int kTw2Stride = MS_FB_TW2S;          // 9 complex + pad
     static constexpr int kTw2 = kTw1 + 16 * kTw1Stride;    // [16 r][20] complex W_512^{r+16s}, s = 0..8
-    static constexpr int kTCount = kTw2 + 16 * kTw2Stride; // 1408 elements of T
+    static constexpr int kTCount = kTw2 + 16 * kTw2Stride; // 1344 elements of T
     // mel section, float offsets from its own base
     static constexpr int kMelStart = 0;                                // [kBlmSlots*16] ints
     static constexpr int kMelW = (kBlmSlots * kFbLanes + 3) & ~3;      // pairs [slot][r][16][2]
