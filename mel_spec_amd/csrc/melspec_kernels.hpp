@@ -2585,7 +2585,7 @@ template <int LOGM, int FLAVOR>
 __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_kernel(const GenericParams p) {
     using S = Pow2Shape<LOGM>;
     constexpr int M = S::M, LF = S::LF, FW = S::FW, P = S::P;
-    constexpr bool kAhead = P == 8 || MS_POW2_AHEAD16;   // the next frame's samples are loaded while this one is transformed
+    constexpr bool kAhead = P == 8 || (MS_POW2_AHEAD16 && !(S::kHalves && !MS_POW2_AHEADH));   // the next frame's samples are loaded while this one is transformed
     constexpr bool kWinLds = M <= MS_POW2_WINLDS;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x, n_threads = blockDim.x, n_waves = n_threads >> 6;     // the host picks the waves per workgroup (LDS)
@@ -2598,7 +2598,10 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     for (int i = tid; i < M + 2; i += n_threads) tw[i] = p.d_tw[i];
     if (kWinLds) for (int i = tid; i < 2 * M; i += n_threads) lwin[i] = p.d_win[i];
     for (int i = tid; i < S::kT2; i += n_threads) stc(t2 + 2 * i, pow2_table_entry(p.d_tw, M, 8, S::R1, i));
-    for (int i = tid; i < S::kT3; i += n_threads) stc(t3 + 2 * i, pow2_table_entry(p.d_tw, M, S::R3 > 1 ? S::R3 : 2, S::R1 * 8, i));
+    constexpr bool kHalves = S::kHalves;
+    for (int i = tid; i < S::kT3; i += n_threads) stc(t3 + 2 * i, pow2_table_entry(p.d_tw, M, kHalves ? 8 : (S::R3 > 1 ? S::R3 : 2), kHalves ? 64 : S::R1 * 8, i));
+    double *tc = ldsd + at.tc;                           // kHalves: W_M^k = W_N^{2k}, k < M / 2
+    for (int i = tid; i < S::kTc; i += n_threads) stc(tc + 2 * i, pow2_root(p.d_tw, 2 * i, M));
     for (int i = tid; i < 8 * p.n_jobs; i += n_threads) ljw[i] = p.d_jw[i];
     for (int i = tid; i < p.n_jobs; i += n_threads) ljob[i] = p.d_job[i];
     __syncthreads();
@@ -2612,9 +2615,15 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     const int last = p.frame_len - 1;
 
     // the twiddles of pass 2 depend on the lane only: W_{8 R1}^{k r}, k = l mod R1 (kept in registers; pass 3's come from the LDS table)
-    constexpr bool kTw2Reg = P == 8 && MS_POW2_TW2REG;
+    constexpr bool kTw2Reg = (P == 8 && MS_POW2_TW2REG) || kHalves;
     cpx<double> tw2[kTw2Reg ? 7 : 1];
-    if (kTw2Reg) {
+    // complex point r of the lane: l + r LF, or (kHalves) point l + 64 (r / 2) of the even (r even) / odd half: 2 (l + 64 (r / 2)) + (r & 1)
+    auto pt = [&](int r) { return kHalves ? 2 * (l + 64 * (r >> 1)) + (r & 1) : l + r * LF; };
+    if (kHalves) {
+        const int k2 = l & 7;
+#pragma unroll
+        for (int r = 1; r < 8; ++r) tw2[r - 1] = pow2_root(p.d_tw, r * k2 * (2 * M / 64), M);
+    } else if (kTw2Reg) {
         const int k2 = l & (S::R1 - 1);
 #pragma unroll
         for (int r = 1; r < 8; ++r) tw2[r - 1] = pow2_root(p.d_tw, r * k2 * (2 * M / (S::R1 * 8)), M);
@@ -2644,11 +2653,13 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     };
     // Every load is unconditional (clamped index, the value selected afterwards): a load behind its own branch is a serialised memory
     // round trip, and the first form of this kernel -- one predicate per sample -- spent 80 % of its time in them.
-    auto fetch = [&](const Frame &f, Pow2Raw<P, FLAVOR> &raw) {
+    // part: 2 = every point; 0 / 1 (kHalves): the even / the odd points only (r = 2 r' + part)
+    auto fetch = [&](const Frame &f, Pow2Raw<P, FLAVOR> &raw, int part = 2) {
         if (!f.real) return;
 #pragma unroll
         for (int r = 0; r < P; ++r) {
-            const int i0 = 2 * (l + r * LF);
+            if (part != 2 && (r & 1) != part) continue;
+            const int i0 = 2 * pt(r);
             if (FLAVOR == 2) {                           // sample s of the frame = clip[start + s - pad], zero outside the clip
                 const long long s0 = (long long)f.start + i0 - p.pad, hi = p.clip_len - 1;
                 const long long c0 = s0 < 0 ? 0 : (s0 > hi ? hi : s0), c1 = s0 + 1 < 0 ? 0 : (s0 + 1 > hi ? hi : s0 + 1);
@@ -2662,15 +2673,9 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         }
     };
 
-    // The lane's window values are the same for every frame, but 2 P doubles are too many to hold through the passes: read per frame
-    d2 wnd[P];
-    auto load_window = [&]() {
-#pragma unroll
-        for (int r = 0; r < P; ++r) wnd[r] = *reinterpret_cast<const d2 *>((kWinLds ? lwin : p.d_win) + 2 * (l + r * LF));
-    };
     // the jobs of a lane are the same for every frame too: the records of its first kJ stay in registers
     const int n_jobs = p.n_jobs;
-    constexpr int kJ = (FLAVOR != 0 && P == 8) ? MS_POW2_JOBS_F : (LF < 64 ? MS_POW2_JOBS_SMALL : MS_POW2_JOBS_BIG);     // rounds of jobs in flight together (the Kaldi / NeMo framings hold more registers: spills)
+    constexpr int kJ = (FLAVOR != 0 && (P == 8 || S::kHalves)) ? MS_POW2_JOBS_F : (LF < 64 ? MS_POW2_JOBS_SMALL : (S::kHalves ? MS_POW2_JOBS_H : MS_POW2_JOBS_BIG));     // rounds of jobs in flight together (the Kaldi / NeMo framings hold more registers: spills)
     int info0[kJ];
 #pragma unroll
     for (int t = 0; t < kJ; ++t) info0[t] = l + t * LF < n_jobs ? ljob[l + t * LF] : 0;
@@ -2678,9 +2683,9 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     uint64_t base = ((uint64_t)blockIdx.x * n_waves + wave) * FW;
     if (base >= n_units) return;
     Frame cur = place(base);
-    if (MS_POW2_WINEARLY) load_window();
+    constexpr bool kFetchPerHalf = S::kHalves && !kAhead;      // the samples of a half are loaded when the half is framed (registers)
     Pow2Raw<P, FLAVOR> raw;
-    fetch(cur, raw);
+    if (!kFetchPerHalf) fetch(cur, raw);
     for (;;) {
         const uint64_t nbase = base + stride;
         const bool more = nbase < n_units;               // wave-uniform
@@ -2695,55 +2700,79 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         }
         if (cur.real) {
             // ---- framing: DC removal / pre-emphasis / window per flavour -> the lane's P complex points z[l + r LF] -----------------
-            cpx<double> reg[P];
-            double v[2 * P];
-            if (!MS_POW2_WINEARLY) load_window();
-            if (FLAVOR == 0) {                           // frame_windows: x[start + i] as f64 (src/stft.rs:160-165)
-#pragma unroll
-                for (int r = 0; r < P; ++r) { v[2 * r] = (double)raw.pair[r].x; v[2 * r + 1] = (double)raw.pair[r].y; }
-            } else if (FLAVOR == 2) {                    // src/mel.rs:696-706: whole-clip pre-emphasis in f32, two roundings; zero centre padding
-                const float coeff = (float)p.preemph;
-#pragma unroll
-                for (int r = 0; r < P; ++r) {
-                    const long long s0 = (long long)cur.start + 2 * (l + r * LF) - p.pad;
-                    const float a = raw.pair[r].x, b0 = raw.pair[r].y;
-                    const float pa = a - f32_mul_rn(coeff, raw.before[r]), pb = b0 - f32_mul_rn(coeff, a);
-                    const float fa = (coeff != 0.0f && s0 > 0) ? pa : a, fb = (coeff != 0.0f && s0 + 1 > 0) ? pb : b0;
-                    v[2 * r] = (s0 >= 0 && s0 < p.clip_len) ? (double)fa : 0.0;
-                    v[2 * r + 1] = (s0 + 1 >= 0 && s0 + 1 < p.clip_len) ? (double)fb : 0.0;
-                }
-            } else {                                     // src/fbank.rs:164-190: DC removal, pre-emphasis
-                double xa[P], xb[P];
+            // point(r): the windowed complex point r of the lane.  FLAVOR 1 needs the frame's mean first.
+            double mean = 0.0;
+            if (FLAVOR == 1) {                           // src/fbank.rs:164-170
+                if (kFetchPerHalf) fetch(cur, raw);
                 double part = 0.0;
 #pragma unroll
                 for (int r = 0; r < P; ++r) {
-                    const int i0 = 2 * (l + r * LF);
-                    xa[r] = (double)(i0 + 1 <= last ? raw.pair[r].x : raw.pair[r].y);     // i0 == last: the clamped pair holds x[last] second
-                    xb[r] = (double)raw.pair[r].y;
-                    part += i0 <= last ? xa[r] : 0.0;
-                    part += i0 + 1 <= last ? xb[r] : 0.0;
+                    const int i0 = 2 * pt(r);
+                    const double xa = (double)(i0 + 1 <= last ? raw.pair[r].x : raw.pair[r].y);     // i0 == last: the clamped pair holds x[last] second
+                    part += i0 <= last ? xa : 0.0;
+                    part += i0 + 1 <= last ? (double)raw.pair[r].y : 0.0;
                 }
                 // (the frame's lanes are all inside this branch or all outside it: a frame owns a whole lane group)
 #pragma unroll
                 for (int d = 1; d < LF; d <<= 1) part += __shfl_xor(part, d, 64);
-                const double mean = part / (double)p.frame_len;
-#pragma unroll
-                for (int r = 0; r < P; ++r) {
-                    const int i0 = 2 * (l + r * LF);
-                    double ta = xa[r] - mean, tb = xb[r] - mean;
-                    if (p.preemph > 0.0) {
-                        tb -= p.preemph * (xa[r] - mean);
-                        if (i0 > 0 || cur.start > 0) ta -= p.preemph * ((double)raw.before[r] - mean);
-                    }
-                    v[2 * r] = ta; v[2 * r + 1] = tb;
-                }
+                mean = part / (double)p.frame_len;
             }
-#pragma unroll
-            for (int r = 0; r < P; ++r) reg[r] = {v[2 * r] * wnd[r].x, v[2 * r + 1] * wnd[r].y};
+            auto point = [&](int r, d2 w) {
+                double va, vb;
+                if (FLAVOR == 0) {                       // frame_windows: x[start + i] as f64 (src/stft.rs:160-165)
+                    va = (double)raw.pair[r].x; vb = (double)raw.pair[r].y;
+                } else if (FLAVOR == 2) {                // src/mel.rs:696-706: whole-clip pre-emphasis in f32, two roundings; zero centre padding
+                    const float coeff = (float)p.preemph;
+                    const long long s0 = (long long)cur.start + 2 * pt(r) - p.pad;
+                    const float a = raw.pair[r].x, b0 = raw.pair[r].y;
+                    const float pa = a - f32_mul_rn(coeff, raw.before[r]), pb = b0 - f32_mul_rn(coeff, a);
+                    const float fa = (coeff != 0.0f && s0 > 0) ? pa : a, fb = (coeff != 0.0f && s0 + 1 > 0) ? pb : b0;
+                    va = (s0 >= 0 && s0 < p.clip_len) ? (double)fa : 0.0;
+                    vb = (s0 + 1 >= 0 && s0 + 1 < p.clip_len) ? (double)fb : 0.0;
+                } else {                                 // src/fbank.rs:171-190: DC removal, pre-emphasis
+                    const int i0 = 2 * pt(r);
+                    const double xa = (double)(i0 + 1 <= last ? raw.pair[r].x : raw.pair[r].y), xb = (double)raw.pair[r].y;
+                    va = xa - mean; vb = xb - mean;
+                    if (p.preemph > 0.0) {
+                        vb -= p.preemph * (xa - mean);
+                        if (i0 > 0 || cur.start > 0) va -= p.preemph * ((double)raw.before[r] - mean);
+                    }
+                }
+                return cpx<double>{va * w.x, vb * w.y};
+            };
+            auto window_of = [&](int r) { return *reinterpret_cast<const d2 *>((kWinLds ? lwin : p.d_win) + 2 * pt(r)); };
             // ---- the complex M-point transform: Stockham passes, in place in the frame's LDS region --------------------------------
-            pow2_pass<LOGM, S::R1, true>(l, 1, nullptr, z, reg, nullptr);
-            pow2_pass<LOGM, 8, false>(l, S::R1, t2, z, nullptr, kTw2Reg ? tw2 : nullptr);
-            if (S::R3 > 1) pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, t3, z, nullptr, nullptr);
+            if (kHalves) {
+                // the even and the odd points as two 512-point transforms, E at z, O behind it
+                // (eight points at a time, window values and all: sixteen at once are the registers of the one-transform form)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    d2 wv[8];
+                    cpx<double> half[8];
+                    if (kFetchPerHalf) fetch(cur, raw, h);      // (Kaldi: again, after the pass for the mean -- holding all sixteen pairs spills more than the reload costs)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) wv[r] = window_of(2 * r + h);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) half[r] = point(2 * r + h, wv[r]);
+                    double *zh = z + h * M;
+                    pow2_pass<9, 8, true>(l, 1, nullptr, zh, half, nullptr);
+                    pow2_pass<9, 8, false>(l, 8, t3, zh, nullptr, tw2);          // (t3: any table; the twiddles are tw2)
+                    pow2_pass<9, 8, false>(l, 64, t3, zh, nullptr, nullptr);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                }
+            } else {
+                cpx<double> reg[P];
+                d2 wv[P];
+#pragma unroll
+                for (int r = 0; r < P; ++r) wv[r] = window_of(r);
+#pragma unroll
+                for (int r = 0; r < P; ++r) reg[r] = point(r, wv[r]);
+                pow2_pass<LOGM, S::R1, true>(l, 1, nullptr, z, reg, nullptr);
+                pow2_pass<LOGM, 8, false>(l, S::R1, t2, z, nullptr, kTw2Reg ? tw2 : nullptr);
+                if (S::R3 > 1) pow2_pass<LOGM, (S::R3 > 1 ? S::R3 : 2), false>(l, S::R1 * 8, t3, z, nullptr, nullptr);
+            }
             // ---- the real-FFT split X[k] = E[k] + W_N^k O[k], E = (Z[k] + conj Z[M-k]) / 2, O = -i (Z[k] - conj Z[M-k]) / 2, and the
             // power row.  X[M-k] comes from the same two points (E -> conj E, O -> conj O, W_N^{M-k} = -conj W_N^k):
             //   X[k] = (er + t1) + i (ei + t2),   X[M-k] = (er - t1) - i (ei - t2),   t1 = di c + dr s,  t2 = di s - dr c
@@ -2759,11 +2788,43 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
                 hi = br * br + bi * bi;
                 if (FLAVOR == 1 && !p.use_power) { lo = sqrt(lo); hi = sqrt(hi); }
             };
+            // kHalves: Z[k] = E[k] + W_M^k O[k] and Z[M - k] = Z[(M/2 - k) + M/2] = E[M/2 - k] + conj(W_M^k) O[M/2 - k] (W_M^{M/2 - k} =
+            // -conj W_M^k) are formed on the way in: the radix-2 step costs no pass of its own.  Bin M / 2: Z[M/2] = E[0] - O[0].
+            auto pair_h = [&](cpx<double> a, cpx<double> b0, int k, double &lo, double &hi) {
+                const cpx<double> w = ldc(tw + 2 * k);
+                const double er = 0.5 * (a.re + b0.re), ei = 0.5 * (a.im - b0.im);
+                const double dr = 0.5 * (a.re - b0.re), di = 0.5 * (a.im + b0.im);
+                const double t1 = di * w.re + dr * w.im, t2v = di * w.im - dr * w.re;
+                const double ar = er + t1, ai = ei + t2v, br = er - t1, bi = ei - t2v;
+                lo = ar * ar + ai * ai;
+                hi = br * br + bi * bi;
+                if (FLAVOR == 1 && !p.use_power) { lo = sqrt(lo); hi = sqrt(hi); }
+            };
+            auto power2h = [&](int k, double &lo, double &hi) {
+                const int km = (M / 2 - k) & (M / 2 - 1);
+                const cpx<double> ek = ldc(z + 2 * pow2_slot<9>(k)), ok = ldc(z + M + 2 * pow2_slot<9>(k));
+                const cpx<double> em = ldc(z + 2 * pow2_slot<9>(km)), om = ldc(z + M + 2 * pow2_slot<9>(km));
+                const cpx<double> wc = ldc(tc + 2 * k);
+                const cpx<double> wo = cmul(wc, ok), wm = cmul(cpx<double>{wc.re, -wc.im}, om);
+                pair_h(cpx<double>{ek.re + wo.re, ek.im + wo.im}, cpx<double>{em.re + wm.re, em.im + wm.im}, k, lo, hi);
+            };
             double plo[P / 2], phi[P / 2];
-#pragma unroll
-            for (int r = 0; r < P / 2; ++r) power2(l + r * LF, plo[r], phi[r]);
             double pmid, pmid2;
-            power2(M / 2, pmid, pmid2);                  // every lane, one address: a broadcast
+            if (kHalves) {
+#pragma unroll
+                for (int r = 0; r < P / 2; ++r) {
+                    power2h(l + r * LF, plo[r], phi[r]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    if (r % MS_POW2_HSPLIT == MS_POW2_HSPLIT - 1) __builtin_amdgcn_sched_barrier(0);      // (a pair is five 16-byte loads: all eight at once are 160 registers)
+#endif
+                }
+                const cpx<double> e0 = ldc(z), o0 = ldc(z + M);              // slot(0) = 0
+                pair_h(cpx<double>{e0.re - o0.re, e0.im - o0.im}, cpx<double>{e0.re - o0.re, e0.im - o0.im}, M / 2, pmid, pmid2);
+            } else {
+#pragma unroll
+                for (int r = 0; r < P / 2; ++r) power2(l + r * LF, plo[r], phi[r]);
+                power2(M / 2, pmid, pmid2);              // every lane, one address: a broadcast
+            }
 #pragma unroll
             for (int r = 0; r < P / 2; ++r) {
                 pw[l + r * LF] = plo[r];
@@ -2772,7 +2833,6 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
             if (l == 0) pw[M / 2] = pmid;
             if (kPwAlias && l < 8) pw[M + 1 + l] = 0.0;      // (the row is where the points were)
         }
-        if (MS_POW2_WINEARLY && more) load_window();
         // ---- banded mel sums, log, per-flavour epilogue ---------------------------------------------------------------------------
         // The bank as JOBS of eight consecutive weights of one mel (the last job of a band padded): every lane takes a job per round,
         // folds its up-to-eight products left to right and adds the partial sum to the mel's word in LDS (ds_add_f64; the LDS executes
@@ -2864,7 +2924,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
             raw = nraw;
         } else {
             cur = place(base);
-            fetch(cur, raw);
+            if (!kFetchPerHalf) fetch(cur, raw);
         }
     }
 }

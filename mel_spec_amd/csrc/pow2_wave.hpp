@@ -14,7 +14,8 @@
 //   128    256     16                4                 8 8 2
 //   256    512     32                2                 8 8 4        (only where the 512-point kernels do not apply)
 //   512    1024    64                1                 8 8 8
-//   1024   2048    64                1                 16 8 8
+//   1024   2048    64                1                 two 512-point transforms (8 8 8 each: the even and the odd points), the radix-2
+//                                                      step between them folded into the split (kHalves; as one transform: 16 8 8)
 //
 // Arithmetic: f64 from the window multiply to the mel sums, as the reference (src/stft.rs:98-111, src/mel.rs:148-168, src/fbank.rs:
 // 165-221) and generic_frame_kernel, which stays the independent on-device cross-check (tests).
@@ -40,9 +41,6 @@
 #ifndef MS_POW2_AHEAD16
 #define MS_POW2_AHEAD16 1
 #endif
-#ifndef MS_POW2_WINEARLY
-#define MS_POW2_WINEARLY 0      // lab: read a frame's window values before the mel phase of the frame before (32-64 VGPRs held across it: spills, 3-90 % slower)
-#endif
 #ifndef MS_POW2_JOBS_F
 #define MS_POW2_JOBS_F 1
 #endif
@@ -58,6 +56,21 @@
 #ifndef MS_POW2_JOBS_BIG
 #define MS_POW2_JOBS_BIG 3
 #endif
+#ifndef MS_POW2_HALVES
+#define MS_POW2_HALVES 1
+#endif
+#ifndef MS_POW2_MAXWH
+#define MS_POW2_MAXWH 6
+#endif
+#ifndef MS_POW2_AHEADH
+#define MS_POW2_AHEADH 0
+#endif
+#ifndef MS_POW2_HSPLIT
+#define MS_POW2_HSPLIT 4
+#endif
+#ifndef MS_POW2_JOBS_H
+#define MS_POW2_JOBS_H 2
+#endif
 #ifndef MS_POW2_TW2REG
 #define MS_POW2_TW2REG 1
 #endif
@@ -72,15 +85,19 @@ template <int LOGM> struct Pow2Shape {
     static constexpr int R1 = P;                             // radix of the first pass
     static constexpr int R3 = M / (R1 * 8);                  // radix of the last pass (1: two passes only)
     static constexpr int kShift = P == 16 ? 4 : 3;           // log2 R1
+    // M = 1024 as TWO 512-point transforms (even and odd points) and a radix-2 step folded into the split: eight points per lane at
+    // a time instead of sixteen -- the registers of the 512-point kernel, two waves per SIMD (pow2_frame_kernel, kHalves)
+    static constexpr bool kHalves = MS_POW2_HALVES && M >= 1024;
+    static constexpr int kTc = kHalves ? M / 2 : 0;          // complex entries of the radix-2 step's table W_M^k, k < M / 2
     static constexpr int kMelsPerLane = LF >= 16 ? 256 / LF : 16;            // banks of up to 256 mels (128 at M = 64)
-    static constexpr int kMaxWaves = M >= 1024 ? MS_POW2_MAXW16 : MS_POW2_MAXW;      // two per SIMD: the kernels hold 185-240 VGPRs (M = 1024: one, its LDS holds four frames and its 16 points per lane want the AGPRs)
-    static constexpr int kT2 = (P == 16 || !MS_POW2_TW2REG) ? 7 * R1 : 0;         // complex entries of the pass-2 table (P == 8: the lane keeps its seven in registers)
-    static constexpr int kT3 = R3 > 1 ? (R3 - 1) * R1 * 8 : 0;               // of the pass-3 table
+    static constexpr int kMaxWaves = M >= 1024 ? (kHalves ? MS_POW2_MAXWH : MS_POW2_MAXW16) : MS_POW2_MAXW;      // two per SIMD: the kernels hold 185-240 VGPRs (M = 1024: one, its LDS holds four frames and its 16 points per lane want the AGPRs)
+    static constexpr int kT2 = kHalves ? 0 : (P == 16 || !MS_POW2_TW2REG) ? 7 * R1 : 0;         // complex entries of the pass-2 table (P == 8: the lane keeps its seven in registers)
+    static constexpr int kT3 = kHalves ? 7 * 64 : R3 > 1 ? (R3 - 1) * R1 * 8 : 0;               // of the pass-3 table
 };
 
 // Where everything is in the workgroup's LDS, in doubles; the host sizes the launch with the same function.
 struct Pow2Lds {
-    int tw, win, t2, t3, jw, job, frames, frame_stride, pw, acc, total;
+    int tw, win, t2, t3, tc, jw, job, frames, frame_stride, pw, acc, total;
 };
 template <int LOGM> MS_HD Pow2Lds pow2_lds(int n_jobs, int n_mels, int waves) {
     using S = Pow2Shape<LOGM>;
@@ -89,7 +106,8 @@ template <int LOGM> MS_HD Pow2Lds pow2_lds(int n_jobs, int n_mels, int waves) {
     o.win = o.tw + S::M + 32;                              // W_N^q, q <= M / 2: what the split reads
     o.t2 = o.win + (S::M <= MS_POW2_WINLDS ? 2 * S::M : 0);           // M = 1024: its 16 KB would cost one of four resident waves, read from L1 / L2
     o.t3 = o.t2 + 2 * S::kT2;
-    o.jw = o.t3 + 2 * S::kT3;
+    o.tc = o.t3 + 2 * S::kT3;
+    o.jw = o.tc + 2 * S::kTc;
     o.job = o.jw + 8 * n_jobs;
     o.frames = (o.job + (n_jobs + 1) / 2 + 31) & ~31;
     // inside a frame: Z, the power row [M + 1] (+ 7 a job may read past it, + pad), the band sums

@@ -887,9 +887,10 @@ static void emu_pow2_run(const double *in /* M complex */, double *out /* M comp
     constexpr int M = S::M;
     std::vector<double> tw(2 * M);
     for (int q = 0; q < M; ++q) { tw[2 * q] = std::cos(2.0 * kPi * q / (2.0 * M)); tw[2 * q + 1] = -std::sin(2.0 * kPi * q / (2.0 * M)); }
-    std::vector<double> t2(2 * 7 * S::R1), t3(2 * (S::kT3 > 0 ? S::kT3 : 1));
+    constexpr int kT3 = S::R3 > 1 ? (S::R3 - 1) * S::R1 * 8 : 0;      // (the one-transform form; the kernel runs M = 1024 as two 512-point halves)
+    std::vector<double> t2(2 * 7 * S::R1), t3(2 * (kT3 > 0 ? kT3 : 1));
     for (int i = 0; i < 7 * S::R1; ++i) { const cpx<double> w = pow2_table_entry(tw.data(), M, 8, S::R1, i); t2[2 * i] = w.re; t2[2 * i + 1] = w.im; }
-    for (int i = 0; i < S::kT3; ++i) { const cpx<double> w = pow2_table_entry(tw.data(), M, S::R3, S::R1 * 8, i); t3[2 * i] = w.re; t3[2 * i + 1] = w.im; }
+    for (int i = 0; i < kT3; ++i) { const cpx<double> w = pow2_table_entry(tw.data(), M, S::R3, S::R1 * 8, i); t3[2 * i] = w.re; t3[2 * i + 1] = w.im; }
     std::vector<double> z(2 * M, 1.0e300);
     auto pass = [&](auto fn) {
         const std::vector<double> snap(z);
