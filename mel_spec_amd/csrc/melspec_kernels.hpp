@@ -2786,7 +2786,6 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
                 const double ar = er + t1, ai = ei + t2v, br = er - t1, bi = ei - t2v;
                 lo = ar * ar + ai * ai;
                 hi = br * br + bi * bi;
-                if (FLAVOR == 1 && !p.use_power) { lo = sqrt(lo); hi = sqrt(hi); }
             };
             // kHalves: Z[k] = E[k] + W_M^k O[k] and Z[M - k] = Z[(M/2 - k) + M/2] = E[M/2 - k] + conj(W_M^k) O[M/2 - k] (W_M^{M/2 - k} =
             // -conj W_M^k) are formed on the way in: the radix-2 step costs no pass of its own.  Bin M / 2: Z[M/2] = E[0] - O[0].
@@ -2798,7 +2797,6 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
                 const double ar = er + t1, ai = ei + t2v, br = er - t1, bi = ei - t2v;
                 lo = ar * ar + ai * ai;
                 hi = br * br + bi * bi;
-                if (FLAVOR == 1 && !p.use_power) { lo = sqrt(lo); hi = sqrt(hi); }
             };
             auto power2h = [&](int k, double &lo, double &hi) {
                 const int km = (M / 2 - k) & (M / 2 - 1);
@@ -2824,6 +2822,14 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
 #pragma unroll
                 for (int r = 0; r < P / 2; ++r) power2(l + r * LF, plo[r], phi[r]);
                 power2(M / 2, pmid, pmid2);              // every lane, one address: a broadcast
+            }
+            // magnitudes instead of powers (FbankConfig::use_power off): ONE wave-uniform branch around all the square roots -- as a select
+            // inside the pair the compiler evaluated the 2 (P / 2 + 1) IEEE f64 roots of every frame unconditionally (~300 instructions, a
+            // third of the Kaldi flavour's arithmetic; the same trap as in fb_phase2_split)
+            if (FLAVOR == 1 && !p.use_power) {
+#pragma unroll
+                for (int r = 0; r < P / 2; ++r) { plo[r] = sqrt(plo[r]); phi[r] = sqrt(phi[r]); }
+                pmid = sqrt(pmid);
             }
 #pragma unroll
             for (int r = 0; r < P / 2; ++r) {

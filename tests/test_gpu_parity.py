@@ -602,6 +602,25 @@ def test_pow2_kernel_kaldi_rates_against_oracle_and_the_workgroup_kernel(gpu, or
     fb.close()
 
 
+@pytest.mark.parametrize("sr", [8000.0, 32000.0, 44100.0])
+def test_pow2_kernel_kaldi_magnitudes(gpu, oracle, jfk, sr):
+    """FbankConfig::use_power off (src/fbank.rs:197-203: |X| instead of |X|^2) on pow2_frame_kernel -- the square roots sit behind one
+    wave-uniform branch after the split (n_fft 2048: after the radix-2 step of its two halves); with use_log off as well the band sums
+    themselves are the output."""
+    x = np.resize(jfk, int(sr * 1.7)).astype(np.float32)
+    for kw in (dict(use_power=False), dict(use_power=False, use_log_fbank=False, apply_cmn=False)):
+        cfg = gpu.FbankConfig(sample_rate=sr, **kw)
+        oc = oracle.fbank_default_config(); oc.sample_rate = sr
+        for k_, v in kw.items():
+            setattr(oc, k_, type(getattr(oc, k_))(v))
+        fb = gpu.Fbank(cfg)
+        assert not fb.uses_fast_path
+        got, want = fb.compute(x), oracle.fbank_compute(x, oc)
+        tol = TOL if kw.get("use_log_fbank", True) else 1e-4 * max(1.0, float(np.abs(want).max()))
+        assert got.shape == want.shape and np.abs(got - want).max() <= tol, kw
+        fb.close()
+
+
 @pytest.mark.parametrize("fft,hop,n_mels,sr", [(128, 32, 20, 8000.0), (128, 64, 40, 8000.0), (256, 64, 40, 8000.0), (256, 100, 80, 16000.0),
                                                (1024, 256, 80, 16000.0), (1024, 160, 128, 22050.0), (2048, 512, 128, 44100.0), (2048, 441, 80, 44100.0)])
 def test_pow2_kernel_whisper_style(gpu, oracle, jfk, fft, hop, n_mels, sr):
