@@ -2585,7 +2585,7 @@ template <int LOGM, int FLAVOR>
 __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_kernel(const GenericParams p) {
     using S = Pow2Shape<LOGM>;
     constexpr int M = S::M, LF = S::LF, FW = S::FW, P = S::P;
-    constexpr bool kAhead = P == 8 || (MS_POW2_AHEAD16 && !(S::kHalves && !MS_POW2_AHEADH));   // the next frame's samples are loaded while this one is transformed
+    constexpr bool kAhead = (P == 8 && !(FLAVOR == 1 && LF < 64 && !MS_POW2_AHEAD_KS)) || (P == 16 && MS_POW2_AHEAD16 && !(S::kHalves && !MS_POW2_AHEADH));   // the next frame's samples are loaded while this one is transformed
     constexpr bool kWinLds = M <= MS_POW2_WINLDS;
     extern __shared__ __attribute__((aligned(16))) double ldsd[];
     const int tid = threadIdx.x, n_threads = blockDim.x, n_waves = n_threads >> 6;     // the host picks the waves per workgroup (LDS)
@@ -2633,23 +2633,48 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         const float *pcm, *x;
         float *o;
         uint64_t ostep, start;
+        uint32_t in_clip, clip;                          // uniform batches: the frame's unit inside its clip, and the clip
         bool have, real;
     };
     const uint64_t n_units = batch_n_units(p.b);
     const uint64_t stride = (uint64_t)gridDim.x * n_waves * FW;
-    auto place = [&](uint64_t base) {
+    const bool uniform = p.b.d_unit_prefix == nullptr;
+    auto frame_at = [&](const UnitLoc &loc, bool have) {
         Frame f;
-        const uint64_t unit = base + fs;
-        f.have = unit < n_units;
-        const UnitLoc loc = locate_unit(p.b, f.have ? unit : base);
-        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
+        f.have = have;
+        const uint64_t width = uniform ? p.b.out_width : loc.frames;
         f.o = p.b.mel_major ? loc.out + loc.unit : loc.out + loc.unit * (uint64_t)p.n_mels;
         f.ostep = p.b.mel_major ? width : 1;
-        f.real = f.have && loc.unit < loc.frames;        // otherwise: a zero column of a padded layout (uniform batches), or nothing
+        f.real = have && loc.unit < loc.frames;          // otherwise: a zero column of a padded layout (uniform batches), or nothing
         f.start = loc.unit * (uint64_t)p.hop;
         f.pcm = loc.pcm;
         f.x = loc.pcm + f.start;
+        f.in_clip = (uint32_t)loc.unit;
+        f.clip = loc.clip;
         return f;
+    };
+    auto place = [&](uint64_t base) {
+        const uint64_t unit = base + fs;
+        const bool have = unit < n_units;
+        return frame_at(locate_unit(p.b, have ? unit : base), have);
+    };
+    // The frame `stride` units further on.  locate_unit divides a 64-bit unit index by the units of a clip -- ~100 VALU instructions per
+    // lane, a sixth of this kernel's at n_fft 256 when it was done per frame; a uniform batch is walked instead: the step in whole
+    // clips and the rest are the same for every lane and every iteration.
+    const uint64_t step_clips = uniform ? stride / p.b.units_per_clip : 0;
+    const uint32_t step_rest = uniform ? (uint32_t)(stride - step_clips * p.b.units_per_clip) : 0;
+    auto advance = [&](const Frame &f, uint64_t nbase) {
+        if (!uniform || !f.have) return place(nbase);
+        UnitLoc loc;
+        uint32_t u = f.in_clip + step_rest;             // (< 2 units_per_clip <= 2^32: the host plans uniform batches with 32-bit unit counts per clip)
+        uint64_t c = (uint64_t)f.clip + step_clips;
+        if (u >= p.b.units_per_clip) { u -= p.b.units_per_clip; ++c; }
+        loc.unit = u;
+        loc.clip = (uint32_t)c;
+        loc.pcm = p.b.pcm + c * p.b.clip_stride;
+        loc.out = p.b.out + c * p.b.out_stride;
+        loc.frames = p.b.frames_per_clip;
+        return frame_at(loc, nbase + fs < n_units);
     };
     // Every load is unconditional (clamped index, the value selected afterwards): a load behind its own branch is a serialised memory
     // round trip, and the first form of this kernel -- one predicate per sample -- spent 80 % of its time in them.
@@ -2692,7 +2717,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         Frame nxt = cur;
         Pow2Raw<P, FLAVOR> nraw;
         if (kAhead && more) {
-            nxt = place(nbase);
+            nxt = advance(cur, nbase);
             fetch(nxt, nraw);
         }
         if (cur.have && !cur.real) {
@@ -2929,7 +2954,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
             cur = nxt;
             raw = nraw;
         } else {
-            cur = place(base);
+            cur = advance(cur, base);
             if (!kFetchPerHalf) fetch(cur, raw);
         }
     }

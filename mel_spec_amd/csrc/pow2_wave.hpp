@@ -71,6 +71,9 @@
 #ifndef MS_POW2_JOBS_H
 #define MS_POW2_JOBS_H 2
 #endif
+#ifndef MS_POW2_AHEAD_KS
+#define MS_POW2_AHEAD_KS 0
+#endif
 #ifndef MS_POW2_TW2REG
 #define MS_POW2_TW2REG 1
 #endif
