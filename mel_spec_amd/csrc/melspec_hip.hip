@@ -496,16 +496,25 @@ unsigned grid_for_xcd(uint64_t units, int cus, int per_cu) {
     return (g + 7u) & ~7u;
 }
 
+// Waves per workgroup pow2_frame_kernel<LOGM, .> gets for a bank -- one persistent workgroup per CU with as many waves as its LDS holds
+// (the tables are paid once), at most two per SIMD (VGPRs); 0: the bank is past the kernel (more mels than its lanes read out, more bins
+// or mels than a job record holds, tables that leave no room for a frame) and the geometry stays on generic_frame_kernel.
+template <int LOGM>
+int pow2_waves(int n_jobs, int n_mels, int n_bins) {
+    using S = Pow2Shape<LOGM>;
+    if (n_mels > S::kMelsPerLane * S::LF) return 0;
+    if (n_jobs < 1 || n_bins > 4088 || n_mels > 256) return 0;
+    int waves = S::kMaxWaves;
+    while (waves > 1 && sizeof(double) * static_cast<size_t>(pow2_lds<LOGM>(n_jobs, n_mels, waves).total) > kLdsLimit) --waves;
+    return sizeof(double) * static_cast<size_t>(pow2_lds<LOGM>(n_jobs, n_mels, waves).total) > kLdsLimit ? 0 : waves;
+}
+
 template <int LOGM, int FLAVOR>
 int launch_pow2(const GenericParams &gp, int cus, hipStream_t stream) {
     using S = Pow2Shape<LOGM>;
-    if (gp.n_mels > S::kMelsPerLane * S::LF) return -1;
-    if (gp.n_jobs < 1 || gp.n_bins > 4088 || gp.n_mels > 256) return -1;
-    // one persistent workgroup per CU with as many waves as its LDS holds (the tables are paid once), at most two per SIMD (VGPRs)
-    int waves = S::kMaxWaves;
-    while (waves > 1 && sizeof(double) * static_cast<size_t>(pow2_lds<LOGM>(gp.n_jobs, gp.n_mels, waves).total) > kLdsLimit) --waves;
+    const int waves = pow2_waves<LOGM>(gp.n_jobs, gp.n_mels, gp.n_bins);
+    if (waves == 0) return -1;
     const size_t lds = sizeof(double) * static_cast<size_t>(pow2_lds<LOGM>(gp.n_jobs, gp.n_mels, waves).total);
-    if (lds > kLdsLimit) return -1;
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&pow2_frame_kernel<LOGM, FLAVOR>, "hipFuncSetAttribute(pow2_frame_kernel)");
@@ -517,6 +526,22 @@ int launch_pow2(const GenericParams &gp, int cus, hipStream_t stream) {
     hipLaunchKernelGGL((pow2_frame_kernel<LOGM, FLAVOR>), dim3(grid), dim3(waves * 64), lds, stream, gp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
+}
+
+// log2 of the complex transform pow2_frame_kernel would run this geometry with (6..10), or 0: generic_frame_kernel
+int pow2_logm(const GenericTables &gt) {
+    static const bool pow2_on = lab_int("MELSPEC_POW2", 1, 0, 1) != 0;
+    if (!pow2_on || gt.force_generic) return 0;
+    int waves = 0;
+    switch (gt.fft_log2) {
+        case 7: waves = pow2_waves<6>(gt.n_jobs, gt.n_mels, gt.n_bins); break;
+        case 8: waves = pow2_waves<7>(gt.n_jobs, gt.n_mels, gt.n_bins); break;
+        case 9: waves = pow2_waves<8>(gt.n_jobs, gt.n_mels, gt.n_bins); break;
+        case 10: waves = pow2_waves<9>(gt.n_jobs, gt.n_mels, gt.n_bins); break;
+        case 11: waves = pow2_waves<10>(gt.n_jobs, gt.n_mels, gt.n_bins); break;
+        default: break;
+    }
+    return waves ? gt.fft_log2 - 1 : 0;
 }
 
 int launch_generic(const GenericTables &gt, const BatchDesc &desc, int hop, int flavour /* 0 Whisper, 1 Kaldi fbank, 2 NeMo */, int use_log, int use_power,
@@ -1120,7 +1145,15 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
     if (!c) return "";
     if (!c->fast) {
         if (c->fast512) return "melspec::fbank512_wave_kernel<double, 8, 1, kFlavorWhisper, RUNS> (n_fft = 512, f64)";
-        return "melspec::generic_frame_kernel<256> (f64 direct DFT)";
+        switch (pow2_logm(c->gt)) {
+            case 6: return "melspec::pow2_frame_kernel<6, kFlavorWhisper> (n_fft = 128, f64, frames owned by lane groups of a wave)";
+            case 7: return "melspec::pow2_frame_kernel<7, kFlavorWhisper> (n_fft = 256, f64, frames owned by lane groups of a wave)";
+            case 8: return "melspec::pow2_frame_kernel<8, kFlavorWhisper> (n_fft = 512, f64, frames owned by lane groups of a wave)";
+            case 9: return "melspec::pow2_frame_kernel<9, kFlavorWhisper> (n_fft = 1024, f64, frames owned by lane groups of a wave)";
+            case 10: return "melspec::pow2_frame_kernel<10, kFlavorWhisper> (n_fft = 2048 as two 512-point halves, f64, frames owned by lane groups of a wave)";
+            default: break;
+        }
+        return "melspec::generic_frame_kernel<256> (f64, one frame per workgroup)";
     }
     if (c->precision == MELSPEC_PRECISION_F64)
         return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";

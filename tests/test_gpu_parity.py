@@ -628,7 +628,7 @@ def test_pow2_kernel_whisper_style(gpu, oracle, jfk, fft, hop, n_mels, sr):
     """Whisper-style log-mel at n_fft 128 / 256 / 1024 / 2048: uniform batches (frames of several clips share a wave at n_fft <= 512),
     ragged batches, the padded and mel-major layouts -- all against the oracle at the f64 paths' gate."""
     m = gpu.HipMelSpectrogram(fft, hop, sr, n_mels)
-    assert not m.uses_fast_path
+    assert not m.uses_fast_path and f"pow2_frame_kernel<{fft.bit_length() - 2}," in m.plain_kernel_name()     # not the workgroup-per-frame fallback
     n = 3 * fft + 11 * hop + 5
     clips = np.stack([jfk[3000 * c:3000 * c + n] for c in range(5)] + [oracle.synth_pcm(c, n) for c in range(4)])
     want = [oracle.compute_mel_spectrogram_cpu(c, fft, hop, n_mels, sr) for c in clips]
@@ -670,6 +670,7 @@ def test_pow2_kernel_with_caller_supplied_banks(gpu, oracle, jfk, fft, hop):
     filters[rows - 3, bins - 1] = 0.5                               # the last bin alone (the job reads seven places past the row)
     filters[rows - 2, 0] = 0.25                                     # the first bin alone; the last row stays empty
     m = gpu.HipMelSpectrogram(fft, hop, SR, rows, filterbank=filters)
+    assert "pow2_frame_kernel" in m.plain_kernel_name()
     want = oracle.compute_mel_spectrogram_with_filters(x, fft, hop, filters)
     got = m.compute_mel_spectrogram(x)
     assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
@@ -679,6 +680,7 @@ def test_pow2_kernel_with_caller_supplied_banks(gpu, oracle, jfk, fft, hop):
     m.close()
     dense = rng.uniform(0.001, 0.002, (200, bins))                  # 200 rows x every bin: past the LDS of the wave kernel at every size here
     d = gpu.HipMelSpectrogram(fft, hop, SR, 200, filterbank=dense)
+    assert "generic_frame_kernel" in d.plain_kernel_name()
     assert np.abs(d.compute_mel_spectrogram(x) - oracle.compute_mel_spectrogram_with_filters(x, fft, hop, dense)).max() <= 2e-6
     d.close()
 
