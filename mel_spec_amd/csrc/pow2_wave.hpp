@@ -32,6 +32,16 @@
 // read groups hold lanes of four frames).
 #pragma once
 #include "device_fft.hpp"
+// Build-time knobs of pow2_frame_kernel (the A/B variants of tools/ab_build.sh; the defaults are what profiles/r04_pow2_lds.txt measured
+// best; every line of that file's sections 3, 6, 7 and 9 is one of them):
+//   MS_POW2_MAXW / _MAXW16 / _MAXWH   waves per workgroup at most: M <= 512 / M = 1024 as one transform / as two halves
+//   MS_POW2_WINLDS                    the window in LDS up to this M (beyond: read from L1 / L2)
+//   MS_POW2_AHEAD16 / _AHEADH / _AHEAD_KS   the next frame's samples loaded a frame ahead: at 16 points per lane / in the halves form /
+//                                     for the Kaldi flavour at n_fft <= 512 (registers decide: off where the prefetch spills)
+//   MS_POW2_JOBS_SMALL / _BIG / _H / _F   rounds of mel jobs in flight: frames of 8-32 lanes / of 64 / the halves form / Kaldi and NeMo
+//   MS_POW2_PWALIAS                   from this M on the power row takes the place of the frame's points
+//   MS_POW2_HALVES, _HSPLIT           M = 1024 as two 512-point transforms; pairs of the split between scheduling barriers
+//   MS_POW2_TW2REG                    pass-2 twiddles in registers (P = 8)
 #ifndef MS_POW2_MAXW
 #define MS_POW2_MAXW 8
 #endif
