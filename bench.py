@@ -51,6 +51,8 @@ def parse_args():
                     help="default 2; with --gpus N > 1 and no --config the line also carries config 5's per-clip split (`config.cfg5`)")
     ap.add_argument("--no-speech", action="store_true", help="skip the real-input leg (`config.speech`: jfk_f32le.wav tiled to the config-2 batch)")
     ap.add_argument("--no-cfg5", action="store_true", help="N > 1 without --config: skip the extra config-5 leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra N = 1 legs next to `value` (`config.cfg3`, `config.cfg4`, `config.f64`, `config.mel_major`, "
+                                                          "`host_api_single_clip_ms`)")
     ap.add_argument("--clips", type=int, default=None, help="override the clip count (per GPU for weak, total for strong)")
     ap.add_argument("--clip-seconds", type=int, default=None)
     ap.add_argument("--n-mels", type=int, default=None)
@@ -98,7 +100,7 @@ def measure_traffic(config: int, timeout_s: float = 150.0):
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-                   "--config", str(config), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech"]
+                   "--config", str(config), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech", "--no-legs"]
             subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
             per_kernel = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -191,6 +193,8 @@ def dry_run(args) -> None:
             line["cfg5"] = {"scaling": "strong", "shards": sh5, "per_rank_frames": [(b - a) * fpc5 for a, b in sh5]}
         if world == 1 and args.config == 2 and not args.no_speech:
             line["speech"] = {"input": "tests/golden/jfk_f32le.wav tiled to the config-2 batch"}
+        if world == 1 and args.config == 2 and not args.no_legs:
+            line["legs"] = list(LEG_NAMES) + ["host_api_single_clip_ms"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -369,6 +373,122 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
     return res
 
 
+LEG_NAMES = ("cfg3", "cfg4", "f64", "mel_major")
+
+
+def _event_timed(torch, run, iters: int, spin_s: float = 0.15) -> float:
+    """ms per launch: HIP events on torch's current stream (the stream every leg launches on) around `iters` launches, after a spin-up"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < spin_s:
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def extra_legs(M, torch, dev, stream) -> dict:
+    """The figures the driver would otherwise never see, NEXT TO `value`, never instead of it; N = 1, default run.
+    Every leg: synthetic clips resident in HBM, a parity check of two clips against the oracle first, HIP events around >= 50 launches;
+    {ms, frames_per_s, frac (algorithmic bytes / ms over 8 TB/s), kernel, parity_max_abs_diff}.  ~1 s of GPU time in all.
+      cfg3       BASELINE configs[2]: Kaldi fbank (25 ms / 10 ms, 512-point FFT, 80 bins, pre-emphasis 0.97, Povey, CMN on), 1024 x 10 s
+      cfg4       BASELINE configs[3] scaled to the timed budget: Whisper large-v3, 128 mels, 1024 x 30 s (the full 8192 x 30 s is
+                 tests/test_full_size.py and `bench.py --config 4`)
+      f64        configs[1] in MELSPEC_PRECISION_F64 (the f64 FFT on every frame: what speech costs without the vote)
+      mel_major  configs[1] stored as interleave_frames(.., false, ..) = [mel][frames], the whisper.cpp layout (src/mel.rs:480-544)"""
+    import numpy as np
+    from oracle import oracle as O
+    legs = {}
+
+    def record(frames, bytes_per_frame, ms, kernel, parity, workload):
+        gbs = frames * bytes_per_frame / (ms * 1e-3) / 1e9
+        return {"workload": workload, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                "kernel": kernel, "parity_max_abs_diff": parity}
+
+    # ---- cfg3: Kaldi fbank + CMN
+    n_clips, clip_len = 1024, 160000
+    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
+    M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, 0, n_clips, stream=stream)
+    fb = M.Fbank(device=dev.index)
+    fpc = fb.num_frames(clip_len)
+    out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
+    run = lambda: fb.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    run(); torch.cuda.synchronize()
+    o3 = out.view(n_clips, fpc, 80)
+    worst = max(float(np.abs(o3[c].cpu().numpy() - O.fbank_compute(O.synth_pcm(c, clip_len))).max()) for c in (0, n_clips - 1))
+    if worst > 1e-4:
+        raise SystemExit(f"cfg3 leg: parity check failed, max|diff| = {worst}")
+    legs["cfg3"] = record(n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), fb.kernel_name() if hasattr(fb, "kernel_name") else
+                          "melspec::fbank512_clip_kernel (f64 FFT, CMN inside)", worst,
+                          "configs[2]: Kaldi fbank 80 bins + CMN on 1024 synthetic 10 s clips, resident in HBM")
+    fb.close()
+    del out
+
+    # ---- f64 and mel-major on the config-2 batch
+    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 80, device=dev.index)
+    fpc = mel.num_frames(clip_len)
+    out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
+    want = {c: O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), N_FFT, HOP, 80, SR) for c in (0, n_clips - 1)}
+    mel.set_precision("f64")
+    run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    run(); torch.cuda.synchronize()
+    o3 = out.view(n_clips, fpc, 80)
+    worst = max(float(np.abs(o3[c].cpu().numpy() - want[c]).max()) for c in want)
+    if worst > 1e-4:
+        raise SystemExit(f"f64 leg: parity check failed, max|diff| = {worst}")
+    legs["f64"] = record(n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), mel.plain_kernel_name(), worst,
+                         "configs[1] (1024 x 10 s, 80 mels) with melspec_set_precision(f64): the f64 FFT on every frame")
+    mel.set_precision("auto")
+    W = mel.interleaved_width(clip_len, 0)
+    outm = torch.empty(n_clips * 80 * W, dtype=torch.float32, device=dev)
+    run = lambda: mel.compute_uniform_device_interleaved(pcm.data_ptr(), clip_len, clip_len, n_clips, outm.data_ptr(), False, 0, stream=stream)
+    run(); torch.cuda.synchronize()
+    om = outm.view(n_clips, 80, W)
+    worst = max(float(np.abs(om[c].cpu().numpy() - O.interleave_frames(want[c], False, 0)).max()) for c in want)
+    if worst > 1e-4:
+        raise SystemExit(f"mel-major leg: parity check failed, max|diff| = {worst}")
+    legs["mel_major"] = record(n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), "melspec::whisper400_six_kernel (mel-major store)", worst,
+                               f"configs[1] stored mel-major [80][{W}] per clip (interleave_frames(.., false, 0), the whisper.cpp layout), default precision mode")
+    # the drop-in call on one clip, host memory in and out (PCIe-inclusive; the reference's published shape, README.md:117-123, src/cuda.rs:547-613)
+    single = {}
+    for secs in (10, 60, 300):
+        x = O.synth_pcm(1, int(secs * SR))
+        mel.compute_mel_spectrogram(x)
+        best, reps = 1e9, 10
+        for _ in range(3):                      # best of three: the staging threads of a > 16 MiB call share the host with torch's pools
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                y = mel.compute_mel_spectrogram(x)
+            best = min(best, (time.perf_counter() - t0) / reps * 1e3)
+        single[f"{secs}s"] = {"ms": best, "frames": int(y.shape[0])}
+    legs["host_api_single_clip_ms"] = single
+    mel.close()
+    del out, outm, pcm
+
+    # ---- cfg4: 128 mels, 30 s clips
+    n_clips, clip_len = 1024, 480000
+    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
+    M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, 0, n_clips, stream=stream)
+    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 128, device=dev.index)
+    fpc = mel.num_frames(clip_len)
+    out = torch.empty(n_clips * fpc * 128, dtype=torch.float32, device=dev)
+    run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    run(); torch.cuda.synchronize()
+    o3 = out.view(n_clips, fpc, 128)
+    worst = max(float(np.abs(o3[c].cpu().numpy() - O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), N_FFT, HOP, 128, SR)).max()) for c in (0, n_clips - 1))
+    if worst > 1e-4:
+        raise SystemExit(f"cfg4 leg: parity check failed, max|diff| = {worst}")
+    legs["cfg4"] = record(n_clips * fpc, HOP * 4 + 128 * 4, _event_timed(torch, run, 50), mel.plain_kernel_name(), worst,
+                          "configs[3] scaled to the timed budget: Whisper large-v3, 128 mels, 1024 synthetic 30 s clips (the full 8192 x 30 s: bench.py --config 4, "
+                          "tests/test_full_size.py), default precision mode (step = f32 kernel + the gated f64 launch)")
+    mel.close()
+    return legs
+
+
 def main() -> None:
     args = parse_args()
     explicit_config = args.explicit_config = args.config is not None
@@ -481,6 +601,9 @@ def main() -> None:
     speech = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_speech and args.precision == "auto" and args.n_mels is None:
         speech = speech_leg(M, torch, dev, stream, n_clips, clip_len, n_mels)
+    legs = None
+    if rank == 0 and world == 1 and args.config == 2 and not args.no_legs and args.precision == "auto" and args.n_mels is None and args.clips is None and args.clip_seconds is None:
+        legs = extra_legs(M, torch, dev, stream)
     cfg5 = None
     if world > 1 and not explicit_config and not args.no_cfg5:
         kernel_name = mel.plain_kernel_name()
@@ -553,6 +676,7 @@ def main() -> None:
                          "kernel": kernel_name,
                          "kernel_ms": dominant_ms,
                          "step_ms_events": kernel_ms,
+                         "frac_of_the_whole_step": algo_bytes_per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_note": ("average launch duration of the dominant kernel from a HIP event pair around it in each of 200 calls after the timed region "
                                             "(melspec_time_first_kernel; `step_ms_events` = HIP events around the K timed steps / K, which in the default mode also "
                                             "holds the gated f64 launch behind every f32 launch, ~5 us that return at once on this input)" if dominant_ms is not kernel_ms else
@@ -567,6 +691,12 @@ def main() -> None:
                                     "reused: pageable memory, and memory from melspec_host_alloc (pinned); never `value`")
         if speech is not None:
             res["config"]["speech"] = speech
+        if legs is not None:
+            res["host_api_single_clip_ms"] = legs.pop("host_api_single_clip_ms")
+            res["host_api_single_clip_note"] = ("HipMelSpectrogram::compute_mel_spectrogram on ONE clip of 10 / 60 / 300 s, host memory in and out (PCIe-inclusive, never `value`): "
+                                                "the shape of the reference's published figures (README.md:117-123) and of its #[ignore] benches (src/cuda.rs:547-613)")
+            for k in LEG_NAMES:
+                res["config"][k] = legs[k]
         if cfg5 is not None:
             res["config"]["cfg5"] = cfg5
         if gather is not None:

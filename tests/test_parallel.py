@@ -211,6 +211,8 @@ def test_plain_bench_line_carries_the_speech_leg_and_config5():
 
     one = run()
     assert one["n_gpus"] == 1 and one["config"] == 2 and "speech" in one and "cfg5" not in one
+    # the legs the driver's plain N = 1 run carries next to `value`
+    assert one["legs"] == ["cfg3", "cfg4", "f64", "mel_major", "host_api_single_clip_ms"] and "legs" not in run("--no-legs")
     two = run("--gpus", "2")
     assert two["n_gpus"] == 2 and two["config"] == 2 and two["scaling"] == "weak" and two["shards"] == [[0, 1024], [1024, 2048]]
     c5 = two["cfg5"]
@@ -251,7 +253,7 @@ def test_bench_distributed_branch_runs_on_rccl_at_world_size_one(gpu):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--clips", "64", "--steps", "5", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-cpu-baseline", "--no-host-io", "--no-traffic", "--no-speech", "--no-legs"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

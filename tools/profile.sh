@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-CMD=${PROFILE_CMD:-"python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-traffic --no-speech"}
+CMD=${PROFILE_CMD:-"python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-io --no-traffic --no-speech --no-legs"}
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \

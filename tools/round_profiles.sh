@@ -15,7 +15,7 @@ d = json.load(open(sys.argv[1]))
 print("bench:", d["value"], d["ms_per_step"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "speech ms", d["config"].get("speech", {}).get("ms"))
 PY
 # kernel statistics of the bench command itself (the timed loop's launches dominate the average)
-PROFILE_CMD="python bench.py --steps 800 --warmup 100 --no-cpu-baseline --no-host-io --no-traffic --no-speech" tools/profile.sh $TAG > $OUT/rocprof_summary.txt 2>&1
+PROFILE_CMD="python bench.py --steps 800 --warmup 100 --no-cpu-baseline --no-host-io --no-traffic --no-speech --no-legs" tools/profile.sh $TAG > $OUT/rocprof_summary.txt 2>&1
 tools/profile_configs.sh $TAG > $OUT/rocprof_configs.txt 2>&1
 python tools/guard_bench.py > $OUT/guard.txt 2>&1
 tools/profile_aux.sh $TAG > /dev/null 2>&1
