@@ -173,6 +173,7 @@ inline bool build_fast_tables(double sr, int n_mels, FastTables &out, bool want_
 
 #include "whisper_wave_f64.hpp"
 #include "whisper_six.hpp"
+#include "whisper_six64.hpp"
 
 namespace melspec {
 
@@ -249,6 +250,44 @@ inline bool build_precise_tables(const FastTables &ft, PreciseTables &out, bool 
     out.blob.assign(t_words + mel_floats, 0u);
     std::memcpy(out.blob.data(), t.data(), t.size() * sizeof(double));
     std::memcpy(out.blob.data() + t_words, ft.blob.data() + FastBlob::kMelStart, mel_floats * sizeof(float));
+    while (out.blob.size() % 4) out.blob.push_back(0u);
+    return true;
+}
+
+// Blob of the f64 six-frame kernel (whisper_six64.hpp): [Six64Blob tables in f64][the mel section of the six-frame f32 blob].
+struct Six64Tables {
+    std::vector<uint32_t> blob;
+    int mel_off_words = 0;
+};
+
+inline bool build_six64_tables(const FastTables &ft6, Six64Tables &out) {
+    if (!ft6.interval) return false;
+    constexpr int N = 400, M = 200;
+    std::vector<double> t(Six64Blob::kCount, 0.0);
+    const std::vector<double> win = hann_window(N);
+    for (int tt = 0; tt < 10; ++tt)
+        for (int n1 = 0; n1 < 20; ++n1)
+            for (int c = 0; c < 2; ++c) t[Six64Blob::kWin + tt * Six64Blob::kWinStride + 2 * n1 + c] = win[20 * n1 + 2 * tt + c];
+    for (int tt = 0; tt < 10; ++tt)
+        for (int k1 = 0; k1 < 20; ++k1) {
+            const double a = -2.0 * kPi * ((tt * k1) % M) / M;
+            t[Six64Blob::kTw1 + tt * Six64Blob::kTw1Stride + 2 * k1] = std::cos(a);
+            t[Six64Blob::kTw1 + tt * Six64Blob::kTw1Stride + 2 * k1 + 1] = std::sin(a);
+        }
+    for (int j = 0; j < kSixLanes; ++j)
+        for (int s = 0; s < 11; ++s) {
+            int k = j + 20 * s;                                   // lanes 1..9 (slot 10 unused)
+            if (j == 0) k = s < 6 ? 20 * s : 10 + 20 * (s - 6);   // lane 0: residue 0, then residue 10
+            const double a = -2.0 * kPi * k / N;
+            t[Six64Blob::kTw2 + j * Six64Blob::kTw2Stride + 2 * s] = 2.0 * std::sin(a);      // the power split of precise_phase2 (whisper_wave_f64.hpp)
+            t[Six64Blob::kTw2 + j * Six64Blob::kTw2Stride + 2 * s + 1] = 4.0 * std::cos(a);
+        }
+    const size_t t_words = t.size() * 2;
+    const size_t mel_floats = ft6.blob.size() - SixBlob::kMelStart;
+    out.mel_off_words = static_cast<int>(t_words);
+    out.blob.assign(t_words + mel_floats, 0u);
+    std::memcpy(out.blob.data(), t.data(), t.size() * sizeof(double));
+    std::memcpy(out.blob.data() + t_words, ft6.blob.data() + SixBlob::kMelStart, mel_floats * sizeof(float));
     while (out.blob.size() % 4) out.blob.push_back(0u);
     return true;
 }

@@ -684,6 +684,12 @@ struct melspec_ctx {
     FastTables ft6;
     DevBuf d_blob6;
     size_t lds6 = 0;
+    // the f64 kernel on the six-frame skeleton (whisper400_six64_kernel): plain batches of the six-frame contexts in MELSPEC_PRECISION_F64,
+    // and AUTO's gated second launch
+    bool six64 = false;
+    Six64Tables t64;
+    DevBuf d_blob64x;
+    size_t lds64x = 0;
     // fused n_fft = 512 build (f64, Whisper flavour of the 512-point kernel): plain and ragged batches
     bool fast512 = false;
     FbankFastTables ft512;
@@ -728,8 +734,12 @@ void auto_poll(melspec_ctx *c) {
 
 // frames per work unit of the kernel a batch is planned for (called once per batch, before it is planned).  AUTO plans for the f32
 // kernel: when the batch's vote says "heavy", the f64 kernel walks the same plan (whisper400_precise_kernel, MODE 2).
-int ctx_frames_per_unit(melspec_ctx *c) {
-    if (c->fast) return (c->six && c->precision != MELSPEC_PRECISION_F64) ? kSixFrames : kFPW;
+// layout: a padded / mel-major batch (the f64 kernel of the layouts is the five-frame one)
+int ctx_frames_per_unit(melspec_ctx *c, bool layout = false) {
+    if (c->fast) {
+        if (c->precision == MELSPEC_PRECISION_F64) return (c->six64 && !layout) ? kSixFrames : kFPW;
+        return c->six ? kSixFrames : kFPW;
+    }
     return c->fast512 ? kFbFPW : 1;
 }
 
@@ -798,6 +808,43 @@ int launch_precise(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
     if (c->ft.slots.n_slots <= 8)
         return c->lens_kind == 1 ? launch_precise_t<8, LensI80>(c, desc, stat, stream, gate, gate_value) : launch_precise_t<8, LensRuntime>(c, desc, stat, stream, gate, gate_value);
     return c->lens_kind == 2 ? launch_precise_t<12, LensI128>(c, desc, stat, stream, gate, gate_value) : launch_precise_t<12, LensRuntime>(c, desc, stat, stream, gate, gate_value);
+}
+
+// the f64 six-frame kernel on a plain batch planned in six-frame units: MELSPEC_PRECISION_F64, or -- gate != nullptr -- AUTO's second
+// launch over the plan of the f32 launch in front of it
+template <class Lens>
+int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream, const unsigned *gate, unsigned gate_value) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_six64_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const uint64_t blocks = (desc.n_units + kSix64Waves - 1) / kSix64Waves;
+    static const int per_cu = lab_int("MELSPEC_SIX64_GRID_PER_CU", 1, 1, 4096);   // one 12-wave workgroup is resident per CU
+    const unsigned grid = grid_for_xcd(blocks, c->dev.cus, per_cu);
+    FixSink armed = sink_armed(c, stat, desc, grid);
+    if (gate) armed.frames |= kStatFromGated;
+    Six64Params pp{};
+    pp.b = desc;
+    pp.stat = armed;
+    pp.d_blob = static_cast<const uint32_t *>(c->d_blob64x.p);
+    pp.blob_words = static_cast<int>(c->t64.blob.size());
+    pp.mel_off_words = c->t64.mel_off_words;
+    pp.hop = c->hop_size;
+    pp.n_mels = c->n_mels;
+    pp.slots = c->ft6.slots;
+    pp.gate = gate; pp.gate_value = gate_value;
+    hipLaunchKernelGGL((whisper400_six64_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
+int launch_six64(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream, const unsigned *gate = nullptr, unsigned gate_value = 0) {
+    return c->six_static == 1 ? launch_six64_t<LensSix80>(c, desc, stat, stream, gate, gate_value)
+         : c->six_static == 2 ? launch_six64_t<LensSix64>(c, desc, stat, stream, gate, gate_value)
+         : c->six_static == 3 ? launch_six64_t<LensSix40>(c, desc, stat, stream, gate, gate_value)
+                              : launch_six64_t<LensRuntime>(c, desc, stat, stream, gate, gate_value);
 }
 
 FastParams fast_params(const BatchDesc &desc, const FastTables &ft, const DevBuf &blob, melspec_ctx *c, const FixSink &sink) {
@@ -897,7 +944,10 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
                                                   : launch_fused512<double, kFlavorWhisper, kBlmSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream);
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, 0, 1, 1, 0.0, 0.0, c->dev.cus, stream);
-    if (c->precision == MELSPEC_PRECISION_F64) return launch_precise(c, desc, FixSink{}, stream);
+    if (c->precision == MELSPEC_PRECISION_F64) {
+        if (c->six64 && !layout_batch && desc.frames_per_unit == kSixFrames) return launch_six64(c, desc, FixSink{}, stream);
+        return launch_precise(c, desc, FixSink{}, stream);
+    }
     FixSink sink{};
     bool vote = false;
     if (c->precision == MELSPEC_PRECISION_AUTO) {
@@ -953,6 +1003,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         return launch_precise(c, p5.desc, stat, stream, sink.decision, gate_value);
     }
     if (layout_batch && desc_in.sync_rounds < 0) desc.sync_rounds = 2;
+    if (c->six64 && !layout_batch && desc.frames_per_unit == kSixFrames) return launch_six64(c, desc, stat, stream, sink.decision, gate_value);
     return launch_precise(c, desc, stat, stream, sink.decision, gate_value);
 }
 
@@ -1048,6 +1099,16 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         c->six_static = runtime_lens ? 0 : lens_match<LensSix80>(c->ft6.slots, n_mels) ? 1 : lens_match<LensSix64>(c->ft6.slots, n_mels) ? 2
                         : lens_match<LensSix40>(c->ft6.slots, n_mels) ? 3 : 0;
         if (c->six && (rc = upload(c->d_blob6, c->ft6.blob))) return bail(rc);
+#ifdef MELSPEC_NO_SIX64          // A/B builds (tools/ab_build.sh): the five-frame f64 kernel everywhere
+        const bool want64 = false;
+#else
+        const bool want64 = lab_int("MELSPEC_SIX64", 1, 0, 1) != 0;
+#endif
+        if (c->six && want64 && build_six64_tables(c->ft6, c->t64)) {
+            c->lds64x = c->t64.blob.size() * 4 + static_cast<size_t>(kSix64Waves) * Six64Layout::slice_doubles() * sizeof(double) + 2 * sizeof(uint32_t);
+            c->six64 = c->lds64x <= kLdsLimit;
+            if (c->six64 && (rc = upload(c->d_blob64x, c->t64.blob))) return bail(rc);
+        }
     }
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
@@ -1106,7 +1167,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->d_blob6.release(); c->gt.release(); c->ragged.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->d_blob6.release(); c->d_blob64x.release(); c->gt.release(); c->ragged.release();
     c->fix.release();
     c->dplan.release();
     c->pipe.release();
@@ -1155,6 +1216,8 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
         }
         return "melspec::generic_frame_kernel<256> (f64, one frame per workgroup)";
     }
+    if (c->precision == MELSPEC_PRECISION_F64 && c->six64)
+        return "melspec::whisper400_six64_kernel<9, .> (f64 FFT, six frames per wave, three waves per SIMD)";
     if (c->precision == MELSPEC_PRECISION_F64)
         return c->ft.slots.n_slots <= 8 ? "melspec::whisper400_precise_kernel<8, ., RUNS> (f64 FFT)" : "melspec::whisper400_precise_kernel<12, ., RUNS> (f64 FFT)";
     const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
@@ -1232,7 +1295,7 @@ int melspec_compute_uniform_device_interleaved(melspec_ctx *c, const float *d_pc
     if (!d_pcm || !d_out) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
     HIP_TRY(hipSetDevice(c->dev.device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c),
+    const BatchPlan pl = plan_uniform(d_pcm, d_out, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c, true),
                                       interleaved_width(fpc, min_width), major_column_order == 0);
     return launch_ctx(c, pl.desc, s);
 }
@@ -2931,7 +2994,7 @@ int melspec_tga_encode_pcm_uniform_device(melspec_tga *q, melspec_ctx *c, const 
     d.img = d_images; d.blob = d_blobs; d.ranges = nullptr;
     if (q->keys_used && q->keys_stream != s) HIP_TRY(hipStreamSynchronize(q->keys_stream));
     q->keys_used = true; q->keys_stream = s;
-    BatchPlan pl = plan_uniform(d_pcm, d_images, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c), width, true);
+    BatchPlan pl = plan_uniform(d_pcm, d_images, clip_stride, fpc, n_clips, c->n_mels, ctx_frames_per_unit(c, true), width, true);
     if ((rc = q->unit_ext.ensure(static_cast<size_t>(pl.desc.n_units) * 2 * sizeof(int) + 16))) return rc;
     pl.desc.d_unit_ext = static_cast<int *>(q->unit_ext.p);
     if ((rc = launch_ctx(c, pl.desc, s))) return rc;

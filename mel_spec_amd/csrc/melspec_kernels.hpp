@@ -15,6 +15,7 @@
 #include "fbank_wave.hpp"
 #include "whisper_wave_f64.hpp"
 #include "whisper_six.hpp"
+#include "whisper_six64.hpp"
 #include "whisper_fix64.hpp"
 #include "stream_plan.hpp"
 #include "pow2_wave.hpp"
@@ -1169,6 +1170,93 @@ __global__ __launch_bounds__(kPreciseWaves * 64) void whisper400_precise_kernel(
         else if (RUNS) ++cr.unit;
     }
     guard_wave_done(p.stat, arrive + WAVES - 2, WAVES, lane, flagged);
+}
+
+// ------------------------------------------------------------------------------------
+// The f64 kernel on the six-frame skeleton (whisper_six64.hpp): plain [frame][mel] batches of <= 80 mels, uniform and ragged, a
+// contiguous run of 6-frame units per wave (ClipRun) -- MELSPEC_PRECISION_F64, and AUTO's gated second launch, which walks the very plan
+// of the f32 launch in front of it (same unit size).  Twelve waves per workgroup, one workgroup per CU, three waves per SIMD.
+// LDS words: [f64 tables][f32 mel section of the six-frame blob][WAVES x slice of 1368 doubles][2 words of guard_wave_done].
+// ------------------------------------------------------------------------------------
+struct Six64Params {
+    BatchDesc b;
+    const uint32_t *d_blob;
+    int blob_words;       // multiple of 4
+    int mel_off_words;    // where the f32 mel section (SixBlob::kMelStart.. of the six-frame blob) starts
+    int hop;
+    int n_mels;
+    MelSlots slots;       // woff[] as in the six-frame blob (float offsets from SixBlob's base)
+    FixSink stat;         // statistics only (tab, list unused): the frames that would have tripped the f32 kernels' guard
+    const unsigned *gate; // AUTO's second launch: runs only when *gate == gate_value (the f32 launch's "heavy" verdict)
+    unsigned gate_value;
+};
+
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kSix64Waves * 64, 3) void whisper400_six64_kernel(const Six64Params p) {
+    constexpr int WAVES = kSix64Waves;
+    if (p.gate != nullptr && *p.gate != p.gate_value) return;        // the batch was light: the f32 launch has finished it
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    unsigned *wg_done = ldsw + p.blob_words + WAVES * Six64Layout::slice_doubles() * 2;
+    if (tid < 2) wg_done[tid] = 0;
+    __syncthreads();
+    const double *tb = reinterpret_cast<const double *>(ldsw);
+    // the shared phase-3 code addresses the mel tables as offsets from the base of the six-frame f32 blob
+    const float *fblob = reinterpret_cast<const float *>(ldsw + p.mel_off_words) - SixBlob::kMelStart;
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    double *rows = reinterpret_cast<double *>(ldsw + p.blob_words) + wave * Six64Layout::slice_doubles();
+    float *slice = reinterpret_cast<float *>(rows);
+    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
+    const bool in = lane < kSixFrames * kSixLanes;
+    const int rofs = Six64Layout::row_offset(j);
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
+    const int *starts = reinterpret_cast<const int *>(fblob + SixBlob::kMelStart) + j;
+    const bool stats = p.stat.acc != nullptr;
+    unsigned flagged = 0;
+
+    ClipRun cr;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) {
+        guard_wave_done(p.stat, wg_done, WAVES, lane, 0);
+        return;
+    }
+    for (; cr.unit < cr.end; ++cr.unit) {
+        cr.enter(p.b);
+        const uint64_t f0 = (cr.unit - cr.c_start) * kSixFrames;
+        const uint64_t left = cr.c_frames - f0;
+        const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv;
+        MS_PRIO(0);
+        // The tables never change, and with __restrict__ the compiler knows it: left alone it hoists the unit loop's ~50 sixteen-byte table
+        // reads out of the loop (200 VGPRs of "loop invariants"), spills them in front of the loop and reloads them from scratch inside it.
+        // An offset it cannot see through makes the reads belong to the iteration.
+        int opaque0 = 0;
+        asm volatile("" : "+s"(opaque0));
+        const double *tbi = tb + opaque0;
+        six64_phases12(fl, j, act, rofs, p.hop, tbi, src, rows, slice);
+        __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
+        float vals[NSLOTS];
+        {
+            int st[NSLOTS];
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];       // lanes 60..63 read valid entries too
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, fblob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float *out_tile = cr.c_out + f0 * (uint64_t)n_mels;
+        const bool flag = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice, vals, out_tile, 0);
+        __builtin_amdgcn_wave_barrier();
+        if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(__builtin_amdgcn_ballot_w64(flag))));
+    }
+    guard_wave_done(p.stat, wg_done, WAVES, lane, flagged);
 }
 
 // STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) -- the complex spectrum itself, f64 phases 1-2 of the

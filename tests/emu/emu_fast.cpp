@@ -755,6 +755,71 @@ extern "C" long long emu_whisper_six(const float *pcm, long long n, int hop, int
     return emu_whisper_six_guard(pcm, n, hop, n_mels, sr, mode, out, nullptr);
 }
 
+// ---- whisper_six64.hpp: the f64 kernel on the six-frame skeleton, exchange through LDS in two halves ---------------------------------
+// Step by step as whisper400_six64_kernel runs them, every step over all 64 lanes before the next (what "LDS operations of a wave execute
+// in program order" gives the device): phase 1 -> rows 0..9 -> every lane reads its first row -> rows 10..19 over them -> second row ->
+// phase 2 -> the f32 phases 3-4 of whisper_six.hpp.
+template <int NSLOTS, class Lens>
+static long long run_six64(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
+    FastTables T;
+    Six64Tables T64;
+    if (!build_six_tables(sr, n_mels, T) || !build_six64_tables(T, T64)) return -1;
+    if (n < 400) return 0;
+    const long long frames = (n - 400) / hop + 1;
+    const double *tb = reinterpret_cast<const double *>(T64.blob.data());
+    const float *fblob = reinterpret_cast<const float *>(T64.blob.data() + T64.mel_off_words) - SixBlob::kMelStart;
+    std::vector<double> rows(Six64Layout::slice_doubles());
+    float *slice = reinterpret_cast<float *>(rows.data());
+    std::vector<float> vals(static_cast<size_t>(64) * NSLOTS);
+    const int *starts = reinterpret_cast<const int *>(fblob + SixBlob::kMelStart);
+    for (long long f0 = 0; f0 < frames; f0 += kSixFrames) {
+        const int nv = static_cast<int>(std::min<long long>(kSixFrames, frames - f0));
+        std::fill(rows.begin(), rows.end(), 1.0e300);
+        const float *src = pcm + f0 * hop;
+        auto info = [&](int lane, int &fl, int &j, bool &act) { fl = lane / kSixLanes; j = lane - fl * kSixLanes; act = lane < kSixFrames * kSixLanes && fl < nv; };
+        std::vector<cd> x(64 * 20), u(64 * 10), v(64 * 10);
+        auto X = [&](int lane) -> cd(&)[20] { return *reinterpret_cast<cd(*)[20]>(&x[static_cast<size_t>(lane) * 20]); };
+        auto U = [&](std::vector<cd> &a, int lane) -> cd(&)[10] { return *reinterpret_cast<cd(*)[10]>(&a[static_cast<size_t>(lane) * 10]); };
+        for (int lane = 0; lane < 64; ++lane) { int fl, j; bool act; info(lane, fl, j, act); six64_phase1(fl, j, act, hop, tb, src, X(lane)); }
+        for (int lane = 0; lane < 64; ++lane) { int fl, j; bool act; info(lane, fl, j, act); six64_store_half(fl, j, act, 0, X(lane), rows.data()); }
+        for (int lane = 0; lane < 64; ++lane) { int fl, j; bool act; info(lane, fl, j, act); six64_read_row(fl, act, Six64Layout::row_offset(j), rows.data(), U(u, lane)); }
+        for (int lane = 0; lane < 64; ++lane) { int fl, j; bool act; info(lane, fl, j, act); six64_store_half(fl, j, act, 1, X(lane), rows.data()); }
+        for (int lane = 0; lane < 64; ++lane) { int fl, j; bool act; info(lane, fl, j, act); six64_read_row(fl, act, Six64Layout::row_offset(j), rows.data(), U(v, lane)); }
+        for (int lane = 0; lane < 64; ++lane) { int fl, j; bool act; info(lane, fl, j, act); six64_phase2(fl, j, act, tb, U(u, lane), U(v, lane), slice); }
+        std::vector<float> rise(64 * NSLOTS), fprev(65 * NSLOTS, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; info(lane, fl, j, act);
+            int st[NSLOTS];
+            for (int i = 0; i < NSLOTS; ++i) st[i] = lane < kSixFrames * kSixLanes ? starts[i * kSixLanes + j] : 0;
+            six_phase3_sums<NSLOTS, Lens>(fl, j, act, T.slots, fblob, slice, st,
+                                          *reinterpret_cast<float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                          *reinterpret_cast<float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane) * NSLOTS]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {     // the maxima go behind the power rows, which every lane has read by now
+            int fl, j; bool act; info(lane, fl, j, act);
+            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, *reinterpret_cast<const float(*)[NSLOTS]>(&rise[static_cast<size_t>(lane) * NSLOTS]),
+                                      *reinterpret_cast<const float(*)[NSLOTS]>(&fprev[static_cast<size_t>(lane + 1) * NSLOTS]), slice,
+                                      *reinterpret_cast<float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            int fl, j; bool act; info(lane, fl, j, act);
+            six_phase4<NSLOTS, false, false>(fl, j, act, act, n_mels, slice, *reinterpret_cast<const float(*)[NSLOTS]>(&vals[static_cast<size_t>(lane) * NSLOTS]),
+                                             out + f0 * n_mels, 0);
+        }
+    }
+    return frames;
+}
+
+// mode 0: run-time slot lengths, 1: the compile-time Whisper-80 bank
+extern "C" long long emu_whisper_six64(const float *pcm, long long n, int hop, int n_mels, double sr, int mode, float *out) {
+    if (mode == 1) {
+        FastTables T;
+        if (!build_six_tables(sr, n_mels, T) || !six_lens_ok<LensSix80>(T.slots, n_mels)) return -2;
+        return run_six64<kSixMaxSlots, LensSix80>(pcm, n, hop, n_mels, sr, out);
+    }
+    return run_six64<kSixMaxSlots, LensRuntime>(pcm, n, hop, n_mels, sr, out);
+}
+
 // The in-kernel f64 recompute of one frame (whisper_fix64.hpp + the f32 phases 3-4 of the kernel that owns the frame), as
 // six_fix_unit / wave_fix_unit run it: frame slot f of a unit, the other slots idle.
 static void emu_fix_power_row(const float *frame, const std::vector<double> &tab, float *prow) {

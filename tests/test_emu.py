@@ -34,6 +34,8 @@ def emu():
     L.emu_whisper_precise.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
     L.emu_whisper_six.restype = C.c_longlong
     L.emu_whisper_six.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
+    L.emu_whisper_six64.restype = C.c_longlong
+    L.emu_whisper_six64.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, C.c_int, f32p]
     L.emu_w512_wave.restype = C.c_longlong
     L.emu_w512_wave.argtypes = [f32p, C.c_longlong, C.c_int, C.c_int, C.c_double, f32p]
     L.emu_blm_wave.restype = C.c_longlong
@@ -180,6 +182,31 @@ def _precise(emu, x, hop=160, n_mels=80, sr=16000.0):
 def test_precise_kernel_is_f64_accurate(emu, oracle, jfk, n_mels):
     want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels)
     assert np.abs(_precise(emu, jfk, n_mels=n_mels) - want).max() <= 2e-6
+
+
+def _six64(emu, x, hop=160, n_mels=80, sr=16000.0, mode=0):
+    x = np.ascontiguousarray(x, np.float32)
+    nf = 0 if len(x) < 400 else (len(x) - 400) // hop + 1
+    out = np.full((nf, n_mels), np.nan, np.float32)
+    f32p = C.POINTER(C.c_float)
+    assert emu.lib.emu_whisper_six64(x.ctypes.data_as(f32p), len(x), hop, n_mels, sr, mode, out.ctypes.data_as(f32p)) == nf
+    return out
+
+
+@pytest.mark.parametrize("hop,n_mels,n,mode", [(160, 80, None, 1), (160, 80, None, 0), (128, 40, 3000, 0), (320, 64, 5000, 0), (160, 80, 400, 1),
+                                               (160, 80, 400 + 5 * 160 + 3, 1), (160, 80, 400 + 6 * 160, 1), (1, 8, 420, 0)])
+def test_six_frame_f64_kernel_exchange_in_two_halves(emu, oracle, jfk, hop, n_mels, n, mode):
+    """whisper_six64.hpp on the host, step by step in the kernel's order (rows 0..9, first read, rows 10..19 over them, second read):
+    f64-accurate on speech and on the tone-over-a-quiet-floor signal the f32 kernels cannot hold, every slot count, partial last units."""
+    x = jfk if n is None else jfk[20000:20000 + n]
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, hop, n_mels)
+    got = _six64(emu, x, hop=hop, n_mels=n_mels, mode=mode)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+    if n is None:
+        t = np.arange(32000) / 16000.0
+        y = (0.9 * np.sin(2 * np.pi * 3333.3 * t) + 10 ** (-70 / 20) * np.random.default_rng(0).standard_normal(32000)).astype(np.float32)
+        assert np.abs(_six64(emu, y, mode=mode) - oracle.compute_mel_spectrogram_cpu(y, 400, 160, 80)).max() <= 2e-6
+        assert (_six64(emu, np.zeros(4000, np.float32), mode=mode) == -1.5).all()
 
 
 def _auto(emu, x, hop=160, n_mels=80, sr=16000.0):

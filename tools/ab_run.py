@@ -46,6 +46,18 @@ if case in ("cfg2", "cfg4", "f64", "mm", "f32") or case.startswith("nm"):
         got = out.download((nf, nm), offset_bytes=5 * nf * nm * 4)
         want = O.compute_mel_spectrogram_cpu(O.synth_pcm(5, clip_len), 400, 160, nm, 16000.0)
         assert np.abs(got - want).max() <= 1e-4, np.abs(got - want).max()
+elif case == "speech":
+    # the reference's own fixture tiled to the config-2 batch, default mode: the launch's vote hands it to the gated f64 kernel
+    jfk = O.load_wav_f32(os.path.join(sys.argv[1], "tests", "golden", "jfk_f32le.wav"))
+    x = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(64)])
+    pcm.upload(np.tile(x, (n_clips // 64, 1)).reshape(-1))
+    m = M.HipMelSpectrogram(400, 160, 16000.0, 80)
+    nf = m.num_frames(clip_len)
+    out = M.DeviceBuffer(n_clips * (nf + 8) * 80 * 4)
+    spin(lambda: m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), m.synchronize)
+    ms = min(m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=50, iters=300) for _ in range(3))
+    got = out.download((nf, 80), offset_bytes=5 * nf * 80 * 4)
+    assert np.abs(got - O.compute_mel_spectrogram_cpu(x[5], 400, 160, 80, 16000.0)).max() <= 1e-4
 elif case == "w512":
     m = M.HipMelSpectrogram(512, 160, 16000.0, 80)
     out = M.DeviceBuffer(n_clips * m.num_frames(clip_len) * 80 * 4)
