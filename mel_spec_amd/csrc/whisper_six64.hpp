@@ -20,7 +20,9 @@
 #include "whisper_six.hpp"
 #include "whisper_wave_f64.hpp"
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MELSPEC_SIX64_NO_FENCE)
+// (Scheduling fences between the pieces of the table reads -- five taps / twiddles at a time -- were built while the first form spilled; with
+// the phases in one divergent region (six64_phases12) the kernel holds 168 VGPRs without them and is 1 % faster: 0.4349 against 0.4394 ms.)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MELSPEC_SIX64_FENCE)
 #define MS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define MS_SCHED_FENCE() ((void)0)
@@ -80,8 +82,6 @@ MS_DEV void six64_phase1(int fl, int t, bool active, int hop, const double *MS_R
     __builtin_amdgcn_sched_barrier(MS_SCHED_LOADS_FIRST);        // six_phase1 (whisper_six.hpp) says why
 #endif
     const double *w = tb + Six64Blob::kWin + t * Six64Blob::kWinStride;
-    // the table reads in pieces of five: issued all at once (what the scheduler does when left alone) twenty 16-byte reads are 80 VGPRs on
-    // top of the 40 of the samples and the 80 of x -- past the 168 of three waves per SIMD, i.e. scratch traffic in the unit loop
 #pragma unroll
     for (int n1 = 0; n1 < 20; ++n1) {
         const cd wv = ldc(w + 2 * n1);
