@@ -183,7 +183,15 @@ __device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg,
     if ((old >> kStatShift) + 1 != fx.n_groups) return;
     const unsigned long long tripped = ((old & kStatMask) + total) & kStatMask;
     __hip_atomic_store(fx.acc, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // every other workgroup of the launch has been here
-    if (fx.vote && (vote_poll(fx) & kVoteHeavy)) return;       // a voting launch that stood down: the f64 launch behind it reports the batch
+    if (fx.vote) {
+        // A voting launch that stood down: the f64 launch behind it reports the batch.  Every sampling workgroup has cast its vote before
+        // it arrived here, so this launch's verdict has been stored -- by relaxed stores that nothing orders against this relaxed load
+        // (ADVICE r04): a stale word would make both launches count the batch.  One wave per launch retries until the word carries this
+        // launch's number (bounded; a fence here or on the stores would write back an XCD's L2).
+        unsigned v = vote_poll(fx);
+        for (unsigned spin = 0; v == 0 && spin < 4096; ++spin) { __builtin_amdgcn_s_sleep(1); v = vote_poll(fx); }
+        if (v & kVoteHeavy) return;
+    }
     if (tripped) __hip_atomic_fetch_add(fx.count, tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long tag = static_cast<unsigned long long>(fx.seq & 0xffffffu) << kStatShift;
     __hip_atomic_store(fx.host, tag | tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2848,7 +2856,10 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
                     va = xa - mean; vb = xb - mean;
                     if (p.preemph > 0.0) {
                         vb -= p.preemph * (xa - mean);
-                        if (i0 > 0 || cur.start > 0) va -= p.preemph * ((double)raw.before[r] - mean);
+                        // the sample in front of xa: the clamped pair of an odd frame's last sample (i0 == last) holds it first (ADVICE r04:
+                        // raw.before is then x[last - 2]; the Povey window's last tap is 0, so no test could see it)
+                        const double xp = (double)(i0 + 1 <= last ? raw.before[r] : raw.pair[r].x);
+                        if (i0 > 0 || cur.start > 0) va -= p.preemph * (xp - mean);
                     }
                 }
                 return cpx<double>{va * w.x, vb * w.y};
@@ -2921,6 +2932,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
             };
             double plo[P / 2], phi[P / 2];
             double pmid, pmid2;
+            __builtin_amdgcn_wave_barrier();                // the split's reads stay behind the last pass's writes ...
             if (kHalves) {
 #pragma unroll
                 for (int r = 0; r < P / 2; ++r) {
@@ -2944,6 +2956,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
                 for (int r = 0; r < P / 2; ++r) { plo[r] = sqrt(plo[r]); phi[r] = sqrt(phi[r]); }
                 pmid = sqrt(pmid);
             }
+            __builtin_amdgcn_wave_barrier();                // ... and in front of the power row's writes, which alias the points at M >= 1024
 #pragma unroll
             for (int r = 0; r < P / 2; ++r) {
                 pw[l + r * LF] = plo[r];

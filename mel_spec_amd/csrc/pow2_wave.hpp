@@ -172,12 +172,21 @@ MS_DEV void pow2_pass(int l, int Ns, const double *tab, double *z, cpx<double> *
     using S = Pow2Shape<LOGM>;
     constexpr int M = S::M, NB = S::P / R;                   // butterflies per lane
     cpx<double> v[NB][R];
+    // The passes work in place: every lane's reads of a pass must be issued before any lane's writes of it, and behind the writes of the
+    // pass before.  The hardware runs a wave's LDS operations in program order; these barriers (no instruction) make the PROGRAM order the
+    // source order -- without them only the compiler's inability to tell the swizzled addresses apart keeps a load from moving over a store.
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = l + S::LF * i;
 #pragma unroll
         for (int r = 0; r < R; ++r) v[i][r] = FIRST ? reg[r] : ldc(z + 2 * pow2_slot<LOGM>(j + r * (M / R)));
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_wave_barrier();
+#endif
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int j = l + S::LF * i;

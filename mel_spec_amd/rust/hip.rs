@@ -853,11 +853,14 @@ impl HipMelSpectrogram {
         assert_eq!(offsets.len(), lengths.len());
         let frames: Vec<usize> = lengths.iter().map(|&n| self.num_frames(n as usize)).collect();
         for (o, n) in offsets.iter().zip(lengths) {
-            if (o + n) as usize > pcm.len() {
-                return Err(HipError::Runtime("clip outside the PCM buffer".into()));
+            // checked: a wrapping `o + n` would let a crafted pair through and drive device reads out of bounds from safe code
+            match o.checked_add(*n) {
+                Some(end) if end <= pcm.len() as u64 => {}
+                _ => return Err(HipError::Runtime("clip outside the PCM buffer".into())),
             }
         }
-        if frames.iter().sum::<usize>() * self.n_mels > out.len() {
+        let need = frames.iter().try_fold(0usize, |a, &f| a.checked_add(f)).and_then(|f| f.checked_mul(self.n_mels));
+        if need.map_or(true, |n| n > out.len()) {
             return Err(HipError::Runtime("output buffer too small".into()));
         }
         check(unsafe {
@@ -883,7 +886,8 @@ impl HipMelSpectrogram {
     pub fn compute_uniform_device_interleaved(&mut self, pcm: &HipDeviceBuffer<f32>, clip_len: usize, n_clips: usize, major_column_order: bool,
                                               min_width: usize, out: &mut HipDeviceBuffer<f32>) -> Result<usize, HipError> {
         let w = unsafe { melspec_interleaved_width(self.ctx, clip_len, min_width) };
-        if n_clips * clip_len > pcm.len() || n_clips * w * self.n_mels > out.len() {
+        let fits = |a: usize, b: usize, c: usize, cap: usize| a.checked_mul(b).and_then(|x| x.checked_mul(c)).map_or(false, |x| x <= cap);
+        if !fits(n_clips, clip_len, 1, pcm.len()) || !fits(n_clips, w, self.n_mels, out.len()) {
             return Err(HipError::Runtime("buffer too small".into()));
         }
         check(unsafe {
@@ -1125,7 +1129,8 @@ impl HipTga {
         let (mut n, mut stride, mut last) = (0u32, 0usize, 0usize);
         check(unsafe { melspec_tga_layout(mel.n_mels as c_int, w, &mut n, &mut stride, &mut last) })?;
         let blob_stride = stride * n as usize;
-        if n_clips * clip_len > pcm.len() || n_clips * mel.n_mels * w > images.len() || n_clips * blob_stride > blobs.len() {
+        let fits = |a: usize, b: usize, c: usize, cap: usize| a.checked_mul(b).and_then(|x| x.checked_mul(c)).map_or(false, |x| x <= cap);
+        if !fits(n_clips, clip_len, 1, pcm.len()) || !fits(n_clips, mel.n_mels, w, images.len()) || !fits(n_clips, blob_stride, 1, blobs.len()) {
             return Err(HipError::Runtime("buffer too small".into()));
         }
         check(unsafe {
