@@ -737,7 +737,7 @@ void auto_poll(melspec_ctx *c) {
 // layout: a padded / mel-major batch (the f64 kernel of the layouts is the five-frame one)
 int ctx_frames_per_unit(melspec_ctx *c, bool layout = false) {
     if (c->fast) {
-        if (c->precision == MELSPEC_PRECISION_F64) return (c->six64 && !layout) ? kSixFrames : kFPW;
+        if (c->precision == MELSPEC_PRECISION_F64) return c->six64 ? kSixFrames : kFPW;
         return c->six ? kSixFrames : kFPW;
     }
     return c->fast512 ? kFbFPW : 1;
@@ -817,6 +817,7 @@ int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_six64_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_kernel)");
+        if (!rc) rc = allow_big_lds(&whisper400_six64_layout_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_layout_kernel)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
@@ -835,7 +836,9 @@ int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
     pp.n_mels = c->n_mels;
     pp.slots = c->ft6.slots;
     pp.gate = gate; pp.gate_value = gate_value;
-    hipLaunchKernelGGL((whisper400_six64_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+    if (layout) hipLaunchKernelGGL((whisper400_six64_layout_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+    else hipLaunchKernelGGL((whisper400_six64_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
@@ -945,6 +948,12 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, 0, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precision == MELSPEC_PRECISION_F64) {
+        if (c->six64 && desc.frames_per_unit == kSixFrames && desc.d_unit_prefix == nullptr) {
+            // mel-major stores of the twelve-wave kernel, measured (tools/mm64_sync_probe.py, 1024 x 10 s): consecutive pairs 0.491 ms, none 0.493,
+            // pairs four apart 0.496, fours 0.512, fours one from each SIMD (the f32 kernel's best) 0.520, workgroup barrier 0.533
+            if (layout_batch && desc_in.sync_rounds < 0) desc.sync_rounds = 2;
+            return launch_six64(c, desc, FixSink{}, stream);
+        }
         if (c->six64 && !layout_batch && desc.frames_per_unit == kSixFrames) return launch_six64(c, desc, FixSink{}, stream);
         return launch_precise(c, desc, FixSink{}, stream);
     }
@@ -996,6 +1005,10 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     const unsigned gate_value = (c->fix.seq & 0xffffffu) << 2 | kVoteDecided | kVoteHeavy;
     FixSink stat{};
     stat.count = sink.count; stat.acc = sink.acc; stat.host = sink.host;
+    if (c->six64 && layout_batch && desc.frames_per_unit == kSixFrames && desc.d_unit_prefix == nullptr) {
+        if (desc_in.sync_rounds < 0) desc.sync_rounds = 2;
+        return launch_six64(c, desc, stat, stream, sink.decision, gate_value);          // the layouts on the six-frame f64 kernel: the f32 launch's own plan
+    }
     if (layout_batch && desc.frames_per_unit != kFPW) {
         // the layouts' f64 kernel deals units of its own size: the same (uniform) batch planned for five frames per unit
         BatchPlan p5 = plan_uniform(desc.pcm, desc.out, desc.clip_stride, desc.frames_per_clip, desc.n_clips, c->n_mels, kFPW, desc.out_width, desc.mel_major != 0);
@@ -1105,7 +1118,8 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         const bool want64 = lab_int("MELSPEC_SIX64", 1, 0, 1) != 0;
 #endif
         if (c->six && want64 && build_six64_tables(c->ft6, c->t64)) {
-            c->lds64x = c->t64.blob.size() * 4 + static_cast<size_t>(kSix64Waves) * Six64Layout::slice_doubles() * sizeof(double) + 2 * sizeof(uint32_t);
+            c->lds64x = c->t64.blob.size() * 4 + static_cast<size_t>(kSix64Waves) * Six64Layout::slice_doubles() * sizeof(double) +
+                        (kSix64Waves + 2) * sizeof(uint32_t);       // + the layout kernel's RoundSync counters + guard_wave_done's two words
             c->six64 = c->lds64x <= kLdsLimit;
             if (c->six64 && (rc = upload(c->d_blob64x, c->t64.blob))) return bail(rc);
         }

@@ -1267,6 +1267,77 @@ __global__ __launch_bounds__(kSix64Waves * 64, 3) void whisper400_six64_kernel(c
     guard_wave_done(p.stat, wg_done, WAVES, lane, flagged);
 }
 
+// The same kernel for the padded / mel-major layouts (interleave_frames, src/mel.rs:480-544; BatchDesc::out_width / mel_major): the units
+// are dealt round-robin and walked in workgroup-uniform rounds, the waves that hold adjacent units kept in step before their stores
+// (RoundSync, as in whisper400_six_kernel) -- MELSPEC_PRECISION_F64 on a layout, and AUTO's gated launch behind a voting layout launch
+// (same six-frame plan).  Uniform batches only (the layouts are).
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kSix64Waves * 64, 3) void whisper400_six64_layout_kernel(const Six64Params p) {
+    constexpr int WAVES = kSix64Waves;
+    if (p.gate != nullptr && *p.gate != p.gate_value) return;
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    unsigned *arrive = ldsw + p.blob_words + WAVES * Six64Layout::slice_doubles() * 2;      // RoundSync counters, then guard_wave_done's two words
+    if (tid < WAVES + 2) arrive[tid] = 0;
+    __syncthreads();
+    const double *tb = reinterpret_cast<const double *>(ldsw);
+    const float *fblob = reinterpret_cast<const float *>(ldsw + p.mel_off_words) - SixBlob::kMelStart;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    double *rows = reinterpret_cast<double *>(ldsw + p.blob_words) + wave * Six64Layout::slice_doubles();
+    float *slice = reinterpret_cast<float *>(rows);
+    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
+    const bool in = lane < kSixFrames * kSixLanes;
+    const int rofs = Six64Layout::row_offset(j);
+    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
+    const int *starts = reinterpret_cast<const int *>(fblob + SixBlob::kMelStart) + j;
+    const bool stats = p.stat.acc != nullptr;
+    unsigned flagged = 0;
+    RoundSync<WAVES> rs(p.b.sync_rounds, wave, arrive);
+    const uint64_t step = (uint64_t)gridDim.x * WAVES;
+    for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES; first < p.b.n_units; first += step) {
+        const uint64_t unit = first + rs.slot;
+        const bool have = unit < p.b.n_units;
+        const UnitLoc loc = locate_unit(p.b, have ? unit : first);
+        const uint64_t f0 = loc.unit * kSixFrames;
+        const uint64_t left = (have && f0 < loc.frames) ? loc.frames - f0 : 0;
+        const int nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
+        const uint64_t width = p.b.out_width;                     // columns per clip: its frames plus the zero columns of a padded layout
+        const uint64_t wleft = have ? width - f0 : 0;
+        const int ns = wleft < (uint64_t)kSixFrames ? (int)wleft : kSixFrames;
+        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
+        const bool act = in && fl < nv;
+        MS_PRIO(0);
+        int opaque0 = 0;
+        asm volatile("" : "+s"(opaque0));
+        six64_phases12(fl, j, act, rofs, p.hop, tb + opaque0, src, rows, slice);
+        __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
+        float vals[NSLOTS];
+        {
+            int st[NSLOTS];
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];
+            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
+            six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, fblob, slice, st, rise, fprev);
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
+        }
+        __builtin_amdgcn_wave_barrier();
+        rs.template before_stores<2>(lane);
+        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
+        int kmin = 0x7fffffff, kmax = 0;
+        const bool flag = six_phase4<NSLOTS, true, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, out_tile, p.b.mel_major ? (long long)width : 0, &kmin, &kmax);
+        __builtin_amdgcn_wave_barrier();
+        if (p.b.d_unit_ext && have) unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
+        if (stats) flagged += static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(__builtin_amdgcn_ballot_w64(flag))));
+        rs.after_round();
+    }
+    guard_wave_done(p.stat, arrive + WAVES, WAVES, lane, flagged);
+}
+
 // STFT export: Spectrogram::compute_all_cpu (src/stft.rs:89-115) -- the complex spectrum itself, f64 phases 1-2 of the
 // precise kernel, a contiguous run of units per wave.  Output [clip][frame][bins] complex<T>; BatchDesc's "floats" are
 // 32-bit words of that layout (floats per frame = bins * 2 * sizeof(T) / 4).

@@ -96,6 +96,7 @@ def test_vote_is_not_wedged_by_non_finite_statistics(gpu, oracle, jfk):
     """A batch full of NaN / Inf frames, then noise, then speech, on one context in the default mode: every batch is decided by its own
     vote (NaN frames never trip the guard: their bands all sit on the floor), and the regime after each is the input's."""
     m = gpu.HipMelSpectrogram(400, 160, SR, 80)
+    m.set_precision("auto")                   # (the suite is also run with MELSPEC_PRECISE=1, which starts contexts in f64)
     n = 32000
     bad = np.stack([np.full(n, np.nan, np.float32) if c % 2 else np.full(n, np.inf, np.float32) for c in range(64)])
     noise = np.stack([_loud(oracle, n, c) for c in range(64)])
