@@ -138,8 +138,10 @@ MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_
 
 // (The sample in front of each pair as a row_ror:1 DPP move of the left neighbour's second sample instead of 12 more loads per lane:
 // 0.7101 vs 0.7103 ms, neutral -- the loads hit L1.)
-// (Loading the samples once for both the frame sum and the column -- one round trip, 26 conversions and 13 loads fewer per unit --
-// was measured: no difference, 0.733 ms either way, and 20 more VGPRs.  The second read hits L1 and two waves hide it.)
+// (Round 2 measured "the samples loaded once for both the frame sum and the column" as no difference.  Round 5 built it again as
+// fb_kaldi_input below -- every load unconditional AND branch-free, so that nothing of the column sits behind the mean's round trip -- and it
+// is -10 %: config 3 0.709 -> 0.642 ms, the kernel without CMN 0.616 -> 0.549 ms, same box.  fb_partial_sum / fb_column stay for the host
+// emulation, which sums the partials across its emulated lanes itself; the arithmetic is the same operation for operation.)
 // phase 1 (after the frame mean is known): lane t does column n2 = t (13 non-zero inputs for t < 8, else 12).
 template <class T>
 MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this frame's first sample */, bool clip_start,
@@ -279,6 +281,51 @@ template <class T> MS_DEV T row_sum16(T v) {
 #else
 template <class T> MS_DEV T row_sum16(T v) { return v; }      // host pass of the kernel source only; tests/emu sums the partials itself
 #endif
+
+// Kaldi input with ONE set of loads: fb_partial_sum + row_sum16 + fb_column's framing -- 13 pairs and the 13 samples in front of them stay
+// in f32 registers (39) for both the frame sum and the column, so the column does not start with a second memory round trip behind the
+// mean.  Same operations in the same order as the two functions (bit-identical).  Every load unconditional and branch-free: the 13th pair of lanes
+// n2 >= 8 re-reads pair 0 and is dropped by selects (a guarded load is a memory round trip of its own).
+template <class T>
+MS_DEV void fb_kaldi_input(const float *frame, int n2, T preemph, bool patch_first, const T *tblob, cpx<T> (&x)[16]) {
+    f2 c[13];
+    float prev[13];
+#pragma unroll
+    for (int n1 = 0; n1 < 13; ++n1) {
+        const int i = (n1 < 12 || n2 < 8) ? 32 * n1 + 2 * n2 : 2;       // (not 0: its predecessor would be frame[-1], which for the first frame of a buffer is not mapped)
+        c[n1] = load2_unaligned(frame + i);
+        prev[n1] = frame[(n1 == 0 && patch_first) ? 0 : i - 1];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(MS_SCHED_LOADS_FIRST);
+#endif
+    const bool has13 = n2 < 8;
+    T s = 0;
+#pragma unroll
+    for (int n1 = 0; n1 < 12; ++n1) s += static_cast<T>(c[n1].x) + static_cast<T>(c[n1].y);
+    {
+        const T t13 = static_cast<T>(c[12].x) + static_cast<T>(c[12].y);
+        s = has13 ? s + t13 : s;
+    }
+    const T mean = row_sum16<T>(s) / T(400);                 // src/fbank.rs:165-166
+    const T dc = (T(1) - preemph) * mean;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+        x[n1] = {T(0), T(0)};
+        if (n1 < 13) {
+            const int i = 32 * n1 + 2 * n2;                  // (n1 == 12, n2 >= 8: past the frame -- the window read stays inside its 512 entries, the result is dropped)
+            const T x0 = static_cast<T>(c[n1].x), x1 = static_cast<T>(c[n1].y);
+            const T pe = (x0 - preemph * static_cast<T>(prev[n1])) - dc;
+            const T y0 = (n1 == 0 && patch_first) ? x0 - mean : pe;
+            const T y1 = (x1 - preemph * x0) - dc;
+            const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
+            const T a = y0 * w.re, b = y1 * w.im;
+            if (n1 < 12) x[n1] = {a, b};
+            else x[n1] = {has13 ? a : T(0), has13 ? b : T(0)};
+        }
+    }
+}
+
 
 // phase 2a: this lane's row of the exchange buffer through a 16-point DFT: own[k2] = Z[r + 16*k2]
 template <class T>

@@ -1612,9 +1612,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         MS_PRIO(0);
         if (FLAVOR == kFlavorKaldi) {
             const float *frame = loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            // frame mean (src/fbank.rs:165-166): the 16 partial sums of the frame's lanes in a fixed tree, over DPP (row_sum16)
-            const T mean = row_sum16<T>(act ? fb_partial_sum<T>(frame, j) : T(0)) / T(400);
-            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+            // the frame mean (src/fbank.rs:165-166: the frame's sixteen lanes, a fixed tree over DPP), DC removal, pre-emphasis and the Povey window
+            // from ONE set of loads (fb_kaldi_input)
+            if (act) {
+                cpx<T> x[16];
+                fb_kaldi_input<T>(frame, j, preemph, f0 + fl == 0 && j == 0, tblob, x);
+                fb_column_finish<T>(x, j, tblob, slice + fl * L::kXStride + 2 * j);
+            }
         } else if (FLAVOR == kFlavorWhisper) {
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
         } else {
@@ -1867,9 +1871,13 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             const bool act = fl < nv;
             MS_PRIO(0);
             const float *frame = pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift;
-            // frame mean (src/fbank.rs:165-166): the 16 partial sums of the frame's lanes in a fixed tree, over DPP (row_sum16)
-            const T mean = row_sum16<T>(act ? fb_partial_sum<T>(frame, j) : T(0)) / T(400);
-            fb_phase1<T>(fl, j, act, frame, f0 + fl == 0, mean, preemph, tblob, slice);
+            // the frame mean (src/fbank.rs:165-166: the frame's sixteen lanes, a fixed tree over DPP), DC removal, pre-emphasis and the Povey window
+            // from ONE set of loads (fb_kaldi_input)
+            if (act) {
+                cpx<T> x[16];
+                fb_kaldi_input<T>(frame, j, preemph, f0 + fl == 0 && j == 0, tblob, x);
+                fb_column_finish<T>(x, j, tblob, slice + fl * L::kXStride + 2 * j);
+            }
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(1);
             {
