@@ -367,7 +367,7 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
            "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
            "frames_tripping_the_guard_per_step": tripped, "fraction_tripping": tripped / frames,
            "kernel_of_each_of_the_first_batches": ["gated f64 kernel (the launch's vote: heavy)" if h else "f32 kernel + f64 recompute of tripped frames" for h in regimes],
-           "kernel": "melspec::whisper400_precise_kernel<8, ., gated walk> (f64 FFT) behind the voting f32 launch", "parity_max_abs_diff": worst, "steps": k}
+           "kernel": "melspec::whisper400_six64_kernel<9, ., gated> (f64 FFT, six frames per wave) behind the voting f32 launch", "parity_max_abs_diff": worst, "steps": k}
     mel.close()
     del pcm, out
     return res
