@@ -102,7 +102,9 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
  *                   both within 1e-4); F32 and F64 do not have that, nor AUTO after melspec_set_auto_adaptive(ctx, 0).
  *   F64             window, FFT and |X|^2 in f64 for every frame: ~4e-7 from the reference, about 60 % of the f32 rate.
  *   F32             the f32 kernel alone: ~3e-5 on speech and noise, up to ~5e-4 on a line over a floor 70..90 dB down.
- * Geometries on the generic kernel and the fused n_fft = 512 kernel always compute in f64. */
+ * Geometries on the generic kernels always compute in f64.  The fused n_fft = 512 kernel (Whisper flavour, 80 / 128 mels) computes in f64
+ * in AUTO and F64 and in f32 -- no guard, the accuracy of the f32 FFT: ~1e-6 on noise, 1e-2 on the quiet bands of speech -- in F32
+ * (round 5; melspec_precision() reports what the next call will use). */
 #define MELSPEC_PRECISION_AUTO 0
 #define MELSPEC_PRECISION_F64  1
 #define MELSPEC_PRECISION_F32  2
@@ -396,6 +398,12 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
 int melspec_blm_compute_batch_host(melspec_blm *b, const float *samples, const uint64_t *offsets, const uint64_t *lengths, uint32_t n_clips,
                                    float *out, const uint64_t *out_offsets, size_t out_capacity_floats, uint64_t *total_columns);
 int melspec_blm_release_scratch(melspec_blm *b);   /* as melspec_fbank_release_scratch */
+/* Arithmetic of the fused kernel (n_fft 512 / win_length 400, 80 or 128 mels).  MELSPEC_PRECISION_F32: f32 window, FFT, power and
+ * projection -- the reference's own arithmetic type for this frontend (src/mel.rs:251-252,356-357), as far from the f64 evaluation of
+ * its definition as upstream's f32 code is (2.4e-4 on jfk_f32le.wav) at ~0.8 x the time.  AUTO (default) / F64: f64 up to |X|^2, within 1e-4
+ * of that evaluation on every input.  melspec_blm_precision: what the next call will use (F32 or F64). */
+int melspec_blm_set_precision(melspec_blm *b, int mode);
+int melspec_blm_precision(const melspec_blm *b);
 int melspec_blm_synchronize(melspec_blm *b, void *stream);
 
 /* ---- streaming: Spectrogram::add + RingBuffer::maybe_mel (src/stft.rs:48-86, src/rb.rs:60-121) ---- */

@@ -86,6 +86,8 @@ SIGNATURES = {
     "melspec_release_scratch": (C.c_int, [_vp]),
     "melspec_fbank_release_scratch": (C.c_int, [_vp]),
     "melspec_blm_release_scratch": (C.c_int, [_vp]),
+    "melspec_blm_set_precision": (C.c_int, [_vp, C.c_int]),
+    "melspec_blm_precision": (C.c_int, [_vp]),
     "melspec_stft_bins": (C.c_size_t, [_vp, C.c_int]),
     "melspec_stft_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, C.c_int, C.c_int, _vp]),
     "melspec_stft_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, C.c_int, C.c_int, _vp]),

@@ -67,7 +67,7 @@ template <class T>
 struct FbankLayout {
     // exchange rows, units of T; padded so that the 9 job lanes of a frame reading 9 different rows hit
     // different banks (f64: 16-byte complex reads, rows 68 words apart)
-    static constexpr int kXRow = sizeof(T) == 8 ? 34 : 32;
+    static constexpr int kXRow = sizeof(T) == 8 ? 34 : 36;            // f32: 144-byte rows, 9 sixteen-byte slots apart (odd)
     static constexpr int kXStride = 16 * kXRow;            // lanes of different frames never share an LDS access group
     static constexpr int kPStride = 259;                   // f32 power rows (bins 0..256), aliased over the rows
     static constexpr int kSumOff = 0;                      // 64 partial sums (units of T): the host form of the frame mean in tests/emu (the kernels: row_sum16)

@@ -603,6 +603,23 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
     // frame-major plain output (Kaldi always, Whisper-512 without a layout): a contiguous run of units per wave, 8-wave shape only
     constexpr bool kCanRun = FLAVOR != kFlavorNemo;
     const bool plain = !fp.b.mel_major && (fp.b.d_unit_prefix != nullptr || fp.b.out_width == fp.b.frames_per_clip);
+    if constexpr (sizeof(T) == 4) {
+        // MELSPEC_PRECISION_F32: the f32 instantiation, twelve waves = three per SIMD (158-168 VGPRs without spills; at sixteen waves the
+        // 128-VGPR budget spills 24-38 registers inside the unit loop and the kernel is slower than the f64 one, profiles/r05_fb512_twelve_waves.txt)
+        static_assert(Lens::kStatic, "the f32 instantiation exists for the compile-time banks");
+        static std::atomic<uint64_t> attr12{0};
+        if (!device_done(attr12)) {
+            int rc = allow_big_lds(&fbank512_wave_kernel<T, 12, 1, FLAVOR, NSLOTS, Lens>, "hipFuncSetAttribute(fbank512_wave_kernel<float>, 12 waves)");
+            if (!rc && kCanRun) rc = allow_big_lds(&fbank512_wave_kernel<T, 12, 1, FLAVOR, NSLOTS, Lens, kCanRun>, "hipFuncSetAttribute(fbank512_wave_kernel<float>, runs)");
+            if (rc) return rc;
+            mark_device_done(attr12);
+        }
+        const unsigned grid12 = grid_for_xcd((fp.b.n_units + 11) / 12, cus, 1);
+        if (kCanRun && plain) hipLaunchKernelGGL((fbank512_wave_kernel<T, 12, 1, FLAVOR, NSLOTS, Lens, kCanRun>), dim3(grid12), dim3(768), lds, s, fp);
+        else hipLaunchKernelGGL((fbank512_wave_kernel<T, 12, 1, FLAVOR, NSLOTS, Lens>), dim3(grid12), dim3(768), lds, s, fp);
+        HIP_TRY(hipGetLastError());
+        return MELSPEC_OK;
+    }
     const bool runs = kCanRun && plain && waves == 8;
     static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
     if (!device_done(attr_done)) {
@@ -633,6 +650,39 @@ bool fb_lens_match(const MelSlots &ms) {
     for (int i = 0; i < Lens::kSlots; ++i)
         if (ms.len[i] != Lens::len(i) || ms.woff[i] != Lens::woff(i)) return false;
     return true;
+}
+
+// The f32 side of a fused 512-point context (MELSPEC_PRECISION_F32; NeMo / Whisper-512 with one of the compile-time banks).
+constexpr int kFused512F32Waves = 12;
+struct Fused512F32 {
+    bool ok = false;
+    FbankFastTables ft;
+    DevBuf d_blob;
+    size_t lds = 0;
+    // extra: bytes per wave behind the slice (the Whisper flavour's frame maxima live inside the slice; slack as on the f64 side)
+    int finish(size_t extra) {
+        lds = ft.blob.size() * 4 + static_cast<size_t>(kFused512F32Waves) * (FbankLayout<float>::slice_elems() * sizeof(float) + extra) + 64;
+        ok = lds <= kLdsLimit;
+        return ok ? upload(d_blob, ft.blob) : MELSPEC_OK;
+    }
+    void params(FbankFastParams &fp) const {
+        fp.d_blob = static_cast<const uint32_t *>(d_blob.p);
+        fp.blob_words = static_cast<int>(ft.blob.size());
+        fp.mel_off_words = ft.mel_off_words;
+        fp.slots = ft.slots;
+    }
+};
+bool w512_f32_bank(const MelSlots &ms) { return fb_lens_match<LensSlaney80W>(ms) || fb_lens_match<LensSlaney128>(ms); }
+bool nemo_f32_bank(const MelSlots &ms) { return fb_lens_match<LensSlaney128>(ms) || fb_lens_match<LensSlaney80>(ms); }
+int launch_w512_f32(const Fused512F32 &f, FbankFastParams fp, int cus, hipStream_t s) {
+    f.params(fp);
+    if (fb_lens_match<LensSlaney80W>(f.ft.slots)) return launch_fused512<float, kFlavorWhisper, kFbSlots, LensSlaney80W>(kFused512F32Waves, fp, f.lds, cus, s);
+    return launch_fused512<float, kFlavorWhisper, kBlmSlots, LensSlaney128>(kFused512F32Waves, fp, f.lds, cus, s);
+}
+int launch_nemo_f32(const Fused512F32 &f, FbankFastParams fp, int cus, hipStream_t s) {
+    f.params(fp);
+    if (fb_lens_match<LensSlaney128>(f.ft.slots)) return launch_fused512<float, kFlavorNemo, kBlmSlots, LensSlaney128>(kFused512F32Waves, fp, f.lds, cus, s);
+    return launch_fused512<float, kFlavorNemo, kFbSlots, LensSlaney80>(kFused512F32Waves, fp, f.lds, cus, s);
 }
 }  // namespace
 
@@ -696,6 +746,7 @@ struct melspec_ctx {
     DevBuf d_blob512;
     size_t lds512 = 0;
     int waves512 = 4;
+    Fused512F32 f512;           // MELSPEC_PRECISION_F32 at n_fft = 512 (the 80- and 128-mel banks)
     // f64 FFT build of the n_fft = 400 kernel: the whole batch (MELSPEC_PRECISION_F64) or the queued frames (AUTO)
     int precision = MELSPEC_PRECISION_AUTO;
     PreciseTables pt;
@@ -941,6 +992,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
         fp.n_mels = c->n_mels;
         fp.use_log = 1; fp.use_power = 1;
         fp.slots = c->ft512.slots;
+        if (c->precision == MELSPEC_PRECISION_F32 && c->f512.ok) return launch_w512_f32(c->f512, fp, c->dev.cus, stream);
         if (fb_lens_match<LensSlaney80W>(c->ft512.slots)) return launch_fused512<double, kFlavorWhisper, kFbSlots, LensSlaney80W>(c->waves512, fp, c->lds512, c->dev.cus, stream);
         if (fb_lens_match<LensSlaney128>(c->ft512.slots)) return launch_fused512<double, kFlavorWhisper, kBlmSlots, LensSlaney128>(c->waves512, fp, c->lds512, c->dev.cus, stream);
         return c->ft512.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorWhisper, kFbSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream)
@@ -1105,6 +1157,7 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         c->lds512 = c->ft512.blob.size() * 4 + static_cast<size_t>(c->waves512) * slice_bytes;
         c->fast512 = c->lds512 <= kLdsLimit;
         if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
+        if (c->fast512 && w512_f32_bank(c->ft512.slots) && build_whisper512_tables<float>(c->dense, n_mels, c->f512.ft) && (rc = c->f512.finish(512))) return bail(rc);
     }
     if (c->fast && build_six_tables(c->dense, n_mels, c->ft6)) {
         c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves + 4);   // + arrival counters + the vote's words
@@ -1181,7 +1234,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->d_blob6.release(); c->d_blob64x.release(); c->gt.release(); c->ragged.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->f512.d_blob.release(); c->d_blob6.release(); c->d_blob64x.release(); c->gt.release(); c->ragged.release();
     c->fix.release();
     c->dplan.release();
     c->pipe.release();
@@ -1208,17 +1261,22 @@ int melspec_set_precision(melspec_ctx *c, int mode) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
     if (mode != MELSPEC_PRECISION_AUTO && mode != MELSPEC_PRECISION_F64 && mode != MELSPEC_PRECISION_F32)
         return fail(MELSPEC_ERR_INVALID_ARG, "precision must be MELSPEC_PRECISION_AUTO, _F64 or _F32");
-    c->precision = mode;        // geometries on the generic / fused-512 kernels are f64 whatever the mode
+    c->precision = mode;        // geometries on the generic kernels are f64 whatever the mode; the fused n_fft = 512 kernel is f64 unless F32 is asked for
     return MELSPEC_OK;
 }
-int melspec_precision(const melspec_ctx *c) { return !c ? MELSPEC_PRECISION_AUTO : (c->fast ? c->precision : MELSPEC_PRECISION_F64); }
+int melspec_precision(const melspec_ctx *c) {
+    if (!c) return MELSPEC_PRECISION_AUTO;
+    if (c->fast) return c->precision;
+    return c->precision == MELSPEC_PRECISION_F32 && c->fast512 && c->f512.ok ? MELSPEC_PRECISION_F32 : MELSPEC_PRECISION_F64;
+}
 int melspec_set_precise(melspec_ctx *c, int on) { return melspec_set_precision(c, on ? MELSPEC_PRECISION_F64 : MELSPEC_PRECISION_AUTO); }
-int melspec_is_precise(const melspec_ctx *c) { return c && (c->precision == MELSPEC_PRECISION_F64 || !c->fast) ? 1 : 0; }   // generic and fused-512 paths are f64
+int melspec_is_precise(const melspec_ctx *c) { return c && melspec_precision(c) == MELSPEC_PRECISION_F64 ? 1 : 0; }   // the generic kernels are f64 whatever the mode
 
 const char *melspec_plain_kernel_name(const melspec_ctx *c) {
     // the same decisions launch_ctx takes for a plain (uniform or ragged, [frame][mel]) batch
     if (!c) return "";
     if (!c->fast) {
+        if (c->fast512 && c->precision == MELSPEC_PRECISION_F32 && c->f512.ok) return "melspec::fbank512_wave_kernel<float, 12, 1, kFlavorWhisper, RUNS> (n_fft = 512, f32, three waves per SIMD)";
         if (c->fast512) return "melspec::fbank512_wave_kernel<double, 8, 1, kFlavorWhisper, RUNS> (n_fft = 512, f64)";
         switch (pow2_logm(c->gt)) {
             case 6: return "melspec::pow2_frame_kernel<6, kFlavorWhisper> (n_fft = 128, f64, frames owned by lane groups of a wave)";
@@ -3230,6 +3288,8 @@ struct melspec_blm {
     DevBuf d_blob;
     size_t fast_lds = 0;
     int waves = 4;
+    int precision = MELSPEC_PRECISION_AUTO;     // melspec_blm_set_precision
+    Fused512F32 f32;            // MELSPEC_PRECISION_F32: the reference's own arithmetic type for this frontend (src/mel.rs:251-252,356-357)
     DevBuf h2d, d2h;
     HostPipe pipe;              // melspec_blm_compute_batch_host
 };
@@ -3294,6 +3354,8 @@ int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *
     }
     if (b->fast) {
         if ((rc = upload(b->d_blob, b->ft.blob))) return bail(rc);
+        if (nemo_f32_bank(b->ft.slots) && build_blm_fast_tables<float>(cfg->sample_rate, cfg->n_mels, cfg->f_min, f_max, cfg->htk != 0, cfg->norm != 0, b->f32.ft) &&
+            (rc = b->f32.finish(0))) return bail(rc);
     } else {
         // the reference's f32 tables: symmetric Hann(win_length) centred in the n_fft frame (src/mel.rs:708-719), f32 weights
         const int N = cfg->n_fft, bins = N / 2 + 1;
@@ -3321,8 +3383,23 @@ void melspec_blm_destroy(melspec_blm *b) {
     if (!b) return;
     if (b->dev.device >= 0) (void)hipSetDevice(b->dev.device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    b->d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release(); b->ragged.release(); b->aux.release(); b->pipe.release();
+    b->d_blob.release(); b->f32.d_blob.release(); b->h2d.release(); b->d2h.release(); b->gt.release(); b->ragged.release(); b->aux.release(); b->pipe.release();
     delete b;
+}
+
+// F32: the reference's own arithmetic type for this frontend (f32 window, FFT, power and projection, src/mel.rs:251-252,356-357) on the
+// f32 instantiation of the fused kernel -- as far from the f64 evaluation of the definition as upstream's own f32 code is (2.4e-4 on
+// jfk_f32le.wav, 5e-4 on a chirp; tools/f32_512_probe.py).  AUTO / F64 (the default): f64 from the window to |X|^2, within 1e-4 of that
+// evaluation on every input.  Contexts without an f32 kernel (other geometries, other banks) compute in f64 whatever the mode.
+int melspec_blm_set_precision(melspec_blm *b, int mode) {
+    if (!b) return fail(MELSPEC_ERR_INVALID_ARG, "blm is NULL");
+    if (mode != MELSPEC_PRECISION_AUTO && mode != MELSPEC_PRECISION_F64 && mode != MELSPEC_PRECISION_F32)
+        return fail(MELSPEC_ERR_INVALID_ARG, "precision must be MELSPEC_PRECISION_AUTO, _F64 or _F32");
+    b->precision = mode;
+    return MELSPEC_OK;
+}
+int melspec_blm_precision(const melspec_blm *b) {       // the arithmetic the next call will use: MELSPEC_PRECISION_F32 or _F64
+    return b && b->precision == MELSPEC_PRECISION_F32 && b->fast && b->f32.ok ? MELSPEC_PRECISION_F32 : MELSPEC_PRECISION_F64;
 }
 
 size_t melspec_blm_num_frames(const melspec_blm *b, size_t n) { return b ? static_cast<size_t>(blm_valid_frames(b, n)) : 0; }
@@ -3361,7 +3438,8 @@ int melspec_blm_compute_uniform_device(melspec_blm *b, const float *d_pcm, uint6
     fp.clip_len = static_cast<long long>(clip_len);
     fp.org0 = b->cfg.center ? -200 : 56;      // tap 0 of the window sits at position (512-400)/2 of the frame
     fp.slots = b->ft.slots;
-    if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+    if (b->precision == MELSPEC_PRECISION_F32 && b->f32.ok) rc = launch_nemo_f32(b->f32, fp, b->dev.cus, s);
+    else if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
     else if (fb_lens_match<LensSlaney80>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kFbSlots, LensSlaney80>(b->waves, fp, b->fast_lds, b->dev.cus, s);
     else rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
                                               : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);
@@ -3481,7 +3559,8 @@ int melspec_blm_compute_ragged_device(melspec_blm *b, const float *d_pcm, const 
         fp.d_len = static_cast<const uint64_t *>(b->aux.p);
         fp.d_valid = fp.d_len + n_clips;
         fp.slots = b->ft.slots;
-        if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
+        if (b->precision == MELSPEC_PRECISION_F32 && b->f32.ok) rc = launch_nemo_f32(b->f32, fp, b->dev.cus, s);
+        else if (fb_lens_match<LensSlaney128>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kBlmSlots, LensSlaney128>(b->waves, fp, b->fast_lds, b->dev.cus, s);
         else if (fb_lens_match<LensSlaney80>(b->ft.slots)) rc = launch_fused512<double, kFlavorNemo, kFbSlots, LensSlaney80>(b->waves, fp, b->fast_lds, b->dev.cus, s);
         else rc = b->ft.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorNemo, kFbSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s)
                                                   : launch_fused512<double, kFlavorNemo, kBlmSlots>(b->waves, fp, b->fast_lds, b->dev.cus, s);

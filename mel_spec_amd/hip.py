@@ -616,6 +616,16 @@ class BatchLogMelSpectrogram:
         _check(rc, construct=True)
         self._h = h
 
+    def set_precision(self, mode: str) -> None:
+        """melspec_blm_set_precision: "f32" = the reference's own arithmetic type for this frontend (src/mel.rs:251-252,356-357) on the
+        f32 kernel; "auto" (default) / "f64" = f64 up to |X|^2, within 1e-4 of the f64 evaluation of the definition on every input."""
+        _check(lib().melspec_blm_set_precision(self._h, HipMelSpectrogram.PRECISION[mode]))
+
+    @property
+    def precision(self) -> str:
+        """what the next call computes in: 'f32' or 'f64'"""
+        return "f32" if int(lib().melspec_blm_precision(self._h)) == 2 else "f64"
+
     def num_frames(self, n_samples: int) -> int:
         return int(lib().melspec_blm_num_frames(self._h, n_samples))
 

@@ -74,6 +74,8 @@ unsafe extern "C" {
     // BatchLogMelSpectrogram (src/mel.rs:171-418)
     fn melspec_blm_create(out: *mut *mut BlmHandle, device: c_int, cfg: *const BlmConfigC) -> c_int;
     fn melspec_blm_destroy(b: *mut BlmHandle);
+    fn melspec_blm_set_precision(b: *mut BlmHandle, mode: c_int) -> c_int;
+    fn melspec_blm_precision(b: *const BlmHandle) -> c_int;
     fn melspec_blm_padded_frames(b: *const BlmHandle, n: usize) -> usize;
     fn melspec_blm_num_frames(b: *const BlmHandle, n: usize) -> usize;
     fn melspec_blm_compute_host(b: *mut BlmHandle, samples: *const f32, n: usize, out: *mut f32, cap: usize, rows: *mut usize, cols: *mut usize) -> c_int;
@@ -616,6 +618,14 @@ impl HipBatchLogMel {
             return Err(crate::mel::BatchLogMelError::InvalidConfig(last_error()));
         }
         Ok(Self { b, n_mels: config.n_mels })
+    }
+    /// Additive: `true` = the reference's own f32 arithmetic for this frontend (src/mel.rs:251-252,356-357) on the f32 kernel; `false`
+    /// (default) = f64 up to |X|^2.  Returns what the next call will use.
+    pub fn set_f32(&mut self, on: bool) -> bool {
+        unsafe {
+            melspec_blm_set_precision(self.b, if on { 2 } else { 0 });
+            melspec_blm_precision(self.b) == 2
+        }
     }
     /// `compute(&self, samples) -> Array2<f32>` (n_mels, padded frames), src/mel.rs:299-302; the second value is
     /// `BatchLogMelOutput::valid_frames` (src/mel.rs:387-395).
