@@ -106,6 +106,15 @@ MS_HD float f32_mul_rn(float a, float b) {
     return p;
 #endif
 }
+// `v`, as a value the optimiser has to take from here: what is derived from it is no loop invariant.  Lane constants hoisted out of
+// the unit loop are what the register allocator spills first in the twelve-wave kernels, and a reload inside the loop waits (vmcnt)
+// for the previous unit's stores; a v_xor per address is cheaper.  A scheduling boundary: once per phase, not per access.
+MS_DEV int fresh_lane_value(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 // a / b correctly rounded in f32 (the reference's plain `/`)
 MS_HD float f32_div_rn(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)

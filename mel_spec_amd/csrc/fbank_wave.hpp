@@ -67,8 +67,16 @@ template <class T>
 struct FbankLayout {
     // exchange rows, units of T; padded so that the 9 job lanes of a frame reading 9 different rows hit
     // different banks (f64: 16-byte complex reads, rows 68 words apart)
-    static constexpr int kXRow = sizeof(T) == 8 ? 34 : 36;            // f32: 144-byte rows, 9 sixteen-byte slots apart (odd)
+    // f32 (MELSPEC_PRECISION_F32, round 5): unpadded 128-byte rows whose eight 16-byte slots are XOR-swizzled with the row number --
+    // the sixteen lanes that read their rows with ds_read_b128 meet eight different slots twice (256 bytes over a 128-byte port: nothing
+    // to gain), the sixteen lanes that write a row fill it; a frame is 2 KB, a wave's slice 8 KB (rows 144 bytes apart: 9 KB, and the
+    // staged feature-major store of the NeMo flavour would not fit beside twelve slices)
+    static constexpr int kXRow = sizeof(T) == 8 ? 34 : 32;
     static constexpr int kXStride = 16 * kXRow;            // lanes of different frames never share an LDS access group
+    // offset (units of T) of element n2 of exchange row k1 from the frame's first row
+    MS_HD static constexpr int xoff(int k1, int n2) {
+        return sizeof(T) == 8 ? k1 * kXRow + 2 * n2 : k1 * kXRow + ((((n2 >> 1) ^ (k1 & 7)) << 2) | ((n2 & 1) << 1));
+    }
     static constexpr int kPStride = 259;                   // f32 power rows (bins 0..256), aliased over the rows
     static constexpr int kSumOff = 0;                      // 64 partial sums (units of T): the host form of the frame mean in tests/emu (the kernels: row_sum16)
     static constexpr int slice_elems() { return (kFbFPW * kXStride + 1) & ~1; }   // units of T
@@ -91,20 +99,22 @@ MS_DEV T fb_partial_sum(const float *frame, int t) {
 }
 
 // DFT over n1 of one column, twiddle by W_256^{n2*k1}, write the 16 exchange rows.
-template <class T>
-MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *MS_RESTRICT tblob, T *MS_RESTRICT xo /* &row[0][n2] */) {
+// FRESH (the f32 NeMo kernel, which has no register to spare): the swizzled offsets are recomputed per unit, see fresh_lane_value
+template <class T, bool FRESH = false>
+MS_DEV void fb_column_finish(cpx<T> (&x)[16], int n2, const T *MS_RESTRICT tblob, T *MS_RESTRICT xf /* the frame's first exchange row */) {
     using L = FbankLayout<T>;
     fft16(x);
     const T *tw = tblob + FbankBlob::kTw1 + n2 * FbankBlob::kTw1Stride;
-    stc(xo, x[0]);
+    const int e = FRESH ? fresh_lane_value(n2) : n2;
+    stc(xf + L::xoff(0, e), x[0]);
 #pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) stc(xo + k1 * L::kXRow, cmul(x[k1], ldc(tw + 2 * k1)));
+    for (int k1 = 1; k1 < 16; ++k1) stc(xf + L::xoff(k1, e), cmul(x[k1], ldc(tw + 2 * k1)));
 }
 
 // One 16-point column n2: samples frame[32*n1 + 2*n2 + {0,1}] below 400 (the rest of the 512-point frame is
 // zero padding), pre-emphasis, DC removal, window, DFT over n1, twiddle by W_256^{n2*k1}, exchange rows.
 template <class T>
-MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_first, const T *tblob, T *xo /* &row[0][n2] */) {
+MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_first, const T *tblob, T *xo /* the frame's first exchange row */) {
     cpx<T> x[16];
     const T dc = (T(1) - preemph) * mean;
     // every load first and unconditional: 13 pairs (lanes n2 >= 8 have no 13th pair: they re-read pair 0 and drop it) and
@@ -147,7 +157,7 @@ template <class T>
 MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this frame's first sample */, bool clip_start,
                       T mean, T preemph, const T *tblob, T *slice) {
     if (!active) return;
-    fb_column<T>(frame, t, preemph, mean, clip_start && t == 0, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
+    fb_column<T>(frame, t, preemph, mean, clip_start && t == 0, tblob, slice + fl * FbankLayout<T>::kXStride);
 }
 
 // ---- Whisper flavour with n_fft = 512 (Spectrogram::compute_mel_spectrogram_cpu, src/stft.rs:119-138, at the
@@ -165,7 +175,7 @@ MS_DEV void w512_phase1(int fl, int t, bool active, const float *frame, const T 
         const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
         x[n1] = {static_cast<T>(s.x) * w.re, static_cast<T>(s.y) * w.im};
     }
-    fb_column_finish<T>(x, t, tblob, slice + fl * FbankLayout<T>::kXStride + 2 * t);
+    fb_column_finish<T>(x, t, tblob, slice + fl * FbankLayout<T>::kXStride);
 }
 
 // ---- NeMo/Parakeet flavour (BatchLogMelSpectrogram, src/mel.rs:299-385) --------------------------
@@ -173,12 +183,7 @@ MS_DEV void w512_phase1(int fl, int t, bool active, const float *frame, const T 
 // |X|, so they are processed at positions 0..399 exactly like the Kaldi frame.  Sample `s` of the clip is
 // the pre-emphasised waveform (f32, two roundings like `current - (coeff * prev)`, src/mel.rs:696-706),
 // zero outside [0, len) (centre padding, src/mel.rs:685-694).
-MS_DEV float nemo_sample(const float *clip, long long s, long long len, float coeff) {
-    if (s < 0 || s >= len) return 0.0f;
-    const float cur = clip[s];
-    if (coeff == 0.0f || s == 0) return cur;
-    return cur - f32_mul_rn(coeff, clip[s - 1]);
-}
+// (nemo_sample(s): 0 for s outside [0, len); clip[s] for s == 0 or coeff == 0; clip[s] - f32(coeff * clip[s - 1]) otherwise.)
 
 // `inside`: every sample this frame touches, and the one before its first, lies inside the clip (all frames
 // but the first two and last two of a centred clip), so the guards and the clip-start special case drop out
@@ -191,6 +196,11 @@ MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2,
     cpx<T> x[16];
     f2 c[13];
     float prev[13];
+    // the clip in the frame's own coordinates: sample k of the frame is clip[org + k], inside the clip for lo <= k < hi (32-bit: the
+    // frame is 400 samples long; a frame that touches its clip at all has lo < 400 and hi > 0)
+    const long long lo64 = -org, hi64 = len - org;
+    const int lo = lo64 < -1024 ? -1024 : (lo64 > 1024 ? 1024 : static_cast<int>(lo64));
+    const int hi = hi64 < -1024 ? -1024 : (hi64 > 1024 ? 1024 : static_cast<int>(hi64));
     if (INSIDE) {
         // interior frame: every load first (13 pairs and the 13 samples in front of them), arithmetic afterwards
 #pragma unroll
@@ -203,6 +213,18 @@ MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2,
                 if (PRE) prev[n1] = s[-1];
             }
         }
+    } else {
+        // a frame at an end of its clip (two units per clip): the same loads from CLAMPED positions, all of them issued before anything
+        // is used, and nemo_sample's cases as selects below.  (Round 5; the form before -- nemo_sample per sample, a branch and a wait
+        // around each of its 52 loads -- was a chain of memory round trips, and since round 5's staged store every wave of the workgroup
+        // waits at most one round for the wave that walks it.)
+#pragma unroll
+        for (int n1 = 0; n1 < 13; ++n1) {
+            const int i = 32 * n1 + 2 * n2;
+            auto at = [&](int k) { return clip[org + (k < lo ? lo : (k >= hi ? hi - 1 : k))]; };
+            prev[n1] = at(i - 1);
+            c[n1] = {at(i), at(i + 1)};
+        }
     }
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
@@ -214,14 +236,17 @@ MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2,
                 y0 = PRE ? c[n1].x - f32_mul_rn(coeff, prev[n1]) : c[n1].x;
                 y1 = PRE ? c[n1].y - f32_mul_rn(coeff, c[n1].x) : c[n1].y;
             } else {
-                y0 = nemo_sample(clip, org + i, len, coeff);
-                y1 = nemo_sample(clip, org + i + 1, len, coeff);
+                // nemo_sample(s): 0 outside [0, len); clip[0] for s == 0; clip[s] - coeff * clip[s - 1] otherwise (coeff == 0: the product is
+                // an exact zero of either sign and cur - (+-0) == cur, except that -0 - (+0) keeps its sign: the same bits as `cur`)
+                const float p0 = c[n1].x - f32_mul_rn(coeff, prev[n1]), p1 = c[n1].y - f32_mul_rn(coeff, c[n1].x);
+                y0 = (i < lo || i >= hi) ? 0.0f : ((i == lo || coeff == 0.0f) ? c[n1].x : p0);
+                y1 = (i + 1 < lo || i + 1 >= hi) ? 0.0f : ((i + 1 == lo || coeff == 0.0f) ? c[n1].y : p1);
             }
             const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
             x[n1] = {static_cast<T>(y0) * w.re, static_cast<T>(y1) * w.im};
         }
     }
-    fb_column_finish<T>(x, n2, tblob, xo);
+    fb_column_finish<T, sizeof(T) == 4>(x, n2, tblob, xo);
 }
 
 // all_inside: wave-uniform -- every active frame of the wave is an interior frame (the guarded form runs only for the
@@ -229,7 +254,7 @@ MS_DEV void nemo_column(const float *clip, long long org, long long len, int n2,
 template <class T>
 MS_DEV void nemo_phase1(int fl, int t, bool active, bool all_inside, const float *clip, long long org, long long len, float coeff,
                         const T *tblob, T *slice) {
-    T *xo = slice + fl * FbankLayout<T>::kXStride + 2 * t;
+    T *xo = slice + fl * FbankLayout<T>::kXStride;
     if (all_inside) {
         if (coeff != 0.0f) {
             if (active) nemo_column<T, true, true>(clip, org, len, t, coeff, tblob, xo);
@@ -328,12 +353,23 @@ MS_DEV void fb_kaldi_input(const float *frame, int n2, T preemph, bool patch_fir
 
 
 // phase 2a: this lane's row of the exchange buffer through a 16-point DFT: own[k2] = Z[r + 16*k2]
-template <class T>
+template <class T, bool FRESH = false>
 MS_DEV void fb_phase2_dft(int fl, int r, bool active, const T *slice, cpx<T> (&own)[16]) {
     if (!active) return;
     const T *row = slice + fl * FbankLayout<T>::kXStride + r * FbankLayout<T>::kXRow;
+    if constexpr (sizeof(T) == 4) {
+        // two elements per 16-byte slot, logical slot i at physical slot i ^ (r & 7) (FbankLayout::xoff)
+        const int sw = FRESH ? fresh_lane_value((r & 7) << 2) : (r & 7) << 2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) own[i] = ldc(row + 2 * i);
+        for (int i = 0; i < 8; ++i) {
+            const f4 v = *reinterpret_cast<const f4 *>(row + ((i << 2) ^ sw));
+            own[2 * i] = {v.x, v.y};
+            own[2 * i + 1] = {v.z, v.w};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) own[i] = ldc(row + 2 * i);
+    }
     fft16(own);
 }
 

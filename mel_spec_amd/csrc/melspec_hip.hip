@@ -352,7 +352,7 @@ BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_stride, u
     // together (RoundSync in melspec_kernels.hpp): -1 = the measured best of the kernel that runs, resolved in launch_ctx.
     // Lab builds: MELSPEC_MM_SYNC 0 none, 1 one workgroup barrier per round, 2/4/8 sub-group barrier over consecutive waves,
     // 16 + 2/4/8 over waves WAVES / size apart; MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
-    static const int mm_mode = [] { const int v = lab_int("MELSPEC_MM_SYNC", -1, -1, 31); const int sz = v & 15; return (v <= 1 || ((sz == 2 || sz == 4 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();
+    static const int mm_mode = [] { const int v = lab_int("MELSPEC_MM_SYNC", -1, -1, 31); const int sz = v & 15; return (v <= 1 || ((sz == 2 || sz == 3 || sz == 4 || sz == 6 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();   // 3 / 6: the twelve-wave kernels only
     static const bool fm_on = lab_int("MELSPEC_FM_SYNC", 0, 0, 1) != 0;
     b.sync_rounds = mel_major ? mm_mode : (fm_on ? 1 : 0);
     b.frames_per_unit = frames_per_unit;
@@ -660,8 +660,9 @@ struct Fused512F32 {
     DevBuf d_blob;
     size_t lds = 0;
     // extra: bytes per wave behind the slice (the Whisper flavour's frame maxima live inside the slice; slack as on the f64 side)
-    int finish(size_t extra) {
-        lds = ft.blob.size() * 4 + static_cast<size_t>(kFused512F32Waves) * (FbankLayout<float>::slice_elems() * sizeof(float) + extra) + 64;
+    // tail: bytes behind the slices and the sixteen counter words (the NeMo flavour's staged rows)
+    int finish(size_t extra, size_t tail = 0) {
+        lds = ft.blob.size() * 4 + static_cast<size_t>(kFused512F32Waves) * (FbankLayout<float>::slice_elems() * sizeof(float) + extra) + 64 + tail;
         ok = lds <= kLdsLimit;
         return ok ? upload(d_blob, ft.blob) : MELSPEC_OK;
     }
@@ -681,6 +682,7 @@ int launch_w512_f32(const Fused512F32 &f, FbankFastParams fp, int cus, hipStream
 }
 int launch_nemo_f32(const Fused512F32 &f, FbankFastParams fp, int cus, hipStream_t s) {
     f.params(fp);
+    fp.b.sync_rounds = 0;        // StagedRows instead of RoundSync
     if (fb_lens_match<LensSlaney128>(f.ft.slots)) return launch_fused512<float, kFlavorNemo, kBlmSlots, LensSlaney128>(kFused512F32Waves, fp, f.lds, cus, s);
     return launch_fused512<float, kFlavorNemo, kFbSlots, LensSlaney80>(kFused512F32Waves, fp, f.lds, cus, s);
 }
@@ -3355,7 +3357,7 @@ int melspec_blm_create(melspec_blm **out, int device, const melspec_blm_config *
     if (b->fast) {
         if ((rc = upload(b->d_blob, b->ft.blob))) return bail(rc);
         if (nemo_f32_bank(b->ft.slots) && build_blm_fast_tables<float>(cfg->sample_rate, cfg->n_mels, cfg->f_min, f_max, cfg->htk != 0, cfg->norm != 0, b->f32.ft) &&
-            (rc = b->f32.finish(0))) return bail(rc);
+            (rc = b->f32.finish(0, StagedRows<kFused512F32Waves>::bytes(cfg->n_mels)))) return bail(rc);
     } else {
         // the reference's f32 tables: symmetric Hann(win_length) centred in the n_fft frame (src/mel.rs:708-719), f32 weights
         const int N = cfg->n_fft, bins = N / 2 + 1;

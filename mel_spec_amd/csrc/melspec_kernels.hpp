@@ -1550,6 +1550,81 @@ struct FbankFastParams {
 
 constexpr int kFlavorKaldi = 0, kFlavorNemo = 1, kFlavorWhisper = 2;
 
+// The feature-major store of the f32 NeMo kernel, staged through LDS (round 5).  A wave's unit is four adjacent columns of every mel
+// row: stored directly that is 16 bytes per row and wave (32 with pairs of waves kept in step, RoundSync) -- 135 write requests per
+// unit, 1.5 x write amplification, and a fifth of the kernel's time.  Here the WAVES units of a round (adjacent units: WAVES x 4
+// adjacent columns) are put into an LDS image [mel][WAVES x 4] and stored as runs of WAVES x 16 bytes per mel row by all threads, a
+// 16-byte piece each.  Two images: a wave drains round r - 1 (after its own phases of round r, when every wave has long staged r - 1:
+// the wait below has a round of slack, so the waves keep drifting up to one round apart) and then stages round r over the image of
+// round r - 2, which every wave drained before it staged r - 1.  One LDS counter, no workgroup barrier.
+// Rows are kCols + 4 floats apart (13 sixteen-byte pieces at twelve waves): the sixteen lanes of a frame (mels j, j + 15, ...) write
+// sixteen different 4-bank groups, and a lane's NSLOTS stores are one base address + compile-time offsets (an XOR swizzle of unpadded
+// rows costs a VGPR per slot, which the twelve-wave kernel does not have).
+template <int WAVES>
+struct StagedRows {
+    static constexpr int kCols = WAVES * kFbFPW;
+    static constexpr int kPitch = kCols + 4;
+    struct alignas(16) UnitInfo {
+        float *col;          // &out[mel 0][first column of the unit]
+        long long row_w;     // floats between mel rows
+        int ns;              // columns of the unit that exist in the output (0: no unit this round)
+        int pad;
+    };
+    MS_HD static constexpr size_t image_floats(int n_mels) { return static_cast<size_t>(n_mels) * kPitch; }
+    MS_HD static constexpr size_t bytes(int n_mels) { return 2 * (image_floats(n_mels) * sizeof(float) + WAVES * sizeof(UnitInfo)); }
+
+    float *image;            // [2][n_mels][kPitch]
+    UnitInfo *info;          // [2][WAVES]
+    unsigned *count;         // units staged by the workgroup so far (every wave stages every round, with or without a unit)
+    int n_mels;
+    unsigned round = 0;
+
+    __device__ __forceinline__ StagedRows(void *base, unsigned *counter, int mels) : count(counter), n_mels(mels) {
+        image = static_cast<float *>(base);
+        info = reinterpret_cast<UnitInfo *>(image + 2 * image_floats(n_mels));
+    }
+    __device__ __forceinline__ void wait_staged(unsigned rounds, int lane) const {
+        if (lane == 0)
+            while (__hip_atomic_load(count, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < rounds * WAVES) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // all threads: the image of round `r` to global memory.  tid: the thread's index, opaque to the optimiser (the task -> row / piece
+    // arithmetic is wanted here, once per round, not hoisted out of the unit loop into registers that spill)
+    __device__ __forceinline__ void drain(unsigned r, int tid) const {
+        typedef float v4u __attribute__((ext_vector_type(4), aligned(4)));
+        const float *img = image + (r & 1u) * image_floats(n_mels);
+        const UnitInfo *ui = info + (r & 1u) * WAVES;
+        for (int task = tid; task < n_mels * WAVES; task += WAVES * 64) {
+            const int m = task / WAVES, c = task - m * WAVES;
+            const UnitInfo u = ui[c];
+            const f4 v = ld4(img + m * kPitch + (c << 2));
+            float *dst = u.col + static_cast<long long>(m) * u.row_w;
+            if (u.ns == kFbFPW) {
+                *reinterpret_cast<v4u *>(dst) = v4u{v.x, v.y, v.z, v.w};
+            } else {
+                if (u.ns > 0) dst[0] = v.x;
+                if (u.ns > 1) dst[1] = v.y;
+                if (u.ns > 2) dst[2] = v.z;
+            }
+        }
+    }
+    // a wave's unit of this round (every lane calls; vals: this lane's mel j + 15 i of frame fl, zero for a column past the valid frames)
+    template <int NSLOTS>
+    __device__ __forceinline__ void put(int wave, int lane, const float (&vals)[NSLOTS], float *col, long long row_w, int ns) {
+        const int l = fresh_lane_value(lane), fl = l / kFbLanes, j = l - fl * kFbLanes;      // derived here, not held across the unit loop
+        float *mine = image + (round & 1u) * image_floats(n_mels) + j * kPitch + (wave << 2) + fl;
+        if (j < kFbOwn) {
+#pragma unroll
+            for (int i = 0; i < NSLOTS; ++i)
+                if (j + kFbOwn * i < n_mels) mine[i * kFbOwn * kPitch] = vals[i];
+        }
+        if (lane == 0) info[(round & 1u) * WAVES + wave] = UnitInfo{col, row_w, ns, 0};
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) __hip_atomic_fetch_add(count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++round;
+    }
+};
+
 // FLAVOR = Kaldi: Fbank::compute (src/fbank.rs:141-236), frame-major output, CMN by cmn_kernel.
 // FLAVOR = Whisper: compute_mel_spectrogram_cpu at n_fft = 512 (src/stft.rs:119-138): 512-sample frames, Hann,
 //                 log10 / per-frame clamp / (x+4)/4, frame-major output (plain and ragged batches).
@@ -1565,8 +1640,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     // NeMo: the feature-major store gives every wave 16 bytes of each mel row per unit; the units are walked in workgroup-uniform
     // rounds and the waves that hold adjacent units are kept in step before their stores (RoundSync, as in the mel-major Whisper kernels)
     constexpr bool ROUNDS = FLAVOR == kFlavorNemo;
-    unsigned *arrive = ldsw + p.blob_words + WAVES * L::slice_elems() * (sizeof(T) / 4);
-    if (ROUNDS && tid < WAVES) arrive[tid] = 0;
+    // the f32 NeMo kernel stages its feature-major rows in LDS (StagedRows) instead of keeping pairs of waves in step
+    constexpr bool STAGE = FLAVOR == kFlavorNemo && sizeof(T) == 4;
+    unsigned *arrive = ldsw + p.blob_words + WAVES * L::slice_elems() * (sizeof(T) / 4);     // 16 words: RoundSync counters; [15]: StagedRows
+    if (ROUNDS && tid < 16) arrive[tid] = 0;
     __syncthreads();
     const T *tblob = reinterpret_cast<const T *>(ldsw);
     const float *mel = reinterpret_cast<const float *>(ldsw + p.mel_off_words);
@@ -1580,7 +1657,9 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     // re-read the ten words in front of phase 3 instead (they sit at the 256-VGPR limit: holding them spilled inside the loop)
     int st[NSLOTS];
     const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
-    if (Lens::kStatic) {
+    // (the twelve-wave f32 NeMo kernel has no registers to hold them either)
+    constexpr bool HOLD_STARTS = Lens::kStatic && !(FLAVOR == kFlavorNemo && sizeof(T) == 4);
+    if (HOLD_STARTS) {
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
     }
@@ -1590,9 +1669,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
     static_assert(!(RUNS && FLAVOR == kFlavorNemo), "the feature-major store wants adjacent units in adjacent waves");
     ClipRun cr;
     if (RUNS && !cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) return;
-    RoundSync<WAVES> rs(ROUNDS ? p.b.sync_rounds : 0, wave, arrive);
+    RoundSync<WAVES> rs((ROUNDS && !STAGE) ? p.b.sync_rounds : 0, wave, arrive);
+    StagedRows<STAGE ? WAVES : 4> staged(arrive + 16, arrive + 15, p.n_mels);
     // batches planned on the device (plan_ragged_device_kernel) keep the real unit count in d_n_units; n_units is the host's bound
     const uint64_t n_units = RUNS ? 0 : scalar64(batch_n_units(p.b));
+    // (STAGE with a contiguous range of units per workgroup instead of rounds dealt over the grid -- consecutive rounds extending the same
+    // mel rows, no division per unit -- was measured: +1.4 %, profiles/r05_f32_512.txt)
     for (uint64_t first = (uint64_t)xcd_logical_block() * WAVES + (ROUNDS ? 0 : wave);; first += (uint64_t)gridDim.x * WAVES) {
         const uint64_t unit = ROUNDS ? first + rs.slot : first;
         if (RUNS) {
@@ -1602,7 +1684,13 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             break;
         }
         const bool have = !ROUNDS || unit < n_units;       // a wave without a unit idles through the round
-        const UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
+        UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
+        if (STAGE) {
+            // wave-uniform, but locate_unit's 64-bit division runs on the vector unit and leaves them in VGPRs, which this kernel does not have
+            loc.unit = scalar64(loc.unit); loc.frames = scalar64(loc.frames); loc.clip = __builtin_amdgcn_readfirstlane(loc.clip);
+            loc.pcm = reinterpret_cast<const float *>(scalar64(reinterpret_cast<uint64_t>(loc.pcm)));
+            loc.out = reinterpret_cast<float *>(scalar64(reinterpret_cast<uint64_t>(loc.out)));
+        }
         const uint64_t f0 = loc.unit * kFbFPW;
         // valid frames of the clip (NeMo ragged: loc.frames is the padded width there)
         const uint64_t vframes = (FLAVOR == kFlavorNemo && p.d_valid) ? p.d_valid[loc.clip] : loc.frames;
@@ -1617,7 +1705,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             if (act) {
                 cpx<T> x[16];
                 fb_kaldi_input<T>(frame, j, preemph, f0 + fl == 0 && j == 0, tblob, x);
-                fb_column_finish<T>(x, j, tblob, slice + fl * L::kXStride + 2 * j);
+                fb_column_finish<T>(x, j, tblob, slice + fl * L::kXStride);
             }
         } else if (FLAVOR == kFlavorWhisper) {
             w512_phase1<T>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
@@ -1632,7 +1720,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         MS_PRIO(1);
         {
             cpx<T> own[16], part[8];
-            fb_phase2_dft<T>(fl, j, act, slice, own);
+            fb_phase2_dft<T, STAGE>(fl, j, act, slice, own);
 #pragma unroll
             for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
             if (FLAVOR == kFlavorWhisper) fb_phase2_split<T, true, true>(fl, j, act, tblob, own, part, slice);
@@ -1642,9 +1730,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         __builtin_amdgcn_wave_barrier();
         MS_PRIO(2);
         float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
-        if (!Lens::kStatic) {
+        if (!HOLD_STARTS) {
+            const int *mine = starts + (STAGE ? fresh_lane_value(j) : j);
 #pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
+            for (int i = 0; i < NSLOTS; ++i) st[i] = in ? mine[i * kFbLanes] : 0;
         }
         fb_phase3_sums<T, NSLOTS, Lens>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
 #pragma unroll
@@ -1668,12 +1757,29 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             const uint64_t row_w = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
             const uint64_t wleft = have ? row_w - f0 : 0;
             const int ns = wleft < (uint64_t)kFbFPW ? (int)wleft : kFbFPW;
-            rs.template before_stores<2>(lane);
-            nemo_phase3_store<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, p.floor_v, rise, fnext, loc.out + f0, (long long)row_w);
+            if (STAGE) {
+                float vals[NSLOTS];
+#pragma unroll
+                for (int i = 0; i < NSLOTS; ++i) vals[i] = act ? fast_ln((rise[i] + fnext[i]) + p.floor_v) : 0.0f;     // nemo_phase3_store's value
+                if (staged.round > 0) {
+                    int dtid = tid;
+                    asm volatile("" : "+v"(dtid));          // see StagedRows::drain
+                    staged.wait_staged(staged.round, lane);
+                    staged.drain(staged.round - 1, dtid);
+                }
+                staged.template put<NSLOTS>(wave, lane, vals, loc.out + f0, (long long)row_w, ns);
+            } else {
+                rs.template before_stores<2>(lane);
+                nemo_phase3_store<NSLOTS>(fl, j, in && fl < ns, act, p.n_mels, p.floor_v, rise, fnext, loc.out + f0, (long long)row_w);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         if (ROUNDS) rs.after_round();
         if (RUNS) ++cr.unit;
+    }
+    if (STAGE && staged.round > 0) {
+        staged.wait_staged(staged.round, lane);
+        staged.drain(staged.round - 1, tid);
     }
 }
 
@@ -1876,7 +1982,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             if (act) {
                 cpx<T> x[16];
                 fb_kaldi_input<T>(frame, j, preemph, f0 + fl == 0 && j == 0, tblob, x);
-                fb_column_finish<T>(x, j, tblob, slice + fl * L::kXStride + 2 * j);
+                fb_column_finish<T>(x, j, tblob, slice + fl * L::kXStride);
             }
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(1);

@@ -58,9 +58,11 @@ elif case == "speech":
     ms = min(m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=50, iters=300) for _ in range(3))
     got = out.download((nf, 80), offset_bytes=5 * nf * 80 * 4)
     assert np.abs(got - O.compute_mel_spectrogram_cpu(x[5], 400, 160, 80, 16000.0)).max() <= 1e-4
-elif case == "w512":
-    m = M.HipMelSpectrogram(512, 160, 16000.0, 80)
-    out = M.DeviceBuffer(n_clips * m.num_frames(clip_len) * 80 * 4)
+elif case in ("w512", "w512_f32", "w512_128", "w512_128_f32"):
+    nm = 128 if "128" in case else 80
+    m = M.HipMelSpectrogram(512, 160, 16000.0, nm)
+    if case.endswith("f32"): m.set_precision("f32")
+    out = M.DeviceBuffer(n_clips * m.num_frames(clip_len) * nm * 4)
     spin(lambda: m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), m.synchronize)
     ms = min(m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=20, iters=200) for _ in range(3))
 elif case == "fbank":
@@ -69,8 +71,9 @@ elif case == "fbank":
     ms = wall(lambda: fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), fb.synchronize, 100)
     got = out.download((fb.num_frames(clip_len), 80), offset_bytes=0)
     assert np.abs(got - O.fbank_compute(O.synth_pcm(0, clip_len))).max() <= 1e-4
-elif case in ("nemo", "nemo_norm"):
-    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, normalize_per_feature=(case == "nemo_norm")))
+elif case in ("nemo", "nemo_norm", "nemo_f32", "nemo_norm_f32", "nemo80", "nemo80_f32"):
+    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=80 if "80" in case else 128, preemphasis=0.97, normalize_per_feature=("norm" in case)))
+    if case.endswith("f32"): fe.set_precision("f32")
     out = M.DeviceBuffer(n_clips * (fe.num_frames(clip_len) + 16) * 128 * 4)
     ms = wall(lambda: fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), fe.synchronize, 100)
 print("MS", ms)
@@ -86,6 +89,9 @@ for r in range(reps):
         env = dict(os.environ, MELSPEC_LIB=os.path.join(ROOT, "mel_spec_amd", "ab", f"lib_{n.split('+')[0]}.so"))
         if n.endswith("+nv"):
             env["AB_NOVOTE"] = "1"
+        for kv in n.split("+")[1:]:                 # name+MELSPEC_X=1+...: lab switches of a -DMELSPEC_LAB build
+            if "=" in kv:
+                env[kv.split("=")[0]] = kv.split("=", 1)[1]
         p = subprocess.run([sys.executable, "-c", WORKER, ROOT, case], env=env, capture_output=True, text=True, timeout=600)
         ms = [float(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("MS")]
         if not ms:
@@ -96,4 +102,4 @@ base = statistics.median(res[args[0]]) if res[args[0]] else 0
 for n in args:
     if res[n]:
         med = statistics.median(res[n])
-        print(f"{case:6s} {n:16s} min {min(res[n]):.4f}  median {med:.4f}  ({(med / base - 1) * 100:+.2f} % vs {args[0]})  {['%.4f' % v for v in res[n]]}", flush=True)
+        print(f"{case:6s} {n:28s} min {min(res[n]):.4f}  median {med:.4f}  ({(med / base - 1) * 100:+.2f} % vs {args[0]})  {['%.4f' % v for v in res[n]]}", flush=True)
