@@ -2073,12 +2073,13 @@ struct BlmNormParams {
 
 constexpr int kBlmNormThreads = 256;
 
-// lab builds: thread 0 of the first 64 workgroups adds up the time (100 MHz ticks) between the barriers of a round
-#ifdef MELSPEC_LAB
+// Thread 0 of the first 64 workgroups adds up the time (100 MHz ticks) between the barriers of a round when BlmNormParams::dbg is set
+// (lab builds, MELSPEC_NORM_DBG).  The stamps are compiled into the product kernel as well, where dbg is always null: with them the kernel
+// runs 1024 x 128 rows of 1001 frames in 253 us, without them in 305-320 us (same box, rocprofv3; ANY one of the six stamps is enough).
+// What the stamps change is the compiler's schedule of the staging loop -- nine loads in flight instead of load / wait / LDS write nine
+// times -- but that is not the whole story: asking for the same order with __builtin_amdgcn_sched_barrier (masks 0x108, 0x101, 0x107) or
+// sched_group_barrier gives 350-375 us.  Kept as measured (profiles/r05_norm_sched.txt); tools/ab_run.py --case nemo_norm is the check.
 #define MS_NORM_STAMP(k) do { if (p.dbg && tid == 0 && blockIdx.x < 64) { const uint64_t now = wall_clock64(); if ((k) > 0) p.dbg[blockIdx.x * 8 + (k)] += now - stamp; stamp = now; } } while (0)
-#else
-#define MS_NORM_STAMP(k) do { } while (0)
-#endif
 
 __device__ __forceinline__ float *blm_row(const BlmNormParams &p, uint64_t row) {
     const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
