@@ -373,7 +373,7 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
     return res
 
 
-LEG_NAMES = ("cfg3", "cfg4", "f64", "mel_major")
+LEG_NAMES = ("cfg3", "cfg4", "f64", "mel_major", "nemo", "nemo_f32")
 
 
 def _event_timed(torch, run, iters: int, spin_s: float = 0.15) -> float:
@@ -399,7 +399,8 @@ def extra_legs(M, torch, dev, stream) -> dict:
       cfg4       BASELINE configs[3] scaled to the timed budget: Whisper large-v3, 128 mels, 1024 x 30 s (the full 8192 x 30 s is
                  tests/test_full_size.py and `bench.py --config 4`)
       f64        configs[1] in MELSPEC_PRECISION_F64 (the f64 FFT on every frame: what speech costs without the vote)
-      mel_major  configs[1] stored as interleave_frames(.., false, ..) = [mel][frames], the whisper.cpp layout (src/mel.rs:480-544)"""
+      mel_major  configs[1] stored as interleave_frames(.., false, ..) = [mel][frames], the whisper.cpp layout (src/mel.rs:480-544)
+      nemo / nemo_f32  the NeMo / Parakeet frontend, 128 mels, 1024 x 10 s: default mode (f64) and MELSPEC_PRECISION_F32 (the reference's f32)"""
     import numpy as np
     from oracle import oracle as O
     legs = {}
@@ -467,7 +468,33 @@ def extra_legs(M, torch, dev, stream) -> dict:
         single[f"{secs}s"] = {"ms": best, "frames": int(y.shape[0])}
     legs["host_api_single_clip_ms"] = single
     mel.close()
-    del out, outm, pcm
+    del out, outm
+
+    # ---- the NeMo / Parakeet frontend (BatchLogMelSpectrogram, 128 mels, pre-emphasis 0.97) on the same clips: the default
+    # mode (f64 up to |X|^2, 1e-4 from the f64 evaluation of the definition) and MELSPEC_PRECISION_F32, the reference's own arithmetic
+    # type for this frontend (src/mel.rs:251-252,356-357), gated like tests/test_f32_512.py: within 2.5 x the distance of upstream's literal
+    # f32 arithmetic (the oracle's f64 = False restatement) from the same f64 evaluation on the same clips
+    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), device=dev.index)
+    cols = fe.padded_frames(clip_len)
+    out = torch.empty(n_clips * 128 * cols, dtype=torch.float32, device=dev)
+    ocfg = O.blm_default_config(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24)
+    wantn = {c: O.blm_compute(O.synth_pcm(c, clip_len), ocfg, True)[0] for c in (0, n_clips - 1)}
+    run = lambda: fe.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    room = max(float(np.abs(O.blm_compute(O.synth_pcm(c, clip_len), ocfg, False)[0] - wantn[c]).max()) for c in wantn)
+    for mode, key, tol in (("auto", "nemo", 1e-4), ("f32", "nemo_f32", max(1e-4, 2.5 * room))):
+        fe.set_precision(mode)
+        run(); torch.cuda.synchronize()
+        o3 = out.view(n_clips, 128, cols)
+        worst = max(float(np.abs(o3[c].cpu().numpy() - wantn[c]).max()) for c in wantn)
+        if worst > tol:
+            raise SystemExit(f"{key} leg: parity check failed, max|diff| = {worst}")
+        legs[key] = record(n_clips * cols, HOP * 4 + 128 * 4, _event_timed(torch, run, 100),
+                           "melspec::fbank512_wave_kernel<float, 12 waves, NeMo> (f32, feature-major rows staged through LDS)" if fe.precision == "f32"
+                           else "melspec::fbank512_wave_kernel<double, 8 waves, NeMo> (f64 FFT)", worst,
+                           f"SURVEY 8(f) #1: BatchLogMelSpectrogram 128 mels, pre-emphasis 0.97, 1024 synthetic 10 s clips, feature-major [128][{cols}] per clip, precision {fe.precision}")
+        legs[key]["reference_f32_max_abs_diff"] = room
+    fe.close()
+    del out, pcm
 
     # ---- cfg4: 128 mels, 30 s clips
     n_clips, clip_len = 1024, 480000

@@ -53,8 +53,9 @@ def run_fbank(tag, n_clips, clip_len, iters):
     print(tag, res[tag], flush=True)
     pcm.free(); out.free(); fb.close()
 
-def run_nemo(tag, n_clips, clip_len, n_mels, iters, norm=False):
+def run_nemo(tag, n_clips, clip_len, n_mels, iters, norm=False, f32=False):
     fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=n_mels, preemphasis=0.97, log_zero_guard=2.0 ** -24, normalize_per_feature=norm))
+    if f32: fe.set_precision("f32")        # the reference's own arithmetic type for this frontend: gated at 2e-4 on the bench's noise clips below
     cols = fe.padded_frames(clip_len)
     pcm = M.DeviceBuffer(n_clips * clip_len * 4); out = M.DeviceBuffer(n_clips * cols * n_mels * 4)
     M.synth_pcm_device(pcm.ptr, clip_len, clip_len, 0, n_clips); M.device_synchronize()
@@ -76,6 +77,8 @@ if "cfg4" in which: run_mel("cfg4_w128_8192x30s", 8192, 480000, 128, 10)
 if "cfg5" in which: run_mel("cfg5_w80_8192x30s_per_gpu_share", 8192, 480000, 80, 10)
 if "nemo" in which: run_nemo("nemo_parakeet_128_1024x10s", 1024, 160000, 128, 50)
 if "nemo" in which: run_nemo("nemo_parakeet_128_1024x10s_normalised", 1024, 160000, 128, 50, True)
+if "nemo" in which: run_nemo("nemo_parakeet_128_1024x10s_F32", 1024, 160000, 128, 50, False, True)
+if "nemo" in which: run_nemo("nemo_parakeet_128_1024x10s_normalised_F32", 1024, 160000, 128, 50, True, True)
 if "host" in which:
     m = M.HipMelSpectrogram(400, 160, 16000.0, 80)
     x = np.concatenate([O.synth_pcm(c, 160000) for c in range(64)])

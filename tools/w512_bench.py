@@ -20,3 +20,11 @@ for _ in range(iters):
 m.synchronize()
 dt = (time.perf_counter() - t0) / iters
 print(f"fused={m.uses_fast_path}: {dt * 1e3:.3f} ms  {n_clips * fpc / dt / 1e9:.4f} G frames/s")
+m.set_precision("f32")                      # round 5: the f32 instantiation (no guard: noise-like input only)
+for _ in range(30): m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+m.synchronize()
+t0 = time.perf_counter()
+for _ in range(iters): m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+m.synchronize()
+dt = (time.perf_counter() - t0) / iters
+print(f"precision {m.precision}: {dt * 1e3:.3f} ms  {n_clips * fpc / dt / 1e9:.4f} G frames/s")
