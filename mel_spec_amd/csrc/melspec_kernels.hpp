@@ -166,6 +166,16 @@ __device__ __forceinline__ uint64_t scalar64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
 }
 
+// locate_unit's results are wave-uniform when `unit` is, but its 64-bit division runs on the vector unit and leaves them in VGPRs; this
+// moves them into SGPRs.  Only where the registers are missing (the twelve-wave f32 NeMo kernel: spills gone, -1.1 %): on the other
+// round-robin kernels the readfirstlanes put the division's latency in front of everything that follows -- mel-major +1.7 %, mel-major
+// F64 +1.5 %, f64 NeMo +5.2 / +6.5 % (128 / 80 mels), same box (profiles/r05_f32_512.txt)
+__device__ __forceinline__ UnitLoc scalar_loc(UnitLoc r) {
+    r.unit = scalar64(r.unit); r.frames = scalar64(r.frames); r.clip = __builtin_amdgcn_readfirstlane(r.clip);
+    r.pcm = reinterpret_cast<const float *>(scalar64(reinterpret_cast<uint64_t>(r.pcm)));
+    r.out = reinterpret_cast<float *>(scalar64(reinterpret_cast<uint64_t>(r.out)));
+    return r;
+}
 constexpr int kStatShift = 40;
 constexpr unsigned long long kStatMask = (1ull << kStatShift) - 1;
 
@@ -1685,12 +1695,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         }
         const bool have = !ROUNDS || unit < n_units;       // a wave without a unit idles through the round
         UnitLoc loc = RUNS ? cr.loc() : locate_unit(p.b, have ? unit : first);
-        if (STAGE) {
-            // wave-uniform, but locate_unit's 64-bit division runs on the vector unit and leaves them in VGPRs, which this kernel does not have
-            loc.unit = scalar64(loc.unit); loc.frames = scalar64(loc.frames); loc.clip = __builtin_amdgcn_readfirstlane(loc.clip);
-            loc.pcm = reinterpret_cast<const float *>(scalar64(reinterpret_cast<uint64_t>(loc.pcm)));
-            loc.out = reinterpret_cast<float *>(scalar64(reinterpret_cast<uint64_t>(loc.out)));
-        }
+        if (STAGE) loc = scalar_loc(loc);          // this kernel has no VGPRs for them
         const uint64_t f0 = loc.unit * kFbFPW;
         // valid frames of the clip (NeMo ragged: loc.frames is the padded width there)
         const uint64_t vframes = (FLAVOR == kFlavorNemo && p.d_valid) ? p.d_valid[loc.clip] : loc.frames;
