@@ -148,6 +148,8 @@ MS_DEV void fb_column(const float *frame, int n2, T preemph, T mean, bool patch_
 
 // (The sample in front of each pair as a row_ror:1 DPP move of the left neighbour's second sample instead of 12 more loads per lane:
 // 0.7101 vs 0.7103 ms, neutral -- the loads hit L1.)
+// (Round 5, the same for the NeMo flavour's 13 predecessor samples: f32 kernel +0.8 % / +1.3 % (128 / 80 mels), f64 +0.3 / +1.4 % -- slower.
+// Without pre-emphasis the f32 kernel runs 6 % faster (0.4255 vs 0.452 ms): that is the 26 separately rounded products, not the loads.)
 // (Round 2 measured "the samples loaded once for both the frame sum and the column" as no difference.  Round 5 built it again as
 // fb_kaldi_input below -- every load unconditional AND branch-free, so that nothing of the column sits behind the mean's round trip -- and it
 // is -10 %: config 3 0.709 -> 0.642 ms, the kernel without CMN 0.616 -> 0.549 ms, same box.  fb_partial_sum / fb_column stay for the host

@@ -71,8 +71,8 @@ elif case == "fbank":
     ms = wall(lambda: fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), fb.synchronize, 100)
     got = out.download((fb.num_frames(clip_len), 80), offset_bytes=0)
     assert np.abs(got - O.fbank_compute(O.synth_pcm(0, clip_len))).max() <= 1e-4
-elif case in ("nemo", "nemo_norm", "nemo_f32", "nemo_norm_f32", "nemo80", "nemo80_f32"):
-    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=80 if "80" in case else 128, preemphasis=0.97, normalize_per_feature=("norm" in case)))
+elif case in ("nemo", "nemo_norm", "nemo_f32", "nemo_norm_f32", "nemo80", "nemo80_f32", "nemo_nopre", "nemo_nopre_f32"):
+    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=80 if "80" in case else 128, preemphasis=0.0 if "nopre" in case else 0.97, normalize_per_feature=("norm" in case)))
     if case.endswith("f32"): fe.set_precision("f32")
     out = M.DeviceBuffer(n_clips * (fe.num_frames(clip_len) + 16) * 128 * 4)
     ms = wall(lambda: fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), fe.synchronize, 100)
