@@ -204,9 +204,62 @@ def case_nemo_batch():
             note("nemo_batch", d)
     fe.close()
 
+def case_f32_512():
+    """MELSPEC_PRECISION_F32 on the fused 512-point kernels (round 5).  NeMo: the largest difference from the f64 evaluation within
+    max(1e-4, 2.5 x) of the reference's own literal f32 arithmetic on the same input, the mean difference within 1.5 x (tests/test_f32_512.py);
+    uniform device batches of several clips as well (rounds of twelve units, the staged rows, partial last rounds).  Whisper-512: the mode
+    has no guard; what is checked is that the device batch agrees with the one-clip call bit for bit and stays finite."""
+    if rng.random() < 0.75:
+        kw = dict(n_mels=int(rng.choice([80, 128])), preemphasis=float(rng.choice([0.97, 0.0, 0.5])), center=bool(rng.random() < 0.8),
+                  log_zero_guard=float(rng.choice([2.0 ** -24, float(np.finfo(np.float32).eps)])), pad_to=int(rng.choice([0, 0, 16])))
+        fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(**kw))
+        fe.set_precision("f32")
+        assert fe.precision == "f32"
+        cfg = O.blm_default_config(**kw)
+        n_clips = int(rng.integers(1, 40))
+        clip_len = int(rng.integers(600, 30000))
+        clips = np.stack([signal(clip_len) for _ in range(n_clips)])
+        pcm = M.DeviceBuffer(clips.nbytes); pcm.upload(clips.reshape(-1))
+        cols = fe.padded_frames(clip_len)
+        out = M.DeviceBuffer(max(16, n_clips * kw["n_mels"] * cols * 4))
+        fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); fe.synchronize()
+        got = out.download((n_clips, kw["n_mels"], cols))
+        for c in sorted(set([0, n_clips - 1, int(rng.integers(0, n_clips))])):
+            want, valid = O.blm_compute(clips[c], cfg, True)
+            lit, _ = O.blm_compute(clips[c], cfg, False)
+            assert got[c].shape == want.shape, ("nemo f32", kw, got[c].shape, want.shape)
+            if want.size == 0: continue
+            e = np.abs(got[c].astype(np.float64) - want); e_ref = np.abs(lit.astype(np.float64) - want)
+            assert e.max() <= max(1e-4, 2.5 * e_ref.max()) and e.mean() <= 1.5 * e_ref.mean() + 1e-6, ("nemo f32", kw, clip_len, c, float(e.max()), float(e_ref.max()), float(e.mean()), float(e_ref.mean()))
+            assert np.all(got[c][:, valid:] == 0.0), ("nemo f32 padding", kw, clip_len, c)
+            assert np.array_equal(fe.compute(clips[c]), got[c]), ("nemo f32: one-clip call against the batch", kw, clip_len, c)
+            note("nemo_f32_over_reference_f32", float(e.max() / max(e_ref.max(), 1e-7)))
+        pcm.free(); out.free(); fe.close()
+    else:
+        nm = int(rng.choice([80, 128]))
+        hop = int(rng.choice([160, 128, 256]))
+        m = M.HipMelSpectrogram(512, hop, 16000.0, nm)
+        m.set_precision("f32")
+        assert m.precision == "f32"
+        n_clips = int(rng.integers(1, 30)); clip_len = int(rng.integers(512, 30000))
+        clips = np.stack([signal(clip_len) for _ in range(n_clips)])
+        pcm = M.DeviceBuffer(clips.nbytes); pcm.upload(clips.reshape(-1))
+        nf = m.num_frames(clip_len)
+        out = M.DeviceBuffer(max(16, n_clips * nf * nm * 4))
+        m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); m.synchronize()
+        got = out.download((n_clips, nf, nm))
+        c = int(rng.integers(0, n_clips))
+        one = m.compute_mel_spectrogram(clips[c])
+        assert np.array_equal(one, got[c]) and np.isfinite(one).all(), ("w512 f32", nm, clip_len, c)
+        m.set_precision("auto")                      # back on the f64 kernel: the tolerance
+        d = float(np.abs(m.compute_mel_spectrogram(clips[c]) - O.compute_mel_spectrogram_cpu(clips[c], 512, hop, nm, 16000.0)).max()) if nf else 0.0
+        assert d <= 1e-4, ("w512 auto after f32", nm, hop, clip_len, d)
+        note("w512_auto_after_f32", d)
+        pcm.free(); out.free(); m.close()
+
 n = 0
 while time.time() < t_end:
     r = rng.random()
-    (case_whisper if r < 0.66 else case_fbank if r < 0.78 else case_fbank_batch if r < 0.84 else case_nemo if r < 0.95 else case_nemo_batch)()
+    (case_whisper if r < 0.60 else case_fbank if r < 0.72 else case_fbank_batch if r < 0.78 else case_nemo if r < 0.88 else case_nemo_batch if r < 0.92 else case_f32_512)()
     n += 1
 print("cases", n, {k: (v[0], float(f"{v[1]:.3g}")) for k, v in stats.items()})
