@@ -788,9 +788,14 @@ void auto_poll(melspec_ctx *c) {
 // frames per work unit of the kernel a batch is planned for (called once per batch, before it is planned).  AUTO plans for the f32
 // kernel: when the batch's vote says "heavy", the f64 kernel walks the same plan (whisper400_precise_kernel, MODE 2).
 // layout: a padded / mel-major batch (the f64 kernel of the layouts is the five-frame one)
+// The six-frame f64 kernel serves a padded / mel-major batch only with one of the compile-time banks: its run-time-lens layout instantiation
+// keeps 141 SGPRs' worth of slot tables and reloads 13 spilled registers inside the unit loop (tools/hotloop_spills.py); those banks stay
+// on whisper400_precise_kernel's layout form.
+bool six64_layout_ok(const melspec_ctx *c) { return c->six64 && c->six_static != 0; }
+
 int ctx_frames_per_unit(melspec_ctx *c, bool layout = false) {
     if (c->fast) {
-        if (c->precision == MELSPEC_PRECISION_F64) return c->six64 ? kSixFrames : kFPW;
+        if (c->precision == MELSPEC_PRECISION_F64) return (layout ? six64_layout_ok(c) : c->six64) ? kSixFrames : kFPW;
         return c->six ? kSixFrames : kFPW;
     }
     return c->fast512 ? kFbFPW : 1;
@@ -870,7 +875,8 @@ int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_six64_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_kernel)");
-        if (!rc) rc = allow_big_lds(&whisper400_six64_layout_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_layout_kernel)");
+        if constexpr (Lens::kStatic)          // the layout form exists for the compile-time banks only (six64_layout_ok)
+            if (!rc) rc = allow_big_lds(&whisper400_six64_layout_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_layout_kernel)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
@@ -890,8 +896,12 @@ int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
     pp.slots = c->ft6.slots;
     pp.gate = gate; pp.gate_value = gate_value;
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-    if (layout) hipLaunchKernelGGL((whisper400_six64_layout_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
-    else hipLaunchKernelGGL((whisper400_six64_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+    if (layout) {
+        if constexpr (Lens::kStatic) hipLaunchKernelGGL((whisper400_six64_layout_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+        else return fail(MELSPEC_ERR_INTERNAL, "whisper400_six64_layout_kernel has no run-time-lens form");      // launch_ctx never asks (six64_layout_ok)
+    } else {
+        hipLaunchKernelGGL((whisper400_six64_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+    }
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
@@ -1002,7 +1012,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     }
     if (!c->fast) return launch_generic(c->gt, desc, c->hop_size, 0, 1, 1, 0.0, 0.0, c->dev.cus, stream);
     if (c->precision == MELSPEC_PRECISION_F64) {
-        if (c->six64 && desc.frames_per_unit == kSixFrames && desc.d_unit_prefix == nullptr) {
+        if ((layout_batch ? six64_layout_ok(c) : c->six64) && desc.frames_per_unit == kSixFrames && desc.d_unit_prefix == nullptr) {
             // mel-major stores of the twelve-wave kernel, measured (tools/mm64_sync_probe.py, 1024 x 10 s): consecutive pairs 0.491 ms, none 0.493,
             // pairs four apart 0.496, fours 0.512, fours one from each SIMD (the f32 kernel's best) 0.520, workgroup barrier 0.533
             if (layout_batch && desc_in.sync_rounds < 0) desc.sync_rounds = 2;
@@ -1059,7 +1069,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     const unsigned gate_value = (c->fix.seq & 0xffffffu) << 2 | kVoteDecided | kVoteHeavy;
     FixSink stat{};
     stat.count = sink.count; stat.acc = sink.acc; stat.host = sink.host;
-    if (c->six64 && layout_batch && desc.frames_per_unit == kSixFrames && desc.d_unit_prefix == nullptr) {
+    if (six64_layout_ok(c) && layout_batch && desc.frames_per_unit == kSixFrames && desc.d_unit_prefix == nullptr) {
         if (desc_in.sync_rounds < 0) desc.sync_rounds = 2;
         return launch_six64(c, desc, stat, stream, sink.decision, gate_value);          // the layouts on the six-frame f64 kernel: the f32 launch's own plan
     }
