@@ -191,3 +191,31 @@ def test_whisper512_f32_mode(gpu, oracle, jfk, n_mels):
 
 def want_speech(oracle, x, n_mels):
     return oracle.compute_mel_spectrogram_cpu(x, 512, 160, n_mels, SR)
+
+
+def test_nemo_f32_staged_rows_many_rounds_same_bits_every_time(gpu, oracle):
+    """StagedRows has no workgroup barrier: a wave drains round r - 1 and stages round r on the strength of one LDS counter.
+    A race there would show as a difference between repeated launches or between a clip inside a big batch and the same clip alone:
+    2600 clips of 0.33 s..3 s at 80 and 128 mels (thousands of rounds per launch, partial last rounds, rounds that span two and more
+    clips), thirty launches, the same bits every time and the bits of the one-clip call."""
+    rng = np.random.default_rng(23)
+    for n_mels, clip_len, n_clips in ((128, 5300, 2600), (80, 48000, 300), (128, 161, 700)):
+        fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_mels=n_mels, preemphasis=0.97, pad_to=int(rng.choice([0, 16]))))
+        fe.set_precision("f32")
+        clips = (0.1 * rng.standard_normal((n_clips, clip_len))).astype(np.float32)
+        pcm = gpu.DeviceBuffer(clips.nbytes)
+        pcm.upload(clips.reshape(-1))
+        cols = fe.padded_frames(clip_len)
+        out = gpu.DeviceBuffer(n_clips * n_mels * cols * 4)
+        first = None
+        for it in range(30):
+            fe.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+            fe.synchronize()
+            got = out.download((n_clips, n_mels, cols))
+            if first is None:
+                first = got
+                for c in (0, 1, n_clips // 2, n_clips - 1):
+                    assert np.array_equal(fe.compute(clips[c]), got[c]), (n_mels, clip_len, c)
+            else:
+                assert np.array_equal(got, first), (n_mels, clip_len, it)
+        pcm.free(); out.free(); fe.close()
