@@ -472,7 +472,7 @@ def extra_legs(M, torch, dev, stream) -> dict:
 
     # ---- the NeMo / Parakeet frontend (BatchLogMelSpectrogram, 128 mels, pre-emphasis 0.97) on the same clips: the default
     # mode (f64 up to |X|^2, 1e-4 from the f64 evaluation of the definition) and MELSPEC_PRECISION_F32, the reference's own arithmetic
-    # type for this frontend (src/mel.rs:251-252,356-357), gated like tests/test_f32_512.py: within 2.5 x the distance of upstream's literal
+    # type for this frontend (src/mel.rs:251-252,356-357), gated like tests/test_f32_512.py: within 4 x the distance of upstream's literal
     # f32 arithmetic (the oracle's f64 = False restatement) from the same f64 evaluation on the same clips
     fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), device=dev.index)
     cols = fe.padded_frames(clip_len)
@@ -481,7 +481,7 @@ def extra_legs(M, torch, dev, stream) -> dict:
     wantn = {c: O.blm_compute(O.synth_pcm(c, clip_len), ocfg, True)[0] for c in (0, n_clips - 1)}
     run = lambda: fe.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
     room = max(float(np.abs(O.blm_compute(O.synth_pcm(c, clip_len), ocfg, False)[0] - wantn[c]).max()) for c in wantn)
-    for mode, key, tol in (("auto", "nemo", 1e-4), ("f32", "nemo_f32", max(1e-4, 2.5 * room))):
+    for mode, key, tol in (("auto", "nemo", 1e-4), ("f32", "nemo_f32", max(1e-4, 4.0 * room))):
         fe.set_precision(mode)
         run(); torch.cuda.synchronize()
         o3 = out.view(n_clips, 128, cols)

@@ -2348,7 +2348,6 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(c
     const int PP = kBlmNormThreads / R;
     constexpr int kRowsAtOnce = 9;
     const uint32_t out_f = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p.out) >> 2) & 3u;
-    const uint32_t nq_max = (p.longest + 6) / 4;
     const f4 *out_base = reinterpret_cast<const f4 *>(p.out - out_f);        // the 16-byte granule `out` starts in
     for (;;) {
         if (tid == 0) next[0] = atomicAdd(p.ctr, 1u);
@@ -2365,8 +2364,13 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(c
             info[4 * tid + 3] = static_cast<uint32_t>(cols);
         }
         __syncthreads();
+        // granules of the longest row OF THIS GROUP (round 5: both copy loops ran to the longest row of the batch -- clips of 5..15 s
+        // made a third of their iterations re-read and re-write a short row's last granule)
+        uint32_t gmax = 0;
+        for (int rr = 0; rr < nr; ++rr) gmax = info[4 * rr + 2] > gmax ? info[4 * rr + 2] : gmax;
+        const uint32_t nq_grp = gmax ? (gmax + 6) / 4 : 0;
         for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
-            for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
+            for (uint32_t q = tid; q < nq_grp; q += kBlmNormThreads) {
                 f4 v[kRowsAtOnce];
                 uint32_t to[kRowsAtOnce];
                 uint64_t from[kRowsAtOnce];          // float index of the granule (from the 16-byte aligned base of `out`)
@@ -2430,7 +2434,7 @@ __global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(c
         }
         __syncthreads();
         for (int rr0 = 0; rr0 < nr; rr0 += kRowsAtOnce) {
-            for (uint32_t q = tid; q < nq_max; q += kBlmNormThreads) {
+            for (uint32_t q = tid; q < nq_grp; q += kBlmNormThreads) {
 #pragma unroll
                 for (int i = 0; i < kRowsAtOnce; ++i) {
                     const int rr = rr0 + i < nr ? rr0 + i : nr - 1;
@@ -2921,7 +2925,14 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         float *o;
         uint64_t ostep, start;
         uint32_t in_clip, clip;                          // uniform batches: the frame's unit inside its clip, and the clip
-        bool have, real;
+        // The two flags as 32-bit words, not `bool`, for the frame sizes up to 512: with two byte-sized members the tail of the struct
+        // (clip + the flags) is not split into registers -- `Frame nxt = cur` and `cur = nxt` go through scratch memory, a load /
+        // s_waitcnt vmcnt(0) / store pair at both ends of every iteration of the frame loop, each wait also draining the loads issued
+        // ahead for the next frame (found by tools/hotloop_spills.py, round 5): n_fft 128 -4 %, 256 -4.5 / -5 %.  The 1024- and 2048-point
+        // instances sit at 256 VGPRs: there the two registers cost more than the scratch copy did (+1..3 %), so they keep `bool`
+        // (same box, profiles/r05_pow2.txt).
+        using Flag = std::conditional_t<(LOGM <= 8), uint32_t, bool>;
+        Flag have, real;
     };
     const uint64_t n_units = batch_n_units(p.b);
     const uint64_t stride = (uint64_t)gridDim.x * n_waves * FW;

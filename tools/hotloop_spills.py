@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Compiles csrc/melspec_hip.hip to gfx950 assembly and reports, per kernel, the scratch (spill) instructions that sit INSIDE the unit
 loop -- between the first `s_setprio 0` (phase 1 of a unit) and the loop's back edge -- as opposed to the recompute tail behind it.
-A spill in the tail is cheap; one in the loop is paid per unit (the mel-major kernel once lost 20 % that way)."""
+A spill in the tail is cheap; one in the loop is paid per unit (the mel-major kernel once lost 20 % that way).
+Kernels without phase priorities (pow2_frame_kernel, the normalisers, ...): every scratch instruction inside ANY loop, by the compiler's own
+block annotations ("in Loop: Header=... Depth=n") -- reported as "loop" in lower case and not counted into the exit status: the n_fft = 2048
+instances of pow2_frame_kernel are known to spill there, and the spill-free form of that kernel was measured 11-14 % slower
+(profiles/r05_fb512_twelve_waves.txt)."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(tempfile.gettempdir(), "melspec_hotloop.s")
@@ -17,6 +21,18 @@ name, body, bad = None, [], 0
 def report(name, body):
     prio = [i for i, l in enumerate(body) if "s_setprio" in l]
     if not prio:
+        depth, inside, total = 0, 0, 0
+        for l in body:
+            m = re.match(r"^\.LBB\d+_\d+:\s*;?(.*)", l)
+            if m:
+                d = re.search(r"Depth[= ](\d)", m.group(1))
+                depth = int(d.group(1)) if d else 0
+            if "scratch_" in l:
+                total += 1
+                inside += depth > 0
+        if total:
+            dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()[:100]
+            print(f"{'loop ' if inside else '     '}{inside:3d} inside a loop,   {total:3d} in all   {dem}")
         return 0
     first = prio[0]
     # the back edge of the unit loop: the last branch to a label defined before the first s_setprio
