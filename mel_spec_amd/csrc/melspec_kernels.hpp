@@ -2924,30 +2924,31 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         const float *pcm, *x;
         float *o;
         uint64_t ostep, start;
-        uint32_t in_clip, clip;                          // uniform batches: the frame's unit inside its clip, and the clip
-        // The two flags as 32-bit words, not `bool`, for the frame sizes up to 512: with two byte-sized members the tail of the struct
-        // (clip + the flags) is not split into registers -- `Frame nxt = cur` and `cur = nxt` go through scratch memory, a load /
-        // s_waitcnt vmcnt(0) / store pair at both ends of every iteration of the frame loop, each wait also draining the loads issued
-        // ahead for the next frame (found by tools/hotloop_spills.py, round 5): n_fft 128 -4 %, 256 -4.5 / -5 %.  The 1024- and 2048-point
-        // instances sit at 256 VGPRs: there the two registers cost more than the scratch copy did (+1..3 %), so they keep `bool`
-        // (same box, profiles/r05_pow2.txt).
-        using Flag = std::conditional_t<(LOGM <= 8), uint32_t, bool>;
-        Flag have, real;
+        // tag = the frame's unit inside its clip (uniform batches; < 2^30) | have << 30 | real << 31, and the clip.  The flags were two
+        // `bool` members: with byte-sized members the tail of the struct is not split into registers -- `Frame nxt = cur` and `cur = nxt`
+        // went through scratch memory, a load / s_waitcnt vmcnt(0) / store pair at both ends of every iteration of the frame loop, each
+        // wait also draining the loads issued ahead for the next frame (found by tools/hotloop_spills.py, round 5).  As two 32-bit words
+        // they cost the 1024- and 2048-point instances (at 256 VGPRs) more than the scratch copy did (+1..3 %; n_fft 256 -5 %); packed:
+        // n_fft 128 -3 %, 256 -4 %, Kaldi 32 kHz -2 %, 1024 / 2048 unchanged (same box, profiles/r05_pow2.txt).
+        uint32_t tag, clip;
+        __device__ __forceinline__ bool have() const { return (tag >> 30) & 1u; }
+        __device__ __forceinline__ bool real() const { return (tag >> 31) != 0; }
+        __device__ __forceinline__ uint32_t in_clip() const { return tag & 0x3fffffffu; }
     };
     const uint64_t n_units = batch_n_units(p.b);
     const uint64_t stride = (uint64_t)gridDim.x * n_waves * FW;
     const bool uniform = p.b.d_unit_prefix == nullptr;
+    const bool walk = uniform && p.b.units_per_clip < (1u << 29);     // Frame::tag holds the unit inside its clip in 30 bits
     auto frame_at = [&](const UnitLoc &loc, bool have) {
         Frame f;
-        f.have = have;
         const uint64_t width = uniform ? p.b.out_width : loc.frames;
         f.o = p.b.mel_major ? loc.out + loc.unit : loc.out + loc.unit * (uint64_t)p.n_mels;
         f.ostep = p.b.mel_major ? width : 1;
-        f.real = have && loc.unit < loc.frames;          // otherwise: a zero column of a padded layout (uniform batches), or nothing
+        const bool real = have && loc.unit < loc.frames;     // otherwise: a zero column of a padded layout (uniform batches), or nothing
         f.start = loc.unit * (uint64_t)p.hop;
         f.pcm = loc.pcm;
         f.x = loc.pcm + f.start;
-        f.in_clip = (uint32_t)loc.unit;
+        f.tag = ((uint32_t)loc.unit & 0x3fffffffu) | (have ? 1u << 30 : 0u) | (real ? 1u << 31 : 0u);
         f.clip = loc.clip;
         return f;
     };
@@ -2962,9 +2963,9 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     const uint64_t step_clips = uniform ? stride / p.b.units_per_clip : 0;
     const uint32_t step_rest = uniform ? (uint32_t)(stride - step_clips * p.b.units_per_clip) : 0;
     auto advance = [&](const Frame &f, uint64_t nbase) {
-        if (!uniform || !f.have) return place(nbase);
+        if (!walk || !f.have()) return place(nbase);
         UnitLoc loc;
-        uint32_t u = f.in_clip + step_rest;             // (< 2 units_per_clip <= 2^32: the host plans uniform batches with 32-bit unit counts per clip)
+        uint32_t u = f.in_clip() + step_rest;             // (< 2 units_per_clip <= 2^32: the host plans uniform batches with 32-bit unit counts per clip)
         uint64_t c = (uint64_t)f.clip + step_clips;
         if (u >= p.b.units_per_clip) { u -= p.b.units_per_clip; ++c; }
         loc.unit = u;
@@ -2978,7 +2979,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
     // round trip, and the first form of this kernel -- one predicate per sample -- spent 80 % of its time in them.
     // part: 2 = every point; 0 / 1 (kHalves): the even / the odd points only (r = 2 r' + part)
     auto fetch = [&](const Frame &f, Pow2Raw<P, FLAVOR> &raw, int part = 2) {
-        if (!f.real) return;
+        if (!f.real()) return;
 #pragma unroll
         for (int r = 0; r < P; ++r) {
             if (part != 2 && (r & 1) != part) continue;
@@ -3018,10 +3019,10 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
             nxt = advance(cur, nbase);
             fetch(nxt, nraw);
         }
-        if (cur.have && !cur.real) {
+        if (cur.have() && !cur.real()) {
             for (int m = l; m < p.n_mels; m += LF) cur.o[m * cur.ostep] = 0.0f;
         }
-        if (cur.real) {
+        if (cur.real()) {
             // ---- framing: DC removal / pre-emphasis / window per flavour -> the lane's P complex points z[l + r LF] -----------------
             // point(r): the windowed complex point r of the lane.  FLAVOR 1 needs the frame's mean first.
             double mean = 0.0;
@@ -3203,7 +3204,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
                 double e = w[t][0].x * pv[t][0];
                 e += w[t][0].y * pv[t][1]; e += w[t][1].x * pv[t][2]; e += w[t][1].y * pv[t][3];
                 e += w[t][2].x * pv[t][4]; e += w[t][2].y * pv[t][5]; e += w[t][3].x * pv[t][6]; e += w[t][3].y * pv[t][7];
-                if (cur.real && (info[t] >> 20) > 0) unsafeAtomicAdd(acc + ((info[t] >> 12) & 0xff), e);       // (count 0: the host's padding, or past the last job)
+                if (cur.real() && (info[t] >> 20) > 0) unsafeAtomicAdd(acc + ((info[t] >> 12) & 0xff), e);       // (count 0: the host's padding, or past the last job)
             }
         };
         job_triple(info0, l);
@@ -3220,7 +3221,7 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
         for (int i = 0; i < kMaxPer; ++i) {
             const int m = l + LF * i;
             mv[i] = 0.0f;
-            if (cur.real && m < p.n_mels) {
+            if (cur.real() && m < p.n_mels) {
                 const double e = acc[m];
                 float vv;
                 if (FLAVOR == 0) {
@@ -3242,13 +3243,13 @@ __global__ __launch_bounds__(Pow2Shape<LOGM>::kMaxWaves * 64) void pow2_frame_ke
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i) {
                 const int m = l + LF * i;
-                if (cur.real && m < p.n_mels) cur.o[m * cur.ostep] = ((mv[i] > lo ? mv[i] : lo) + 4.0f) * 0.25f;
+                if (cur.real() && m < p.n_mels) cur.o[m * cur.ostep] = ((mv[i] > lo ? mv[i] : lo) + 4.0f) * 0.25f;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i) {
                 const int m = l + LF * i;
-                if (cur.real && m < p.n_mels) cur.o[m * cur.ostep] = mv[i];
+                if (cur.real() && m < p.n_mels) cur.o[m * cur.ostep] = mv[i];
             }
         }
         if (!more) break;
