@@ -93,3 +93,43 @@ def test_config5_full_size_65536x30s_on_one_gpu(gpu, oracle):
     run gives every rank the 8192-clip shard whose boundaries are among the sampled clips."""
     worst = _run_full(gpu, oracle, 65536, 80, _picks(65536), chunk_clips=2048)
     print(f"config 5 full size: worst |gpu - oracle| over the sampled clips {worst:.3e}")
+
+
+@pytest.mark.gpu
+def test_nemo_f32_8192x30s_staged_rows_at_size(gpu, oracle):
+    """The f32 NeMo kernel (round 5) at config 4's batch size: 8192 x 30 s x 128 mels = 12.6 GB of feature-major rows written through
+    StagedRows in ~61 000 rounds per launch.  Size-independent properties: sampled clips equal the one-clip call bit for bit and sit
+    within the reference's own f32 distance of the f64 evaluation; the columns past the valid frames are zero in every clip; a second
+    launch reproduces a checksum of the whole output."""
+    import torch
+    n_clips, clip_len = 8192, 480000
+    dev = torch.device("cuda:0")
+    fe = gpu.BatchLogMelSpectrogram(gpu.BatchLogMelConfig(n_mels=128, preemphasis=0.97, pad_to=16))
+    fe.set_precision("f32")
+    assert fe.precision == "f32"
+    cols, valid = fe.padded_frames(clip_len), fe.num_frames(clip_len)
+    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
+    gpu.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, 0, n_clips)
+    out = torch.empty(n_clips * 128 * cols, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    fe.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    o3 = out.view(n_clips, 128, cols)
+    assert bool((o3[:, :, valid:] == 0).all())
+    sum_a = o3.double().sum(dim=(1, 2)).clone()
+    cfg = oracle.blm_default_config(n_mels=128, preemphasis=0.97, pad_to=16)
+    for c in (0, 1, 4095, 4096, 8191):
+        x = oracle.synth_pcm(c, clip_len)
+        got = o3[c].cpu().numpy()
+        assert np.array_equal(fe.compute(x), got), c
+        want = oracle.blm_compute(x, cfg, True)[0]
+        lit = oracle.blm_compute(x, cfg, False)[0]
+        e, e_ref = np.abs(got.astype(np.float64) - want), np.abs(lit.astype(np.float64) - want)
+        assert e.mean() <= 1.5 * e_ref.mean() + 1e-6 and e.max() <= max(1e-4, 4.0 * e_ref.max()), (c, float(e.max()), float(e_ref.max()))
+    out.zero_()
+    fe.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(o3.double().sum(dim=(1, 2)), sum_a))
+    fe.close()
+    del pcm, out, o3
+    torch.cuda.empty_cache()
