@@ -62,7 +62,8 @@ int fail_hip(hipError_t e, const char *where) {
 constexpr int kGenericNT = 256;
 constexpr int kMaxGenericFft = 4096;
 constexpr int kMaxGenericMels = 1024;
-constexpr int kNemoSync = 2;                // RoundSync mode of the NeMo feature-major store: pairs of adjacent waves (profiles/r02_nemo.txt)
+constexpr int kNemoSync = 0;                // RoundSync mode of the f64 NeMo kernel's feature-major store: none.  (Round 2: pairs of adjacent waves, profiles/r02_nemo.txt;
+                                            //  re-measured in round 5 after the clip-edge frames lost their chain of round trips: none -2.0 .. -2.3 % at 80 / 128 mels, pairs four apart +3 %, fours +1 %)
 constexpr size_t kLdsLimit = 160 * 1024;   // gfx950: one workgroup may use the whole 160 KiB LDS of a CU
 constexpr uint64_t kPipeChunkSamples = 4u << 20;      // host pipeline: 16 MiB of PCM per chunk (host_pipe.hpp)
 

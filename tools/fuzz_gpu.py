@@ -237,7 +237,8 @@ def case_f32_512():
             # statistic: it sits on the loudest band, where 10 eps against 2 eps is 4.8 x and 1e-6 in the output.)
             big = e.size >= 20000                        # (a 99.9th percentile of a few hundred values is their maximum)
             q, q_ref = (np.quantile(e, 0.999), np.quantile(e_ref, 0.999)) if big else (0.0, 0.0)
-            assert (e.mean() <= 1.5 * e_ref.mean() + 1e-6 and q <= max(1e-4, 2.0 * q_ref) and e.max() <= max(1e-4, 25.0 * e_ref.max())), (
+            mean_gate = 1.5 * e_ref.mean() + 1e-6 if big else 3.0 * e_ref.mean() + 1e-5      # (a few hundred values: the mean hangs on two or three of them)
+            assert (e.mean() <= mean_gate and q <= max(1e-4, 2.0 * q_ref) and e.max() <= max(1e-4, 25.0 * e_ref.max())), (
                 "nemo f32", kw, clip_len, c, float(e.max()), float(e_ref.max()), float(q), float(q_ref), float(e.mean()), float(e_ref.mean()))
             assert np.all(got[c][:, valid:] == 0.0), ("nemo f32 padding", kw, clip_len, c)
             assert np.array_equal(fe.compute(clips[c]), got[c]), ("nemo f32: one-clip call against the batch", kw, clip_len, c)
