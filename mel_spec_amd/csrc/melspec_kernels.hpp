@@ -2078,13 +2078,19 @@ struct BlmNormParams {
 
 constexpr int kBlmNormThreads = 256;
 
-// Thread 0 of the first 64 workgroups adds up the time (100 MHz ticks) between the barriers of a round when BlmNormParams::dbg is set
-// (lab builds, MELSPEC_NORM_DBG).  The stamps are compiled into the product kernel as well, where dbg is always null: with them the kernel
-// runs 1024 x 128 rows of 1001 frames in 253 us, without them in 305-320 us (same box, rocprofv3; ANY one of the six stamps is enough).
-// What the stamps change is the compiler's schedule of the staging loop -- nine loads in flight instead of load / wait / LDS write nine
-// times -- but that is not the whole story: asking for the same order with __builtin_amdgcn_sched_barrier (masks 0x108, 0x101, 0x107) or
-// sched_group_barrier gives 350-375 us.  Kept as measured (profiles/r05_norm_sched.txt); tools/ab_run.py --case nemo_norm is the check.
+// lab builds: thread 0 of the first 64 workgroups adds up the time (100 MHz ticks) between the barriers of a round (MELSPEC_NORM_DBG)
+#if defined(MELSPEC_LAB) && !defined(MELSPEC_NORM_NO_STAMPS)
 #define MS_NORM_STAMP(k) do { if (p.dbg && tid == 0 && blockIdx.x < 64) { const uint64_t now = wall_clock64(); if ((k) > 0) p.dbg[blockIdx.x * 8 + (k)] += now - stamp; stamp = now; } } while (0)
+#else
+#define MS_NORM_STAMP(k) do { } while (0)
+#endif
+// Both normalisers run four 256-thread workgroups per CU (LDS-bound: four waves per SIMD), and the compiler is told so: without the
+// attribute its scheduler minimises registers for an occupancy the kernels never have and SERIALISES the nine staging loads of a thread --
+// one register quad, load / s_waitcnt vmcnt(0) / LDS write nine times over (uniform kernel 305-320 us instead of 253 for 1024 x 128 rows
+// of 1001 frames; ragged, 5..15 s: 0.44 -> 0.34 ms).  Round 5 first met this as "the lab build is 20 % faster": any one of the lab
+// build's disabled time stamps happened to flip the heuristic, while scheduling barriers between the loads and the writes keep the array
+// of loaded values in scratch memory (350-375 us).  profiles/r05_norm_sched.txt has the whole trail.
+#define MS_NORM_OCCUPANCY __attribute__((amdgpu_waves_per_eu(1, 4)))
 
 __device__ __forceinline__ float *blm_row(const BlmNormParams &p, uint64_t row) {
     const uint64_t clip = row / p.n_mels, m = row - clip * p.n_mels;
@@ -2153,7 +2159,7 @@ __device__ __forceinline__ void blm_row_stats_slow(const float *r, uint64_t vali
 }
 
 #ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
-__global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_kernel(const BlmNormParams p) {
+__global__ __launch_bounds__(kBlmNormThreads) MS_NORM_OCCUPANCY void blm_normalize_kernel(const BlmNormParams p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
     const int tid = threadIdx.x;
@@ -2336,7 +2342,7 @@ struct BlmNormRaggedParams {
 };
 
 #ifndef MELSPEC_TEMPLATE_KERNELS_ONLY
-__global__ __launch_bounds__(kBlmNormThreads) void blm_normalize_ragged_kernel(const BlmNormRaggedParams p) {
+__global__ __launch_bounds__(kBlmNormThreads) MS_NORM_OCCUPANCY void blm_normalize_ragged_kernel(const BlmNormRaggedParams p) {
     extern __shared__ __attribute__((aligned(16))) float tile[];
     const uint64_t rows = (uint64_t)p.n_clips * p.n_mels;
     const int tid = threadIdx.x;
