@@ -179,11 +179,12 @@ namespace melspec {
 
 // Tables of the six-frames-per-wave kernel (SixBlob in whisper_six.hpp).  false: filterbank outside its coverage
 // (more than 9 slots of 9 intervals, or not a two-filters-per-bin bank).
-inline bool build_six_tables(const std::vector<double> &dense, int n_mels, FastTables &out) {
+// max_slots = kSixWideSlots: the fifteen-slot mel section of the f64 six-frame kernel at 81..134 mels (start bins [15][10], then weights)
+inline bool build_six_tables(const std::vector<double> &dense, int n_mels, FastTables &out, int max_slots = kSixMaxSlots) {
     constexpr int N = 400, M = 200;
-    if (n_mels < 1 || n_mels > kSixOwn * kSixMaxSlots - 1) return false;
+    if (n_mels < 1 || n_mels > kSixOwn * max_slots - 1) return false;
     std::vector<float> &b = out.blob;
-    b.assign(SixBlob::kMelW, 0.0f);
+    b.assign((SixBlob::kMelStart + max_slots * kSixLanes + 3) & ~3, 0.0f);
     const std::vector<double> win = hann_window(N);
     for (int t = 0; t < 10; ++t)
         for (int n1 = 0; n1 < 20; ++n1)
@@ -205,7 +206,7 @@ inline bool build_six_tables(const std::vector<double> &dense, int n_mels, FastT
     const int bins = N / 2 + 1;
     out.n_mels = n_mels;
     out.nnz = 0;
-    out.interval = build_interval_mel(dense, n_mels, bins, M, b, out.slots, kSixLanes, 0.25, SixBlob::kMelStart, kSixMaxSlots);
+    out.interval = build_interval_mel(dense, n_mels, bins, M, b, out.slots, kSixLanes, 0.25, SixBlob::kMelStart, max_slots);
     while (b.size() % 4) b.push_back(0.0f);
     return out.interval;
 }

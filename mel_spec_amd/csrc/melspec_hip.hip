@@ -740,6 +740,7 @@ struct melspec_ctx {
     // the f64 kernel on the six-frame skeleton (whisper400_six64_kernel): plain batches of the six-frame contexts in MELSPEC_PRECISION_F64,
     // and AUTO's gated second launch
     bool six64 = false;
+    bool six64_wide = false;    // ... with fifteen mel slots (Whisper large-v3's 128-mel bank): plain batches only, c->six is false there
     Six64Tables t64;
     DevBuf d_blob64x;
     size_t lds64x = 0;
@@ -792,7 +793,7 @@ void auto_poll(melspec_ctx *c) {
 // The six-frame f64 kernel serves a padded / mel-major batch only with one of the compile-time banks: its run-time-lens layout instantiation
 // keeps 141 SGPRs' worth of slot tables and reloads 13 spilled registers inside the unit loop (tools/hotloop_spills.py); those banks stay
 // on whisper400_precise_kernel's layout form.
-bool six64_layout_ok(const melspec_ctx *c) { return c->six64 && c->six_static != 0; }
+bool six64_layout_ok(const melspec_ctx *c) { return c->six64 && !c->six64_wide && c->six_static != 0; }
 
 int ctx_frames_per_unit(melspec_ctx *c, bool layout = false) {
     if (c->fast) {
@@ -871,12 +872,12 @@ int launch_precise(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
 
 // the f64 six-frame kernel on a plain batch planned in six-frame units: MELSPEC_PRECISION_F64, or -- gate != nullptr -- AUTO's second
 // launch over the plan of the f32 launch in front of it
-template <class Lens>
+template <class Lens, int NS = kSixMaxSlots>
 int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream, const unsigned *gate, unsigned gate_value) {
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_six64_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_kernel)");
-        if constexpr (Lens::kStatic)          // the layout form exists for the compile-time banks only (six64_layout_ok)
+        int rc = allow_big_lds(&whisper400_six64_kernel<NS, Lens>, "hipFuncSetAttribute(whisper400_six64_kernel)");
+        if constexpr (Lens::kStatic && NS == kSixMaxSlots)          // the layout form exists for the compile-time banks of up to 80 mels only (six64_layout_ok)
             if (!rc) rc = allow_big_lds(&whisper400_six64_layout_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six64_layout_kernel)");
         if (rc) return rc;
         mark_device_done(attr_done);
@@ -898,16 +899,17 @@ int launch_six64_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, h
     pp.gate = gate; pp.gate_value = gate_value;
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
     if (layout) {
-        if constexpr (Lens::kStatic) hipLaunchKernelGGL((whisper400_six64_layout_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+        if constexpr (Lens::kStatic && NS == kSixMaxSlots) hipLaunchKernelGGL((whisper400_six64_layout_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
         else return fail(MELSPEC_ERR_INTERNAL, "whisper400_six64_layout_kernel has no run-time-lens form");      // launch_ctx never asks (six64_layout_ok)
     } else {
-        hipLaunchKernelGGL((whisper400_six64_kernel<kSixMaxSlots, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
+        hipLaunchKernelGGL((whisper400_six64_kernel<NS, Lens>), dim3(grid), dim3(kSix64Waves * 64), c->lds64x, stream, pp);
     }
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
 
 int launch_six64(melspec_ctx *c, const BatchDesc &desc, const FixSink &stat, hipStream_t stream, const unsigned *gate = nullptr, unsigned gate_value = 0) {
+    if (c->six64_wide) return launch_six64_t<LensSix128, kSixWideSlots>(c, desc, stat, stream, gate, gate_value);
     return c->six_static == 1 ? launch_six64_t<LensSix80>(c, desc, stat, stream, gate, gate_value)
          : c->six_static == 2 ? launch_six64_t<LensSix64>(c, desc, stat, stream, gate, gate_value)
          : c->six_static == 3 ? launch_six64_t<LensSix40>(c, desc, stat, stream, gate, gate_value)
@@ -1082,6 +1084,12 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     }
     if (layout_batch && desc_in.sync_rounds < 0) desc.sync_rounds = 2;
     if (c->six64 && !layout_batch && desc.frames_per_unit == kSixFrames) return launch_six64(c, desc, stat, stream, sink.decision, gate_value);
+    if (c->six64_wide && !layout_batch && desc.d_unit_prefix == nullptr) {
+        // 128 mels: the f32 launch walked five-frame units, the gated kernel deals six -- the same uniform batch planned again (arithmetic only;
+        // a ragged batch's plan lives in device arrays made for five-frame units: those stay on the precise kernel)
+        const BatchPlan p6 = plan_uniform(desc.pcm, desc.out, desc.clip_stride, desc.frames_per_clip, desc.n_clips, c->n_mels, kSixFrames);
+        return launch_six64(c, p6.desc, stat, stream, sink.decision, gate_value);
+    }
     return launch_precise(c, desc, stat, stream, sink.decision, gate_value);
 }
 
@@ -1190,6 +1198,21 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
             if (c->six64 && (rc = upload(c->d_blob64x, c->t64.blob))) return bail(rc);
         }
     }
+#ifndef MELSPEC_NO_SIX64
+    // Whisper large-v3's bank (128 mels) is past the nine slots of the f32 six-frame kernel, but the f64 one runs its mel phase when its
+    // f64 arrays are dead and has the registers for fifteen: MELSPEC_PRECISION_F64 and AUTO's gated launch on plain batches (round 5)
+    if (c->fast && !c->six && !runtime_lens && lab_int("MELSPEC_SIX64", 1, 0, 1) != 0) {
+        FastTables wide;
+        if (build_six_tables(c->dense, n_mels, wide, kSixWideSlots) && lens_match<LensSix128>(wide.slots, n_mels) && build_six64_tables(wide, c->t64)) {
+            c->lds64x = c->t64.blob.size() * 4 + static_cast<size_t>(kSix64Waves) * Six64Layout::slice_doubles() * sizeof(double) + (kSix64Waves + 2) * sizeof(uint32_t);
+            c->six64 = c->six64_wide = c->lds64x <= kLdsLimit;
+            if (c->six64) {
+                c->ft6.slots = wide.slots;          // the launch's copy of the slot table (run-time-lens code paths; unused by LensSix128)
+                if ((rc = upload(c->d_blob64x, c->t64.blob))) return bail(rc);
+            }
+        }
+    }
+#endif
     if (c->fast) {
         if ((rc = upload(c->d_blob, c->ft.blob))) return bail(rc);
         if ((rc = upload(c->d_blob64, c->pt.blob))) return bail(rc);
@@ -1301,6 +1324,8 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
         }
         return "melspec::generic_frame_kernel<256> (f64, one frame per workgroup)";
     }
+    if (c->precision == MELSPEC_PRECISION_F64 && c->six64_wide)
+        return "melspec::whisper400_six64_kernel<15, LensSix128> (f64 FFT, six frames per wave, three waves per SIMD, fifteen mel slots)";
     if (c->precision == MELSPEC_PRECISION_F64 && c->six64)
         return "melspec::whisper400_six64_kernel<9, .> (f64 FFT, six frames per wave, three waves per SIMD)";
     if (c->precision == MELSPEC_PRECISION_F64)

@@ -27,6 +27,10 @@ constexpr int kSixOwn = 9;        // intervals a 10-lane group owns per slot (la
 #endif
 constexpr int kSixWaves = MELSPEC_SIX_WAVES;     // waves per workgroup (one workgroup per CU)
 constexpr int kSixMaxSlots = 9;   // ceil(81 / 9): up to 80 mel bins
+// the f64 six-frame kernel (whisper_six64.hpp) also serves the banks of 81..134 mels -- Whisper large-v3's 128 -- with fifteen slots per
+// lane: its mel phase runs after the f64 arrays are dead, so the registers are there (the f32 six-frame kernel has no such room at 128
+// VGPRs: those banks stay on the five-frame kernels there)
+constexpr int kSixWideSlots = 15;
 
 struct SixBlob {                  // float offsets inside the table blob
     // the 40 taps of lane t in the order it uses them, w[20*n1 + 2t + {0, 1}] at [t][2*n1 + {0, 1}]: ten 16-byte reads per unit;
@@ -82,6 +86,25 @@ struct LensSixStatic {
     }
 };
 using LensSix80 = LensSixStatic<80, 1, 1, 1, 2, 2, 3, 4, 6, 7>;
+// the same over the fifteen-slot mel section (start bins [15][10], then the weights): Whisper large-v3's 128-mel bank
+template <int MELS, int... L>
+struct LensSixWideStatic {
+    static constexpr bool kStatic = true;
+    static constexpr int kSlots = sizeof...(L);
+    static constexpr int kMels = MELS;
+    static constexpr int kMelW = (SixBlob::kMelStart + kSixWideSlots * kSixLanes + 3) & ~3;
+    MS_HD static constexpr int len(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        return t[i];
+    }
+    MS_HD static constexpr int woff(int i) {
+        constexpr int t[sizeof...(L)] = {L...};
+        int s = 0;
+        for (int k = 0; k < i; ++k) s += t[k];
+        return kMelW + 2 * kSixLanes * s;
+    }
+};
+using LensSix128 = LensSixWideStatic<128, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 3, 3, 4, 5, 5>;
 // Whisper-style banks of 64 and 40 mels at 16 kHz (mel(16000, 400, n_mels), src/mel.rs:547-643): with run-time slot lengths the mel
 // phase pays one LDS round trip per bin (64 mels: 0.378 ms at 1024 x 10 s against 0.292 for the 80-mel bank, profiles/r03_sched.txt)
 using LensSix64 = LensSixStatic<64, 2, 2, 2, 3, 4, 6, 10, 10>;

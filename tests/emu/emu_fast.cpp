@@ -763,7 +763,7 @@ template <int NSLOTS, class Lens>
 static long long run_six64(const float *pcm, long long n, int hop, int n_mels, double sr, float *out) {
     FastTables T;
     Six64Tables T64;
-    if (!build_six_tables(sr, n_mels, T) || !build_six64_tables(T, T64)) return -1;
+    if (!build_six_tables(mel_filterbank(sr, 400, n_mels, -1.0, -1.0, false, true), n_mels, T, NSLOTS) || !build_six64_tables(T, T64)) return -1;
     if (n < 400) return 0;
     const long long frames = (n - 400) / hop + 1;
     const double *tb = reinterpret_cast<const double *>(T64.blob.data());
@@ -817,6 +817,12 @@ extern "C" long long emu_whisper_six64(const float *pcm, long long n, int hop, i
         if (!build_six_tables(sr, n_mels, T) || !six_lens_ok<LensSix80>(T.slots, n_mels)) return -2;
         return run_six64<kSixMaxSlots, LensSix80>(pcm, n, hop, n_mels, sr, out);
     }
+    if (mode == 2) {        // fifteen mel slots: Whisper large-v3's 128-mel bank (the f64 kernel only)
+        FastTables T;
+        if (!build_six_tables(mel_filterbank(sr, 400, n_mels, -1.0, -1.0, false, true), n_mels, T, kSixWideSlots) || !six_lens_ok<LensSix128>(T.slots, n_mels)) return -2;
+        return run_six64<kSixWideSlots, LensSix128>(pcm, n, hop, n_mels, sr, out);
+    }
+    if (mode == 3) return run_six64<kSixWideSlots, LensRuntime>(pcm, n, hop, n_mels, sr, out);      // fifteen slots, run-time lengths (81..134 mels)
     return run_six64<kSixMaxSlots, LensRuntime>(pcm, n, hop, n_mels, sr, out);
 }
 

@@ -209,6 +209,16 @@ def test_six_frame_f64_kernel_exchange_in_two_halves(emu, oracle, jfk, hop, n_me
         assert (_six64(emu, np.zeros(4000, np.float32), mode=mode) == -1.5).all()
 
 
+@pytest.mark.parametrize("n_mels,n,mode", [(128, None, 2), (128, 400 + 6 * 160 + 1, 2), (128, None, 3), (100, 9000, 3), (96, 5000, 3), (134, 5000, 3)])
+def test_six_frame_f64_kernel_with_fifteen_mel_slots(emu, oracle, jfk, n_mels, n, mode):
+    """The same kernel over the fifteen-slot mel section (round 5: Whisper large-v3's 128-mel bank, LensSix128; run-time lengths for the other
+    banks of 81..134 mels, which the library leaves on the five-frame kernel): slot tables, start bins, the ghost lane of every slot."""
+    x = jfk if n is None else jfk[30000:30000 + n]
+    want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, n_mels)
+    got = _six64(emu, x, n_mels=n_mels, mode=mode)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 2e-6
+
+
 def _auto(emu, x, hop=160, n_mels=80, sr=16000.0):
     """MELSPEC_PRECISION_AUTO emulated: f32 kernel + the frames its guard queues recomputed by the f64 kernel."""
     x = np.ascontiguousarray(x, np.float32)

@@ -1,0 +1,67 @@
+"""whisper400_six64_kernel<15, LensSix128> (round 5): the f64 six-frame kernel on Whisper large-v3's 128-mel bank -- MELSPEC_PRECISION_F64 on
+plain batches (uniform and ragged) and AUTO's gated launch on uniform plain batches, which plans the batch a second time in six-frame
+units (the f32 launch in front of it walks five-frame units).  Layouts and ragged AUTO batches stay on whisper400_precise_kernel."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SR = 16000.0
+
+
+def test_f64_mode_at_128_mels_runs_the_six_frame_kernel(gpu, oracle, jfk):
+    m = gpu.HipMelSpectrogram(400, 160, SR, 128)
+    m.set_precision("f64")
+    assert "whisper400_six64_kernel<15" in m.plain_kernel_name()
+    # uniform: clips whose frame counts are 0, 1 .. 5 past a multiple of six, and one shorter than a unit
+    for n_frames in (1, 5, 6, 7, 11, 12, 313, 998):
+        clip_len = 400 + (n_frames - 1) * 160 + 7
+        n_clips = 37
+        clips = np.stack([np.roll(jfk, -977 * c)[:clip_len] for c in range(n_clips)]).astype(np.float32)
+        pcm = gpu.DeviceBuffer(clips.nbytes)
+        pcm.upload(clips.reshape(-1))
+        out = gpu.DeviceBuffer(n_clips * n_frames * 128 * 4)
+        m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+        m.synchronize()
+        got = out.download((n_clips, n_frames, 128))
+        for c in (0, 18, 36):
+            assert np.abs(got[c] - oracle.compute_mel_spectrogram_cpu(clips[c], 400, 160, 128, SR)).max() <= 2e-6, (n_frames, c)
+        pcm.free(); out.free()
+    # ragged
+    lens = [0, 399, 400, 1360, 16000, 5003, 48000, 1361]
+    xs = [jfk[1000 * i:1000 * i + n].copy() for i, n in enumerate(lens)]
+    flat = np.concatenate(xs)
+    offs = np.cumsum([0] + lens[:-1]).astype(np.uint64)
+    out, total = m.compute_batch_host(flat, offs, np.asarray(lens, np.uint64))
+    cur = 0
+    for x in xs:
+        want = oracle.compute_mel_spectrogram_cpu(x, 400, 160, 128, SR)
+        g = out[cur:cur + want.size].reshape(want.shape)
+        cur += want.size
+        if want.size:
+            assert np.abs(g - want).max() <= 2e-6, len(x)
+    # a layout at 128 mels stays on the five-frame f64 kernel and agrees
+    img = m.compute_batch_interleaved(np.stack([jfk[:16000], jfk[16000:32000]]), False, 0)
+    for k in range(2):
+        want = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(jfk[16000 * k:16000 * (k + 1)], 400, 160, 128, SR), False, 0)
+        assert np.abs(img[k] - want).max() <= 2e-6
+
+
+def test_auto_at_128_mels_hands_speech_to_the_six_frame_kernel_and_noise_to_nobody(gpu, oracle, jfk):
+    m = gpu.HipMelSpectrogram(400, 160, SR, 128)
+    assert m.precision == "auto"
+    n_clips, clip_len = 300, 48000
+    speech = np.stack([np.roll(jfk, -1237 * c)[:clip_len] for c in range(n_clips)]).astype(np.float32)
+    noise = np.stack([oracle.synth_pcm(8 * c, clip_len) for c in range(n_clips)])
+    nf = m.num_frames(clip_len)
+    pcm = gpu.DeviceBuffer(speech.nbytes)
+    out = gpu.DeviceBuffer(n_clips * nf * 128 * 4)
+    for name, clips, heavy_want in (("speech", speech, True), ("noise", noise, False), ("speech again", speech, True)):
+        pcm.upload(clips.reshape(-1))
+        m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr)
+        m.synchronize()
+        got = out.download((n_clips, nf, 128))
+        heavy = bool(m.auto_state()[0])
+        assert heavy == heavy_want, (name, m.auto_state())
+        for c in (0, 149, 299):
+            d = np.abs(got[c] - oracle.compute_mel_spectrogram_cpu(clips[c], 400, 160, 128, SR)).max()
+            assert d <= (2e-6 if heavy else 1e-4), (name, c, d)      # heavy: every frame came from the f64 kernel

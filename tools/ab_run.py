@@ -28,10 +28,10 @@ def wall(fn, sync, iters):
         sync()
         best = min(best, (time.perf_counter() - t0) / iters * 1e3)
     return best
-if case in ("cfg2", "cfg4", "f64", "mm", "mm64", "f32") or case.startswith("nm"):
-    nm = 128 if case == "cfg4" else (int(case[2:]) if case.startswith("nm") else 80)      # nm<k>: k mels (run-time-lens kernels for non-default banks)
+if case in ("cfg2", "cfg4", "f64", "f64_128", "mm", "mm64", "f32") or case.startswith("nm"):
+    nm = 128 if case in ("cfg4", "f64_128") else (int(case[2:]) if case.startswith("nm") else 80)      # nm<k>: k mels (run-time-lens kernels for non-default banks)
     m = M.HipMelSpectrogram(400, 160, 16000.0, nm)
-    if case in ("f64", "mm64"): m.set_precision("f64")
+    if case in ("f64", "f64_128", "mm64"): m.set_precision("f64")
     if case == "f32": m.set_precision("f32")
     if os.environ.get("AB_NOVOTE"): m.set_auto_adaptive(False)      # variant "name+nv": AUTO without the vote (one launch per call)
     nf = m.num_frames(clip_len)
@@ -46,18 +46,19 @@ if case in ("cfg2", "cfg4", "f64", "mm", "mm64", "f32") or case.startswith("nm")
         got = out.download((nf, nm), offset_bytes=5 * nf * nm * 4)
         want = O.compute_mel_spectrogram_cpu(O.synth_pcm(5, clip_len), 400, 160, nm, 16000.0)
         assert np.abs(got - want).max() <= 1e-4, np.abs(got - want).max()
-elif case == "speech":
+elif case in ("speech", "speech128"):
     # the reference's own fixture tiled to the config-2 batch, default mode: the launch's vote hands it to the gated f64 kernel
     jfk = O.load_wav_f32(os.path.join(sys.argv[1], "tests", "golden", "jfk_f32le.wav"))
     x = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(64)])
     pcm.upload(np.tile(x, (n_clips // 64, 1)).reshape(-1))
-    m = M.HipMelSpectrogram(400, 160, 16000.0, 80)
+    nm = 128 if case == "speech128" else 80
+    m = M.HipMelSpectrogram(400, 160, 16000.0, nm)
     nf = m.num_frames(clip_len)
-    out = M.DeviceBuffer(n_clips * (nf + 8) * 80 * 4)
+    out = M.DeviceBuffer(n_clips * (nf + 8) * nm * 4)
     spin(lambda: m.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), m.synchronize)
     ms = min(m.time_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, warmup=50, iters=300) for _ in range(3))
-    got = out.download((nf, 80), offset_bytes=5 * nf * 80 * 4)
-    assert np.abs(got - O.compute_mel_spectrogram_cpu(x[5], 400, 160, 80, 16000.0)).max() <= 1e-4
+    got = out.download((nf, nm), offset_bytes=5 * nf * nm * 4)
+    assert np.abs(got - O.compute_mel_spectrogram_cpu(x[5], 400, 160, nm, 16000.0)).max() <= 1e-4
 elif case in ("w512", "w512_f32", "w512_128", "w512_128_f32"):
     nm = 128 if "128" in case else 80
     m = M.HipMelSpectrogram(512, 160, 16000.0, nm)
