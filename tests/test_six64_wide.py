@@ -1,6 +1,7 @@
 """whisper400_six64_kernel<15, LensSix128> (round 5): the f64 six-frame kernel on Whisper large-v3's 128-mel bank -- MELSPEC_PRECISION_F64 on
 plain batches (uniform and ragged) and AUTO's gated launch on uniform plain batches, which plans the batch a second time in six-frame
-units (the f32 launch in front of it walks five-frame units).  Layouts and ragged AUTO batches stay on whisper400_precise_kernel."""
+units (the f32 launch in front of it walks five-frame units).  Layouts and ragged AUTO batches stay on whisper400_precise_kernel: the
+fifteen-slot LAYOUT instantiation was built and measured 1.7 % slower than the precise kernel's (mel-major F64 at 128 mels 0.5604 -> 0.5697 ms)."""
 import numpy as np
 import pytest
 
@@ -48,7 +49,7 @@ def test_f64_mode_at_128_mels_runs_the_six_frame_kernel(gpu, oracle, jfk):
 
 def test_auto_at_128_mels_hands_speech_to_the_six_frame_kernel_and_noise_to_nobody(gpu, oracle, jfk):
     m = gpu.HipMelSpectrogram(400, 160, SR, 128)
-    assert m.precision == "auto"
+    m.set_precision("auto")                 # (the suite is also run with MELSPEC_PRECISE=1)
     n_clips, clip_len = 300, 48000
     speech = np.stack([np.roll(jfk, -1237 * c)[:clip_len] for c in range(n_clips)]).astype(np.float32)
     noise = np.stack([oracle.synth_pcm(8 * c, clip_len) for c in range(n_clips)])

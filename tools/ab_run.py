@@ -28,15 +28,15 @@ def wall(fn, sync, iters):
         sync()
         best = min(best, (time.perf_counter() - t0) / iters * 1e3)
     return best
-if case in ("cfg2", "cfg4", "f64", "f64_128", "mm", "mm64", "f32") or case.startswith("nm"):
-    nm = 128 if case in ("cfg4", "f64_128") else (int(case[2:]) if case.startswith("nm") else 80)      # nm<k>: k mels (run-time-lens kernels for non-default banks)
+if case in ("cfg2", "cfg4", "f64", "f64_128", "mm", "mm64", "mm64_128", "mm_128", "f32") or case.startswith("nm"):
+    nm = 128 if case in ("cfg4", "f64_128", "mm64_128", "mm_128") else (int(case[2:]) if case.startswith("nm") else 80)      # nm<k>: k mels (run-time-lens kernels for non-default banks)
     m = M.HipMelSpectrogram(400, 160, 16000.0, nm)
-    if case in ("f64", "f64_128", "mm64"): m.set_precision("f64")
+    if case in ("f64", "f64_128", "mm64", "mm64_128"): m.set_precision("f64")
     if case == "f32": m.set_precision("f32")
     if os.environ.get("AB_NOVOTE"): m.set_auto_adaptive(False)      # variant "name+nv": AUTO without the vote (one launch per call)
     nf = m.num_frames(clip_len)
     out = M.DeviceBuffer(n_clips * (nf + 8) * nm * 4)
-    if case in ("mm", "mm64"):
+    if case in ("mm", "mm64", "mm64_128", "mm_128"):
         fn = lambda: m.compute_uniform_device_interleaved(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, False, 2)
         ms = wall(fn, m.synchronize, 200)
         got = None
