@@ -193,6 +193,7 @@ def dry_run(args) -> None:
             line["cfg5"] = {"scaling": "strong", "shards": sh5, "per_rank_frames": [(b - a) * fpc5 for a, b in sh5]}
         if world == 1 and args.config == 2 and not args.no_speech:
             line["speech"] = {"input": "tests/golden/jfk_f32le.wav tiled to the config-2 batch"}
+            line["speech128"] = {"input": "the same through the 128-mel bank (Whisper large-v3)"}
         if world == 1 and args.config == 2 and not args.no_legs:
             line["legs"] = list(LEG_NAMES) + ["host_api_single_clip_ms"]
         print(json.dumps(line), flush=True)
@@ -367,7 +368,8 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
            "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
            "frames_tripping_the_guard_per_step": tripped, "fraction_tripping": tripped / frames,
            "kernel_of_each_of_the_first_batches": ["gated f64 kernel (the launch's vote: heavy)" if h else "f32 kernel + f64 recompute of tripped frames" for h in regimes],
-           "kernel": "melspec::whisper400_six64_kernel<9, ., gated> (f64 FFT, six frames per wave) behind the voting f32 launch", "parity_max_abs_diff": worst, "steps": k}
+           "kernel": ("melspec::whisper400_six64_kernel<15, LensSix128, gated> (f64 FFT, six frames per wave, fifteen mel slots) behind the voting f32 launch" if n_mels == 128 else
+                      "melspec::whisper400_six64_kernel<9, ., gated> (f64 FFT, six frames per wave) behind the voting f32 launch"), "parity_max_abs_diff": worst, "steps": k}
     mel.close()
     del pcm, out
     return res
@@ -625,9 +627,11 @@ def main() -> None:
         pin_in.free(); pin_out.free()
 
     # the real-input leg (N = 1, the default workload) and, for N > 1 without --config, north_star's 65 536 x 30 s per-clip split
-    speech = None
+    speech = speech128 = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_speech and args.precision == "auto" and args.n_mels is None:
         speech = speech_leg(M, torch, dev, stream, n_clips, clip_len, n_mels)
+        # the same real input through Whisper large-v3's bank (configs[3]'s 128 mels, on the config-2 batch): the kernel real large-v3 input runs on
+        speech128 = speech_leg(M, torch, dev, stream, n_clips, clip_len, 128)
     legs = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_legs and args.precision == "auto" and args.n_mels is None and args.clips is None and args.clip_seconds is None:
         legs = extra_legs(M, torch, dev, stream)
@@ -718,6 +722,8 @@ def main() -> None:
                                     "reused: pageable memory, and memory from melspec_host_alloc (pinned); never `value`")
         if speech is not None:
             res["config"]["speech"] = speech
+        if speech128 is not None:
+            res["config"]["speech128"] = speech128
         if legs is not None:
             res["host_api_single_clip_ms"] = legs.pop("host_api_single_clip_ms")
             res["host_api_single_clip_note"] = ("HipMelSpectrogram::compute_mel_spectrogram on ONE clip of 10 / 60 / 300 s, host memory in and out (PCIe-inclusive, never `value`): "
