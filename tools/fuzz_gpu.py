@@ -133,6 +133,8 @@ def case_nemo():
               log_zero_guard=2.0 ** -24, normalize_per_feature=bool(rng.integers(0, 2)))
     fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(**kw))
     x = signal(int(rng.integers(600, 50000)))
+    if os.environ.get("FUZZ_DUMP"):
+        np.save(os.environ["FUZZ_DUMP"], x)          # the input of the case in flight (a failing run leaves it behind)
     got = fe.compute(x)
     want, valid = O.blm_compute(x, O.blm_default_config(**kw), True)
     assert got.shape == want.shape, ("nemo", kw, got.shape, want.shape)
@@ -157,8 +159,14 @@ def case_nemo():
         good = std >= 0.5
         if good.any():
             # relative to max(1, |z|): a z-score of 40 (an outlier frame in a flat row) carries the row's 4e-6 relative error of std as 1.6e-4
-            d2 = float((np.abs(got[good] - want[good]) / np.maximum(1.0, np.abs(want[good]))).max())
-            assert d2 <= 1e-4, ("nemo normalised, well-conditioned rows", kw, len(x), d2)
+            # ... plus what the f32 left fold of the mean can move when the rows differ in their last bit: up to valid * 2^-24 * |mean|
+            # (a quarter of it allowed), divided by the row's std -- a row of ~300 values on the floor ln(2^-24) = -16.6 with a handful
+            # of louder frames (std 0.54) showed 1.5e-4 in round 5, and the round-4 library gives the same bits for it
+            mean_abs = np.abs(raw_want[:, :valid].astype(np.float64).mean(axis=1))
+            row_tol = 1e-4 + 0.25 * valid * 2.0 ** -24 * mean_abs[good] / std[good]
+            d_rows = (np.abs(got[good] - want[good]) / np.maximum(1.0, np.abs(want[good]))).max(axis=1)
+            d2 = float(d_rows.max())
+            assert np.all(d_rows <= row_tol), ("nemo normalised, well-conditioned rows", kw, len(x), d2, float(row_tol[np.argmax(d_rows - row_tol)]))
             note("nemo_norm_rows_std>=0.5", d2)
         note("nemo", d0)
     fe.close()
