@@ -11,9 +11,10 @@ LIB_PATH = os.path.join(PKG_DIR, "libmelspec_hip.so")
 import glob
 
 LAB_LIB_PATH = os.path.join(PKG_DIR, "libmelspec_hip_lab.so")   # -DMELSPEC_LAB: tuning switches for tools/, never loaded by default
-# translation units and the flags only they get: melspec_runs.hip holds the run-per-wave f32 Whisper kernels, scheduled for ILP
-# (csrc/melspec_runs.hip says why; the default strategy is the better one for everything else)
-SOURCES = ["melspec_hip.hip", "melspec_runs.hip"]
+# translation units (one kernel family each, csrc/host_common.hpp has the map) and the flags only they get: melspec_runs.hip holds the
+# run-per-wave f32 Whisper kernels, scheduled for ILP (csrc/melspec_runs.hip says why; the default strategy is the better one for
+# everything else)
+SOURCES = ["host_api.hip", "whisper400.hip", "fbank512.hip", "pow2.hip", "aux.hip", "melspec_runs.hip"]
 UNIT_FLAGS = {"melspec_runs.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 

@@ -6,11 +6,10 @@
 // 5-frame run kernel with the compile-time 128-mel bank (config 4) -6.2 %, the six-frame run kernel (config 2, 5) -0.7 %; the
 // run-time-lens variants of the same kernels +0.1...+2 %, the f64 kernels +5...+11 %, the layout kernel of the six-frame family
 // +25 % -- so the flag cannot be given to the library, only to these specialisations.  There is no
-// source-level spelling of the per-function attribute ("amdgpu-sched-strategy"), hence the file: melspec_hip.hip declares these
-// specialisations `extern template`, their device code and host stubs are emitted here, and mel_spec_amd/build.py compiles the two
-// files to objects with their own flags and links them into libmelspec_hip.so.
-#define MELSPEC_TEMPLATE_KERNELS_ONLY      // the plain (non-template) kernels of the header belong to melspec_hip.hip
-#include "melspec_kernels.hpp"
+// source-level spelling of the per-function attribute ("amdgpu-sched-strategy"), hence the file: whisper400.hip declares these
+// specialisations `extern template`, their device code and host stubs are emitted here, and mel_spec_amd/build.py compiles every
+// unit to an object with its own flags and links them into libmelspec_hip.so.
+#include "whisper400_kernels.hpp"
 
 namespace melspec {
 

@@ -1,6 +1,6 @@
 // stream_plan.hpp -- host bookkeeping of the streaming bank (plain C++, no HIP): which frames a push emits
 // and where they start, restating Spectrogram::add (src/stft.rs:48-86) driven hop by hop the way
-// RingBuffer::maybe_mel does (src/rb.rs:86-121).  Shared by melspec_hip.hip and tests/emu.
+// RingBuffer::maybe_mel does (src/rb.rs:86-121).  Shared by aux.hip and tests/emu.
 #pragma once
 
 #include <algorithm>

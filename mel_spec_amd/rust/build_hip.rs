@@ -7,7 +7,7 @@ fn link_hip_backend() {
     println!("cargo:rerun-if-env-changed=MELSPEC_HIP_DIR");
     println!("cargo:rerun-if-env-changed=ROCM_PATH");
     // directory holding libmelspec_hip.so (built by `python -m mel_spec_amd.build`: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize
-    // -fPIC -c csrc/melspec_hip.hip and csrc/melspec_runs.hip -- the latter with -mllvm -amdgpu-sched-strategy=max-ilp -- then hipcc -shared)
+    // -fPIC -c of every unit in csrc/*.hip -- melspec_runs.hip with -mllvm -amdgpu-sched-strategy=max-ilp -- then hipcc -shared)
     let dir = std::env::var("MELSPEC_HIP_DIR").expect("set MELSPEC_HIP_DIR to the directory of libmelspec_hip.so");
     let rocm = std::env::var("ROCM_PATH").unwrap_or_else(|_| "/opt/rocm".into());
     println!("cargo:rustc-link-search=native={dir}");

@@ -1,8 +1,7 @@
 #!/bin/bash
 # same-box A/B (boxes differ by up to 10 %): a previous commit's library against the current one.  Build the former first:
-#   rm -rf /tmp/prev && mkdir /tmp/prev && git archive <commit> mel_spec_amd/csrc include | tar -x -C /tmp/prev &&
-#   (cd /tmp/prev && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -DMELSPEC_LAB \
-#      -o $REPO/mel_spec_amd/libmelspec_hip_prev.so mel_spec_amd/csrc/melspec_hip.hip)
+#   git worktree add /tmp/prev <commit> && SRC_ROOT=/tmp/prev tools/ab_build.sh prev:"-DMELSPEC_LAB" &&
+#   cp mel_spec_amd/ab/lib_prev.so mel_spec_amd/libmelspec_hip_prev.so
 # then: gpurun -- tools/ab_same_box.sh
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/probe_g.txt

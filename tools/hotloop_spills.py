@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Compiles csrc/melspec_hip.hip to gfx950 assembly and reports, per kernel, the scratch (spill) instructions that sit INSIDE the unit
+"""Compiles every unit of the library (mel_spec_amd.build.SOURCES) to gfx950 assembly and reports, per kernel, the scratch (spill) instructions that sit INSIDE the unit
 loop -- between the first `s_setprio 0` (phase 1 of a unit) and the loop's back edge -- as opposed to the recompute tail behind it.
 A spill in the tail is cheap; one in the loop is paid per unit (the mel-major kernel once lost 20 % that way).
 Kernels without phase priorities (pow2_frame_kernel, the normalisers, ...): every scratch instruction inside ANY loop, by the compiler's own
