@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--no-speech", action="store_true", help="skip the real-input leg (`config.speech`: jfk_f32le.wav tiled to the config-2 batch)")
     ap.add_argument("--no-cfg5", action="store_true", help="N > 1 without --config: skip the extra config-5 leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra N = 1 legs next to `value` (`config.cfg3`, `config.cfg4`, `config.f64`, `config.mel_major`, "
-                                                          "`host_api_single_clip_ms`)")
+                                                          "`config.w512`, `config.nemo`, `config.nemo_f32`, `host_api_single_clip_ms`)")
     ap.add_argument("--clips", type=int, default=None, help="override the clip count (per GPU for weak, total for strong)")
     ap.add_argument("--clip-seconds", type=int, default=None)
     ap.add_argument("--n-mels", type=int, default=None)
@@ -300,6 +300,18 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
 
     elapsed = timed_steps(timed_step, torch.cuda.synchronize, steps, 0, dist if distributed else None, red_dev)
     my_kernel_ms = ev0.elapsed_time(ev1) / steps      # HIP events on the launch stream: a whole step (AUTO: the f32 kernel + the gated f64 launch)
+    # dispersion of the figure: five more windows of the same K steps (at most 200), event-timed back to back behind the
+    # timed region; `value` stays what the contract says (the K steps above), `value_ci` says how far a window of that length moves
+    windows = []
+    if primary:
+        wsteps = max(1, min(steps, 200))
+        for _ in range(5):
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record()
+            for _ in range(wsteps):
+                step()
+            w1.record(); torch.cuda.synchronize()
+            windows.append(frames_per_step * wsteps / (w0.elapsed_time(w1) * 1e-3))
     # the dominant kernel on its own: an event pair around the first kernel of each of 200 more calls (melspec_time_first_kernel), the
     # figure a kernel trace reports -- `roofline.achieved` is quoted on it; the step time above stays what `value` is made of
     first_ms = None
@@ -318,7 +330,7 @@ def run_workload(args, config: int, primary: bool, steps: int, warmup: int, M, t
     mel_name = mel.plain_kernel_name()
     res = dict(elapsed=elapsed, per_rank=per_rank, kernel_ms=kernel_ms, frames_per_step=frames_per_step, n_clips=n_clips, sub=sub,
                parity=parity, queued=queued, spinup_steps=spinup_steps, scaling=scaling, n_mels=n_mels, clip_seconds=clip_seconds,
-               clip_len=clip_len, total_or_per=total_or_per, fpc=fpc, kernel=mel_name, mel=mel, out=out, pcm=pcm, stream=stream, first_ms=first_ms)
+               clip_len=clip_len, total_or_per=total_or_per, fpc=fpc, kernel=mel_name, mel=mel, out=out, pcm=pcm, stream=stream, first_ms=first_ms, windows=windows)
     return res
 
 
@@ -370,12 +382,16 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
            "kernel_of_each_of_the_first_batches": ["gated f64 kernel (the launch's vote: heavy)" if h else "f32 kernel + f64 recompute of tripped frames" for h in regimes],
            "kernel": ("melspec::whisper400_six64_kernel<15, LensSix128, gated> (f64 FFT, six frames per wave, fifteen mel slots) behind the voting f32 launch" if n_mels == 128 else
                       "melspec::whisper400_six64_kernel<9, ., gated> (f64 FFT, six frames per wave) behind the voting f32 launch"), "parity_max_abs_diff": worst, "steps": k}
+    v = valu_fields("speech128" if n_mels == 128 else "speech", res["frames_per_s"])
+    if v is not None:
+        res["valu"] = v
     mel.close()
     del pcm, out
     return res
 
 
-LEG_NAMES = ("cfg3", "cfg4", "f64", "mel_major", "nemo", "nemo_f32")
+LEG_NAMES = ("cfg3", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32")
+F64_VECTOR_PEAK_TFLOPS = 78.6       # MI355X f64 vector peak (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 FMA lanes x 2 flops x 2.4 GHz
 
 
 def _event_timed(torch, run, iters: int, spin_s: float = 0.15) -> float:
@@ -393,128 +409,244 @@ def _event_timed(torch, run, iters: int, spin_s: float = 0.15) -> float:
     return e0.elapsed_time(e1) / iters
 
 
+_ISA = None
+
+
+def valu_fields(leg: str, frames_per_s: float):
+    """The compute-side roofline of a leg (VERDICT r05 'missing' 4): VALU wave-instructions per frame of the kernel's unit loop, from the ISA
+    histogram of the shipped library (tools/isa_legs.py -> profiles/isa_hist.json; static counts: one pass of the unit loop / frames per
+    unit), and the f64 issue they amount to at the measured rate against the 78.6 TFLOP/s f64 vector peak (every f64 VALU instruction
+    counted as one 64-lane FMA slot = 128 flops).  None when the table has no row for the leg."""
+    global _ISA
+    if _ISA is None:
+        try:
+            _ISA = json.load(open(os.path.join(ROOT, "profiles", "isa_hist.json")))
+        except Exception:
+            _ISA = {}
+    row = (_ISA.get("legs") or {}).get(leg)
+    if not row:
+        return None
+    fpu = float(row["frames_per_unit"])
+    f64 = row.get("f64", 0) / fpu
+    other = (row.get("valu32", 0) + row.get("cvt", 0) + row.get("dpp/lane", 0) + row.get("pk", 0)) / fpu
+    out = {"f64_insts_per_frame": f64, "other_valu_per_frame": other, "lds_insts_per_frame": row.get("lds", 0) / fpu,
+           "frac_of_f64_vector_peak": f64 * 128.0 * frames_per_s / (F64_VECTOR_PEAK_TFLOPS * 1e12),
+           "kernel_symbol": row.get("kernel"), "isa_of_source_hash": _ISA.get("source_hash")}
+    try:
+        from mel_spec_amd import build as hip_build
+        if _ISA.get("source_hash") != hip_build.source_hash():
+            out["stale"] = "profiles/isa_hist.json was made from other sources than this library (re-run tools/isa_legs.py)"
+    except Exception:
+        pass
+    return out
+
+
 def extra_legs(M, torch, dev, stream) -> dict:
     """The figures the driver would otherwise never see, NEXT TO `value`, never instead of it; N = 1, default run.
-    Every leg: synthetic clips resident in HBM, a parity check of two clips against the oracle first, HIP events around >= 50 launches;
-    {ms, frames_per_s, frac (algorithmic bytes / ms over 8 TB/s), kernel, parity_max_abs_diff}.  ~1 s of GPU time in all.
+    Every leg: synthetic clips resident in HBM, a parity check of two clips against the oracle first, HIP events around >= 10 launches;
+    {ms, frames_per_s, frac (algorithmic bytes / ms over 8 TB/s), valu (instructions per frame, fraction of the f64 vector peak), kernel,
+    parity_max_abs_diff}.  A leg that fails -- a parity miss, an allocation that does not fit -- records {"error": ...} and the next
+    one runs: nothing here can cost the line its `value`.  ~2 s of GPU time in all.
       cfg3       BASELINE configs[2]: Kaldi fbank (25 ms / 10 ms, 512-point FFT, 80 bins, pre-emphasis 0.97, Povey, CMN on), 1024 x 10 s
-      cfg4       BASELINE configs[3] scaled to the timed budget: Whisper large-v3, 128 mels, 1024 x 30 s (the full 8192 x 30 s is
-                 tests/test_full_size.py and `bench.py --config 4`)
+      cfg4       BASELINE configs[3] at its stated size when the device has the room: Whisper large-v3, 128 mels, 8192 x 30 s (28.3 GB
+                 resident); otherwise 1024 x 30 s with the reason in the record
       f64        configs[1] in MELSPEC_PRECISION_F64 (the f64 FFT on every frame: what speech costs without the vote)
       mel_major  configs[1] stored as interleave_frames(.., false, ..) = [mel][frames], the whisper.cpp layout (src/mel.rs:480-544)
+      w512       Whisper at n_fft 512 / hop 160 / 80 mels -- the geometry of the reference's golden (src/rb.rs:134-179) -- default mode
       nemo / nemo_f32  the NeMo / Parakeet frontend, 128 mels, 1024 x 10 s: default mode (f64) and MELSPEC_PRECISION_F32 (the reference's f32)"""
+    import gc
     import numpy as np
     from oracle import oracle as O
     legs = {}
 
-    def record(frames, bytes_per_frame, ms, kernel, parity, workload):
+    def record(leg, frames, bytes_per_frame, ms, kernel, parity, workload):
         gbs = frames * bytes_per_frame / (ms * 1e-3) / 1e9
-        return {"workload": workload, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
-                "kernel": kernel, "parity_max_abs_diff": parity}
+        r = {"workload": workload, "ms": ms, "frames_per_s": frames / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+             "kernel": kernel, "parity_max_abs_diff": parity}
+        v = valu_fields(leg, r["frames_per_s"])
+        if v is not None:
+            r["valu"] = v
+        return r
 
-    # ---- cfg3: Kaldi fbank + CMN
+    def guarded(name, fn):
+        try:
+            legs[name] = fn()
+        except BaseException as e:          # SystemExit of a parity miss included: the leg is lost, the line is not
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            legs[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        gc.collect()
+        try:
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+
     n_clips, clip_len = 1024, 160000
     pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
     M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, 0, n_clips, stream=stream)
-    fb = M.Fbank(device=dev.index)
-    fpc = fb.num_frames(clip_len)
-    out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
-    run = lambda: fb.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
-    run(); torch.cuda.synchronize()
-    o3 = out.view(n_clips, fpc, 80)
-    worst = max(float(np.abs(o3[c].cpu().numpy() - O.fbank_compute(O.synth_pcm(c, clip_len))).max()) for c in (0, n_clips - 1))
-    if worst > 1e-4:
-        raise SystemExit(f"cfg3 leg: parity check failed, max|diff| = {worst}")
-    legs["cfg3"] = record(n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), fb.kernel_name() if hasattr(fb, "kernel_name") else
+
+    def leg_cfg3():         # Kaldi fbank + CMN
+        fb = M.Fbank(device=dev.index)
+        try:
+            fpc = fb.num_frames(clip_len)
+            out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
+            run = lambda: fb.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+            run(); torch.cuda.synchronize()
+            o3 = out.view(n_clips, fpc, 80)
+            worst = max(float(np.abs(o3[c].cpu().numpy() - O.fbank_compute(O.synth_pcm(c, clip_len))).max()) for c in (0, n_clips - 1))
+            if worst > 1e-4:
+                raise SystemExit(f"cfg3 leg: parity check failed, max|diff| = {worst}")
+            return record("cfg3", n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), fb.kernel_name() if hasattr(fb, "kernel_name") else
                           "melspec::fbank512_clip_kernel (f64 FFT, CMN inside)", worst,
                           "configs[2]: Kaldi fbank 80 bins + CMN on 1024 synthetic 10 s clips, resident in HBM")
-    fb.close()
-    del out
+        finally:
+            fb.close()
 
-    # ---- f64 and mel-major on the config-2 batch
-    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 80, device=dev.index)
-    fpc = mel.num_frames(clip_len)
-    out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
-    want = {c: O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), N_FFT, HOP, 80, SR) for c in (0, n_clips - 1)}
-    mel.set_precision("f64")
-    run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
-    run(); torch.cuda.synchronize()
-    o3 = out.view(n_clips, fpc, 80)
-    worst = max(float(np.abs(o3[c].cpu().numpy() - want[c]).max()) for c in want)
-    if worst > 1e-4:
-        raise SystemExit(f"f64 leg: parity check failed, max|diff| = {worst}")
-    legs["f64"] = record(n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), mel.plain_kernel_name(), worst,
-                         "configs[1] (1024 x 10 s, 80 mels) with melspec_set_precision(f64): the f64 FFT on every frame")
-    mel.set_precision("auto")
-    W = mel.interleaved_width(clip_len, 0)
-    outm = torch.empty(n_clips * 80 * W, dtype=torch.float32, device=dev)
-    run = lambda: mel.compute_uniform_device_interleaved(pcm.data_ptr(), clip_len, clip_len, n_clips, outm.data_ptr(), False, 0, stream=stream)
-    run(); torch.cuda.synchronize()
-    om = outm.view(n_clips, 80, W)
-    worst = max(float(np.abs(om[c].cpu().numpy() - O.interleave_frames(want[c], False, 0)).max()) for c in want)
-    if worst > 1e-4:
-        raise SystemExit(f"mel-major leg: parity check failed, max|diff| = {worst}")
-    legs["mel_major"] = record(n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), "melspec::whisper400_six_kernel (mel-major store)", worst,
-                               f"configs[1] stored mel-major [80][{W}] per clip (interleave_frames(.., false, 0), the whisper.cpp layout), default precision mode")
-    # the drop-in call on one clip, host memory in and out (PCIe-inclusive; the reference's published shape, README.md:117-123, src/cuda.rs:547-613)
-    single = {}
-    for secs in (10, 60, 300):
-        x = O.synth_pcm(1, int(secs * SR))
-        mel.compute_mel_spectrogram(x)
-        best, reps = 1e9, 10
-        for _ in range(3):                      # best of three: the staging threads of a > 16 MiB call share the host with torch's pools
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                y = mel.compute_mel_spectrogram(x)
-            best = min(best, (time.perf_counter() - t0) / reps * 1e3)
-        single[f"{secs}s"] = {"ms": best, "frames": int(y.shape[0])}
-    legs["host_api_single_clip_ms"] = single
-    mel.close()
-    del out, outm
+    want = {}
 
-    # ---- SURVEY 8(f) #1: the NeMo / Parakeet frontend (BatchLogMelSpectrogram, 128 mels, pre-emphasis 0.97) on the same clips: the default
-    # mode (f64 up to |X|^2, 1e-4 from the f64 evaluation of the definition) and MELSPEC_PRECISION_F32, the reference's own arithmetic
-    # type for this frontend (src/mel.rs:251-252,356-357), gated like tests/test_f32_512.py: within 4 x the distance of upstream's literal
-    # f32 arithmetic (the oracle's f64 = False restatement) from the same f64 evaluation on the same clips
-    fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), device=dev.index)
-    cols = fe.padded_frames(clip_len)
-    out = torch.empty(n_clips * 128 * cols, dtype=torch.float32, device=dev)
-    ocfg = O.blm_default_config(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24)
-    wantn = {c: O.blm_compute(O.synth_pcm(c, clip_len), ocfg, True)[0] for c in (0, n_clips - 1)}
-    run = lambda: fe.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
-    room = max(float(np.abs(O.blm_compute(O.synth_pcm(c, clip_len), ocfg, False)[0] - wantn[c]).max()) for c in wantn)
-    for mode, key, tol in (("auto", "nemo", 1e-4), ("f32", "nemo_f32", max(1e-4, 4.0 * room))):
-        fe.set_precision(mode)
-        run(); torch.cuda.synchronize()
-        o3 = out.view(n_clips, 128, cols)
-        worst = max(float(np.abs(o3[c].cpu().numpy() - wantn[c]).max()) for c in wantn)
-        if worst > tol:
-            raise SystemExit(f"{key} leg: parity check failed, max|diff| = {worst}")
-        legs[key] = record(n_clips * cols, HOP * 4 + 128 * 4, _event_timed(torch, run, 100),
-                           "melspec::fbank512_wave_kernel<float, 12 waves, NeMo> (f32, feature-major rows staged through LDS)" if fe.precision == "f32"
-                           else "melspec::fbank512_wave_kernel<double, 8 waves, NeMo> (f64 FFT)", worst,
-                           f"SURVEY 8(f) #1: BatchLogMelSpectrogram 128 mels, pre-emphasis 0.97, 1024 synthetic 10 s clips, feature-major [128][{cols}] per clip, precision {fe.precision}")
-        legs[key]["reference_f32_max_abs_diff"] = room
-    fe.close()
-    del out, pcm
+    def want80():
+        if not want:
+            want.update({c: O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), N_FFT, HOP, 80, SR) for c in (0, n_clips - 1)})
+        return want
 
-    # ---- cfg4: 128 mels, 30 s clips
-    n_clips, clip_len = 1024, 480000
-    pcm = torch.empty(n_clips * clip_len, dtype=torch.float32, device=dev)
-    M.synth_pcm_device(pcm.data_ptr(), clip_len, clip_len, 0, n_clips, stream=stream)
-    mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 128, device=dev.index)
-    fpc = mel.num_frames(clip_len)
-    out = torch.empty(n_clips * fpc * 128, dtype=torch.float32, device=dev)
-    run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
-    run(); torch.cuda.synchronize()
-    o3 = out.view(n_clips, fpc, 128)
-    worst = max(float(np.abs(o3[c].cpu().numpy() - O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), N_FFT, HOP, 128, SR)).max()) for c in (0, n_clips - 1))
-    if worst > 1e-4:
-        raise SystemExit(f"cfg4 leg: parity check failed, max|diff| = {worst}")
-    legs["cfg4"] = record(n_clips * fpc, HOP * 4 + 128 * 4, _event_timed(torch, run, 50), mel.plain_kernel_name(), worst,
-                          "configs[3] scaled to the timed budget: Whisper large-v3, 128 mels, 1024 synthetic 30 s clips (the full 8192 x 30 s: bench.py --config 4, "
-                          "tests/test_full_size.py), default precision mode (step = f32 kernel + the gated f64 launch)")
-    mel.close()
+    def leg_f64():          # configs[1] with the f64 FFT on every frame
+        mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 80, device=dev.index)
+        try:
+            fpc = mel.num_frames(clip_len)
+            out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
+            mel.set_precision("f64")
+            run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+            run(); torch.cuda.synchronize()
+            o3 = out.view(n_clips, fpc, 80)
+            worst = max(float(np.abs(o3[c].cpu().numpy() - w).max()) for c, w in want80().items())
+            if worst > 1e-4:
+                raise SystemExit(f"f64 leg: parity check failed, max|diff| = {worst}")
+            return record("f64", n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), mel.plain_kernel_name(), worst,
+                          "configs[1] (1024 x 10 s, 80 mels) with melspec_set_precision(f64): the f64 FFT on every frame")
+        finally:
+            mel.close()
+
+    def leg_mel_major():    # configs[1] in the whisper.cpp layout
+        mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 80, device=dev.index)
+        try:
+            fpc = mel.num_frames(clip_len)
+            W = mel.interleaved_width(clip_len, 0)
+            outm = torch.empty(n_clips * 80 * W, dtype=torch.float32, device=dev)
+            run = lambda: mel.compute_uniform_device_interleaved(pcm.data_ptr(), clip_len, clip_len, n_clips, outm.data_ptr(), False, 0, stream=stream)
+            run(); torch.cuda.synchronize()
+            om = outm.view(n_clips, 80, W)
+            worst = max(float(np.abs(om[c].cpu().numpy() - O.interleave_frames(w, False, 0)).max()) for c, w in want80().items())
+            if worst > 1e-4:
+                raise SystemExit(f"mel-major leg: parity check failed, max|diff| = {worst}")
+            return record("mel_major", n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), "melspec::whisper400_six_kernel (mel-major store)", worst,
+                          f"configs[1] stored mel-major [80][{W}] per clip (interleave_frames(.., false, 0), the whisper.cpp layout), default precision mode")
+        finally:
+            mel.close()
+
+    def leg_single():       # the drop-in call on one clip, host memory in and out (PCIe-inclusive; README.md:117-123, src/cuda.rs:547-613)
+        mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 80, device=dev.index)
+        try:
+            single = {}
+            for secs in (10, 60, 300):
+                x = O.synth_pcm(1, int(secs * SR))
+                mel.compute_mel_spectrogram(x)
+                best, reps = 1e9, 10
+                for _ in range(3):                  # best of three: the staging threads of a > 16 MiB call share the host with torch's pools
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        y = mel.compute_mel_spectrogram(x)
+                    best = min(best, (time.perf_counter() - t0) / reps * 1e3)
+                single[f"{secs}s"] = {"ms": best, "frames": int(y.shape[0])}
+            return single
+        finally:
+            mel.close()
+
+    def leg_w512():         # the geometry of the reference's value-level golden, plain batch, default mode
+        mel = M.HipMelSpectrogram(512, HOP, SR, 80, device=dev.index)
+        try:
+            fpc = mel.num_frames(clip_len)
+            out = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
+            run = lambda: mel.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+            run(); torch.cuda.synchronize()
+            o3 = out.view(n_clips, fpc, 80)
+            worst = max(float(np.abs(o3[c].cpu().numpy() - O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len), 512, HOP, 80, SR)).max()) for c in (0, n_clips - 1))
+            if worst > 1e-4:
+                raise SystemExit(f"w512 leg: parity check failed, max|diff| = {worst}")
+            return record("w512", n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), mel.plain_kernel_name(), worst,
+                          "Whisper at n_fft 512 / hop 160 / 80 mels (the geometry of rust_jfk_golden.npy, src/rb.rs:134-179) on configs[1]'s 1024 x 10 s clips, default precision mode")
+        finally:
+            mel.close()
+
+    def leg_nemo(mode, key):
+        # SURVEY 8(f) #1: the NeMo / Parakeet frontend (BatchLogMelSpectrogram, 128 mels, pre-emphasis 0.97): the default mode (f64 up to |X|^2,
+        # 1e-4 from the f64 evaluation of the definition) and MELSPEC_PRECISION_F32, the reference's own arithmetic type for this frontend
+        # (src/mel.rs:251-252,356-357), gated like tests/test_f32_512.py: within 4 x the distance of upstream's literal f32 arithmetic (the
+        # oracle's f64 = False restatement) from the same f64 evaluation on the same clips
+        fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24), device=dev.index)
+        try:
+            cols = fe.padded_frames(clip_len)
+            out = torch.empty(n_clips * 128 * cols, dtype=torch.float32, device=dev)
+            ocfg = O.blm_default_config(n_mels=128, preemphasis=0.97, log_zero_guard=2.0 ** -24)
+            wantn = {c: O.blm_compute(O.synth_pcm(c, clip_len), ocfg, True)[0] for c in (0, n_clips - 1)}
+            room = max(float(np.abs(O.blm_compute(O.synth_pcm(c, clip_len), ocfg, False)[0] - wantn[c]).max()) for c in wantn)
+            tol = 1e-4 if mode == "auto" else max(1e-4, 4.0 * room)
+            run = lambda: fe.compute_uniform_device(pcm.data_ptr(), clip_len, clip_len, n_clips, out.data_ptr(), stream=stream)
+            fe.set_precision(mode)
+            run(); torch.cuda.synchronize()
+            o3 = out.view(n_clips, 128, cols)
+            worst = max(float(np.abs(o3[c].cpu().numpy() - wantn[c]).max()) for c in wantn)
+            if worst > tol:
+                raise SystemExit(f"{key} leg: parity check failed, max|diff| = {worst}")
+            r = record(key, n_clips * cols, HOP * 4 + 128 * 4, _event_timed(torch, run, 100),
+                       "melspec::fbank512_wave_kernel<float, 12 waves, NeMo> (f32, feature-major rows staged through LDS)" if fe.precision == "f32"
+                       else "melspec::fbank512_wave_kernel<double, 8 waves, NeMo> (f64 FFT)", worst,
+                       f"SURVEY 8(f) #1: BatchLogMelSpectrogram 128 mels, pre-emphasis 0.97, 1024 synthetic 10 s clips, feature-major [128][{cols}] per clip, precision {fe.precision}")
+            r["reference_f32_max_abs_diff"] = room
+            return r
+        finally:
+            fe.close()
+
+    guarded("cfg3", leg_cfg3)
+    guarded("f64", leg_f64)
+    guarded("mel_major", leg_mel_major)
+    guarded("host_api_single_clip_ms", leg_single)
+    guarded("w512", leg_w512)
+    guarded("nemo", lambda: leg_nemo("auto", "nemo"))
+    guarded("nemo_f32", lambda: leg_nemo("f32", "nemo_f32"))
+    del pcm
+    gc.collect(); torch.cuda.empty_cache()
+
+    def leg_cfg4():         # BASELINE configs[3]: 128 mels, 30 s clips -- at its stated size when it fits
+        clip_len4, full = 480000, CONFIGS[4][0]
+        mel = M.HipMelSpectrogram(N_FFT, HOP, SR, 128, device=dev.index)
+        try:
+            fpc = mel.num_frames(clip_len4)
+            per_clip = clip_len4 * 4 + fpc * 128 * 4 + fpc * 4 / 5 * 1.05           # PCM + mel + the guard's note list
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            n4, why = full, None
+            if full * per_clip > 0.85 * free_b:
+                n4 = 1024
+                why = f"scaled: the full {full} x 30 s needs {full * per_clip / 1e9:.1f} GB resident and the device has {free_b / 1e9:.1f} GB free"
+            pcm4 = torch.empty(n4 * clip_len4, dtype=torch.float32, device=dev)
+            out = torch.empty(n4 * fpc * 128, dtype=torch.float32, device=dev)
+            M.synth_pcm_device(pcm4.data_ptr(), clip_len4, clip_len4, 0, n4, stream=stream)
+            run = lambda: mel.compute_uniform_device(pcm4.data_ptr(), clip_len4, clip_len4, n4, out.data_ptr(), stream=stream)
+            run(); torch.cuda.synchronize()
+            o3 = out.view(n4, fpc, 128)
+            worst = max(float(np.abs(o3[c].cpu().numpy() - O.compute_mel_spectrogram_cpu(O.synth_pcm(c, clip_len4), N_FFT, HOP, 128, SR)).max()) for c in (0, n4 // 2 + 1, n4 - 1))
+            if worst > 1e-4:
+                raise SystemExit(f"cfg4 leg: parity check failed, max|diff| = {worst}")
+            r = record("cfg4", n4 * fpc, HOP * 4 + 128 * 4, _event_timed(torch, run, 10 if n4 == full else 50, spin_s=0.3), mel.plain_kernel_name(), worst,
+                       f"configs[3]: Whisper large-v3, 128 mels, {n4} synthetic 30 s clips resident in HBM ({(n4 * per_clip) / 1e9:.1f} GB), default precision "
+                       "mode (step = f32 kernel + the gated f64 launch)")
+            r["clips"], r["full_size"] = n4, n4 == full
+            if why:
+                r["scaled_because"] = why
+            return r
+        finally:
+            mel.close()
+
+    guarded("cfg4", leg_cfg4)
     return legs
 
 
@@ -629,12 +761,24 @@ def main() -> None:
     # the real-input leg (N = 1, the default workload) and, for N > 1 without --config, north_star's 65 536 x 30 s per-clip split
     speech = speech128 = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_speech and args.precision == "auto" and args.n_mels is None:
-        speech = speech_leg(M, torch, dev, stream, n_clips, clip_len, n_mels)
+        def leg_or_error(fn):           # like the extra legs: a failing leg costs its own entry, never the line
+            try:
+                return fn()
+            except BaseException as e:
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                return {"error": f"{type(e).__name__}: {e}"[:400]}
+        speech = leg_or_error(lambda: speech_leg(M, torch, dev, stream, n_clips, clip_len, n_mels))
         # the same real input through Whisper large-v3's bank (configs[3]'s 128 mels, on the config-2 batch): the kernel real large-v3 input runs on
-        speech128 = speech_leg(M, torch, dev, stream, n_clips, clip_len, 128)
+        speech128 = leg_or_error(lambda: speech_leg(M, torch, dev, stream, n_clips, clip_len, 128))
     legs = None
     if rank == 0 and world == 1 and args.config == 2 and not args.no_legs and args.precision == "auto" and args.n_mels is None and args.clips is None and args.clip_seconds is None:
-        legs = extra_legs(M, torch, dev, stream)
+        try:
+            legs = extra_legs(M, torch, dev, stream)
+        except BaseException as e:              # its own set-up (the shared PCM buffer) failed: every leg is lost, the line is not
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            legs = {k: {"error": f"{type(e).__name__}: {e}"[:400]} for k in LEG_NAMES}
     cfg5 = None
     if world > 1 and not explicit_config and not args.no_cfg5:
         kernel_name = mel.plain_kernel_name()
@@ -700,6 +844,9 @@ def main() -> None:
                        "frames_recomputed_in_f64_per_step": queued,
                        "parallelism": f"per-clip split x{world}, no data-path collective"},
             "per_gpu_frames_per_s": value / world,
+            "value_ci": ({"windows": len(w["windows"]), "steps_per_window": max(1, min(steps, 200)), "min": min(w["windows"]), "median": sorted(w["windows"])[len(w["windows"]) // 2],
+                          "max": max(w["windows"]), "note": "rank 0's frames/s over five more event-timed windows of the same K steps (at most 200) right behind the timed region; `value` is the K steps of the contract"}
+                         if (cfg5 is None and w.get("windows")) else None),
             "per_rank": [dict({"frames_per_step": p[0], "kernel_ms": p[1]}, **(idents[r] or {})) for r, p in enumerate(per_rank)],
             "realtime_x": value * (HOP / SR),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -712,7 +859,9 @@ def main() -> None:
                                             "(melspec_time_first_kernel; `step_ms_events` = HIP events around the K timed steps / K, which in the default mode also "
                                             "holds the gated f64 launch behind every f32 launch, ~5 us that return at once on this input)" if dominant_ms is not kernel_ms else
                                             "HIP events on the launch stream around the K timed steps / K"),
-                         "algorithmic_bytes_per_launch": algo_bytes_per_launch},
+                         "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                         "valu": valu_fields("value" if (args.config == 2 and n_mels == 80 and args.precision != "f64") else ("cfg4" if (n_mels == 128 and args.precision != "f64") else "none"),
+                                             frames_per_step / (dominant_ms * 1e-3))},
             "parity_max_abs_diff": parity, "spinup_steps_untimed": spinup_steps,
         }
         if host_io is not None:
@@ -725,11 +874,11 @@ def main() -> None:
         if speech128 is not None:
             res["config"]["speech128"] = speech128
         if legs is not None:
-            res["host_api_single_clip_ms"] = legs.pop("host_api_single_clip_ms")
+            res["host_api_single_clip_ms"] = legs.pop("host_api_single_clip_ms", None)
             res["host_api_single_clip_note"] = ("HipMelSpectrogram::compute_mel_spectrogram on ONE clip of 10 / 60 / 300 s, host memory in and out (PCIe-inclusive, never `value`): "
                                                 "the shape of the reference's published figures (README.md:117-123) and of its #[ignore] benches (src/cuda.rs:547-613)")
             for k in LEG_NAMES:
-                res["config"][k] = legs[k]
+                res["config"][k] = legs.get(k, {"error": "leg did not run"})
         if cfg5 is not None:
             res["config"]["cfg5"] = cfg5
         if gather is not None:

@@ -28,27 +28,28 @@ int launch_fused512(int waves, const FbankFastParams &fp, size_t lds, int cus, h
         else hipLaunchKernelGGL((fbank512_wave_kernel<T, 12, 1, FLAVOR, NSLOTS, Lens>), dim3(grid12), dim3(768), lds, s, fp);
         HIP_TRY(hipGetLastError());
         return MELSPEC_OK;
+    } else {                  // (an else: the f32 instantiation must not instantiate the eight- and four-wave kernels it never launches)
+        const bool runs = kCanRun && plain && waves == 8;
+        static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
+        if (!device_done(attr_done)) {
+            int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
+            if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
+            if (!rc && kCanRun) rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>, "hipFuncSetAttribute(fbank512_wave_kernel, runs)");
+            if (rc) return rc;
+            mark_device_done(attr_done);
+        }
+        const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
+        static const int per_cu = lab_int("MELSPEC_FB_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU; measured best
+        const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
+        if (runs)
+            hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>), dim3(grid), dim3(512), lds, s, fp);
+        else if (waves == 8)
+            hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>), dim3(grid), dim3(512), lds, s, fp);
+        else
+            hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>), dim3(grid), dim3(256), lds, s, fp);
+        HIP_TRY(hipGetLastError());
+        return MELSPEC_OK;
     }
-    const bool runs = kCanRun && plain && waves == 8;
-    static std::atomic<uint64_t> attr_done{0};          // one bit per device: function attributes are per device
-    if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>, "hipFuncSetAttribute(fbank512_wave_kernel, 8 waves)");
-        if (!rc) rc = allow_big_lds(&fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>, "hipFuncSetAttribute(fbank512_wave_kernel, 4 waves)");
-        if (!rc && kCanRun) rc = allow_big_lds(&fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>, "hipFuncSetAttribute(fbank512_wave_kernel, runs)");
-        if (rc) return rc;
-        mark_device_done(attr_done);
-    }
-    const uint64_t blocks = (fp.b.n_units + waves - 1) / waves;
-    static const int per_cu = lab_int("MELSPEC_FB_GRID_PER_CU", 1, 1, 4096);   // one workgroup is resident per CU; measured best
-    const unsigned grid = grid_for_xcd(blocks, cus, per_cu);
-    if (runs)
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens, kCanRun>), dim3(grid), dim3(512), lds, s, fp);
-    else if (waves == 8)
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 8, 1, FLAVOR, NSLOTS, Lens>), dim3(grid), dim3(512), lds, s, fp);
-    else
-        hipLaunchKernelGGL((fbank512_wave_kernel<T, 4, 1, FLAVOR, NSLOTS, LensRuntime>), dim3(grid), dim3(256), lds, s, fp);
-    HIP_TRY(hipGetLastError());
-    return MELSPEC_OK;
 }
 
 void f32_params(const Fused512F32 &f, FbankFastParams &fp) {

@@ -241,7 +241,7 @@ inline BatchPlan plan_uniform(const float *d_pcm, float *d_out, uint64_t clip_st
     b.out_width = out_width;
     b.mel_major = mel_major ? 1 : 0;
     // mel-major stores keep waves that hold adjacent units in step, so that the 24-byte pieces of a 32-byte sector reach L2
-    // together (RoundSync in melspec_kernels.hpp): -1 = the measured best of the kernel that runs, resolved in launch_ctx.
+    // together (RoundSync in kernels_common.hpp): -1 = the measured best of the kernel that runs, resolved in launch_ctx.
     // Lab builds: MELSPEC_MM_SYNC 0 none, 1 one workgroup barrier per round, 2/4/8 sub-group barrier over consecutive waves,
     // 16 + 2/4/8 over waves WAVES / size apart; MELSPEC_FM_SYNC=1: workgroup barrier for the padded frame-major layout too.
     static const int mm_mode = [] { const int v = lab_int("MELSPEC_MM_SYNC", -1, -1, 31); const int sz = v & 15; return (v <= 1 || ((sz == 2 || sz == 3 || sz == 4 || sz == 6 || sz == 8) && (v >> 4) <= 1)) ? v : 1; }();   // 3 / 6: the twelve-wave kernels only
@@ -338,7 +338,7 @@ using namespace melspec::host;
 // ------------------------------------------------------------------------------------
 // Whisper log-mel context
 // ------------------------------------------------------------------------------------
-// MELSPEC_PRECISION_AUTO state (FixSink in melspec_kernels.hpp): the f64 tables of the in-kernel recompute and its counter.
+// MELSPEC_PRECISION_AUTO state (FixSink in kernels_common.hpp): the f64 tables of the in-kernel recompute and its counter.
 struct FixState {
     DevBuf tab, count, list;              // count: {u64 frames that tripped the guard, u64 accumulator of the launch in flight, u64 tally of the vote}
     DevBuf verdicts;                      // FixSink::decision: kVoteSlots copies of the last vote's verdict
@@ -346,7 +346,7 @@ struct FixState {
     bool used = false;
     // Statistics of the guarded launches, published by the kernels into host-mapped memory (FixSink::host) and read here without
     // touching the stream (melspec_auto_state, melspec_guard_count's cheap sibling).  They no longer decide anything: since round 4
-    // the kernel a batch runs on is decided by a vote inside the batch's own launch (FixSink::vote in melspec_kernels.hpp), so the
+    // the kernel a batch runs on is decided by a vote inside the batch's own launch (FixSink::vote in kernels_common.hpp), so the
     // result of a call is a function of its input alone -- round 3 chose from the statistics of the last FINISHED batch, which made
     // the bits of a batch depend on what the context had seen before and on how far the host was ahead of the GPU.
     unsigned long long *host = nullptr;   // {seq << 40 | tripped, seq << 40 | frames (bit 39: published by the gated f64 launch)} of the last finished launch

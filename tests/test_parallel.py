@@ -212,13 +212,56 @@ def test_plain_bench_line_carries_the_speech_leg_and_config5():
     one = run()
     assert one["n_gpus"] == 1 and one["config"] == 2 and "speech" in one and "cfg5" not in one
     # the legs the driver's plain N = 1 run carries next to `value`
-    assert one["legs"] == ["cfg3", "cfg4", "f64", "mel_major", "nemo", "nemo_f32", "host_api_single_clip_ms"] and "legs" not in run("--no-legs")
+    assert one["legs"] == ["cfg3", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32", "host_api_single_clip_ms"] and "legs" not in run("--no-legs")
     two = run("--gpus", "2")
     assert two["n_gpus"] == 2 and two["config"] == 2 and two["scaling"] == "weak" and two["shards"] == [[0, 1024], [1024, 2048]]
     c5 = two["cfg5"]
     assert c5["scaling"] == "strong" and c5["shards"][0][0] == 0 and c5["shards"][-1][1] == 65536
     assert sum(c5["per_rank_frames"]) == 196476928
     assert "cfg5" not in run("--gpus", "2", "--config", "2")
+
+
+def test_a_failing_leg_costs_its_entry_not_the_line():
+    """a parity miss or an allocation failure inside one of the extra legs must not cost the bench line its `value`.  The legs
+    run against a library stand-in whose every constructor raises: each leg records {"error": ...} and extra_legs returns."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Boom:
+        def __getattr__(self, name):
+            if name == "synth_pcm_device":
+                return lambda *a, **k: None
+            if name == "BatchLogMelConfig":
+                return lambda **k: None
+            def ctor(*a, **k):
+                raise RuntimeError(f"{name}: no device in this test")
+            return ctor
+
+    legs = bench.extra_legs(Boom(), torch, torch.device("cpu"), None)
+    assert set(legs) == set(bench.LEG_NAMES) | {"host_api_single_clip_ms"}
+    for name, rec in legs.items():
+        assert set(rec) == {"error"} and "no device in this test" in rec["error"], (name, rec)
+
+
+def test_valu_fields_come_from_the_committed_isa_table():
+    """every leg of the line carries the VALU instructions per frame of its kernel and the fraction of the 78.6 TFLOP/s
+    f64 vector peak they amount to at the measured rate (profiles/isa_hist.json, written by tools/isa_legs.py from the shipped sources)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    from mel_spec_amd import build as hip_build
+    table = json.load(open(os.path.join(ROOT, "profiles", "isa_hist.json")))
+    assert table["source_hash"] == hip_build.source_hash(), "profiles/isa_hist.json is stale: run tools/isa_legs.py"
+    for leg in ("value", "cfg3", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32", "speech", "speech128"):
+        v = bench.valu_fields(leg, 2.0e9)
+        assert v is not None and "stale" not in v, leg
+        assert v["f64_insts_per_frame"] >= 0 and v["other_valu_per_frame"] > 0
+        # 128 flops per f64 wave-instruction at 2 G frames/s against 78.6 TFLOP/s
+        assert abs(v["frac_of_f64_vector_peak"] - v["f64_insts_per_frame"] * 128 * 2.0e9 / 78.6e12) < 1e-12
+    assert bench.valu_fields("f64", 2.4e9)["f64_insts_per_frame"] == 106.0          # 636 f64 instructions per six-frame unit (DESIGN 4.1c)
+    assert bench.valu_fields("value", 3.4e9)["f64_insts_per_frame"] == 0.0
+    assert bench.valu_fields("no such leg", 1.0) is None
 
 
 @pytest.mark.gpu
