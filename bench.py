@@ -178,7 +178,14 @@ def dry_run(args) -> None:
     total = args.clips or cfg_clips
     lo, hi = (rank * total, (rank + 1) * total) if scaling == "weak" else shard_range(total, rank, world)
     elapsed = timed_steps(lambda: time.sleep(0.002 * (rank + 1)), lambda: None, 3, 1, dist if world > 1 else None, None)
-    mine = torch.tensor([lo, hi], dtype=torch.int64)
+    # what the rank would hold resident for its share (run_workload's buffers): PCM, the mel output, the precision guard's note list
+    # (one u64 per six-frame unit + a round of slack, whisper400.hip launch_ctx)
+    clip_len = int((args.clip_seconds or cfg_seconds) * SR)
+    n_mels = args.n_mels or cfg_mels
+    fpc = (clip_len - N_FFT) // HOP + 1
+    n_mine = hi - lo
+    units = n_mine * ((fpc + 5) // 6)
+    mine = torch.tensor([lo, hi, n_mine * clip_len * 4, n_mine * fpc * n_mels * 4, (units + 65536) * 8], dtype=torch.int64)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_gather(allr, mine)
@@ -186,7 +193,10 @@ def dry_run(args) -> None:
         allr = [mine]
     if rank == 0:
         line = {"dry_run": True, "n_gpus": world, "scaling": scaling, "config": args.config,
-                "shards": [[int(t[0]), int(t[1])] for t in allr], "max_over_ranks_s": elapsed}
+                "shards": [[int(t[0]), int(t[1])] for t in allr], "max_over_ranks_s": elapsed,
+                "residency": [{"rank": r, "pcm_bytes": int(t[2]), "mel_bytes": int(t[3]), "guard_list_bytes": int(t[4]), "total_GB": float(int(t[2]) + int(t[3]) + int(t[4])) / 1e9}
+                              for r, t in enumerate(allr)],
+                "hbm_per_gpu_GB": 288.0}
         if world > 1 and not args.explicit_config and not args.no_cfg5:        # the extra leg of a plain `bench.py --gpus N`
             fpc5 = (CONFIGS[5][1] * int(SR) - N_FFT) // HOP + 1
             sh5 = [list(shard_range(CONFIGS[5][0], r, world)) for r in range(world)]
@@ -431,6 +441,9 @@ def valu_fields(leg: str, frames_per_s: float):
     other = (row.get("valu32", 0) + row.get("cvt", 0) + row.get("dpp/lane", 0) + row.get("pk", 0)) / fpu
     out = {"f64_insts_per_frame": f64, "other_valu_per_frame": other, "lds_insts_per_frame": row.get("lds", 0) / fpu,
            "frac_of_f64_vector_peak": f64 * 128.0 * frames_per_s / (F64_VECTOR_PEAK_TFLOPS * 1e12),
+           # a wave's v_fma_f64 measured alone issues every 6.2 cycles at two waves per SIMD, not every 4 (profiles/r04_mfma_f64_probe.txt): the same
+           # count against THAT rate -- what the f64 pipe can be made to do on this part
+           "frac_of_measured_f64_issue_rate": f64 * 128.0 * frames_per_s / (F64_VECTOR_PEAK_TFLOPS * 1e12) * (6.2 / 4.0),
            "kernel_symbol": row.get("kernel"), "isa_of_source_hash": _ISA.get("source_hash")}
     try:
         from mel_spec_amd import build as hip_build
@@ -708,6 +721,12 @@ def main() -> None:
     if distributed:
         idents = [None] * world
         dist.all_gather_object(idents, ident)
+
+    if world > 1 and not args.one_device:
+        # N ranks on fewer than N devices is not an N-GPU measurement: refuse to print a line that looks like one
+        distinct = len({(i or {}).get("uuid") or (i or {}).get("pci_bus_id") or (i or {}).get("device_index") for i in idents})
+        if distinct != world:
+            raise SystemExit(f"bench.py: {world} ranks ran on {distinct} distinct device(s) ({idents}); LOCAL_RANK -> device mapping is broken")
 
     gather = None
     if world > 1 and args.gather and sub == 1 and not args.one_device:

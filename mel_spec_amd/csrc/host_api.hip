@@ -755,23 +755,37 @@ int melspec_gather_peer(int dst_device, void *dst, const int *src_devices, const
     if (!dst || !src_devices || !srcs || !bytes || !dst_offsets) return fail(MELSPEC_ERR_INVALID_ARG, "NULL argument");
     std::vector<hipStream_t> streams(n, nullptr);
     int rc = MELSPEC_OK;
+    // what failed, for whom: on an 8-GPU node "invalid device ordinal" alone does not say which of the seven links it was
+    auto piece_failed = [&](hipError_t e, const char *what, int i) {
+        const int code = fail_hip(e, what);
+        g_last_error = "melspec_gather_peer: piece " + std::to_string(i) + " of " + std::to_string(n) + ", source device " + std::to_string(src_devices[i]) +
+                       " -> destination device " + std::to_string(dst_device) + ": " + g_last_error;
+        return code;
+    };
     for (int i = 0; i < n && !rc; ++i) {
         if (bytes[i] == 0) continue;
         hipError_t e = hipSetDevice(src_devices[i]);
-        if (e == hipSuccess && src_devices[i] != dst_device) {
-            int can = 0;
-            (void)hipDeviceCanAccessPeer(&can, src_devices[i], dst_device);
-            if (can) { const hipError_t pe = hipDeviceEnablePeerAccess(dst_device, 0); if (pe != hipSuccess) (void)hipGetLastError(); }   // already enabled is fine
+        if (e != hipSuccess) { rc = piece_failed(e, "hipSetDevice", i); break; }
+        // Peer access lets the copy run over the xGMI link between the two devices.  Where the runtime says it cannot be had (can == 0:
+        // another node, an IOMMU setting -- and, trivially, a device with itself) the copy below still works, staged by the runtime; where
+        // it can, a failure to enable it other than "already enabled" is the piece's error.
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, src_devices[i], dst_device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        if (can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(dst_device, 0);
+            if (pe != hipSuccess) (void)hipGetLastError();
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { rc = piece_failed(pe, "hipDeviceEnablePeerAccess", i); break; }
         }
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMemcpyPeerAsync(static_cast<char *>(dst) + dst_offsets[i], dst_device, srcs[i], src_devices[i], bytes[i], streams[i]);
-        if (e != hipSuccess) rc = fail_hip(e, "melspec_gather_peer");
+        if ((e = hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking)) != hipSuccess) { rc = piece_failed(e, "hipStreamCreateWithFlags", i); break; }
+        e = hipMemcpyPeerAsync(static_cast<char *>(dst) + dst_offsets[i], dst_device, srcs[i], src_devices[i], bytes[i], streams[i]);
+        if (e != hipSuccess) rc = piece_failed(e, "hipMemcpyPeerAsync", i);
     }
+    // the pieces already queued finish (or fail) before the call returns, whatever happened to a later one: no stream outlives it
     for (int i = 0; i < n; ++i) {
         if (!streams[i]) continue;
         (void)hipSetDevice(src_devices[i]);
         const hipError_t e = hipStreamSynchronize(streams[i]);
-        if (e != hipSuccess && !rc) rc = fail_hip(e, "melspec_gather_peer: hipStreamSynchronize");
+        if (e != hipSuccess && !rc) rc = piece_failed(e, "hipStreamSynchronize", i);
         (void)hipStreamDestroy(streams[i]);
     }
     return rc;

@@ -26,6 +26,29 @@ def pytest_sessionstart(session):
         print(f"conftest: could not build libmelspec_hip.so ({e})", file=sys.stderr)
 
 
+# ---- both precision regimes in ONE driver invocation (VERDICT r05 'next' 7) ---------------------------------------------------------
+# Every GPU test runs twice: in the library's default mode, and with every log-mel context created through the Python mirror starting
+# in MELSPEC_PRECISION_F64 (MELSPEC_PRECISE=1: a switch of the test mirror, mel_spec_amd/hip.py -- libmelspec_hip.so reads no environment
+# variable).  Round 5 ran the second pass by hand; the driver's `pytest -m gpu` now counts both.  A suite started with MELSPEC_PRECISE
+# already set (a builder-side run in one fixed mode) is left alone.
+_FIXED_BY_CALLER = os.environ.get("MELSPEC_PRECISE", "") != ""
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") is not None and not _FIXED_BY_CALLER:
+        metafunc.parametrize("initial_precision", ["default-mode", "f64-initial"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def initial_precision(request, monkeypatch):
+    mode = getattr(request, "param", None)
+    if mode == "f64-initial":
+        monkeypatch.setenv("MELSPEC_PRECISE", "1")
+    elif mode == "default-mode":
+        monkeypatch.delenv("MELSPEC_PRECISE", raising=False)
+    return mode
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

@@ -13,8 +13,8 @@ TOL = 1e-4
 SR = 16000.0
 
 
-@pytest.fixture(scope="module")
-def w80(gpu):
+@pytest.fixture
+def w80(gpu):          # per test: the context starts in the mode of the test's pass (conftest.initial_precision)
     m = gpu.HipMelSpectrogram(400, 160, SR, 80)
     assert m.uses_fast_path
     yield m
@@ -71,7 +71,8 @@ def _tone_over_noise_floor(n=32000, level_db=-70.0, f=3333.3, seed=0):
 # MELSPEC_PRECISION_AUTO decides per batch (a vote inside the batch's launch) between the f32 kernel + recompute of the tripped frames and
 # the f64 kernel: a function of the batch, so the same batch always gives the same bits -- but the same CLIP inside two different batches
 # may not (both within 1e-4).  Tests that compare a clip's bits across batch shapes call set_auto_adaptive(False): no vote, f32 + tail.
-_ENV_MODE = {"1": "f64", "f": "f32"}.get(os.environ.get("MELSPEC_PRECISE", "")[:1], "auto")   # the suite is also run with MELSPEC_PRECISE=1
+def _env_mode():          # every GPU test also runs with MELSPEC_PRECISE=1 (conftest.initial_precision): read per test, not at import
+    return {"1": "f64", "f": "f32"}.get(os.environ.get("MELSPEC_PRECISE", "")[:1], "auto")
 
 
 @pytest.mark.parametrize("n_mels", [80, 128])
@@ -80,7 +81,7 @@ def test_precision_modes(gpu, oracle, jfk, n_mels):
     default: the f32 kernel plus the f64 recompute of the frames its error bound does not cover -- the tone-over-floor
     signal that the bare f32 FFT misses (F32) is within the tolerance."""
     m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
-    assert m.uses_fast_path and m.precision == _ENV_MODE
+    assert m.uses_fast_path and m.precision == _env_mode()
     m.set_precise(True)
     assert m.precise and m.precision == "f64"
     want = oracle.compute_mel_spectrogram_cpu(jfk, 400, 160, n_mels, SR)
@@ -117,7 +118,7 @@ def test_auto_is_a_function_of_the_batch(gpu, oracle, jfk):
     FixSink::vote): speech goes to the f64 kernel on its FIRST batch, on a fresh context, and costs what F64 costs; noise stays on the
     f32 kernel; and -- VERDICT r03 weak #1(ii), the reference is a pure function of its input (src/stft.rs:119-138) -- the bits of a batch
     do not depend on what the context computed before it.  melspec_set_auto_adaptive(0): no vote, f32 kernel + recompute tail."""
-    if _ENV_MODE != "auto":
+    if _env_mode() != "auto":
         pytest.skip("the suite is being run with a fixed precision mode")
     n_clips, clip_len, n_mels = 256, 160000, 80
     speech = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(32)])
@@ -225,7 +226,7 @@ def test_every_precision_mode_through_every_batch_shape(gpu, oracle, jfk, n_mels
 def test_auto_votes_on_the_layouts_too(gpu, oracle, jfk, n_mels, mel_major):
     """The padded / mel-major layouts take the same vote (their sample is the head of the batch): speech goes to the f64 layout kernel
     on its first batch, noise stays on the f32 kernel, and a batch's bits do not depend on what came before it."""
-    if _ENV_MODE != "auto":
+    if _env_mode() != "auto":
         pytest.skip("the suite is being run with a fixed precision mode")
     n_clips, clip_len = 128, 48000
     speech = np.stack([np.resize(np.roll(jfk, -1237 * c), clip_len) for c in range(32)])

@@ -120,6 +120,57 @@ def test_sharded_device_resident_calls(gpu, oracle, jfk, devices):
     single.close(); sh.close()
 
 
+def test_eight_rank_rehearsal_of_config5_plans_what_the_full_size_test_samples():
+    """`bench.py --gpus 8 --config 5` has never run on eight devices.  Its launch path with eight ranks (gloo, no
+    GPU): every rank plans the 8192-clip shard whose boundary clips tests/test_full_size.py compares against the oracle on one GPU,
+    and the residency it would allocate -- 15.7 GB of PCM + 7.9 GB of mel + the guard's note list -- fits a 288 GB device 12 times."""
+    import json
+    from test_full_size import _picks
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--gpus", "8", "--config", "5"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    assert line["shards"] == [[8192 * r, 8192 * (r + 1)] for r in range(8)]
+    sampled = set(_picks(65536))
+    for lo, hi in line["shards"]:
+        assert {lo, hi - 1} <= sampled, (lo, hi)          # first and last clip of every rank's shard are among the clips checked at full size
+    fpc = (480000 - 400) // 160 + 1
+    for r, res in enumerate(line["residency"]):
+        assert res["rank"] == r and res["pcm_bytes"] == 8192 * 480000 * 4 and res["mel_bytes"] == 8192 * fpc * 80 * 4
+        assert res["guard_list_bytes"] == (8192 * 500 + 65536) * 8
+        assert 23.5 < res["total_GB"] < 23.7 and res["total_GB"] * 12 < line["hbm_per_gpu_GB"]
+    assert sum(b - a for a, b in line["shards"]) * fpc == 196476928
+
+
+@pytest.mark.gpu
+def test_gather_peer_names_the_piece_that_failed(gpu):
+    """the error paths of melspec_gather_peer, which no 1-GPU run had executed.  A source device that does not
+    exist fails in hipSetDevice, a destination that does not exist in hipMemcpyPeerAsync; either way the call returns non-zero after the
+    pieces already queued have finished (no stream left behind: the next call works), and melspec_last_error() says which piece, from
+    which device to which."""
+    from mel_spec_amd._lib import lib
+    a = gpu.DeviceBuffer(4096 * 4); b = gpu.DeviceBuffer(4096 * 4); dst = gpu.DeviceBuffer(8192 * 4)
+    xa = np.arange(4096, dtype=np.float32)
+    a.upload(xa); b.upload(-xa)
+    with pytest.raises(Exception) as e1:
+        gpu.gather_peer(0, dst.ptr, [(0, a.ptr, 4096 * 4, 0), (99, b.ptr, 4096 * 4, 4096 * 4)])
+    msg = lib().melspec_last_error().decode()
+    assert "piece 1 of 2" in msg and "source device 99" in msg and "destination device 0" in msg and "hipSetDevice" in msg, msg
+    assert str(e1.value)
+    assert np.array_equal(dst.download((8192,))[:4096], xa)          # piece 0 was queued before the failure and has landed
+    with pytest.raises(Exception):
+        gpu.gather_peer(99, dst.ptr, [(0, a.ptr, 4096 * 4, 0)])
+    msg = lib().melspec_last_error().decode()
+    assert "piece 0 of 1" in msg and "source device 0" in msg and "destination device 99" in msg, msg
+    # a device is no peer of itself (hipDeviceCanAccessPeer: 0): the branch without peer access is the one every 1-GPU call takes
+    gpu.gather_peer(0, dst.ptr, [(0, b.ptr, 4096 * 4, 0), (0, a.ptr, 4096 * 4, 4096 * 4)])
+    got = dst.download((8192,))
+    assert np.array_equal(got[:4096], -xa) and np.array_equal(got[4096:], xa)
+    for x in (a, b, dst):
+        x.free()
+
+
 @pytest.mark.gpu
 def test_gather_peer_consolidates_device_results(gpu):
     """melspec_gather_peer with every piece on device 0 (the only one of this box): the offsets / sizes / streams path."""
@@ -251,7 +302,11 @@ def test_valu_fields_come_from_the_committed_isa_table():
     sys.path.insert(0, ROOT)
     import bench
     from mel_spec_amd import build as hip_build
-    table = json.load(open(os.path.join(ROOT, "profiles", "isa_hist.json")))
+    path = os.path.join(ROOT, "profiles", "isa_hist.json")
+    if json.load(open(path))["source_hash"] != hip_build.source_hash():          # the sources moved on: the table is rebuilt here, like the library
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_legs.py")], check=True, stdout=subprocess.DEVNULL, timeout=900)
+        bench._ISA = None
+    table = json.load(open(path))
     assert table["source_hash"] == hip_build.source_hash(), "profiles/isa_hist.json is stale: run tools/isa_legs.py"
     for leg in ("value", "cfg3", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32", "speech", "speech128"):
         v = bench.valu_fields(leg, 2.0e9)
