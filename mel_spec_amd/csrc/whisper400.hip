@@ -202,6 +202,23 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
     if (layout) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
     else hipLaunchKernelGGL((whisper400_six_runs_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
     HIP_TRY(hipGetLastError());
+#ifdef MELSPEC_LAB_STAMPS
+    // tools/tail_probe.py: the 200th plain launch's per-wave end stamps and per-workgroup start stamps, as one line per workgroup
+    static int stamp_calls = 0;
+    if (!layout && fp.fix.list && lab_int("MELSPEC_LAB_STAMPS", 0, 0, 1) && ++stamp_calls == 200) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        const size_t n = static_cast<size_t>(grid.x) * kSixWaves + grid.x;
+        std::vector<uint64_t> st(n);
+        HIP_TRY(hipMemcpy(st.data(), fp.fix.list + desc.n_units + 4096, n * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        uint64_t t0 = ~0ull;
+        for (unsigned g = 0; g < grid.x; ++g) t0 = std::min(t0, st[static_cast<size_t>(grid.x) * kSixWaves + g]);
+        for (unsigned g = 0; g < grid.x; ++g) {
+            std::fprintf(stderr, "STAMP wg %u start %llu ends", g, static_cast<unsigned long long>(st[static_cast<size_t>(grid.x) * kSixWaves + g] - t0));
+            for (int w = 0; w < kSixWaves; ++w) std::fprintf(stderr, " %llu", static_cast<unsigned long long>(st[static_cast<size_t>(g) * kSixWaves + w] - t0));
+            std::fprintf(stderr, "\n");
+        }
+    }
+#endif
     return MELSPEC_OK;
 }
 

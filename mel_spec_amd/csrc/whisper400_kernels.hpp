@@ -434,6 +434,9 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
     const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
     const bool guard = p.fix.tab != nullptr;
 
+#ifdef MELSPEC_LAB_STAMPS
+    if (guard && tid == 0) p.fix.list[p.b.n_units + 4096 + (uint64_t)gridDim.x * kSixWaves + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+#endif
     ClipRun cr;
     if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) {
         if (guard && p.fix.vote != nullptr && blockIdx.x < p.fix.vote_groups) vote_cast(p.fix, wg_done + 2, kSixWaves, lane, 0, 0);
@@ -538,6 +541,11 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(
         redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
                                           loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
     }
+#ifdef MELSPEC_LAB_STAMPS
+    // lab builds (tools/tail_probe.py): when every wave finished, in 10 ns ticks of the constant clock -- written behind the note list's
+    // slack (whisper400.hip reads them back): the spread of these is what a hand-out of the last units on demand would have to win
+    if (guard && lane == 0) p.fix.list[p.b.n_units + 4096 + (uint64_t)blockIdx.x * kSixWaves + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
     guard_wave_done(p.fix, wg_done, kSixWaves, lane, redone);
 }
 
