@@ -102,9 +102,17 @@ int melspec_uses_fast_path(const melspec_ctx *ctx);
  *                   both within 1e-4); F32 and F64 do not have that, nor AUTO after melspec_set_auto_adaptive(ctx, 0).
  *   F64             window, FFT and |X|^2 in f64 for every frame: ~4e-7 from the reference, about 60 % of the f32 rate.
  *   F32             the f32 kernel alone: ~3e-5 on speech and noise, up to ~5e-4 on a line over a floor 70..90 dB down.
- * Geometries on the generic kernels always compute in f64.  The fused n_fft = 512 kernel (Whisper flavour, 80 / 128 mels) computes in f64
- * in AUTO and F64 and in f32 -- no guard, the accuracy of the f32 FFT: ~1e-6 on noise, 1e-2 on the quiet bands of speech -- in F32
- * (round 5; melspec_precision() reports what the next call will use). */
+ * Geometries on the generic kernels always compute in f64.  The fused n_fft = 512 kernels (Whisper flavour; the 80- and 128-mel banks at
+ * 16 kHz have an f32 instantiation) follow the same three modes since round 6:
+ *   AUTO  plain [clip][frame][mel] batches, uniform and ragged, of at least two work units per f32 wave of the grid (6144 units = 24 576
+ *         frames on an MI355X) run the f32 kernel with the same guard and the same vote; the f64 kernel queued behind it computes the
+ *         whole batch on "heavy" and the units the f32 launch noted on "light" (this family has no in-kernel recompute).  Smaller
+ *         batches, the padded / mel-major layouts, other banks, and AUTO after melspec_set_auto_adaptive(ctx, 0): the f64 kernel.
+ *   F64   the f64 kernel.
+ *   F32   the f32 kernel alone, no guard: 2e-5 on speech, ~1e-6 on noise, up to 4e-4 on a line over a floor 70..90 dB down
+ *         (profiles/r06_guard512.txt; round 5's f32 instantiation split straight to powers and was 7e-2 off on speech: it now splits to
+ *         amplitudes like the n_fft = 400 kernels).
+ * melspec_precision() reports the mode in effect (AUTO only where sizeable plain batches do vote, else F64 / F32). */
 #define MELSPEC_PRECISION_AUTO 0
 #define MELSPEC_PRECISION_F64  1
 #define MELSPEC_PRECISION_F32  2

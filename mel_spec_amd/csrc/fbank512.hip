@@ -71,8 +71,53 @@ int launch_nemo_f32(const Fused512F32 &f, FbankFastParams fp, int cus, hipStream
 }
 }  // namespace
 
+namespace {
+// MELSPEC_PRECISION_AUTO at n_fft = 512: the voting f32 launch and, gated on its verdict, the f64 launch (w512_auto_kernel)
+template <int NSLOTS, class Lens>
+int launch_w512_auto_t(melspec_ctx *c, const FbankFastParams &fp64, const BatchDesc &desc, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&w512_auto_kernel<float, kFused512F32Waves, NSLOTS, Lens>, "hipFuncSetAttribute(w512_auto_kernel<float>)");
+        if (!rc) rc = allow_big_lds(&w512_auto_kernel<double, 8, NSLOTS, Lens>, "hipFuncSetAttribute(w512_auto_kernel<double>)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    FixSink sink{};
+    int rc = auto_sink(c, desc, stream, true, sink);
+    if (rc) return rc;
+    sink.tab = nullptr;
+    const unsigned grid32 = grid_for_xcd((desc.n_units + kFused512F32Waves - 1) / kFused512F32Waves, c->dev.cus, 1);
+    W512AutoParams q{};
+    q.f = fp64;
+    f32_params(c->f512, q.f);
+    q.fix = sink_armed(c, sink, desc, grid32);
+    q.fix.vote_groups = std::min<unsigned>(grid32, static_cast<unsigned>(c->dev.cus));
+    hipLaunchKernelGGL((w512_auto_kernel<float, kFused512F32Waves, NSLOTS, Lens>), dim3(grid32), dim3(kFused512F32Waves * 64), c->f512.lds, stream, q);
+    HIP_TRY(hipGetLastError());
+    // the gated launch: this batch's verdict (its number is c->fix.seq) decides between every unit, the noted units and nothing
+    const unsigned grid64 = grid_for_xcd((desc.n_units + 7) / 8, c->dev.cus, 1);
+    W512AutoParams g{};
+    g.f = fp64;
+    FixSink stat{};
+    stat.count = sink.count; stat.acc = sink.acc; stat.host = sink.host; stat.list = sink.list;
+    g.fix = sink_armed(c, stat, desc, grid64);          // (a launch number of its own: the host tells the two reports apart by kStatFromGated)
+    g.fix.frames |= kStatFromGated;
+    g.gate = sink.decision;
+    g.gate_seq = q.fix.seq;
+    hipLaunchKernelGGL((w512_auto_kernel<double, 8, NSLOTS, Lens>), dim3(grid64), dim3(512), c->lds512, stream, g);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+}  // namespace
+
 namespace melspec {
 namespace host {
+// can a plain batch of this n_fft = 512 context run in MELSPEC_PRECISION_AUTO's f32 / f64 pair?  (the compile-time banks, eight f64 waves)
+bool w512_auto_ok(const melspec_ctx *c) {
+    return c->fast512 && c->f512.ok && c->waves512 == 8 && c->fix.count.p != nullptr &&
+           (fb_lens_match<LensSlaney80W>(c->ft512.slots) || fb_lens_match<LensSlaney128>(c->ft512.slots));
+}
+
 // the Whisper flavour of the 512-point kernel: launch_ctx's branch for the n_fft = 512 contexts
 int launch_whisper512(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream) {
         FbankFastParams fp{};
@@ -85,6 +130,15 @@ int launch_whisper512(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream)
         fp.use_log = 1; fp.use_power = 1;
         fp.slots = c->ft512.slots;
         if (c->precision == MELSPEC_PRECISION_F32 && c->f512.ok) return launch_w512_f32(c->f512, fp, c->dev.cus, stream);
+        // AUTO (round 6): plain batches -- uniform and ragged -- vote like the n_fft = 400 contexts do; the layouts stay on the f64 kernel
+        const bool plain = !desc.mel_major && (desc.d_unit_prefix != nullptr || desc.out_width == desc.frames_per_clip);
+        // ... when there is a batch to speak of: below two units per f32 wave of the grid (6144 units = 24 576 frames on an MI355X) a call is
+        // launch-bound, the pair of launches is slower than the f64 kernel alone, and the f64 kernel it is (also what keeps the streaming
+        // bank's hop-sized pushes on the reference's golden within 1e-6; a rule on the batch's size: still a function of the batch alone)
+        const bool sizeable = desc.n_units >= 2ull * kFused512F32Waves * static_cast<unsigned>(c->dev.cus);
+        if (c->precision == MELSPEC_PRECISION_AUTO && c->fix.adaptive && plain && sizeable && w512_auto_ok(c))
+            return fb_lens_match<LensSlaney80W>(c->ft512.slots) ? launch_w512_auto_t<kFbSlots, LensSlaney80W>(c, fp, desc, stream)
+                                                                : launch_w512_auto_t<kBlmSlots, LensSlaney128>(c, fp, desc, stream);
         if (fb_lens_match<LensSlaney80W>(c->ft512.slots)) return launch_fused512<double, kFlavorWhisper, kFbSlots, LensSlaney80W>(c->waves512, fp, c->lds512, c->dev.cus, stream);
         if (fb_lens_match<LensSlaney128>(c->ft512.slots)) return launch_fused512<double, kFlavorWhisper, kBlmSlots, LensSlaney128>(c->waves512, fp, c->lds512, c->dev.cus, stream);
         return c->ft512.slots.n_slots <= kFbSlots ? launch_fused512<double, kFlavorWhisper, kFbSlots>(c->waves512, fp, c->lds512, c->dev.cus, stream)

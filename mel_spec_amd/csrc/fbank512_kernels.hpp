@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
             fb_phase2_dft<T, STAGE>(fl, j, act, slice, own);
 #pragma unroll
             for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
-            if (FLAVOR == kFlavorWhisper) fb_phase2_split<T, true, true>(fl, j, act, tblob, own, part, slice);
+            if (FLAVOR == kFlavorWhisper) fb_phase2_split<T, true, sizeof(T) == 8>(fl, j, act, tblob, own, part, slice);      // f32: the amplitude form (fbank_tables.hpp)
             else if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
             else fb_phase2_split<T, false>(fl, j, act, tblob, own, part, slice);
         }
@@ -255,6 +255,141 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
         staged.wait_staged(staged.round, lane);
         staged.drain(staged.round - 1, tid);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// MELSPEC_PRECISION_AUTO at n_fft = 512 (round 6): Whisper's log-mel on the 512-point kernels with the n_fft = 400 family's contract --
+// the f32 kernel where its arithmetic can vouch for 1e-4, f64 where it cannot, decided by the batch itself.  Plain [frame][mel] batches
+// (uniform and ragged) of the compile-time banks; two launches of this kernel per call:
+//   T = float  (twelve waves): the unit loop of fbank512_wave_kernel<float, 12, .., Whisper, RUNS> with the guard of w512_phase4 on.  The
+//              first unit of every wave of the resident workgroups is the sample of the vote (FixSink::vote, kernels_common.hpp); every
+//              unit leaves its frame mask in the note list (one 32-bit word per unit of the batch: no atomics).  On "heavy" the waves stop.
+//   T = double (eight waves), queued behind it and gated on ITS verdict: "heavy" -> every unit of the batch; "light" -> the units whose
+//              word in the list is not zero (a wave reads 64 words of its run at a time and walks the set bits), all four frames of each.
+// So a batch costs the f32 rate on noise-like input, the f64 rate on input that trips the guard on more than 1/8 of the sampled frames,
+// and the same batch gives the same bits whatever the context computed before it.  Reference arithmetic: src/stft.rs:99-111, src/mel.rs:148-168.
+// ------------------------------------------------------------------------------------
+struct W512AutoParams {
+    FbankFastParams f;
+    FixSink fix;              // f32 launch: vote + statistics, list = the note words; gated launch: statistics only (+ list)
+    const unsigned *gate;     // gated launch: the voting launch's verdict word
+    unsigned gate_seq;        // ... and its number: anything else in the word = not this launch's verdict = nothing to do
+};
+
+template <class T, int WAVES, int NSLOTS, class Lens>
+__global__ __launch_bounds__(WAVES * 64, 1) void w512_auto_kernel(const W512AutoParams q) {
+    using L = FbankLayout<T>;
+    constexpr bool F32 = sizeof(T) == 4;
+    const FbankFastParams &p = q.f;
+    unsigned verdict = 0;
+    if (!F32) {          // the gated launch: this batch's verdict, or nothing
+        const unsigned g = *q.gate;
+        if ((g >> 2) != (q.gate_seq & 0xffffffu) || !(g & kVoteDecided)) return;
+        verdict = g & 3u;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t ldsw[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.blob_words; i += WAVES * 64) ldsw[i] = p.d_blob[i];
+    unsigned *wg_done = ldsw + p.blob_words + WAVES * L::slice_elems() * (sizeof(T) / 4);     // guard_wave_done's two words, vote_cast's three, vote_check's one
+    if (tid < 6) wg_done[tid] = 0;
+    __syncthreads();
+    const T *tblob = reinterpret_cast<const T *>(ldsw);
+    const float *mel = reinterpret_cast<const float *>(ldsw + p.mel_off_words);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    T *slice = reinterpret_cast<T *>(ldsw + p.blob_words) + wave * L::slice_elems();
+    const int fl = lane / kFbLanes, j = lane - fl * kFbLanes;
+    const bool in = lane < kFbFPW * kFbLanes;
+    int st[NSLOTS];
+    const int *starts = reinterpret_cast<const int *>(mel + FbankBlob::kMelStart);
+#pragma unroll
+    for (int i = 0; i < NSLOTS; ++i) st[i] = in ? starts[i * kFbLanes + j] : 0;
+    unsigned *list = reinterpret_cast<unsigned *>(q.fix.list);
+
+    ClipRun cr;
+    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * WAVES + wave, (uint64_t)gridDim.x * WAVES)) {
+        if (F32 && blockIdx.x < q.fix.vote_groups) vote_cast(q.fix, wg_done + 2, WAVES, lane, 0, 0);
+        if (F32 || (verdict & kVoteHeavy)) guard_wave_done(q.fix, wg_done, WAVES, lane, 0);          // (who reports: see the end of the kernel)
+        return;
+    }
+    int nv = 0;
+    // one work unit (the Whisper flavour of fbank512_wave_kernel's body, plain store); returns the frames whose guard tripped as a mask
+    auto unit = [&]() __attribute__((always_inline)) -> unsigned {
+        cr.enter(p.b);
+        const UnitLoc loc = cr.loc();
+        const uint64_t f0 = loc.unit * kFbFPW;
+        const uint64_t left = f0 < loc.frames ? loc.frames - f0 : 0;
+        nv = left < (uint64_t)kFbFPW ? (int)left : kFbFPW;
+        const bool act = in && fl < nv;
+        MS_PRIO(0);
+        w512_phase1<T, true>(fl, j, act, loc.pcm + (f0 + (uint64_t)(act ? fl : 0)) * (uint64_t)p.shift, tblob, slice);
+        __builtin_amdgcn_wave_barrier();
+        MS_PRIO(1);
+        {
+            cpx<T> own[16], part[8];
+            fb_phase2_dft<T, false>(fl, j, act, slice, own);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
+            fb_phase2_split<T, true, sizeof(T) == 8>(fl, j, act, tblob, own, part, slice);
+        }
+        __builtin_amdgcn_wave_barrier();
+        MS_PRIO(2);
+        float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS], vals[NSLOTS];
+        fb_phase3_sums<T, NSLOTS, Lens>(fl, j, act, p.slots, mel, slice, st, rise, fprev);
+#pragma unroll
+        for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
+        float *slice_f = reinterpret_cast<float *>(slice);
+        w512_phase3_log<NSLOTS>(fl, j, act, p.n_mels, rise, fnext, slice_f, vals);
+        __builtin_amdgcn_wave_barrier();
+        const bool flag = w512_phase4<NSLOTS, true>(fl, j, act, act, p.n_mels, slice_f, vals, loc.out + f0 * (uint64_t)p.n_mels, 0);
+        __builtin_amdgcn_wave_barrier();
+        return frame_mask<kFbLanes, kFbFPW>(__builtin_amdgcn_ballot_w64(flag));
+    };
+    unsigned flagged = 0;
+    if (F32) {
+        // the vote: the first units run in a loop of their own until the verdict is known (whisper400_six_runs_kernel says why)
+        bool sample = blockIdx.x < q.fix.vote_groups;
+        unsigned polled = 0;
+        for (; cr.unit < cr.end && verdict == 0; ++cr.unit) {
+            const unsigned mask = unit();
+            if (lane == 0) list[cr.unit] = mask;
+            flagged += static_cast<unsigned>(__builtin_popcount(mask));
+            if (sample) {
+                vote_cast(q.fix, wg_done + 2, WAVES, lane, static_cast<unsigned>(__builtin_popcount(mask)), static_cast<unsigned>(nv));
+                sample = false;
+            }
+            verdict = vote_check(q.fix, wg_done + 2, ++polled, wave);
+        }
+        if (verdict == 0) verdict = vote_poll(q.fix);                  // a run shorter than the vote
+        if (verdict & kVoteHeavy) {                                    // the gated launch computes the whole batch and reports it
+            guard_wave_done(q.fix, wg_done, WAVES, lane, 0);
+            return;
+        }
+        for (; cr.unit < cr.end; ++cr.unit) {
+            const unsigned mask = unit();
+            if (lane == 0) list[cr.unit] = mask;
+            flagged += static_cast<unsigned>(__builtin_popcount(mask));
+        }
+    } else if (verdict & kVoteHeavy) {
+        for (; cr.unit < cr.end; ++cr.unit) flagged += static_cast<unsigned>(__builtin_popcount(unit()));
+    } else {
+        // light: the units the f32 launch could not vouch for, 64 note words at a time
+        flagged = 0;
+        for (uint64_t base = cr.unit; base < cr.end; base += 64) {
+            const uint64_t u = base + lane;
+            const unsigned word = u < cr.end ? list[u] : 0u;
+            uint64_t todo = __builtin_amdgcn_ballot_w64(word != 0);
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                cr.seek(p.b, base + k);
+                unit();
+            }
+        }
+    }
+    // light batches: the voting launch reports (its flagged frames = the frames recomputed); heavy ones: the gated launch (the frames that
+    // would have tripped the guard); a light gated launch reports nothing (FixSink::acc is shared: one report per batch)
+    if (F32 || (verdict & kVoteHeavy)) guard_wave_done(q.fix, wg_done, WAVES, lane, flagged);
 }
 
 // Kaldi fbank with the CMN inside (Fbank::compute incl. src/fbank.rs:224-233), for uniform batches of many clips: a workgroup

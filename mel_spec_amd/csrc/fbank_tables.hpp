@@ -84,7 +84,10 @@ inline bool build_blm_fast_tables(int sample_rate, int n_mels, double f_min, dou
 // project_stft_log10 uses those below n_fft/2 = 256 (src/mel.rs:155-163).
 template <class T>
 inline bool build_whisper512_tables(const std::vector<double> &dense /* [n_mels][257] */, int n_mels, FbankFastTables &out) {
-    return build_fused512_tables<T>(hann_window(512), dense, n_mels, 0.25, kBlmSlots, out, 256, true);
+    // f64: the table of the direct power form (fb_phase2_split<.., FAST>); f32: plain W_512^k -- the direct form is a difference of large
+    // numbers in the weaker bin of a pair, eps x the power of its MIRROR bin: fine at 2^-53, and in f32 it cost the bare kernel three decades
+    // (7e-2 on speech; profiles/r06_guard512.txt has the error by depth under the frame maximum before and after)
+    return build_fused512_tables<T>(hann_window(512), dense, n_mels, 0.25, kBlmSlots, out, 256, sizeof(T) == 8);
 }
 template <class T>
 inline bool build_whisper512_tables(double sample_rate, int n_mels, FbankFastTables &out) {

@@ -166,16 +166,33 @@ MS_DEV void fb_phase1(int fl, int t, bool active, const float *frame /* this fra
 // geometry the reference's RingBuffer golden test and its WGPU tests use: 512/160/80) --------------------------
 // Frame = 512 samples, periodic Hann(512), no pre-emphasis / DC removal: every one of the 16 inputs of a column is a
 // real sample pair.  Phase 2 is shared; the epilogue is Whisper's log10 / max-8 clamp / (x+4)/4.
-template <class T>
+// PIN (w512_auto_kernel, round 6): all sixteen loads first, in a loop of their own with a scheduling barrier behind it -- six_phase1
+// (whisper_six.hpp) says why: left to itself the machine scheduler put them into the butterflies two at a time behind
+// s_waitcnt vmcnt(1) in the 128-mel instance of that kernel's unit loop: sixteen serialised round trips per unit, 0.55 ms instead of 0.37.
+template <class T, bool PIN = false>
 MS_DEV void w512_phase1(int fl, int t, bool active, const float *frame, const T *tblob, T *slice) {
     if (!active) return;
     cpx<T> x[16];
+    if (PIN) {
+        f2 sv[16];
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-        const int i = 32 * n1 + 2 * t;
-        const f2 s = load2_unaligned(frame + i);
-        const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
-        x[n1] = {static_cast<T>(s.x) * w.re, static_cast<T>(s.y) * w.im};
+        for (int n1 = 0; n1 < 16; ++n1) sv[n1] = load2_unaligned(frame + 32 * n1 + 2 * t);
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_sched_barrier(MS_SCHED_LOADS_FIRST);
+#endif
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const cpx<T> w = ldc(tblob + FbankBlob::kWin + 32 * n1 + 2 * t);
+            x[n1] = {static_cast<T>(sv[n1].x) * w.re, static_cast<T>(sv[n1].y) * w.im};
+        }
+    } else {
+#pragma unroll
+        for (int n1 = 0; n1 < 16; ++n1) {
+            const int i = 32 * n1 + 2 * t;
+            const f2 s = load2_unaligned(frame + i);
+            const cpx<T> w = ldc(tblob + FbankBlob::kWin + i);
+            x[n1] = {static_cast<T>(s.x) * w.re, static_cast<T>(s.y) * w.im};
+        }
     }
     fb_column_finish<T>(x, t, tblob, slice + fl * FbankLayout<T>::kXStride);
 }
@@ -544,10 +561,12 @@ MS_DEV void w512_phase3_log(int fl, int j, bool active, int n_mels, const float 
 }
 // store: this lane's column exists in the output; valid: it is a real frame (otherwise a zero column of a padded
 // layout).  row_w == 0: [frame][mel] rows of n_mels; row_w > 0: [mel][row_w] rows (interleave_frames, src/mel.rs:480-544).
-template <int NSLOTS>
-MS_DEV void w512_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice_f, const float (&vals)[NSLOTS],
+// GUARD (MELSPEC_PRECISION_AUTO at n_fft = 512, round 6): true on the lanes that hold a band within kGuardBand decades of the clamp -- the
+// bands an f32 FFT cannot vouch for at 1e-4 (wave_phase4 in whisper_wave.hpp has the calibration; the same test on the same biased values)
+template <int NSLOTS, bool GUARD = false>
+MS_DEV bool w512_phase4(int fl, int j, bool store, bool valid, int n_mels, const float *slice_f, const float (&vals)[NSLOTS],
                         float *out_tile, long long row_w) {
-    if (!store || j >= kFbOwn) return;
+    if (!store || j >= kFbOwn) return false;
     int lo = 0;
     if (valid) {
         const int *pm = reinterpret_cast<const int *>(slice_f) + kW512PmaxOff + fl * kFbLanes;
@@ -561,11 +580,17 @@ MS_DEV void w512_phase4(int fl, int j, bool store, bool valid, int n_mels, const
     }
     float *o = row_w ? out_tile + static_cast<long long>(j) * row_w + fl : out_tile + static_cast<long long>(fl) * n_mels + j;
     const long long step = row_w ? kFbOwn * row_w : kFbOwn;
+    int cmin = 0x7f000000;
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kFbOwn * i;
-        if (m < n_mels) o[i * step] = valid ? wave_float(wave_imax(wave_bits(vals[i]), lo)) * 0.25f - 3.0f : 0.0f;
+        if (m < n_mels) {
+            const int c = wave_imax(wave_bits(vals[i]), lo);
+            o[i * step] = valid ? wave_float(c) * 0.25f - 3.0f : 0.0f;
+            if (GUARD) cmin = wave_imin(cmin, c);
+        }
     }
+    return GUARD && valid && wave_float(cmin) < wave_float(lo) + kGuardBand;
 }
 
 }  // namespace melspec

@@ -110,6 +110,11 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
         c->fast512 = c->lds512 <= kLdsLimit;
         if (c->fast512 && (rc = upload(c->d_blob512, c->ft512.blob))) return bail(rc);
         if (c->fast512 && w512_f32_bank(c->ft512.slots) && build_whisper512_tables<float>(c->dense, n_mels, c->f512.ft) && (rc = c->f512.finish(512))) return bail(rc);
+        // MELSPEC_PRECISION_AUTO on the pair of 512-point kernels (round 6): the statistics words, the vote's tally and verdicts
+        if (c->fast512 && c->f512.ok) {
+            if ((rc = upload(c->fix.count, std::vector<uint64_t>(8, 0ull)))) return bail(rc);
+            if ((rc = upload(c->fix.verdicts, std::vector<uint32_t>(static_cast<size_t>(kVoteSlots) * kVoteSlotStride, 0u)))) return bail(rc);
+        }
     }
     if (c->fast && build_six_tables(c->dense, n_mels, c->ft6)) {
         c->lds6 = sizeof(float) * (c->ft6.blob.size() + static_cast<size_t>(kSixWaves) * SixLayout::slice_floats() + kSixWaves + 4);   // + arrival counters + the vote's words
@@ -234,7 +239,9 @@ int melspec_set_precision(melspec_ctx *c, int mode) {
 int melspec_precision(const melspec_ctx *c) {
     if (!c) return MELSPEC_PRECISION_AUTO;
     if (c->fast) return c->precision;
-    return c->precision == MELSPEC_PRECISION_F32 && c->fast512 && c->f512.ok ? MELSPEC_PRECISION_F32 : MELSPEC_PRECISION_F64;
+    if (c->precision == MELSPEC_PRECISION_F32 && c->fast512 && c->f512.ok) return MELSPEC_PRECISION_F32;
+    if (c->precision == MELSPEC_PRECISION_AUTO && c->fix.adaptive && w512_auto_ok(c)) return MELSPEC_PRECISION_AUTO;      // plain batches vote (the layouts: f64)
+    return MELSPEC_PRECISION_F64;
 }
 int melspec_set_precise(melspec_ctx *c, int on) { return melspec_set_precision(c, on ? MELSPEC_PRECISION_F64 : MELSPEC_PRECISION_AUTO); }
 int melspec_is_precise(const melspec_ctx *c) { return c && melspec_precision(c) == MELSPEC_PRECISION_F64 ? 1 : 0; }   // the generic kernels are f64 whatever the mode
@@ -244,6 +251,8 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
     if (!c) return "";
     if (!c->fast) {
         if (c->fast512 && c->precision == MELSPEC_PRECISION_F32 && c->f512.ok) return "melspec::fbank512_wave_kernel<float, 12, 1, kFlavorWhisper, RUNS> (n_fft = 512, f32, three waves per SIMD)";
+        if (c->precision == MELSPEC_PRECISION_AUTO && c->fix.adaptive && w512_auto_ok(c))
+            return "melspec::w512_auto_kernel<float, 12> (n_fft = 512, f32, precision guard + vote) + the gated melspec::w512_auto_kernel<double, 8>";
         if (c->fast512) return "melspec::fbank512_wave_kernel<double, 8, 1, kFlavorWhisper, RUNS> (n_fft = 512, f64)";
         switch (pow2_logm(c->gt)) {
             case 6: return "melspec::pow2_frame_kernel<6, kFlavorWhisper> (n_fft = 128, f64, frames owned by lane groups of a wave)";
@@ -291,8 +300,9 @@ int melspec_set_auto_adaptive(melspec_ctx *c, int on) {
 
 int melspec_auto_state(melspec_ctx *c, int *heavy, double *fraction) {
     if (!c) return fail(MELSPEC_ERR_INVALID_ARG, "ctx is NULL");
-    if (c->fast && c->precision == MELSPEC_PRECISION_AUTO) auto_poll(c);
-    if (heavy) *heavy = (c->fast && c->precision == MELSPEC_PRECISION_AUTO && c->fix.heavy) ? 1 : 0;
+    const bool voting = c->precision == MELSPEC_PRECISION_AUTO && (c->fast || w512_auto_ok(c));
+    if (voting) auto_poll(c);
+    if (heavy) *heavy = (voting && c->fix.heavy) ? 1 : 0;
     if (fraction) *fraction = c->fix.fraction;
     return MELSPEC_OK;
 }

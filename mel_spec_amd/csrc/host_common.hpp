@@ -421,11 +421,17 @@ namespace host {
 
 // ---- whisper400.hip ------------------------------------------------------------------------------------------------------------------
 void auto_poll(melspec_ctx *c);
+// the launch-specific part of a guarded launch's statistics sink (frames, grid, the launch's number)
+FixSink sink_armed(melspec_ctx *c, FixSink sink, const BatchDesc &desc, unsigned grid);
+// MELSPEC_PRECISION_AUTO: the context's sink for a launch on `stream` (note list sized for the batch, statistics words, host-mapped
+// figures; with_vote: the vote's tally and verdict words too)
+int auto_sink(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool with_vote, FixSink &sink);
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream);
 int launch_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipStream_t s);
 // ---- pow2.hip / fbank512.hip: the parts of launch_ctx / launch_stft that run on their kernels ---------------------------------------
 int launch_generic_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipStream_t s);
 int launch_whisper512(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream);
+bool w512_auto_ok(const melspec_ctx *c);
 
 // frames per work unit of the kernel a batch is planned for (called once per batch, before it is planned).  AUTO plans for the f32
 // kernel: when the batch's vote says "heavy", the f64 kernel walks the same plan (whisper400_precise_kernel, MODE 2).

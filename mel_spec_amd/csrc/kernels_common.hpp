@@ -190,7 +190,8 @@ __device__ __forceinline__ void guard_wave_done(const FixSink &fx, unsigned *wg,
         // launch's number (bounded; a fence here or on the stores would write back an XCD's L2).
         unsigned v = vote_poll(fx);
         for (unsigned spin = 0; v == 0 && spin < 4096; ++spin) { __builtin_amdgcn_s_sleep(1); v = vote_poll(fx); }
-        if (v & kVoteHeavy) return;
+        if (v == 0 || (v & kVoteHeavy)) return;       // heavy: the f64 launch reports; still unknown after the bounded wait: nobody reports this
+                                                      // launch (the host keeps the previous figures) rather than both launches counting it
     }
     if (tripped) __hip_atomic_fetch_add(fx.count, tripped, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long tag = static_cast<unsigned long long>(fx.seq & 0xffffffu) << kStatShift;
@@ -307,6 +308,15 @@ __device__ __forceinline__ void unit_ext_merge(int *ext, int lane, int kmin, int
     }
 }
 
+// ballot of wave_phase4's result -> one bit per frame of the unit (LANES lanes per frame)
+template <int LANES, int FRAMES>
+__device__ __forceinline__ unsigned frame_mask(uint64_t any) {
+    unsigned m = 0;
+#pragma unroll
+    for (int f = 0; f < FRAMES; ++f) m |= ((any >> (LANES * f)) & ((1ull << LANES) - 1)) ? (1u << f) : 0u;
+    return m;
+}
+
 // Sub-group barrier of the mel-major stores (BatchDesc::sync_rounds = gsize + 16 * across, gsize in {2, 4, 8}): only the
 // gsize waves that hold adjacent units of a round wait for each other (LDS arrival counters, the waiting wave at priority 0
 // polling with s_sleep), so the pieces of a 32-byte sector reach L2 together while the other waves of the workgroup keep
@@ -365,6 +375,18 @@ struct ClipRun {
         c_pcm = b.pcm + scalar64(b.d_off[clip]);
         c_out = b.out + scalar64(b.d_out_off[clip]);
     }
+    // the clip that holds `unit` (unit < the batch's units)
+    __device__ __forceinline__ void place(const BatchDesc &b) {
+        if (b.d_unit_prefix == nullptr) {
+            clip = static_cast<uint32_t>(unit / b.units_per_clip);
+            load_clip(b);
+            return;
+        }
+        clip = __builtin_amdgcn_readfirstlane(b.d_unit_block[unit / kUnitBlock]);
+        c_end = scalar64(b.d_unit_prefix[clip + 1]);
+        while (c_end <= unit) { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); }     // prefix[n_clips] = n_units > unit
+        load_clip(b);
+    }
     // false: this wave has no units
     __device__ __forceinline__ bool init(const BatchDesc &b, uint64_t wave_id, uint64_t waves) {
         const uint64_t nu = b.d_n_units ? ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(*b.d_n_units >> 32)) << 32 |
@@ -373,16 +395,13 @@ struct ClipRun {
         unit = wave_id * run;
         end = unit + run < nu ? unit + run : nu;
         if (unit >= end) return false;
-        if (b.d_unit_prefix == nullptr) {
-            clip = static_cast<uint32_t>(unit / b.units_per_clip);
-            load_clip(b);
-            return true;
-        }
-        clip = __builtin_amdgcn_readfirstlane(b.d_unit_block[unit / kUnitBlock]);
-        c_end = scalar64(b.d_unit_prefix[clip + 1]);
-        while (c_end <= unit) { ++clip; c_end = scalar64(b.d_unit_prefix[clip + 1]); }     // prefix[n_clips] = n_units > unit
-        load_clip(b);
+        place(b);
         return true;
+    }
+    // jump to another unit of the wave's run (the walkers of a note list: w512_auto_kernel's gated launch); u < end
+    __device__ __forceinline__ void seek(const BatchDesc &b, uint64_t u) {
+        unit = u;
+        place(b);
     }
     __device__ __forceinline__ UnitLoc loc() const {
         UnitLoc r;

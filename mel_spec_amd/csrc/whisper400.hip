@@ -28,6 +28,32 @@ void auto_poll(melspec_ctx *c) {
     fx.fraction = static_cast<double>(tripped) / static_cast<double>(frames);
 }
 
+int auto_sink(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream, bool with_vote, FixSink &sink) {
+    FixState &fx = c->fix;
+    if (fx.used && fx.last_stream != stream) HIP_TRY(hipStreamSynchronize(fx.last_stream));
+    const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
+    if (need > fx.list.cap) {
+        if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
+        int rc = fx.list.ensure(need);
+        if (rc) return rc;
+    }
+    sink.tab = static_cast<const double *>(fx.tab.p);
+    sink.list = static_cast<uint64_t *>(fx.list.p);
+    if (!fx.host) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&fx.host), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(fx.host, 0, 64);
+    }
+    fx.used = true; fx.last_stream = stream;
+    sink.count = static_cast<unsigned long long *>(fx.count.p);
+    sink.acc = sink.count + 1;
+    sink.host = fx.host;
+    if (with_vote) {
+        sink.vote = sink.count + 2;
+        sink.decision = static_cast<unsigned *>(fx.verdicts.p);
+    }
+    return MELSPEC_OK;
+}
+
 // the launch-specific part of a guarded launch's statistics sink (the grid is only known where the launch is made)
 FixSink sink_armed(melspec_ctx *c, FixSink sink, const BatchDesc &desc, unsigned grid) {
     if (!sink.acc) return sink;
@@ -249,32 +275,12 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     FixSink sink{};
     bool vote = false;
     if (c->precision == MELSPEC_PRECISION_AUTO) {
-        FixState &fx = c->fix;
-        if (fx.used && fx.last_stream != stream) HIP_TRY(hipStreamSynchronize(fx.last_stream));
-        const size_t need = (static_cast<size_t>(desc.n_units) + 65536) * sizeof(uint64_t);      // one note per unit + a round of slack
-        if (need > fx.list.cap) {
-            if (fx.used) HIP_TRY(hipStreamSynchronize(fx.last_stream));       // a launch in flight may still write the old list
-            int rc = fx.list.ensure(need);
-            if (rc) return rc;
-        }
-        sink.tab = static_cast<const double *>(fx.tab.p);
-        sink.list = static_cast<uint64_t *>(fx.list.p);
-        if (!fx.host) {
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&fx.host), 64, hipHostMallocMapped | hipHostMallocCoherent));
-            std::memset(fx.host, 0, 64);
-        }
-        fx.used = true; fx.last_stream = stream;
-        sink.count = static_cast<unsigned long long *>(fx.count.p);
-        sink.acc = sink.count + 1;
-        sink.host = fx.host;
         // The vote (FixSink::vote): plain batches and the padded / mel-major layouts (whose sample is the head of the batch: they deal
         // their units round-robin).  Not where the mel kernel also leaves the image extremes for the TGA quantiser (d_unit_ext: the two
         // kernels' units differ): PCM -> TGA keeps the f32 kernel + recompute tail whatever the input.
-        vote = fx.adaptive && (!layout_batch || desc.d_unit_ext == nullptr);
-        if (vote) {
-            sink.vote = sink.count + 2;
-            sink.decision = static_cast<unsigned *>(fx.verdicts.p);
-        }
+        vote = c->fix.adaptive && (!layout_batch || desc.d_unit_ext == nullptr);
+        int rc = auto_sink(c, desc, stream, vote, sink);
+        if (rc) return rc;
     }
     int rc;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;

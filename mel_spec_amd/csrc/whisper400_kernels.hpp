@@ -30,14 +30,6 @@ __device__ __forceinline__ void fix_power_row(int lane, FixSamples &smp, const f
     __builtin_amdgcn_wave_barrier();
 }
 
-// ballot of wave_phase4's result -> one bit per frame of the unit (LANES lanes per frame)
-template <int LANES, int FRAMES>
-__device__ __forceinline__ unsigned frame_mask(uint64_t any) {
-    unsigned m = 0;
-#pragma unroll
-    for (int f = 0; f < FRAMES; ++f) m |= ((any >> (LANES * f)) & ((1ull << LANES) - 1)) ? (1u << f) : 0u;
-    return m;
-}
 
 // The frames `mask` of a unit: their f64 power rows one after the other, then the kernel's own phases 3-4 once for all of them.
 // The f32 kernels do not call this inside their unit loop -- with the f64 code in the loop body the register allocator gives the

@@ -620,11 +620,12 @@ impl HipBatchLogMel {
         Ok(Self { b, n_mels: config.n_mels })
     }
     /// Additive: `true` = the reference's own f32 arithmetic for this frontend (src/mel.rs:251-252,356-357) on the f32 kernel; `false`
-    /// (default) = f64 up to |X|^2.  Returns what the next call will use.
-    pub fn set_f32(&mut self, on: bool) -> bool {
+    /// (default) = f64 up to |X|^2.  `Ok(true)`: the next call runs the f32 kernel; `Ok(false)`: the mode was accepted but this context has
+    /// no f32 kernel (another bank or geometry): it keeps computing in f64; `Err`: the library refused the call.
+    pub fn set_f32(&mut self, on: bool) -> Result<bool, HipError> {
         unsafe {
-            melspec_blm_set_precision(self.b, if on { 2 } else { 0 });
-            melspec_blm_precision(self.b) == 2
+            check(melspec_blm_set_precision(self.b, if on { 2 } else { 0 }))?;
+            Ok(melspec_blm_precision(self.b) == 2)
         }
     }
     /// `compute(&self, samples) -> Array2<f32>` (n_mels, padded frames), src/mel.rs:299-302; the second value is

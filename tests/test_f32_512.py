@@ -158,7 +158,8 @@ def test_contexts_without_an_f32_kernel_stay_f64(gpu, oracle, jfk):
 @pytest.mark.parametrize("n_mels", [80, 128])
 def test_whisper512_f32_mode(gpu, oracle, jfk, n_mels):
     m = gpu.HipMelSpectrogram(512, 160, SR, n_mels)
-    assert m.precision == "f64" and m.precise         # AUTO at n_fft = 512 computes in f64
+    m.set_precision("auto")
+    assert m.precision == "auto" and not m.precise    # round 6: plain batches of these banks vote between the f32 and the f64 kernel (tests/test_auto_512.py)
     m.set_precision("f32")
     assert m.precision == "f32" and not m.precise and "float" in m.plain_kernel_name()
     ins = _inputs(oracle, jfk)
@@ -170,7 +171,9 @@ def test_whisper512_f32_mode(gpu, oracle, jfk, n_mels):
     want = oracle.compute_mel_spectrogram_cpu(ins["speech"], 512, 160, n_mels, SR)
     got = m.compute_mel_spectrogram(ins["speech"])
     d = np.abs(got - want)
-    assert d.max() <= 0.5 and (d > TOL).mean() <= 0.08, (float(d.max()), float((d > TOL).mean()))
+    # round 6: the f32 instantiation splits to amplitudes, not straight to powers (fbank_tables.hpp): 7.4e-2 -> 2.1e-5 on this clip
+    # (profiles/r06_guard512.txt); gated at ~5 x
+    assert d.max() <= 1e-4 and (d > 5e-5).mean() <= 1e-3, (float(d.max()), float((d > 5e-5).mean()))
     # device batches: uniform, ragged offsets, mel-major -- noise-like clips at the tolerance
     n_clips, clip_len = 50, 16000
     clips = np.stack([oracle.synth_pcm(c * 8, clip_len) for c in range(n_clips)])
@@ -188,8 +191,8 @@ def test_whisper512_f32_mode(gpu, oracle, jfk, n_mels):
         want = oracle.interleave_frames(oracle.compute_mel_spectrogram_cpu(clips[c], 512, 160, n_mels, SR), False, 0)
         assert img[k].shape == want.shape and np.abs(img[k] - want).max() <= F32_TOL
     m.set_precision("auto")
-    assert m.precision == "f64"
-    assert np.abs(m.compute_mel_spectrogram(ins["speech"]) - want_speech(oracle, ins["speech"], n_mels)).max() <= TOL
+    assert m.precision == "auto"
+    assert np.abs(m.compute_mel_spectrogram(ins["speech"]) - want_speech(oracle, ins["speech"], n_mels)).max() <= 2e-6      # one clip: the f64 kernel
 
 
 def want_speech(oracle, x, n_mels):

@@ -20,7 +20,8 @@ LEGS = {
     "speech128": ("whisper400.hip", ["whisper400_six64_kernelILi15E"], 6),
     # the compile-time banks are LensFbStatic<slot lengths>: Kaldi-80 <2,2,3,5,7,9>, Whisper-512's 80 mels <2,2,3,5,8,9>, NeMo-128 <1,1,1,2,2,3,4,5,7>
     "cfg3":      ("fbank512.hip", ["fbank512_clip_kernelILi6E", "LensFbStaticIJLi2ELi2ELi3ELi5ELi7ELi9E", "Lb0E"], 4),
-    "w512":      ("fbank512.hip", ["fbank512_wave_kernelIdLi8ELi1ELi2ELi6E", "LensFbStaticIJLi2ELi2ELi3ELi5ELi8ELi9E", "Lb1E"], 4),
+    "w512":      ("fbank512.hip", ["w512_auto_kernelIfLi12ELi6E"], 4),          # default mode on noise-like input: the voting f32 launch
+    "w512_f64":  ("fbank512.hip", ["fbank512_wave_kernelIdLi8ELi1ELi2ELi6E", "LensFbStaticIJLi2ELi2ELi3ELi5ELi8ELi9E", "Lb1E"], 4),
     "w512_f32":  ("fbank512.hip", ["fbank512_wave_kernelIfLi12ELi1ELi2ELi6E", "LensFbStaticIJLi2ELi2ELi3ELi5ELi8ELi9E", "Lb1E"], 4),
     "nemo":      ("fbank512.hip", ["fbank512_wave_kernelIdLi8ELi1ELi1ELi10E", "LensFbStaticIJLi1ELi1ELi1E", "Lb0E"], 4),
     "nemo_f32":  ("fbank512.hip", ["fbank512_wave_kernelIfLi12ELi1ELi1ELi10E", "LensFbStaticIJLi1ELi1ELi1E", "Lb0E"], 4),
