@@ -52,7 +52,7 @@ def parse_args():
     ap.add_argument("--no-speech", action="store_true", help="skip the real-input leg (`config.speech`: jfk_f32le.wav tiled to the config-2 batch)")
     ap.add_argument("--no-cfg5", action="store_true", help="N > 1 without --config: skip the extra config-5 leg")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra N = 1 legs next to `value` (`config.cfg3`, `config.cfg4`, `config.f64`, `config.mel_major`, "
-                                                          "`config.w512`, `config.nemo`, `config.nemo_f32`, `host_api_single_clip_ms`)")
+                                                          "`config.cfg3_split`, `config.w512`, `config.nemo`, `config.nemo_f32`, `host_api_single_clip_ms`)")
     ap.add_argument("--clips", type=int, default=None, help="override the clip count (per GPU for weak, total for strong)")
     ap.add_argument("--clip-seconds", type=int, default=None)
     ap.add_argument("--n-mels", type=int, default=None)
@@ -400,7 +400,7 @@ def speech_leg(M, torch, dev, stream, n_clips: int, clip_len: int, n_mels: int) 
     return res
 
 
-LEG_NAMES = ("cfg3", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32")
+LEG_NAMES = ("cfg3", "cfg3_split", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32")
 F64_VECTOR_PEAK_TFLOPS = 78.6       # MI355X f64 vector peak (MI355X_MICROARCH.md): 256 CUs x 4 SIMDs x 16 FMA lanes x 2 flops x 2.4 GHz
 
 
@@ -461,6 +461,7 @@ def extra_legs(M, torch, dev, stream) -> dict:
     parity_max_abs_diff}.  A leg that fails -- a parity miss, an allocation that does not fit -- records {"error": ...} and the next
     one runs: nothing here can cost the line its `value`.  ~2 s of GPU time in all.
       cfg3       BASELINE configs[2]: Kaldi fbank (25 ms / 10 ms, 512-point FFT, 80 bins, pre-emphasis 0.97, Povey, CMN on), 1024 x 10 s
+      cfg3_split the same batch through the additive split output (rows before CMN + means: no second pass over the rows)
       cfg4       BASELINE configs[3] at its stated size when the device has the room: Whisper large-v3, 128 mels, 8192 x 30 s (28.3 GB
                  resident); otherwise 1024 x 30 s with the reason in the record
       f64        configs[1] in MELSPEC_PRECISION_F64 (the f64 FFT on every frame: what speech costs without the vote)
@@ -512,6 +513,24 @@ def extra_legs(M, torch, dev, stream) -> dict:
             return record("cfg3", n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), fb.kernel_name() if hasattr(fb, "kernel_name") else
                           "melspec::fbank512_clip_kernel (f64 FFT, CMN inside)", worst,
                           "configs[2]: Kaldi fbank 80 bins + CMN on 1024 synthetic 10 s clips, resident in HBM")
+        finally:
+            fb.close()
+
+    def leg_cfg3_split():   # the same batch as rows before CMN + the means (melspec_fbank_compute_uniform_device_split, additive, round 6)
+        fb = M.Fbank(device=dev.index)
+        try:
+            fpc = fb.num_frames(clip_len)
+            rows = torch.empty(n_clips * fpc * 80, dtype=torch.float32, device=dev)
+            means = torch.empty(n_clips * 80, dtype=torch.float32, device=dev)
+            run = lambda: fb.compute_uniform_device_split(pcm.data_ptr(), clip_len, clip_len, n_clips, rows.data_ptr(), means.data_ptr(), stream=stream)
+            run(); torch.cuda.synchronize()
+            got = (rows.view(n_clips, fpc, 80) - means.view(n_clips, 1, 80))
+            worst = max(float(np.abs(got[c].cpu().numpy() - O.fbank_compute(O.synth_pcm(c, clip_len))).max()) for c in (0, n_clips - 1))
+            if worst > 1e-4:
+                raise SystemExit(f"cfg3_split leg: parity check failed, max|diff| = {worst}")
+            return record("cfg3", n_clips * fpc, HOP * 4 + 80 * 4, _event_timed(torch, run, 100), "melspec::fbank512_clip_kernel (f64 FFT; rows before CMN + the clips' means)", worst,
+                          "configs[2]'s batch as the split output {rows before CMN, means[clip][80]} for a consumer that folds the subtraction into its own read "
+                          "(additive API; rows - means is bit for bit the fused output); parity checked on rows - means")
         finally:
             fb.close()
 
@@ -620,6 +639,7 @@ def extra_legs(M, torch, dev, stream) -> dict:
             fe.close()
 
     guarded("cfg3", leg_cfg3)
+    guarded("cfg3_split", leg_cfg3_split)
     guarded("f64", leg_f64)
     guarded("mel_major", leg_mel_major)
     guarded("host_api_single_clip_ms", leg_single)

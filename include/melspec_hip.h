@@ -343,6 +343,14 @@ int melspec_fbank_compute_host(melspec_fbank *fb, const float *samples, size_t n
 /* Many equal-length clips, device resident; CMN (src/fbank.rs:224-233) is per clip. */
 int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride,
                                          uint64_t clip_len, uint32_t n_clips, float *d_out, void *stream);
+/* Additive (round 6; the reference has one output contract, Fbank::compute, src/fbank.rs:141-236): the same batch as TWO outputs --
+ * d_rows [clip][frame][num_mel_bins] as they are BEFORE the CMN of src/fbank.rs:224-233, and d_means [clip][num_mel_bins], the column
+ * means that CMN subtracts (the fixed summation tree of the fused path: d_rows[c][f][m] - d_means[c][m] in f32 is, bit for bit, what
+ * melspec_fbank_compute_uniform_device stores).  For a consumer that folds the subtraction into its own first read of the rows: the CMN's
+ * second pass over them is a third of the fused kernel's memory traffic (profiles/r06_fbank_split.txt).  Needs FbankConfig::apply_cmn
+ * (without it there are no means: MELSPEC_ERR_INVALID_ARG). */
+int melspec_fbank_compute_uniform_device_split(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                               uint32_t n_clips, float *d_rows, float *d_means, void *stream);
 /* Fbank::compute for clips of any length in one launch (src/fbank.rs:141 is per clip): host or device clip tables, as
  * melspec_compute_ragged_device / _desc; offsets of the output in floats; CMN per clip. */
 int melspec_fbank_compute_ragged_device(melspec_fbank *fb, const float *d_pcm, const uint64_t *h_offsets, const uint64_t *h_lengths,

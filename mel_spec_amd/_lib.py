@@ -129,6 +129,7 @@ SIGNATURES = {
     "melspec_fbank_use_generic": (C.c_int, [_vp, C.c_int]),
     "melspec_fbank_compute_host": (C.c_int, [_vp, _f32p, C.c_size_t, _f32p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "melspec_fbank_compute_uniform_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "melspec_fbank_compute_uniform_device_split": (C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp, _vp]),
     "melspec_fbank_compute_ragged_device": (C.c_int, [_vp, _vp, _u64p, _u64p, C.c_uint32, _vp, _u64p, _vp]),
     "melspec_fbank_compute_batch_host": (C.c_int, [_vp, _f32p, _u64p, _u64p, C.c_uint32, _f32p, _u64p, C.c_size_t, _u64p]),
     "melspec_fbank_compute_ragged_device_desc": (C.c_int, [_vp, _vp, _vp, _vp, C.c_uint32, _vp, _vp, C.c_uint64, _vp]),

@@ -247,7 +247,7 @@ int melspec_fbank_use_generic(melspec_fbank *fb, int on) {
     return MELSPEC_OK;
 }
 
-static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips, uint64_t fpc, hipStream_t s);
+static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips, uint64_t fpc, hipStream_t s, float *d_means = nullptr);
 
 int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
                                          uint32_t n_clips, float *d_out, void *stream) {
@@ -264,8 +264,29 @@ int melspec_fbank_compute_uniform_device(melspec_fbank *fb, const float *d_pcm, 
     return fbank_launch(fb, pl, n_clips, fpc, s);
 }
 
+int melspec_fbank_compute_uniform_device_split(melspec_fbank *fb, const float *d_pcm, uint64_t clip_stride, uint64_t clip_len,
+                                               uint32_t n_clips, float *d_rows, float *d_means, void *stream) {
+    if (!fb) return fail(MELSPEC_ERR_INVALID_ARG, "fbank is NULL");
+    if (!fb->cfg.apply_cmn) return fail(MELSPEC_ERR_INVALID_ARG, "the split output is the CMN's two halves: FbankConfig::apply_cmn is off");
+    if (n_clips == 0) return MELSPEC_OK;
+    const uint64_t fpc = fbank_frames(fb, clip_len);
+    if (!d_means) return fail(MELSPEC_ERR_INVALID_ARG, "d_means is NULL");
+    HIP_TRY(hipSetDevice(fb->dev.device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : fb->stream;
+    const int nm = fb->cfg.num_mel_bins;
+    if (fpc == 0) {                     // zeros((0, num_mel_bins)): no rows; the mean of nothing is reported as 0
+        HIP_TRY(hipMemsetAsync(d_means, 0, static_cast<size_t>(n_clips) * nm * sizeof(float), s));
+        return MELSPEC_OK;
+    }
+    if (!d_pcm || !d_rows) return fail(MELSPEC_ERR_INVALID_ARG, "device pointer is NULL");
+    const bool fused = fb->fast && !fb->use_generic;
+    const BatchPlan pl = plan_uniform(d_pcm, d_rows, clip_stride, fpc, n_clips, nm, fused ? kFbFPW : 1);
+    return fbank_launch(fb, pl, n_clips, fpc, s, d_means);
+}
+
 // kernels of one batch (uniform or ragged plan): fused 512-point kernel or the generic one, then CMN per clip
-static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips, uint64_t fpc /* frames of the longest clip (LDS budget of the CMN) */, hipStream_t s) {
+static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips, uint64_t fpc /* frames of the longest clip (LDS budget of the CMN) */, hipStream_t s,
+                        float *d_means /* not nullptr: the split output -- un-normalised rows + the clips' column means */) {
     const int nm = fb->cfg.num_mel_bins;
     const bool fused = fb->fast && !fb->use_generic;
     const double floor_v = fb->cfg.energy_floor > 0.0 ? fb->cfg.energy_floor : static_cast<double>(FLT_EPSILON);
@@ -309,6 +330,7 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
             q.frames = fpc;
             static const int clip_skip = lab_int("MELSPEC_FB_CLIP_SKIP", 0, 0, 15);
             q.lab_skip = clip_skip;
+            q.d_means = d_means;
             const size_t lds = fb->fast_lds + sizeof(ClipCmnShared<8>);
             if (lds <= kLdsLimit) {
                 const bool k80 = fb_lens_match<LensKaldi80>(fb->ft.slots), k40 = fb_lens_match<LensKaldi40>(fb->ft.slots);
@@ -349,6 +371,7 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         uint64_t rows = (budget / (static_cast<size_t>(nm) * sizeof(float))) & ~3ull;
         if (rows > ((fpc + 3) & ~3ull)) rows = (fpc + 3) & ~3ull;
         cp.rows_per_chunk = staged ? static_cast<int>(rows) : 0;
+        cp.d_means = d_means;
         static std::atomic<uint64_t> cmn_attr{0};
         if (!device_done(cmn_attr)) {
             if ((rc = allow_big_lds(&cmn_kernel<512>, "hipFuncSetAttribute(cmn_kernel)"))) return rc;

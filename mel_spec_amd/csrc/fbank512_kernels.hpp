@@ -412,6 +412,9 @@ struct FbankClipParams {
     FbankFastParams f;
     uint64_t frames;        // per clip (uniform batches)
     int lab_skip;           // lab builds, timing ablations (wrong results): 1 = no subtraction, 2 = its loads only, 4 = its stores only
+    float *d_means;         // melspec_fbank_compute_uniform_device_split: the clip's column means go here ([clip][n_mels]) and the rows stay
+                            // un-normalised -- the second pass over the rows (a third of this kernel's traffic) is left to a consumer that
+                            // can fold the subtraction into its own first read; nullptr: the CMN inside (Fbank::compute, src/fbank.rs:224-233)
 };
 
 template <int WAVES>
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
         // this wave's share of the previous clip's subtraction (its means were published a whole run ago: the wait does not spin).
         // Spreading it over the units of the run -- two pieces loaded after phase 1, stored at the end of the unit -- was measured
         // and is slower (+0.08 ms against +0.07 ms, profiles/r02_fbank.txt): the cost is the extra traffic, not this wave's stall
-        if (gen > 0 && !(q.lab_skip & 1)) {
+        if (gen > 0 && !(q.lab_skip & 1) && q.d_means == nullptr) {
             sub.wait(sh, par ^ 1, prev_turn, lane);
             sub.finish(wave);
         }
@@ -643,7 +646,9 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
             for (int m = lane; m < nm; m += 64) {
                 const float (*pp)[96] = sh->part[par];
                 const float s = ((pp[0][m] + pp[1][m]) + (pp[2][m] + pp[3][m])) + ((pp[4][m] + pp[5][m]) + (pp[6][m] + pp[7][m]));
-                sh->mean[par][m] = f32_div_rn(s, fr);
+                const float mean_m = f32_div_rn(s, fr);
+                sh->mean[par][m] = mean_m;
+                if (q.d_means) q.d_means[(uint64_t)clip * nm + m] = mean_m;
             }
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) __hip_atomic_store(&sh->ready[par], turn, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -651,7 +656,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
         sub.begin(out, frames, nm, wave, lane);        // this clip is the next one to subtract
         ++gen;
     }
-    if (gen > 0 && !(q.lab_skip & 1)) {
+    if (gen > 0 && !(q.lab_skip & 1) && q.d_means == nullptr) {
         sub.wait(sh, (gen - 1) & 1, (gen - 1) / 2 + 1, lane);
         sub.finish(wave);
     }
@@ -1120,6 +1125,7 @@ struct CmnParams {
     BatchDesc b;   // only the clip geometry is used
     int n_mels;
     int rows_per_chunk;
+    float *d_means; // not nullptr: write the clip's column means there ([clip][n_mels]) and leave the rows as they are (the split output)
 };
 
 template <int NT>
@@ -1197,7 +1203,9 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
             const int nr = (int)(frames - f0);
             const int G = NT / nm;
             const int g = tid / nm, m = tid - g * nm;
-            if (g < G) {
+            if (p.d_means) {
+                if (tid < nm) p.d_means[(uint64_t)clip * nm + tid] = mean_s[tid];
+            } else if (g < G) {
                 const float mean = mean_s[m];
                 for (int r = g; r < nr; r += G) o[(f0 + r) * nm + m] = rows[r * nm + m] - mean;
                 // earlier chunks: 8 rows per thread in flight
@@ -1236,7 +1244,9 @@ __global__ __launch_bounds__(NT) void cmn_kernel(const CmnParams p) {
                 rows[tid] = f32_div_rn(tree.finish(), (float)frames);
             }
             __syncthreads();
-            if (g < G) {
+            if (p.d_means) {
+                if (tid < cols) p.d_means[(uint64_t)clip * nm + m0 + tid] = rows[tid];
+            } else if (g < G) {
                 const float mean = rows[tid - g * cols];
                 for (uint64_t f = g; f < frames; f += G) o[f * nm + m] -= mean;
             }

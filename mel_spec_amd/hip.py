@@ -538,6 +538,12 @@ class Fbank:
         _check(lib().melspec_fbank_compute_uniform_device(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
                                                           C.c_void_p(d_out), C.c_void_p(stream)))
 
+    def compute_uniform_device_split(self, d_pcm: int, clip_stride: int, clip_len: int, n_clips: int, d_rows: int, d_means: int,
+                                     stream: int = 0) -> None:
+        """melspec_fbank_compute_uniform_device_split (additive): the rows before CMN + the [clip][num_mel_bins] means CMN subtracts"""
+        _check(lib().melspec_fbank_compute_uniform_device_split(self._h, C.c_void_p(d_pcm), clip_stride, clip_len, n_clips,
+                                                                C.c_void_p(d_rows), C.c_void_p(d_means), C.c_void_p(stream)))
+
     def synchronize(self, stream: int = 0) -> None:
         _check(lib().melspec_fbank_synchronize(self._h, C.c_void_p(stream)))
 

@@ -342,6 +342,33 @@ def test_odd_hops_run_on_the_fused_kernels(gpu, oracle, jfk, hop):
     g.close()
 
 
+def test_fbank_split_output_is_the_two_halves_of_cmn(gpu, oracle):
+    """melspec_fbank_compute_uniform_device_split (round 6, additive): rows before CMN + the column means CMN subtracts.  rows - means in
+    f32 is bit for bit what Fbank::compute's fused path stores (src/fbank.rs:224-233); both on the workgroup-per-clip kernel (>= one clip
+    per CU) and on the wave kernel + cmn_kernel pair (few clips); the rows equal the apply_cmn = false output."""
+    for n_clips, clip_len in ((512, 16000), (7, 24000)):
+        clips = np.stack([oracle.synth_pcm(c, clip_len) for c in range(n_clips)])
+        pcm = gpu.DeviceBuffer(clips.nbytes); pcm.upload(clips.reshape(-1))
+        fb = gpu.Fbank(gpu.FbankConfig())
+        nf = fb.num_frames(clip_len)
+        out = gpu.DeviceBuffer(n_clips * nf * 80 * 4); rows = gpu.DeviceBuffer(n_clips * nf * 80 * 4); means = gpu.DeviceBuffer(n_clips * 80 * 4)
+        fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); fb.synchronize()
+        fb.compute_uniform_device_split(pcm.ptr, clip_len, clip_len, n_clips, rows.ptr, means.ptr); fb.synchronize()
+        o, r, m = out.download((n_clips, nf, 80)), rows.download((n_clips, nf, 80)), means.download((n_clips, 80))
+        assert np.array_equal((r - m[:, None, :]).astype(np.float32), o)
+        raw = gpu.Fbank(gpu.FbankConfig(apply_cmn=False))
+        raw.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr); raw.synchronize()
+        assert np.array_equal(out.download((n_clips, nf, 80)), r)
+        for c in (0, n_clips - 1):
+            want = oracle.fbank_compute(clips[c])
+            assert np.abs((r[c] - m[c]) - want).max() <= TOL
+        with pytest.raises(Exception):
+            raw.compute_uniform_device_split(pcm.ptr, clip_len, clip_len, n_clips, rows.ptr, means.ptr)
+        for x in (pcm, out, rows, means):
+            x.free()
+        fb.close(); raw.close()
+
+
 @pytest.mark.parametrize("n", [0, 1, 399, 400, 559, 560, 400 + 22 * 160, 400 + 23 * 160, 400 + 45 * 160 + 7])
 def test_edge_lengths(w80, oracle, n):
     x = oracle.synth_pcm(2, n) if n else np.zeros(0, np.float32)

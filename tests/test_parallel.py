@@ -263,7 +263,7 @@ def test_plain_bench_line_carries_the_speech_leg_and_config5():
     one = run()
     assert one["n_gpus"] == 1 and one["config"] == 2 and "speech" in one and "cfg5" not in one
     # the legs the driver's plain N = 1 run carries next to `value`
-    assert one["legs"] == ["cfg3", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32", "host_api_single_clip_ms"] and "legs" not in run("--no-legs")
+    assert one["legs"] == ["cfg3", "cfg3_split", "cfg4", "f64", "mel_major", "w512", "nemo", "nemo_f32", "host_api_single_clip_ms"] and "legs" not in run("--no-legs")
     two = run("--gpus", "2")
     assert two["n_gpus"] == 2 and two["config"] == 2 and two["scaling"] == "weak" and two["shards"] == [[0, 1024], [1024, 2048]]
     c5 = two["cfg5"]
