@@ -274,9 +274,51 @@ def case_f32_512():
         note("w512_auto_after_f32", d)
         pcm.free(); out.free(); m.close()
 
+def case_auto_512():
+    """MELSPEC_PRECISION_AUTO at n_fft = 512 (round 6) on batches large enough to vote (>= 6144 units): a random mix of noise-like clips and
+    clips the f32 FFT cannot vouch for (lines / chirps over quiet floors, speech-like material is k = 2, 3 of signal()), uniform or ragged;
+    sampled clips against the oracle at 1e-4 whichever way the vote goes, and the same bits on a second call."""
+    nm = int(rng.choice([80, 128]))
+    hop = int(rng.choice([160, 160, 128, 200]))
+    m = M.HipMelSpectrogram(512, hop, 16000.0, nm)
+    if m.precision != "auto":
+        m.close(); return
+    n_clips = int(rng.integers(260, 700)); base = int(rng.integers(16000, 40000))
+    hard_share = float(rng.choice([0.0, 0.02, 0.05, 0.3, 1.0]))
+    ragged = bool(rng.integers(0, 2))
+    lens = [int(base * rng.uniform(0.5, 1.5)) if ragged else base for _ in range(n_clips)]
+    def clip(n):
+        if rng.random() < hard_share: return signal(n)
+        return rng.standard_normal(n).astype(np.float32) * np.float32(10.0 ** rng.uniform(-3, 0))
+    clips = [clip(n) for n in lens]
+    if ragged:
+        got = m.compute_ragged(clips)
+        again = m.compute_ragged(clips)
+    else:
+        x = np.stack(clips)
+        pcm = M.DeviceBuffer(x.nbytes); pcm.upload(x.reshape(-1))
+        nf = m.num_frames(base)
+        out = M.DeviceBuffer(n_clips * nf * nm * 4)
+        m.compute_uniform_device(pcm.ptr, base, base, n_clips, out.ptr); m.synchronize()
+        got = out.download((n_clips, nf, nm))
+        m.compute_uniform_device(pcm.ptr, base, base, n_clips, out.ptr); m.synchronize()
+        again = out.download((n_clips, nf, nm))
+        pcm.free(); out.free()
+    heavy = m.auto_state()[0]
+    worst = 0.0
+    for c in rng.choice(n_clips, 10, replace=False):
+        w = O.compute_mel_spectrogram_cpu(clips[c], 512, hop, nm, 16000.0)
+        assert got[c].shape == w.shape and np.array_equal(got[c], again[c]), ("auto 512: bits", nm, hop, ragged, int(c))
+        d = float(np.abs(got[c] - w).max()) if w.size else 0.0
+        assert d <= 1e-4, ("auto 512", nm, hop, ragged, hard_share, heavy, int(c), d)
+        worst = max(worst, d)
+    note("auto_512_heavy" if heavy else "auto_512_light", worst)
+    m.close()
+
+
 n = 0
 while time.time() < t_end:
     r = rng.random()
-    (case_whisper if r < 0.60 else case_fbank if r < 0.72 else case_fbank_batch if r < 0.78 else case_nemo if r < 0.88 else case_nemo_batch if r < 0.92 else case_f32_512)()
+    (case_whisper if r < 0.57 else case_fbank if r < 0.69 else case_fbank_batch if r < 0.75 else case_nemo if r < 0.85 else case_nemo_batch if r < 0.89 else case_f32_512 if r < 0.95 else case_auto_512)()
     n += 1
 print("cases", n, {k: (v[0], float(f"{v[1]:.3g}")) for k, v in stats.items()})
