@@ -537,7 +537,11 @@ MS_DEV void nemo_phase3_store(int fl, int j, bool store, bool valid, int n_mels,
 #pragma unroll
     for (int i = 0; i < NSLOTS; ++i) {
         const int m = j + kFbOwn * i;
+#ifdef MS_NEMO_NO_STORE      // timing ablation (tools/ab_build.sh): the value is computed and dropped -- what the feature-major stores cost
+        if (m < n_mels) { float v = valid ? fast_ln((rise[i] + fnext[i]) + guard) : 0.0f; asm volatile("" :: "v"(v)); (void)o; }
+#else
         if (m < n_mels) o[static_cast<long long>(kFbOwn * i) * row_w] = valid ? fast_ln((rise[i] + fnext[i]) + guard) : 0.0f;
+#endif
     }
 }
 
