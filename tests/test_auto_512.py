@@ -141,3 +141,33 @@ def test_auto_512_ragged_batches_and_the_streaming_golden(gpu, oracle, jfk):
     g = m.compute_mel_spectrogram(jfk[128:])
     assert g.shape[0] >= golden.shape[1] and np.abs(g[: golden.shape[1]].T - golden).max() <= 1e-6
     m.close()
+
+
+def test_auto_512_device_planned_ragged_batch(gpu, oracle):
+    """melspec_compute_ragged_device_desc at n_fft = 512 in the default mode: the clip table lives in device memory, the plan is built by a
+    kernel and the host only knows an upper bound of the units -- the pair of launches reads the unit count from the plan.  Same bits as
+    the host-table call; sampled clips against the oracle."""
+    m = gpu.HipMelSpectrogram(512, 160, SR, 80)
+    rng = np.random.default_rng(11)
+    lens = np.array([int(v) for v in rng.integers(600, 90000, 380)] + [0, 511, 700], np.uint64)
+    clips = [oracle.synth_pcm(500 + i, int(n)) if i % 17 else _tone_over_floor(int(n), -80.0, 1800.0, i)[: int(n)] for i, n in enumerate(lens)]
+    offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    flat = np.concatenate([c for c in clips if len(c)])
+    frames = [m.num_frames(int(n)) for n in lens]
+    total = int(sum(frames))
+    oo = (np.concatenate([[0], np.cumsum(frames)[:-1]]) * 80).astype(np.uint64)
+    din = gpu.DeviceBuffer(flat.nbytes); din.upload(flat)
+    d_off, d_len, d_oo = gpu.DeviceBuffer(offs.nbytes), gpu.DeviceBuffer(lens.nbytes), gpu.DeviceBuffer(oo.nbytes)
+    d_off.upload(offs); d_len.upload(lens); d_oo.upload(oo)
+    a, b = gpu.DeviceBuffer(total * 80 * 4), gpu.DeviceBuffer(total * 80 * 4)
+    m.compute_ragged_device(din.ptr, offs, lens, a.ptr, oo); m.synchronize()
+    m.compute_ragged_device_desc(din.ptr, d_off.ptr, d_len.ptr, len(clips), b.ptr, d_oo.ptr, total + 1234); m.synchronize()
+    ga, gb = a.download((total, 80)), b.download((total, 80))
+    assert np.array_equal(ga, gb)
+    for c in (0, 17, 34, 200, 379, 381, 382):
+        w = oracle.compute_mel_spectrogram_cpu(clips[c], 512, 160, 80, SR)
+        lo = int(oo[c]) // 80
+        assert w.shape[0] == frames[c] and (w.size == 0 or np.abs(gb[lo:lo + frames[c]] - w).max() <= TOL), c
+    for x in (din, d_off, d_len, d_oo, a, b):
+        x.free()
+    m.close()
