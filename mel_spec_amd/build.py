@@ -21,7 +21,7 @@ UNIT_FLAGS = {"melspec_runs.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 def _inputs():
     # (the flags of every unit are part of what the library is: hashed through this file's own text would be too broad, so they are
     # appended to the hash explicitly in source_hash)
-    return ([os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp")))
+    return ([os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + sorted(glob.glob(os.path.join(CSRC, "*.inc")))
             + sorted(glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))))
 
 

@@ -145,6 +145,13 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
             if (c->six64) {
                 c->ft6.slots = wide.slots;          // the launch's copy of the slot table (run-time-lens code paths; unused by LensSix128)
                 if ((rc = upload(c->d_blob64x, c->t64.blob))) return bail(rc);
+                // ... and the f32 kernel of the same shape (round 6): plain batches of this bank leave the five-frame kernel
+                c->lds6w = sizeof(float) * (wide.blob.size() + static_cast<size_t>(kSixWideWaves) * SixLayout::slice_floats() + kSixWideWaves + 4);
+                c->six_wide32 = c->lds6w <= kLdsLimit && lab_int("MELSPEC_SIX_WIDE32", 1, 0, 1) != 0;
+                if (c->six_wide32) {
+                    c->ft6w = wide;
+                    if ((rc = upload(c->d_blob6w, c->ft6w.blob))) return bail(rc);
+                }
             }
         }
     }
@@ -206,7 +213,7 @@ void melspec_destroy(melspec_ctx *c) {
     if (!c) return;
     if (c->dev.device >= 0) (void)hipSetDevice(c->dev.device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->f512.d_blob.release(); c->d_blob6.release(); c->d_blob64x.release(); c->gt.release(); c->ragged.release();
+    c->d_blob.release(); c->d_blob64.release(); c->d_blob64s.release(); c->d_blob512.release(); c->f512.d_blob.release(); c->d_blob6.release(); c->d_blob6w.release(); c->d_blob64x.release(); c->gt.release(); c->ragged.release();
     c->fix.release();
     c->dplan.release();
     c->pipe.release();
@@ -276,6 +283,8 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
              : c->six_static == 2 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix64> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix64>")
              : c->six_static == 3 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix40> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix40>")
                              : (fix ? "melspec::whisper400_six_runs_kernel<9, LensRuntime> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensRuntime>");
+    if (c->six_wide32) return fix ? "melspec::whisper400_six_wide_runs_kernel<15, LensSix128> (six frames per wave, twelve waves; precision guard on)"
+                                  : "melspec::whisper400_six_wide_runs_kernel<15, LensSix128> (six frames per wave, twelve waves)";
     if (c->ft.slots.n_slots <= 8) return fix ? "melspec::whisper400_wave_runs_kernel<8, .> (precision guard on)" : "melspec::whisper400_wave_runs_kernel<8, .>";
     return fix ? "melspec::whisper400_wave_runs_kernel<12, .> (precision guard on)" : "melspec::whisper400_wave_runs_kernel<12, .>";
 }

@@ -17,5 +17,6 @@ template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>(con
 template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix40>(const FastParams);
 template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
 template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);
+template __global__ void whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>(const FastParams);
 
 }  // namespace melspec

@@ -8,6 +8,7 @@ extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix
 extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix40>(const FastParams);
 extern template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
 extern template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);
+extern template __global__ void whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>(const FastParams);
 }  // namespace melspec
 
 namespace melspec {
@@ -248,6 +249,24 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
     return MELSPEC_OK;
 }
 
+// the fifteen-slot f32 kernel on twelve waves: plain batches of Whisper large-v3's 128-mel bank
+int launch_six_wide(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipStream_t stream) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (!device_done(attr_done)) {
+        int rc = allow_big_lds(&whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>, "hipFuncSetAttribute(whisper400_six_wide_runs_kernel)");
+        if (rc) return rc;
+        mark_device_done(attr_done);
+    }
+    const uint64_t blocks = (desc.n_units + kSixWideWaves - 1) / kSixWideWaves;
+    const dim3 grid(grid_for_xcd(blocks, c->dev.cus, 1)), block(kSixWideWaves * 64);          // one twelve-wave workgroup per CU
+    FixSink armed = sink_armed(c, sink, desc, grid.x);
+    armed.vote_groups = std::min<unsigned>(grid.x, static_cast<unsigned>(c->dev.cus));
+    const FastParams fp = fast_params(desc, c->ft6w, c->d_blob6w, c, armed);
+    hipLaunchKernelGGL((whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>), grid, block, c->lds6w, stream, fp);
+    HIP_TRY(hipGetLastError());
+    return MELSPEC_OK;
+}
+
 int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (desc_in.n_units == 0) return MELSPEC_OK;
     BatchDesc desc = desc_in;
@@ -292,6 +311,8 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (c->six && desc.frames_per_unit == kSixFrames)
         rc = c->six_static == 1 ? launch_six_t<LensSix80>(c, desc, sink, stream) : c->six_static == 2 ? launch_six_t<LensSix64>(c, desc, sink, stream)
            : c->six_static == 3 ? launch_six_t<LensSix40>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
+    else if (c->six_wide32 && !layout_batch && desc.frames_per_unit == kSixFrames)
+        rc = launch_six_wide(c, desc, sink, stream);
     else
         rc = launch_wave(c, desc, sink, stream);
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));

@@ -407,138 +407,19 @@ __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const
 
 template <int NSLOTS, class Lens>
 __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_runs_kernel(const FastParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *blob = lds;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
-    unsigned *wg_done = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());   // guard_wave_done's two words,
-    if (tid < 6) wg_done[tid] = 0;                                                                                 // vote_cast's three, vote_check's one
-    __syncthreads();
+#define MS_SIX_RUNS_WAVES kSixWaves
+#include "whisper400_six_runs_body.inc"
+#undef MS_SIX_RUNS_WAVES
+}
 
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    float *slice = blob + p.blob_len + wave * SixLayout::slice_floats();
-    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
-    const bool in = lane < kSixFrames * kSixLanes;
-    int uoff, voff;
-    SixLayout::row_offsets(j, uoff, voff);
-    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
-    const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    const bool guard = p.fix.tab != nullptr;
-
-#ifdef MELSPEC_LAB_STAMPS
-    if (guard && tid == 0) p.fix.list[p.b.n_units + 4096 + (uint64_t)gridDim.x * kSixWaves + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
-#endif
-    ClipRun cr;
-    if (!cr.init(p.b, (uint64_t)xcd_logical_block() * kSixWaves + wave, (uint64_t)gridDim.x * kSixWaves)) {
-        if (guard && p.fix.vote != nullptr && blockIdx.x < p.fix.vote_groups) vote_cast(p.fix, wg_done + 2, kSixWaves, lane, 0, 0);
-        guard_wave_done(p.fix, wg_done, kSixWaves, lane, 0);
-        return;
-    }
-    uint64_t *notes = guard ? p.fix.list + cr.unit : nullptr;        // this wave's notes: the entries its own run indexes
-    unsigned noted = 0;
-    int nv = 0;
-    // one work unit: phases 1-4 and the note for the tail; returns the lanes whose guard tripped.  `pre` (a std::true_type in the
-    // vote's loop): between the phases the wave looks at the verdict and leaves the unit on "heavy" -- the batch's f64 launch is
-    // waiting for this one to drain, a unit is 7 us long (stand-down 30 -> ~20 us); the unit loop proper is instantiated without it
-    unsigned verdict = 0, polled = 0;
-    bool may_leave = true;
-    auto unit = [&](auto pre) __attribute__((always_inline)) -> uint64_t {
-        constexpr bool kPre = decltype(pre)::value;
-        cr.enter(p.b);
-        const uint64_t f0 = (cr.unit - cr.c_start) * kSixFrames;
-        const uint64_t left = cr.c_frames - f0;
-        nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
-        const float *src = cr.c_pcm + f0 * (uint64_t)p.hop;
-        const bool act = in && fl < nv;
-        MS_PRIO(0);
-        six_phase1(fl, j, act, p.hop, blob, src, slice);
-        __builtin_amdgcn_wave_barrier();
-        if (kPre && may_leave) {
-            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
-            if (verdict & kVoteHeavy) return 0;
-        }
-        MS_PRIO(1);
-        six_phase2(fl, j, act, blob, slice, uoff, voff);
-        __builtin_amdgcn_wave_barrier();
-        if (kPre && may_leave) {
-            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
-            if (verdict & kVoteHeavy) return 0;
-        }
-        MS_PRIO(2);
-        float vals[NSLOTS];
-        {
-            int st[NSLOTS];
-#pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];       // lanes 60..63 (j = 0..3 of a seventh frame) read valid entries too
-            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
-            six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, blob, slice, st, rise, fprev);
-#pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
-        }
-        __builtin_amdgcn_wave_barrier();
-        float *out_tile = cr.c_out + f0 * (uint64_t)n_mels;
-        const bool flag = six_phase4<NSLOTS, false, true>(fl, j, act, act, n_mels, slice, vals, out_tile, 0);
-        __builtin_amdgcn_wave_barrier();
-        uint64_t any = 0;
-        if (guard) {
-            any = __builtin_amdgcn_ballot_w64(flag);
-            if (any != 0) {
-                if (lane == 0) notes[noted] = (cr.unit << 8) | frame_mask<kSixLanes, kSixFrames>(any);
-                ++noted;
-            }
-        }
-        return any;
-    };
-    // AUTO's vote (FixSink::vote).  The first units of a voting launch run in a loop of their own until the verdict is known: the
-    // same code in the unit loop proper -- a handful of scalar branches that are never taken after the second unit -- cost that loop
-    // 19 % (same-box A/B, round 4: the register allocator and the scheduler see one more loop-carried state and two more exits).
-    if (guard && p.fix.vote != nullptr) {
-        bool sample = blockIdx.x < p.fix.vote_groups;                  // the first unit of every wave of the first vote_groups workgroups is the sample
-        may_leave = !sample;                                           // a sampling wave finishes its first unit: the tally waits for it
-        for (; cr.unit < cr.end && verdict == 0; ++cr.unit) {
-            const uint64_t any = unit(std::true_type{});
-            if (verdict & kVoteHeavy) break;
-            if (sample) {
-                vote_cast(p.fix, wg_done + 2, kSixWaves, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(any))), static_cast<unsigned>(nv));
-                sample = false;
-                may_leave = true;
-            }
-            verdict = vote_check(p.fix, wg_done + 2, ++polled, wave);
-        }
-        if (verdict == 0) verdict = vote_poll(p.fix);                  // a run shorter than the vote
-        if (verdict & kVoteHeavy) {                                    // the f64 kernel behind this launch computes the whole batch
-            guard_wave_done(p.fix, wg_done, kSixWaves, lane, 0);
-            return;
-        }
-    }
-    for (; cr.unit < cr.end; ++cr.unit) unit(std::false_type{});
-    // the units whose frames tripped the precision guard, again, in f64
-    unsigned redone = 0;
-    FixTw tw;
-    // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
-    // SAME values as the hot loop's they stayed live across the tail's register-hungry f64 code, and the allocator spilled them for
-    // the loop as well (the mel-major kernel reloaded one from scratch eight times per unit: 0.37 -> 0.45 ms).
-    int tlane = lane;
-    float *tslice = slice;
-    asm volatile("" : "+v"(tlane));
-    if (noted) fix_load_tw(tlane, p.fix.tab, tw);
-    for (unsigned k = 0; k < noted; ++k) {
-        uint64_t e = 0;
-        if (lane == 0) e = notes[k];
-        e = scalar64(e);
-        const UnitLoc loc = locate_unit(p.b, e >> 8);
-        const uint64_t f0 = loc.unit * kSixFrames;
-        redone += six_fix_unit<NSLOTS, Lens, false>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
-                                          loc.pcm + f0 * (uint64_t)p.hop, loc.out + f0 * (uint64_t)n_mels, 0);
-    }
-#ifdef MELSPEC_LAB_STAMPS
-    // lab builds (tools/tail_probe.py): when every wave finished, in 10 ns ticks of the constant clock -- written behind the note list's
-    // slack (whisper400.hip reads them back): the spread of these is what a hand-out of the last units on demand would have to win
-    if (guard && lane == 0) p.fix.list[p.b.n_units + 4096 + (uint64_t)blockIdx.x * kSixWaves + wave] = __builtin_amdgcn_s_memrealtime();
-#endif
-    guard_wave_done(p.fix, wg_done, kSixWaves, lane, redone);
+// The same on twelve waves per CU (three per SIMD, up to 168 VGPRs) with FIFTEEN mel slots: Whisper large-v3's 128-mel bank (81..134 mels)
+// on the six-frame skeleton.  At sixteen waves the fifteen slots' registers pushed the unit loop into scratch (round 3: 9.5 % slower than
+// the five-frame kernel); the f64 twin (whisper400_six64_kernel<15, LensSix128>) has run this shape since round 5.
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kSixWideWaves * 64, 3) void whisper400_six_wide_runs_kernel(const FastParams p) {
+#define MS_SIX_RUNS_WAVES kSixWideWaves
+#include "whisper400_six_runs_body.inc"
+#undef MS_SIX_RUNS_WAVES
 }
 
 // The same for the 5-frame kernel (81..131 mels): interval mel scheme, direct PCM reads, 8-wave workgroups.

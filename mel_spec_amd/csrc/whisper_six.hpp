@@ -31,6 +31,7 @@ constexpr int kSixMaxSlots = 9;   // ceil(81 / 9): up to 80 mel bins
 // lane: its mel phase runs after the f64 arrays are dead, so the registers are there (the f32 six-frame kernel has no such room at 128
 // VGPRs: those banks stay on the five-frame kernels there)
 constexpr int kSixWideSlots = 15;
+constexpr int kSixWideWaves = 12; // waves per workgroup of the f32 six-frame kernel with fifteen slots (whisper400_six_wide_runs_kernel): three per SIMD
 
 struct SixBlob {                  // float offsets inside the table blob
     // the 40 taps of lane t in the order it uses them, w[20*n1 + 2t + {0, 1}] at [t][2*n1 + {0, 1}]: ten 16-byte reads per unit;

@@ -13,7 +13,7 @@ from mel_spec_amd import build as B
 # leg -> (unit, substrings the mangled name must contain, frames per unit)
 LEGS = {
     "value":     ("melspec_runs.hip", ["whisper400_six_runs_kernel", "LensSixStaticILi80E"], 6),
-    "cfg4":      ("melspec_runs.hip", ["whisper400_wave_runs_kernel", "ILi12E"], 5),
+    "cfg4":      ("melspec_runs.hip", ["whisper400_six_wide_runs_kernel"], 6),
     "mel_major": ("whisper400.hip", ["whisper400_six_kernelILi9E", "LensSixStaticILi80E"], 6),
     "f64":       ("whisper400.hip", ["whisper400_six64_kernelILi9E", "LensSixStaticILi80E"], 6),
     "speech":    ("whisper400.hip", ["whisper400_six64_kernelILi9E", "LensSixStaticILi80E"], 6),
