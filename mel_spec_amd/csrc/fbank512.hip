@@ -311,7 +311,7 @@ static int fbank_launch(melspec_fbank *fb, const BatchPlan &pl, uint32_t n_clips
         const uint32_t passes = (n_clips + cus - 1) / cus;
         const bool ragged_by_clip = pl.desc.d_order != nullptr;       // melspec_fbank_compute_ragged_device decided (and checked the alignment)
         if (clip_on && (ragged_by_clip ||
-            (fb->cfg.apply_cmn && fb->waves == 8 && pl.desc.d_unit_prefix == nullptr && nm % 4 == 0 && nm <= 89 &&
+            (fb->cfg.apply_cmn && fb->cfg.use_power && fb->waves == 8 && pl.desc.d_unit_prefix == nullptr && nm % 4 == 0 && nm <= 89 &&
              (reinterpret_cast<uintptr_t>(pl.desc.out) & 15) == 0 && pl.desc.out_stride % 4 == 0 &&
              n_clips >= cus && static_cast<uint64_t>(n_clips) * 100 >= static_cast<uint64_t>(passes) * cus * 85))) {
             static std::atomic<uint64_t> attr_done{0};
@@ -406,7 +406,7 @@ int melspec_fbank_compute_ragged_device(melspec_fbank *fb, const float *d_pcm, c
     // whole clips per workgroup (fbank512_clip_kernel) when the batch can keep every CU busy: at least two clips per CU and no clip
     // longer than half a CU's share; outputs at 16-byte offsets (packed outputs of n_mels % 4 == 0 are)
     const int nm = fb->cfg.num_mel_bins;
-    bool by_clip = fused && fb->cfg.apply_cmn && fb->waves == 8 && nm % 4 == 0 && nm <= 89 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
+    bool by_clip = fused && fb->cfg.apply_cmn && fb->cfg.use_power && fb->waves == 8 && nm % 4 == 0 && nm <= 89 && (reinterpret_cast<uintptr_t>(d_out) & 15) == 0 &&
                    n_clips >= 2u * static_cast<uint32_t>(fb->dev.cus) && longest * 2 * static_cast<uint64_t>(fb->dev.cus) <= total && longest < (1ull << 31);
     if (by_clip && h_out_offsets)
         for (uint32_t i = 0; i < n_clips && by_clip; ++i) by_clip = h_out_offsets[i] % 4 == 0;

@@ -549,7 +549,7 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
 #pragma unroll
         for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kFbLanes + j];
     }
-    const bool use_power = p.use_power != 0, use_log = p.use_log != 0;
+    const bool use_log = p.use_log != 0;
     const T preemph = static_cast<T>(p.preemph);
     const int nm = p.n_mels;
     unsigned gen = 0;                      // clips this workgroup has finished
@@ -603,8 +603,9 @@ __global__ __launch_bounds__(8 * 64, 1) void fbank512_clip_kernel(const FbankCli
                 fb_phase2_dft<T>(fl, j, act, slice, own);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
-                if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
-            else fb_phase2_split<T, false>(fl, j, act, tblob, own, part, slice);
+                // power spectra only (FbankConfig::use_power, the default): magnitudes run on the two-kernel path -- with both forms of the
+                // split behind a run-time branch the unit loop carried 123 f64 + 170 other instructions it never executed
+                fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
             }
             __builtin_amdgcn_wave_barrier();
             MS_PRIO(2);

@@ -351,7 +351,13 @@ MS_DEV void fb_kaldi_input(const float *frame, int n2, T preemph, bool patch_fir
         const T t13 = static_cast<T>(c[12].x) + static_cast<T>(c[12].y);
         s = has13 ? s + t13 : s;
     }
+#ifdef MS_KALDI_MEAN_DIV
     const T mean = row_sum16<T>(s) / T(400);                 // src/fbank.rs:165-166
+#else
+    // sum * (1 / 400) for src/fbank.rs:165-166's sum / 400: at most one ulp of an f64 away, and a dozen instructions (v_div_scale, v_rcp,
+    // the Newton steps, v_div_fmas, v_div_fixup) shorter per unit
+    const T mean = row_sum16<T>(s) * (T(1) / T(400));
+#endif
     const T dc = (T(1) - preemph) * mean;
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {

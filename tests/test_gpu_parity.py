@@ -842,6 +842,29 @@ def test_fbank_clip_kernel_against_the_two_kernel_path(gpu, oracle, jfk, n_mels,
     fb.close()
 
 
+def test_fbank_magnitude_batches_take_the_two_kernel_path(gpu, oracle, jfk):
+    """FbankConfig::use_power = false (magnitudes, src/fbank.rs:193-200) on a batch that would fill the CUs: the workgroup-per-clip kernel is
+    compiled for power spectra only since round 6 (the other form of the Hermitian split sat in its unit loop behind a run-time branch), so
+    these batches run the fused kernel + cmn_kernel -- same tree of column sums, same bits as a small batch, within the oracle's tolerance."""
+    cfg = gpu.FbankConfig(use_power=False)
+    fb = gpu.Fbank(cfg)
+    oc = oracle.fbank_default_config(); oc.use_power = False
+    n_clips, clip_len = 512, 11357
+    src = np.concatenate([jfk, jfk])
+    x = np.stack([(src[c * 300:c * 300 + clip_len] if c % 2 else oracle.synth_pcm(c, clip_len)) for c in range(n_clips)]).astype(np.float32)
+    big = fb.compute_batch(x)
+    assert np.array_equal(big[:40], fb.compute_batch(x[:40]))
+    for c in (0, 1, 150, n_clips - 1):
+        assert np.abs(big[c] - oracle.fbank_compute(x[c], oc)).max() <= TOL
+    assert np.abs(big.mean(axis=1)).max() < 1e-4
+    # ragged, many clips (the by-clip plan is for power spectra only as well)
+    lens = [4000 + 37 * (c % 90) for c in range(n_clips)]
+    rag = fb.compute_ragged([x[c][:n] for c, n in enumerate(lens)])
+    for c in (0, 89, 300, n_clips - 1):
+        assert np.abs(rag[c] - oracle.fbank_compute(x[c][:lens[c]], oc)).max() <= TOL
+    fb.close()
+
+
 def test_cpp_host_mirror(gpu, oracle, tmp_path):
     """include/melspec_hip.hpp (the C++ twin of HipMelSpectrogram / Fbank / mel) against the oracle."""
     import subprocess

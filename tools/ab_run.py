@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of library variants (boxes differ by several percent, so variants are interleaved and repeated):
-tools/ab_run.py [--case cfg2|cfg4|f64|fbank|nemo|w512|mm] name1 name2 ...   (libraries mel_spec_amd/ab/lib_<name>.so).
+tools/ab_run.py [--case cfg2|cfg4|f64|fbank|fbank_split|nemo|w512|mm] name1 name2 ...   (libraries mel_spec_amd/ab/lib_<name>.so).
 Each measurement runs in its own process (MELSPEC_LIB), event-timed, after a spin-up; prints per variant min / median over reps."""
 import os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -72,6 +72,11 @@ elif case == "fbank":
     ms = wall(lambda: fb.compute_uniform_device(pcm.ptr, clip_len, clip_len, n_clips, out.ptr), fb.synchronize, 100)
     got = out.download((fb.num_frames(clip_len), 80), offset_bytes=0)
     assert np.abs(got - O.fbank_compute(O.synth_pcm(0, clip_len))).max() <= 1e-4
+elif case == "fbank_split":          # rows before CMN + the clips' means (melspec_fbank_compute_uniform_device_split)
+    fb = M.Fbank()
+    out = M.DeviceBuffer(n_clips * fb.num_frames(clip_len) * 80 * 4)
+    means = M.DeviceBuffer(n_clips * 80 * 4)
+    ms = wall(lambda: fb.compute_uniform_device_split(pcm.ptr, clip_len, clip_len, n_clips, out.ptr, means.ptr), fb.synchronize, 100)
 elif case in ("nemo", "nemo_norm", "nemo_f32", "nemo_norm_f32", "nemo80", "nemo80_f32", "nemo_nopre", "nemo_nopre_f32"):
     fe = M.BatchLogMelSpectrogram(M.BatchLogMelConfig(n_mels=80 if "80" in case else 128, preemphasis=0.0 if "nopre" in case else 0.97, normalize_per_feature=("norm" in case)))
     if case.endswith("f32"): fe.set_precision("f32")
