@@ -445,6 +445,8 @@ def valu_fields(leg: str, frames_per_s: float):
            # count against THAT rate -- what the f64 pipe can be made to do on this part
            "frac_of_measured_f64_issue_rate": f64 * 128.0 * frames_per_s / (F64_VECTOR_PEAK_TFLOPS * 1e12) * (6.2 / 4.0),
            "kernel_symbol": row.get("kernel"), "isa_of_source_hash": _ISA.get("source_hash")}
+    if row.get("note"):
+        out["note"] = row["note"]
     try:
         from mel_spec_amd import build as hip_build
         if _ISA.get("source_hash") != hip_build.source_hash():

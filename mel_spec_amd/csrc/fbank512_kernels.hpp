@@ -198,7 +198,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void fbank512_wave_kernel(const F
 #pragma unroll
             for (int i = 0; i < 8; ++i) part[i] = {partner16(own[8 + i].re), partner16(own[8 + i].im)};
             if (FLAVOR == kFlavorWhisper) fb_phase2_split<T, true, sizeof(T) == 8>(fl, j, act, tblob, own, part, slice);      // f32: the amplitude form (fbank_tables.hpp)
-            else if (use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
+            // NeMo: power spectra always (src/mel.rs:356-357) -- the magnitude form stays out of its unit loop (742 -> ~400 instructions in phase 2)
+            else if (FLAVOR == kFlavorNemo || use_power) fb_phase2_split<T, true>(fl, j, act, tblob, own, part, slice);
             else fb_phase2_split<T, false>(fl, j, act, tblob, own, part, slice);
         }
         __builtin_amdgcn_wave_barrier();

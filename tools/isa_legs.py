@@ -55,6 +55,14 @@ def unit_loop(lines):
     end = next((k for k in range(g[2], len(lines)) if lines[k].startswith(('s_cbranch', 's_branch'))), len(lines))
     return lines[g[0]:end], True
 
+# legs whose unit loop holds code a pass does not execute (wave-uniform branches): the static count overstates them
+NOTES = {
+    "nemo": "phase 1 is in the loop three times (interior frames, interior without pre-emphasis, frames at a clip's ends: wave-uniform branches, "
+            "one executes): the executed count is lower than this static one",
+    "nemo_f32": "phase 1 is in the loop three times (interior frames, interior without pre-emphasis, frames at a clip's ends: wave-uniform branches, "
+                "one executes): the executed count is lower than this static one",
+}
+
 asm = {}
 with tempfile.TemporaryDirectory() as tmp:
     procs = {}
@@ -81,6 +89,7 @@ for leg, (unit, subs, fpu) in LEGS.items():
     body, marked = unit_loop(lines)
     c = collections.Counter(klass(l) for l in body)
     row = dict(c); row.update(kernel=name, frames_per_unit=fpu, unit_loop_marked=marked)
+    if leg in NOTES: row["note"] = NOTES[leg]
     res["legs"][leg] = row
     other = c['valu32'] + c['cvt'] + c['dpp/lane'] + c['pk']
     print(f"  {leg:10s} {fpu:3d} {c['f64']:5d} {c['cvt']:4d} {c['valu32']:4d} {c['dpp/lane']:4d} {c['lds']:4d} {c['vmem']:4d} {c['salu']:4d} {c['wait']:4d} | {c['f64'] / fpu:7.1f} {other / fpu:7.1f} | "
