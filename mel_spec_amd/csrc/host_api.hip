@@ -3,6 +3,9 @@
 // this ABI is shipped as source in mel_spec_amd/rust/.  melspec_ctx mirrors CudaMelSpectrogram (src/cuda.rs:27-148): it owns the device
 // tables, a stream and grow-only device scratch; melspec_compute_host is compute_mel_spectrogram.
 #include "host_common.hpp"
+#ifndef MS_WIDE_LAYOUTS_DEFAULT
+#define MS_WIDE_LAYOUTS_DEFAULT 1
+#endif
 
 namespace melspec {
 namespace host {
@@ -148,6 +151,7 @@ int create_ctx(melspec_ctx **out, int device, int fft_size, int hop_size, double
                 // ... and the f32 kernel of the same shape (round 6): plain batches of this bank leave the five-frame kernel
                 c->lds6w = sizeof(float) * (wide.blob.size() + static_cast<size_t>(kSixWideWaves) * SixLayout::slice_floats() + kSixWideWaves + 4);
                 c->six_wide32 = c->lds6w <= kLdsLimit && lab_int("MELSPEC_SIX_WIDE32", 1, 0, 1) != 0;
+                c->six_wide32_layouts = c->six_wide32 && lab_int("MELSPEC_SIX_WIDE32_LAYOUTS", MS_WIDE_LAYOUTS_DEFAULT, 0, 1) != 0;
                 if (c->six_wide32) {
                     c->ft6w = wide;
                     if ((rc = upload(c->d_blob6w, c->ft6w.blob))) return bail(rc);

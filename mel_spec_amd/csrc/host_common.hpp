@@ -389,6 +389,7 @@ struct melspec_ctx {
     bool six64_wide = false;    // ... with fifteen mel slots (Whisper large-v3's 128-mel bank): plain batches only, c->six is false there
     // the f32 six-frame kernel with fifteen mel slots on twelve waves (whisper400_six_wide_runs_kernel, round 6): plain batches of that bank
     bool six_wide32 = false;
+    bool six_wide32_layouts = false;   // ... its padded / mel-major layouts too (whisper400_six_wide_kernel)
     FastTables ft6w;
     DevBuf d_blob6w;
     size_t lds6w = 0;
@@ -449,7 +450,7 @@ inline bool six64_layout_ok(const melspec_ctx *c) { return c->six64 && !c->six64
 inline int ctx_frames_per_unit(melspec_ctx *c, bool layout = false) {
     if (c->fast) {
         if (c->precision == MELSPEC_PRECISION_F64) return (layout ? six64_layout_ok(c) : c->six64) ? kSixFrames : kFPW;
-        if (!layout && c->six_wide32) return kSixFrames;          // the 128-mel bank's plain batches: six frames per wave on twelve waves
+        if (c->six_wide32 && (!layout || c->six_wide32_layouts)) return kSixFrames;          // the 128-mel bank: six frames per wave on twelve waves
         return c->six ? kSixFrames : kFPW;
     }
     return c->fast512 ? kFbFPW : 1;

@@ -249,11 +249,12 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
     return MELSPEC_OK;
 }
 
-// the fifteen-slot f32 kernel on twelve waves: plain batches of Whisper large-v3's 128-mel bank
+// the fifteen-slot f32 kernels on twelve waves: Whisper large-v3's 128-mel bank, plain batches (runs) and layouts (rounds)
 int launch_six_wide(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipStream_t stream) {
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
         int rc = allow_big_lds(&whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>, "hipFuncSetAttribute(whisper400_six_wide_runs_kernel)");
+        if (!rc) rc = allow_big_lds(&whisper400_six_wide_kernel<kSixWideSlots, LensSix128>, "hipFuncSetAttribute(whisper400_six_wide_kernel)");
         if (rc) return rc;
         mark_device_done(attr_done);
     }
@@ -262,7 +263,9 @@ int launch_six_wide(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, 
     FixSink armed = sink_armed(c, sink, desc, grid.x);
     armed.vote_groups = std::min<unsigned>(grid.x, static_cast<unsigned>(c->dev.cus));
     const FastParams fp = fast_params(desc, c->ft6w, c->d_blob6w, c, armed);
-    hipLaunchKernelGGL((whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>), grid, block, c->lds6w, stream, fp);
+    const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
+    if (layout) hipLaunchKernelGGL((whisper400_six_wide_kernel<kSixWideSlots, LensSix128>), grid, block, c->lds6w, stream, fp);
+    else hipLaunchKernelGGL((whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>), grid, block, c->lds6w, stream, fp);
     HIP_TRY(hipGetLastError());
     return MELSPEC_OK;
 }
@@ -274,7 +277,10 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (desc.sync_rounds < 0) {
         // measured (profiles/r01_variants.txt): six-frame kernel, 16 waves: four waves 4 apart; precise kernel, 8 waves:
         // consecutive pairs; 5-frame kernel, two 8-wave workgroups per CU: pairs 4 apart
-        if (c->fast && desc.frames_per_unit == kSixFrames) desc.sync_rounds = 20;
+        // (the groups that work are the waves of one SIMD: sixteen waves -> fours 4 apart, twelve -> threes 4 apart: the wide kernel's
+        // mel-major store at 128 mels 0.532 ms with fours, 0.405-0.424 with threes, profiles/r06_wide_layouts.txt)
+        // (the 80-mel layouts on twelve waves, built: 0.350 ms with threes or consecutive pairs against 0.339-0.342 on sixteen)
+        if (c->fast && desc.frames_per_unit == kSixFrames) desc.sync_rounds = c->six_wide32 ? 19 : 20;
         else if (c->fast && c->precision == MELSPEC_PRECISION_F64) desc.sync_rounds = 2;
         else if (c->fast) desc.sync_rounds = 18;
         else desc.sync_rounds = 1;
@@ -311,7 +317,7 @@ int launch_ctx(melspec_ctx *c, const BatchDesc &desc_in, hipStream_t stream) {
     if (c->six && desc.frames_per_unit == kSixFrames)
         rc = c->six_static == 1 ? launch_six_t<LensSix80>(c, desc, sink, stream) : c->six_static == 2 ? launch_six_t<LensSix64>(c, desc, sink, stream)
            : c->six_static == 3 ? launch_six_t<LensSix40>(c, desc, sink, stream) : launch_six_t<LensRuntime>(c, desc, sink, stream);
-    else if (c->six_wide32 && !layout_batch && desc.frames_per_unit == kSixFrames)
+    else if (c->six_wide32 && desc.frames_per_unit == kSixFrames)
         rc = launch_six_wide(c, desc, sink, stream);
     else
         rc = launch_wave(c, desc, sink, stream);

@@ -260,140 +260,16 @@ __global__ __launch_bounds__(kWaveWaves * 64, 4) void whisper400_wave_kernel(con
 // Padded and/or mel-major output: workgroup-uniform rounds like whisper400_wave_kernel.
 template <int NSLOTS, class Lens>
 __global__ __launch_bounds__(kSixWaves * 64, 4) void whisper400_six_kernel(const FastParams p) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *blob = lds;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < p.blob_len; i += kSixWaves * 64) blob[i] = p.d_blob[i];
-    // arrival counters of the sub-group barrier (mel-major stores), behind the last slice
-    unsigned *arrive = reinterpret_cast<unsigned *>(blob + p.blob_len + kSixWaves * SixLayout::slice_floats());
-    if (tid < kSixWaves + 4) arrive[tid] = 0;                          // + the vote's four words
-    __syncthreads();
-
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    float *slice = blob + p.blob_len + wave * SixLayout::slice_floats();
-    const int fl = lane / kSixLanes, j = lane - fl * kSixLanes;
-    const bool in = lane < kSixFrames * kSixLanes;
-    int uoff, voff;
-    SixLayout::row_offsets(j, uoff, voff);
-    const int n_mels = Lens::kStatic ? Lens::kMels : p.n_mels;
-    const int *starts = reinterpret_cast<const int *>(blob + SixBlob::kMelStart) + j;
-    const bool guard = p.fix.tab != nullptr;
-    RoundSync<kSixWaves> rs(p.b.sync_rounds, wave, arrive);
-    const uint64_t rounds = (p.b.n_units + (uint64_t)gridDim.x * kSixWaves - 1) / ((uint64_t)gridDim.x * kSixWaves);
-    uint64_t *notes = guard ? p.fix.list + ((uint64_t)xcd_logical_block() * kSixWaves + rs.slot) * rounds : nullptr;
-    unsigned noted = 0;
-    int nv = 0;
-    // one round of the workgroup: this wave's unit through phases 1-4; returns the lanes whose guard tripped
-    auto round = [&](uint64_t first) __attribute__((always_inline)) -> uint64_t {
-        const uint64_t unit = first + rs.slot;
-        const bool have = unit < p.b.n_units;
-        const UnitLoc loc = locate_unit(p.b, have ? unit : first);
-        const uint64_t f0 = loc.unit * kSixFrames;
-        const uint64_t left = (have && f0 < loc.frames) ? loc.frames - f0 : 0;
-        nv = left < (uint64_t)kSixFrames ? (int)left : kSixFrames;
-        // columns this unit stores: the clip's frames plus, for padded layouts, zero columns up to out_width
-        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
-        const uint64_t wleft = have ? width - f0 : 0;
-        const int ns = wleft < (uint64_t)kSixFrames ? (int)wleft : kSixFrames;
-        const float *src = loc.pcm + f0 * (uint64_t)p.hop;
-        const bool act = in && fl < nv;
-        MS_PRIO(0);
-        six_phase1(fl, j, act, p.hop, blob, src, slice);
-        __builtin_amdgcn_wave_barrier();
-        MS_PRIO(1);
-        six_phase2(fl, j, act, blob, slice, uoff, voff);
-        __builtin_amdgcn_wave_barrier();
-        MS_PRIO(2);
-        float vals[NSLOTS];
-        {
-            // per-lane start bins: re-read every unit (9 LDS words) rather than held in registers across the loop
-            int st[NSLOTS];
-#pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) st[i] = starts[i * kSixLanes];       // lanes 60..63 (j = 0..3 of a seventh frame) read valid entries too
-            float rise[NSLOTS], fprev[NSLOTS], fnext[NSLOTS];
-            six_phase3_sums<NSLOTS, Lens>(fl, j, act, p.slots, blob, slice, st, rise, fprev);
-#pragma unroll
-            for (int i = 0; i < NSLOTS; ++i) fnext[i] = wave_shift_down1(fprev[i]);
-            six_phase3_finish<NSLOTS>(fl, j, act, n_mels, rise, fnext, slice, vals);
-        }
-        __builtin_amdgcn_wave_barrier();
-        rs.template before_stores<3>(lane);
-        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        const long long row_w = p.b.mel_major ? (long long)width : 0;
-        int kmin = 0x7fffffff, kmax = 0;
-        const bool flag = six_phase4<NSLOTS, true, true, true>(fl, j, in && fl < ns, act, n_mels, slice, vals, out_tile, row_w, &kmin, &kmax);
-        __builtin_amdgcn_wave_barrier();
-        unsigned redo = 0;                  // frames of this unit that the tail recomputes
-        uint64_t any = 0;
-        if (guard) {
-            any = __builtin_amdgcn_ballot_w64(flag);
-            if (any != 0) {
-                redo = frame_mask<kSixLanes, kSixFrames>(any);
-                if (lane == 0) notes[noted] = (unit << 8) | redo;
-                ++noted;
-            }
-        }
-        if (p.b.d_unit_ext && have) {       // wave-uniform; a frame that is recomputed reports its extremes then
-            if ((redo >> fl) & 1u) { kmin = 0x7fffffff; kmax = 0; }
-            unit_ext_store(p.b.d_unit_ext + 2 * unit, lane, kmin, kmax);
-        }
-        rs.after_round();
-        return any;
-    };
-    uint64_t first = (uint64_t)xcd_logical_block() * kSixWaves;
-    const uint64_t step = (uint64_t)gridDim.x * kSixWaves;
-    // AUTO's vote (FixSink::vote), layouts: the sample is the first round of the first vote_groups workgroups, and the workgroup
-    // leaves TOGETHER -- its waves wait for each other in RoundSync, so the verdict is read behind a workgroup barrier.  In a loop of
-    // its own, like the run-per-wave kernels' (the same code inside the round loop proper cost that loop 19 %).
-    if (guard && p.fix.vote != nullptr) {
-        unsigned *votew = arrive + kSixWaves;                          // vote_cast's three words, the workgroup's copy of the verdict
-        bool sample = blockIdx.x < p.fix.vote_groups;
-        unsigned verdict = 0, polled = 0;
-        if (sample && first >= p.b.n_units) {                          // a workgroup of the grid's round-up to the 8 XCDs: it still has to be counted
-            vote_cast(p.fix, votew, kSixWaves, lane, 0, 0);
-            sample = false;
-        }
-        for (; first < p.b.n_units && verdict == 0; first += step) {
-            const uint64_t any = round(first);
-            if (sample) {
-                vote_cast(p.fix, votew, kSixWaves, lane, static_cast<unsigned>(__builtin_popcount(frame_mask<kSixLanes, kSixFrames>(any))), static_cast<unsigned>(nv));
-                sample = false;
-            }
-            (void)vote_check(p.fix, votew, ++polled, wave);
-            __syncthreads();
-            verdict = __builtin_amdgcn_readfirstlane(__hip_atomic_load(votew + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            __syncthreads();                                           // nobody publishes a verdict between two waves' reads of it
-        }
-        if (verdict & kVoteHeavy) {                                    // the f64 kernel behind this launch computes the whole batch
-            guard_wave_done(p.fix, arrive + kSixWaves - 2, kSixWaves, lane, 0);
-            return;
-        }
-    }
-    for (; first < p.b.n_units; first += step) round(first);
-    unsigned redone = 0;
-    FixTw tw;
-    // The tail derives its lane constants (frame slot, start bins, row offsets) afresh from an opaque copy of `lane`: as the
-    // SAME values as the hot loop's they stayed live across the tail's register-hungry f64 code, and the allocator spilled them for
-    // the loop as well (the mel-major kernel reloaded one from scratch eight times per unit: 0.37 -> 0.45 ms).
-    int tlane = lane;
-    float *tslice = slice;
-    asm volatile("" : "+v"(tlane));
-    if (noted) fix_load_tw(tlane, p.fix.tab, tw);
-    for (unsigned k = 0; k < noted; ++k) {
-        uint64_t e = 0;
-        if (lane == 0) e = notes[k];
-        e = scalar64(e);
-        const uint64_t unit = e >> 8;
-        const UnitLoc loc = locate_unit(p.b, unit);
-        const uint64_t f0 = loc.unit * kSixFrames;
-        const uint64_t width = p.b.d_unit_prefix == nullptr ? p.b.out_width : loc.frames;
-        float *out_tile = p.b.mel_major ? loc.out + f0 : loc.out + f0 * (uint64_t)n_mels;
-        redone += six_fix_unit<NSLOTS, Lens, true>(static_cast<unsigned>(e & 0xff), tlane, p.hop, n_mels, p.slots, blob, tslice, p.fix, tw,
-                                         loc.pcm + f0 * (uint64_t)p.hop, out_tile, p.b.mel_major ? (long long)width : 0,
-                                         p.b.d_unit_ext ? p.b.d_unit_ext + 2 * unit : nullptr);
-    }
-    guard_wave_done(p.fix, arrive + kSixWaves - 2, kSixWaves, lane, redone);
+#define MS_SIX_LAYOUT_WAVES kSixWaves
+#include "whisper400_six_body.inc"
+#undef MS_SIX_LAYOUT_WAVES
+}
+// ... with fifteen mel slots on twelve waves (168 VGPRs): the layouts of Whisper large-v3's 128-mel bank (see whisper400_six_wide_runs_kernel)
+template <int NSLOTS, class Lens>
+__global__ __launch_bounds__(kSixWideWaves * 64, 3) void whisper400_six_wide_kernel(const FastParams p) {
+#define MS_SIX_LAYOUT_WAVES kSixWideWaves
+#include "whisper400_six_body.inc"
+#undef MS_SIX_LAYOUT_WAVES
 }
 
 // Plain [frame][mel] output, uniform and ragged batches, on the six-frame build -- the default kernel of the bench workload.

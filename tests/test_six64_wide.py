@@ -1,9 +1,9 @@
 """whisper400_six64_kernel<15, LensSix128> (round 5): the f64 six-frame kernel on Whisper large-v3's 128-mel bank -- MELSPEC_PRECISION_F64 on
 plain batches (uniform and ragged) and AUTO's gated launch on plain batches.  Since round 6 the f32 launch in front of it is
 whisper400_six_wide_runs_kernel<15, LensSix128> -- six frames per wave on twelve waves, 168 VGPRs -- so both launches walk ONE six-frame
-plan, ragged batches included (round 5's f32 kernel dealt five-frame units and the uniform batch was planned twice).  Layouts stay on the
-five-frame kernels: the fifteen-slot LAYOUT instantiation of the f64 kernel was built and measured 1.7 % slower than the precise kernel's
-(mel-major F64 at 128 mels 0.5604 -> 0.5697 ms)."""
+plan, ragged batches included (round 5's f32 kernel dealt five-frame units and the uniform batch was planned twice).  The f32 layouts run
+whisper400_six_wide_kernel (rounds, the barrier over the three waves of a SIMD); F64 layouts stay on the five-frame precise kernel: the
+fifteen-slot LAYOUT instantiation of the f64 kernel was built and measured 1.7 % slower (mel-major F64 at 128 mels 0.5604 -> 0.5697 ms)."""
 import numpy as np
 import pytest
 
