@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/melspec_hip.h"
@@ -438,6 +439,7 @@ int launch_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipS
 int launch_generic_stft(melspec_ctx *c, const BatchDesc &desc, int bins, int dtype, hipStream_t s);
 int launch_whisper512(melspec_ctx *c, const BatchDesc &desc, hipStream_t stream);
 bool w512_auto_ok(const melspec_ctx *c);
+bool twelve_waves_for(const melspec_ctx *c, bool layout);      // whisper400.hip: the six-frame family's batches that run on twelve waves per CU
 
 // frames per work unit of the kernel a batch is planned for (called once per batch, before it is planned).  AUTO plans for the f32
 // kernel: when the batch's vote says "heavy", the f64 kernel walks the same plan (whisper400_precise_kernel, MODE 2).

@@ -419,6 +419,25 @@ def test_compile_time_banks_for_40_and_64_mels(gpu, oracle, jfk, n_mels):
             w = oracle.compute_mel_spectrogram_cpu(clips[c], 400, 160, n_mels, SR)
             g = img[c][: w.shape[0]] if mco else img[c].T[: w.shape[0]]
             assert np.abs(g - w).max() <= TOL
+    # batches that fill the GPU and vote (round 6: the 64-mel bank, and the 40-mel bank's layouts, run the twelve-wave kernels
+    # whisper400_six_wide_runs_kernel / whisper400_six_wide_kernel<9, .>): noise stays on the f32 launch, speech goes to the gated f64 launch
+    n_big, big_len = 300, 48000
+    nf = m.num_frames(big_len)
+    pcm = gpu.DeviceBuffer(n_big * big_len * 4)
+    out = gpu.DeviceBuffer(n_big * (nf + 2) * n_mels * 4)
+    for name, mk in (("noise", lambda c: oracle.synth_pcm(3 * c, big_len)), ("speech", lambda c: np.roll(jfk, -1237 * c)[:big_len].astype(np.float32))):
+        big = np.stack([mk(c) for c in range(n_big)])
+        pcm.upload(big.reshape(-1))
+        m.compute_uniform_device(pcm.ptr, big_len, big_len, n_big, out.ptr); m.synchronize()
+        got = out.download((n_big, nf, n_mels))
+        m.compute_uniform_device_interleaved(pcm.ptr, big_len, big_len, n_big, out.ptr, False, 2); m.synchronize()
+        mm = out.download((n_big, n_mels, m.interleaved_width(big_len, 2)))
+        assert bool(m.auto_state()[0]) == (name == "speech"), (name, m.auto_state())
+        for c in (0, 151, n_big - 1):
+            w = oracle.compute_mel_spectrogram_cpu(big[c], 400, 160, n_mels, SR)
+            assert np.abs(got[c] - w).max() <= TOL, (name, c)
+            assert np.abs(mm[c][:, :nf].T - w).max() <= TOL, (name, c, "mel-major")
+    pcm.free(); out.free()
     m.close()
 
 
