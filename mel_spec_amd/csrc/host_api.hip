@@ -284,10 +284,8 @@ const char *melspec_plain_kernel_name(const melspec_ctx *c) {
     const bool fix = c->precision == MELSPEC_PRECISION_AUTO;
     if (c->six)
         return c->six_static == 1 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix80> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix80>")
-             : c->six_static == 2 ? (twelve_waves_for(c, false)
-                                         ? (fix ? "melspec::whisper400_six_wide_runs_kernel<9, LensSix64> (twelve waves; precision guard on)" : "melspec::whisper400_six_wide_runs_kernel<9, LensSix64> (twelve waves)")
-                                         : (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix64> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix64>"))
-             : c->six_static == 3 ? (fix ? "melspec::whisper400_six_runs_kernel<9, LensSix40> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensSix40>")
+             : c->six_static == 2 ? (fix ? "melspec::whisper400_six_wide_runs_kernel<9, LensSix64> (twelve waves; precision guard on)" : "melspec::whisper400_six_wide_runs_kernel<9, LensSix64> (twelve waves)")
+             : c->six_static == 3 ? (fix ? "melspec::whisper400_six_wide_runs_kernel<9, LensSix40> (twelve waves; precision guard on)" : "melspec::whisper400_six_wide_runs_kernel<9, LensSix40> (twelve waves)")
                              : (fix ? "melspec::whisper400_six_runs_kernel<9, LensRuntime> (precision guard on)" : "melspec::whisper400_six_runs_kernel<9, LensRuntime>");
     if (c->six_wide32) return fix ? "melspec::whisper400_six_wide_runs_kernel<15, LensSix128> (six frames per wave, twelve waves; precision guard on)"
                                   : "melspec::whisper400_six_wide_runs_kernel<15, LensSix128> (six frames per wave, twelve waves)";

@@ -14,6 +14,10 @@
 namespace melspec {
 
 template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>(const FastParams);
+// NOT dispatched any more (the 40-mel bank runs whisper400_six_wide_runs_kernel since round 6) and kept on purpose: with this instantiation
+// in the unit the compiler emits the LensSix80 kernel above as the 5552 instructions every measurement of the headline was made on;
+// without it 5573, and config 2 is 1.1-1.3 % slower (same-box A/B both ways, profiles/r06_wide_layouts.txt).  tools/isa_compare.py before
+// touching this list.
 template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix40>(const FastParams);
 template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
 template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);

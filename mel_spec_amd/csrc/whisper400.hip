@@ -5,7 +5,6 @@
 namespace melspec {
 // emitted by melspec_runs.hip (compiled with its own scheduling strategy; see there)
 extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix80>(const FastParams);
-extern template __global__ void whisper400_six_runs_kernel<kSixMaxSlots, LensSix40>(const FastParams);
 extern template __global__ void whisper400_wave_runs_kernel<8, LensI80>(const FastParams);
 extern template __global__ void whisper400_wave_runs_kernel<12, LensI128>(const FastParams);
 extern template __global__ void whisper400_six_wide_runs_kernel<kSixWideSlots, LensSix128>(const FastParams);
@@ -209,59 +208,45 @@ int launch_wave(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipS
 }
 
 // Which batches of the six-frame family run on TWELVE waves per CU (whisper400_six_wide_*: three waves per SIMD, 168 VGPRs): the 128-mel bank
-// always (fifteen slots), and the compile-time banks whose sixteen-wave kernels reload spilled registers inside the unit loop
-// (tools/unit_loop_spills.py; measured in profiles/r06_wide_layouts.txt).  Lab builds: MELSPEC_TWELVE_BANKS, bit 0: 64 mels plain, 1: 64 mels
-// layouts, 2: 40 mels plain, 3: 40 mels layouts.
-bool twelve_waves_for(const melspec_ctx *c, bool layout) {
-    if (c->six_wide32) return true;
-    if (!c->six || (c->six_static != 2 && c->six_static != 3)) return false;
-    // measured at 1024 x 10 s (sixteen -> twelve waves): 64 mels plain 0.381-0.386 -> 0.309-0.314 ms, mel-major 0.491-0.501 -> 0.350-0.357; 40 mels plain
-    // 0.2979 -> 0.2951 (kept on sixteen: its max-ilp build has no spill), mel-major 0.373 -> 0.335; the 80-mel bank: plain 0.298 -> 0.306, mel-major
-    // 0.340 -> 0.350 -- nine slots of its lengths fit 128 VGPRs and the fourth wave per SIMD is worth more
-    static const int banks = lab_int("MELSPEC_TWELVE_BANKS", 11, 0, 15);
-    return (banks >> ((c->six_static == 3 ? 2 : 0) + (layout ? 1 : 0))) & 1;
+// (fifteen slots) and the compile-time banks of 64 and 40 mels, whose slot lengths (two slots of ten intervals; slots of eleven and fourteen)
+// made the sixteen-wave kernels reload spilled registers inside the unit loop (tools/isa_legs.py lists such kernels).  Measured at
+// 1024 x 10 s, sixteen -> twelve waves (profiles/r06_wide_layouts.txt): 64 mels plain 0.381-0.386 -> 0.309-0.314 ms, mel-major 0.491-0.501
+// -> 0.350-0.357; 40 mels plain 0.2979 -> 0.2951, mel-major 0.373 -> 0.335.  The 80-mel bank does not spill at sixteen and stays there
+// (twelve: plain 0.298 -> 0.306, mel-major 0.340 -> 0.350), as do the run-time banks.
+bool twelve_waves_for(const melspec_ctx *c, bool /*layout*/) {
+    return c->six_wide32 || (c->six && (c->six_static == 2 || c->six_static == 3));
 }
 
 template <class Lens>
 int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hipStream_t stream) {
+    constexpr bool kTwelve = std::is_same_v<Lens, LensSix64> || std::is_same_v<Lens, LensSix40>;       // twelve_waves_for
+    constexpr int kWaves = kTwelve ? kSixWideWaves : kSixWaves;
     static std::atomic<uint64_t> attr_done{0};
     if (!device_done(attr_done)) {
-        int rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_kernel)");
-        if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
+        int rc;
+        if constexpr (kTwelve) {
+            rc = allow_big_lds(&whisper400_six_wide_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_wide_kernel<9, .>)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_wide_runs_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_wide_runs_kernel<9, .>)");
+        } else {
+            rc = allow_big_lds(&whisper400_six_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_kernel)");
+            if (!rc) rc = allow_big_lds(&whisper400_six_runs_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_runs_kernel)");
+        }
         if (rc) return rc;
         mark_device_done(attr_done);
     }
-    const uint64_t blocks = (desc.n_units + kSixWaves - 1) / kSixWaves;
-    static const int per_cu = lab_int("MELSPEC_SIX_GRID_PER_CU", 1, 1, 4096);     // one 16-wave workgroup per CU
-    const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kSixWaves * 64);
+    const uint64_t blocks = (desc.n_units + kWaves - 1) / kWaves;
+    static const int per_cu = lab_int("MELSPEC_SIX_GRID_PER_CU", 1, 1, 4096);     // one workgroup per CU
+    const dim3 grid(grid_for_xcd(blocks, c->dev.cus, per_cu)), block(kWaves * 64);
     FixSink armed = sink_armed(c, sink, desc, grid.x);
     armed.vote_groups = std::min<unsigned>(grid.x, static_cast<unsigned>(c->dev.cus));        // the workgroups resident when the launch starts (one per CU)
     const FastParams fp = fast_params(desc, c->ft6, c->d_blob6, c, armed);
     const bool layout = desc.mel_major || desc.out_width != desc.frames_per_clip;   // ragged batches: both zero
-    if constexpr (std::is_same_v<Lens, LensSix64> || std::is_same_v<Lens, LensSix40>) {
-        // the 64- and 40-mel banks: their slot lengths (two slots of ten intervals; slots of eleven and fourteen) do not fit 128 VGPRs in every
-        // kernel -- three to eight scratch reloads inside the unit loop at sixteen waves -- and do fit 168: twelve waves per CU, like the
-        // 128-mel bank's kernels (twelve_waves_for says which batches)
-        static std::atomic<uint64_t> attr12_done{0};
-        if (!device_done(attr12_done)) {
-            int rc = allow_big_lds(&whisper400_six_wide_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_wide_kernel<9, .>)");
-            if (!rc) rc = allow_big_lds(&whisper400_six_wide_runs_kernel<kSixMaxSlots, Lens>, "hipFuncSetAttribute(whisper400_six_wide_runs_kernel<9, .>)");
-            if (rc) return rc;
-            mark_device_done(attr12_done);
-        }
-        if (twelve_waves_for(c, layout)) {
-            const uint64_t blocks12 = (desc.n_units + kSixWideWaves - 1) / kSixWideWaves;
-            const dim3 grid12(grid_for_xcd(blocks12, c->dev.cus, 1));
-            FixSink armed12 = armed;
-            armed12.n_groups = grid12.x;
-            armed12.vote_groups = std::min<unsigned>(grid12.x, static_cast<unsigned>(c->dev.cus));
-            const FastParams fp12 = fast_params(desc, c->ft6, c->d_blob6, c, armed12);
-            if (layout) hipLaunchKernelGGL((whisper400_six_wide_kernel<kSixMaxSlots, Lens>), grid12, dim3(kSixWideWaves * 64), c->lds6, stream, fp12);
-            else hipLaunchKernelGGL((whisper400_six_wide_runs_kernel<kSixMaxSlots, Lens>), grid12, dim3(kSixWideWaves * 64), c->lds6, stream, fp12);
-            HIP_TRY(hipGetLastError());
-            return MELSPEC_OK;
-        }
-    }
+    if constexpr (kTwelve) {
+        if (layout) hipLaunchKernelGGL((whisper400_six_wide_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
+        else hipLaunchKernelGGL((whisper400_six_wide_runs_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
+        HIP_TRY(hipGetLastError());
+        return MELSPEC_OK;
+    } else {
     // plain batches, uniform and ragged, take the run-per-wave kernel (no division per unit, the clip record in scalar registers, a
     // wave re-reads its own frame-tail halo): cfg2 0.3105 -> 0.3055 ms, 8192 x 30 s 7.55 -> 7.42 ms against the round-robin deal
     if (layout) hipLaunchKernelGGL((whisper400_six_kernel<kSixMaxSlots, Lens>), grid, block, c->lds6, stream, fp);
@@ -285,6 +270,7 @@ int launch_six_t(melspec_ctx *c, const BatchDesc &desc, const FixSink &sink, hip
     }
 #endif
     return MELSPEC_OK;
+    }
 }
 
 // the fifteen-slot f32 kernels on twelve waves: Whisper large-v3's 128-mel bank, plain batches (runs) and layouts (rounds)

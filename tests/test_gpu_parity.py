@@ -400,7 +400,7 @@ def test_compile_time_banks_for_40_and_64_mels(gpu, oracle, jfk, n_mels):
     paid one LDS round trip per bin: 64 mels 0.378 ms at 1024 x 10 s against 0.292 for 80).  Same values as before, and as the oracle."""
     m = gpu.HipMelSpectrogram(400, 160, SR, n_mels)
     m.set_precision("auto")                      # (the suite's second pass starts every context in F64: MELSPEC_PRECISE=1)
-    assert m.uses_fast_path and f"LensSix{n_mels}" in m.plain_kernel_name()
+    assert m.uses_fast_path and f"whisper400_six_wide_runs_kernel<9, LensSix{n_mels}>" in m.plain_kernel_name()      # twelve waves since round 6
     clips = np.stack([jfk[8000 * c:8000 * c + 32000] for c in range(4)] + [oracle.synth_pcm(c, 32000) for c in range(4)])
     for mode, tol in (("auto", TOL), ("f32", 6e-4), ("f64", 2e-6)):
         m.set_precision(mode)

@@ -314,6 +314,12 @@ def test_valu_fields_come_from_the_committed_isa_table():
         assert v["f64_insts_per_frame"] >= 0 and v["other_valu_per_frame"] > 0
         # 128 flops per f64 wave-instruction at 2 G frames/s against 78.6 TFLOP/s
         assert abs(v["frac_of_f64_vector_peak"] - v["f64_insts_per_frame"] * 128 * 2.0e9 / 78.6e12) < 1e-12
+    # no kernel the library dispatches reloads a spilled register inside its unit loop (a scratch load's vmcnt(0) also waits for the previous
+    # unit's stores: the 64-mel bank's sixteen-wave kernels were 19-29 % slower for six to eight of them, round 6).  The one exception is
+    # emitted but never launched: csrc/melspec_runs.hip says why it is still there.
+    spilled = {k: v for k, v in table["unit_loop_scratch"].items() if v}
+    assert len(table["unit_loop_scratch"]) >= 60
+    assert all("whisper400_six_runs_kernelILi9ENS_13LensSixStaticILi40E" in k for k in spilled), spilled
     assert bench.valu_fields("f64", 2.4e9)["f64_insts_per_frame"] == 106.0          # 636 f64 instructions per six-frame unit
     assert bench.valu_fields("value", 3.4e9)["f64_insts_per_frame"] == 0.0
     assert bench.valu_fields("no such leg", 1.0) is None

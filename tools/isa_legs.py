@@ -66,7 +66,7 @@ NOTES = {
 asm = {}
 with tempfile.TemporaryDirectory() as tmp:
     procs = {}
-    for unit in sorted({u for u, _, _ in LEGS.values()}):
+    for unit in sorted({u for u, _, _ in LEGS.values()} | {"melspec_runs.hip", "whisper400.hip", "fbank512.hip"}):
         out = os.path.join(tmp, unit + ".s")
         procs[unit] = (out, subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", out,
                                              os.path.join(B.CSRC, unit)] + B.UNIT_FLAGS.get(unit, []), stderr=subprocess.DEVNULL))
@@ -94,4 +94,30 @@ for leg, (unit, subs, fpu) in LEGS.items():
     other = c['valu32'] + c['cvt'] + c['dpp/lane'] + c['pk']
     print(f"  {leg:10s} {fpu:3d} {c['f64']:5d} {c['cvt']:4d} {c['valu32']:4d} {c['dpp/lane']:4d} {c['lds']:4d} {c['vmem']:4d} {c['salu']:4d} {c['wait']:4d} | {c['f64'] / fpu:7.1f} {other / fpu:7.1f} | "
           + subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()[:110] + ("" if marked else "   [no priority markers: whole kernel]"))
+
+# Scratch (spill) instructions inside any copy of a unit loop, for EVERY kernel of the compiled units that marks its phases (tools/unit_loop_spills.py's
+# rule): a scratch reload inside a unit waits on vmcnt(0), i.e. also for the previous unit's stores -- round 6 found the 64-mel bank's kernels 19-29 %
+# slower for six to eight of them.  tests/test_parallel.py holds the kernels the library dispatches to zero.
+def loop_scratch(lines):
+    prio0 = [k for k, l in enumerate(lines) if l.startswith('s_setprio 0')]
+    prio2 = [k for k, l in enumerate(lines) if l.startswith('s_setprio 2')]
+    total, copies = 0, 0
+    for a in prio0:
+        b = next((k for k in prio2 if k > a), None)
+        if b is None: continue
+        e = next((k for k in range(b, len(lines)) if lines[k].startswith(('s_cbranch', 's_branch'))), len(lines))
+        total += sum('scratch_' in l for l in lines[a:e]); copies += 1
+    return total if copies else None
+
+res["unit_loop_scratch"] = {}
+for unit, s in asm.items():
+    for name in re.findall(r'^(_ZN7melspec\S+):\s*; @', s, re.M):
+        i = s.index('\n' + name + ':'); j = s.index('s_endpgm', i)
+        lines = [l.strip() for l in s[i:j].splitlines() if l.strip() and not l.strip().startswith((';', '.'))]
+        n = loop_scratch(lines)
+        if n is not None: res["unit_loop_scratch"][name] = n
+spilled = {k: v for k, v in res["unit_loop_scratch"].items() if v}
+print(f"# unit loops with scratch instructions: {len(spilled)} of {len(res['unit_loop_scratch'])} kernels with marked phases")
+for k, v in sorted(spilled.items()):
+    print(f"#   {v:3d}  " + subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip()[:150])
 json.dump(res, open(os.path.join(ROOT, "profiles", "isa_hist.json"), "w"), indent=1)
