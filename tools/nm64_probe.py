@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Plain and mel-major launches of a compile-time bank of the six-frame family at 1024 x 10 s (profiles/r06_wide_layouts.txt):
+tools/nm64_probe.py [n_mels = 64]   (MELSPEC_LIB selects a library variant)."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
